@@ -1,0 +1,130 @@
+'''
+ctypes binding of libdanet_hip.so (the C ABI declared in include/danet_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised.  PyTorch is used only to own device memory and streams;
+tensors cross the boundary as raw device pointers.
+'''
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libdanet_hip.so')
+
+c_int, c_i64, c_f32, c_sz, c_p = (ctypes.c_int, ctypes.c_int64, ctypes.c_float,
+                                  ctypes.c_size_t, ctypes.c_void_p)
+
+# name -> (restype, argtypes); mirrors include/danet_hip.h
+PROTOTYPES = {
+    'danet_abi_version': (c_int, []),
+    'danet_last_error': (ctypes.c_char_p, []),
+    'danet_stft_num_frames': (c_int, [c_i64, c_int, c_int]),
+    'danet_stft': (c_int, [c_p, c_int, c_i64, c_int, c_int, c_p, c_p, c_p]),
+    'danet_istft_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int]),
+    'danet_istft': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_sz]),
+    'danet_frontend_fwd': (c_int, [c_p, c_int, c_int, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'danet_reattach_phase': (c_int, [c_p, c_int, c_int, c_i64, c_p, c_p, c_p, c_p]),
+    'danet_center_mean_elems': (c_int, [c_int]),
+    'danet_center': (c_int, [c_p, c_int, c_int, c_int, c_p, c_int, c_int, c_p, c_int, c_int, c_p]),
+    'danet_gemm_f32_workspace_bytes': (c_sz, [c_int, c_int, c_int]),
+    'danet_gemm_f32': (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_int,
+                               c_p, c_int, c_p, c_f32, c_p, c_sz]),
+    'danet_colsum_f32_workspace_bytes': (c_sz, [c_int, c_int]),
+    'danet_colsum_f32': (c_int, [c_p, c_int, c_int, c_p, c_int, c_p, c_f32, c_p, c_sz]),
+    'danet_lstm_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int]),
+    'danet_lstm_fwd': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_int,
+                               c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_sz]),
+    'danet_lstm_bwd': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_int,
+                               c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz]),
+    'danet_attractor_truth_workspace_bytes': (c_sz, [c_int, c_int, c_i64, c_int]),
+    'danet_attractor_truth_fwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p,
+                                          c_f32, c_p, c_p, c_p, c_sz]),
+    'danet_attractor_truth_bwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p,
+                                          c_p, c_f32, c_p]),
+    'danet_attractor_anchor_workspace_bytes': (c_sz, [c_int, c_int, c_i64, c_int, c_int]),
+    'danet_attractor_anchor_fwd': (c_int, [c_p, c_int, c_int, c_i64, c_int, c_int, c_p, c_p, c_p,
+                                           c_p, c_p, c_p, c_p, c_sz]),
+    'danet_attractor_anchor_bwd': (c_int, [c_p, c_int, c_int, c_i64, c_int, c_int, c_p, c_p, c_p,
+                                           c_p, c_p, c_p, c_p, c_p, c_p, c_sz]),
+    'danet_separate_fwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p, c_p, c_p]),
+    'danet_separate_bwd_workspace_bytes': (c_sz, [c_int, c_int, c_i64, c_int]),
+    'danet_separate_bwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p, c_p,
+                                   c_p, c_p, c_p, c_sz]),
+    'danet_pit_mse_workspace_bytes': (c_sz, [c_int, c_int, c_i64]),
+    'danet_pit_mse_fwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_p, c_p, c_p, c_f32, c_p,
+                                  c_p, c_p, c_p, c_sz]),
+    'danet_pit_mse_bwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_p, c_p, c_p, c_p, c_f32, c_p]),
+    'danet_adam_clip_step': (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_f32, c_f32, c_f32, c_f32,
+                                     c_f32, c_f32]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class DanetHipError(RuntimeError):
+    pass
+
+
+def load():
+    '''dlopen libdanet_hip.so (after torch, so both share ONE libamdhip64).'''
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise DanetHipError(
+                'libdanet_hip.so not found at %s -- the HIP extension is required '
+                '(there is no CPU fallback); build it with '
+                '`python -c "import __graft_entry__ as g; g.build()"`' % LIB_PATH)
+        # torch already mapped its bundled libamdhip64.so (SONAME libamdhip64.so.7);
+        # our DT_NEEDED of the same SONAME resolves to that copy.
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_LOCAL)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)      # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if lib.danet_abi_version() != 1:
+            raise DanetHipError('libdanet_hip.so ABI version mismatch')
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().danet_last_error()
+        raise DanetHipError('libdanet_hip error %d: %s' % (
+            rc, msg.decode() if msg else '?'))
+
+
+def ptr(t):
+    '''raw device pointer of a torch tensor (None -> NULL)'''
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ---- scratch ---------------------------------------------------------------
+_ws = {}
+
+
+def workspace(nbytes, device):
+    '''per-device grow-only scratch; safe because every library call is
+    stream-ordered on the current stream and finishes with `ws` before the next
+    call on that stream starts.'''
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream().cuda_stream)
+    t = _ws.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = t
+    return t

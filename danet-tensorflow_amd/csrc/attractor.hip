@@ -1,0 +1,828 @@
+// Attractor estimators and dot-product separators of the DANet hot path
+// (gfx950) -- reference app/modules.py:382-603 + app/ops.py:273-292.
+//
+// All of these stream the [B][N][E] embedding (42 MB at B=32,T=128,F=129,E=20)
+// once per call and are HBM-bound; one thread owns one time-frequency bin and
+// keeps its E-vector in registers (16-B loads when E % 4 == 0), per-utterance
+// [C][E] tables live in LDS, and cross-bin sums are reduced
+// wave-shuffle -> LDS -> per-chunk partials in `ws` -> a small deterministic
+// finalize kernel (no float atomics: results are run-to-run identical).
+// The anchor estimator never materialises the reference's [B][P][T][F][C]
+// assignment tensor (63 MB x2, app/modules.py:513-516): soft assignments for a
+// 128-bin tile are formed in LDS and contracted against the tile immediately.
+#include "common.h"
+
+#define CHUNK_N 2048       // bins per workgroup (reduction granularity)
+#define MAXC 4
+#define MAXA 8
+#define MAXP 70            // C(8,4)
+
+__host__ __device__ static inline int n_chunks(int64_t N) { return (int)((N + CHUNK_N - 1) / CHUNK_N); }
+
+// ---- per-thread embedding row -------------------------------------------------
+template <int EP>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, int E, float (&x)[EP]) {
+  if ((E & 3) == 0) {
+#pragma unroll
+    for (int q = 0; q < EP / 4; ++q) {
+      if (q * 4 < E) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + q * 4);
+        x[q * 4 + 0] = v.x; x[q * 4 + 1] = v.y; x[q * 4 + 2] = v.z; x[q * 4 + 3] = v.w;
+      } else {
+        x[q * 4 + 0] = x[q * 4 + 1] = x[q * 4 + 2] = x[q * 4 + 3] = 0.f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < EP; ++e) x[e] = (e < E) ? p[e] : 0.f;
+  }
+}
+
+template <int EP>
+__device__ __forceinline__ void store_row(float* __restrict__ p, int E, const float (&x)[EP]) {
+  if ((E & 3) == 0) {
+#pragma unroll
+    for (int q = 0; q < EP / 4; ++q)
+      if (q * 4 < E)
+        *reinterpret_cast<f32x4*>(p + q * 4) =
+            (f32x4){x[q * 4 + 0], x[q * 4 + 1], x[q * 4 + 2], x[q * 4 + 3]};
+  } else {
+#pragma unroll
+    for (int e = 0; e < EP; ++e)
+      if (e < E) p[e] = x[e];
+  }
+}
+
+// block-reduce `cnt` per-thread values (static-indexed array) into dst[cnt]
+// (global), using LDS scratch red[4][cnt_max].  blockDim.x == 256.
+template <int CNT>
+__device__ __forceinline__ void block_reduce_store(float (&v)[CNT], int cnt, float* red,
+                                                   float* __restrict__ dst) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < CNT; ++i) {
+    if (i < cnt) {
+      const float s = wave_sum(v[i]);
+      if (lane == 0) red[wave * CNT + i] = s;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x)
+    dst[i] = red[i] + red[CNT + i] + red[2 * CNT + i] + red[3 * CNT + i];
+  __syncthreads();
+}
+
+// tf.argmax over the speaker axis, first index on ties (K9)
+__device__ __forceinline__ int argmax_src(const float* __restrict__ src_pwr, int C, int64_t N,
+                                          int64_t n) {
+  int best = 0;
+  float bv = src_pwr[n];
+  for (int c = 1; c < C; ++c) {
+    const float v = src_pwr[(int64_t)c * N + n];
+    if (v > bv) { bv = v; best = c; }
+  }
+  return best;
+}
+
+__device__ __forceinline__ float truth_weight(int mode, float mix) {
+  if (mode == 0) return 1.f;                       // app/modules.py:404-406
+  if (mode == 1) return (5.f < mix) ? 1.f : 0.f;   // app/modules.py:433-434
+  return mix;                                      // app/modules.py:468-469
+}
+
+// =========================================================================
+// truth family forward (app/modules.py:390-487)
+// =========================================================================
+template <int EP>
+__global__ __launch_bounds__(256) void truth_fwd_kernel(
+    int mode, int C, int64_t N, int E, const float* __restrict__ embed,
+    const float* __restrict__ src_pwr, const float* __restrict__ mix_pwr,
+    float* __restrict__ partial /* [B][chunks][C][EP+1] */) {
+  __shared__ float red[4 * (EP + 1)];
+  const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  const int64_t n0 = (int64_t)ch * CHUNK_N, n1 = min(N, n0 + CHUNK_N);
+  const float* eb = embed + (int64_t)b * N * E;
+  const float* sp = src_pwr + (int64_t)b * C * N;
+  const float* mp = mix_pwr + (int64_t)b * N;
+  float* out = partial + ((int64_t)b * nch + ch) * C * (EP + 1);
+  // one speaker at a time keeps the accumulator count at EP+1
+  for (int c = 0; c < C; ++c) {
+    float acc[EP + 1];
+#pragma unroll
+    for (int e = 0; e <= EP; ++e) acc[e] = 0.f;
+    for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
+      if (argmax_src(sp, C, N, n) != c) continue;
+      const float w = truth_weight(mode, mp[n]);
+      float x[EP];
+      load_row<EP>(eb + n * E, E, x);
+#pragma unroll
+      for (int e = 0; e < EP; ++e) acc[e] += w * x[e];
+      acc[EP] += w;
+    }
+    block_reduce_store<EP + 1>(acc, EP + 1, red, out + c * (EP + 1));
+  }
+}
+
+__global__ void truth_final_kernel(int mode, int C, int E, int EP, int nch, float eps,
+                                   const float* __restrict__ partial,
+                                   float* __restrict__ attr, float* __restrict__ denom) {
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < C * E; i += blockDim.x) {
+    const int c = i / E, e = i % E;
+    float s = 0.f, w = 0.f;
+    for (int ch = 0; ch < nch; ++ch) {
+      const float* p = partial + (((int64_t)b * nch + ch) * C + c) * (EP + 1);
+      s += p[e];
+      w += p[EP];
+    }
+    const float add = (mode == 0) ? 1.f : eps;     // modules.py:407 vs :447,:482
+    attr[((int64_t)b * C + c) * E + e] = s / (w + add);
+    if (e == 0) denom[b * C + c] = w;
+  }
+}
+
+// truth family backward: dembed[n][:] += w(n) * dattr[idx(n)][:] / (denom + add)
+template <int EP>
+__global__ __launch_bounds__(256) void truth_bwd_kernel(
+    int mode, int C, int64_t N, int E, const float* __restrict__ dattr,
+    const float* __restrict__ src_pwr, const float* __restrict__ mix_pwr,
+    const float* __restrict__ denom, float eps, float* __restrict__ dembed) {
+  __shared__ float tab[MAXC * EP];
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < C * EP; i += 256) {
+    const int c = i / EP, e = i % EP;
+    const float add = (mode == 0) ? 1.f : eps;
+    tab[i] = (e < E) ? dattr[((int64_t)b * C + c) * E + e] / (denom[b * C + c] + add) : 0.f;
+  }
+  __syncthreads();
+  const float* sp = src_pwr + (int64_t)b * C * N;
+  const float* mp = mix_pwr + (int64_t)b * N;
+  float* db = dembed + (int64_t)b * N * E;
+  for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
+    const int c = argmax_src(sp, C, N, n);
+    const float w = truth_weight(mode, mp[n]);
+    float x[EP];
+    load_row<EP>(db + n * E, E, x);
+#pragma unroll
+    for (int e = 0; e < EP; ++e) x[e] += w * tab[c * EP + e];
+    store_row<EP>(db + n * E, E, x);
+  }
+}
+
+// =========================================================================
+// separators (app/modules.py:556-603)
+// =========================================================================
+template <int EP>
+__global__ __launch_bounds__(256) void separate_fwd_kernel(
+    int act, int C, int64_t N, int E, const float* __restrict__ mix_pwr,
+    const float* __restrict__ attr, const float* __restrict__ embed,
+    float* __restrict__ out, float* __restrict__ masks) {
+  __shared__ float tab[MAXC * EP];
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < C * EP; i += 256) {
+    const int c = i / EP, e = i % EP;
+    tab[i] = (e < E) ? attr[((int64_t)b * C + c) * E + e] : 0.f;
+  }
+  __syncthreads();
+  const float* eb = embed + (int64_t)b * N * E;
+  for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
+    float x[EP];
+    load_row<EP>(eb + n * E, E, x);
+    float lg[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      float s = 0.f;
+      if (c < C) {
+#pragma unroll
+        for (int e = 0; e < EP; ++e) s += x[e] * tab[c * EP + e];   // modules.py:558-560
+      }
+      lg[c] = s;
+    }
+    if (act == 0) {                                   // softmax, modules.py:595
+      float mx = lg[0];
+#pragma unroll
+      for (int c = 1; c < MAXC; ++c) if (c < C) mx = fmaxf(mx, lg[c]);
+      float den = 0.f;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) if (c < C) { lg[c] = expf(lg[c] - mx); den += lg[c]; }
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) if (c < C) lg[c] = lg[c] / den;
+    } else {                                          // sigmoid, modules.py:566
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) if (c < C) lg[c] = sigmoid_acc(lg[c]);
+    }
+    const float mp = mix_pwr[(int64_t)b * N + n];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) {
+        out[((int64_t)b * C + c) * N + n] = mp * lg[c];   // modules.py:567-574
+        if (masks) masks[((int64_t)b * N + n) * C + c] = lg[c];
+      }
+  }
+}
+
+template <int EP, int CP>
+__global__ __launch_bounds__(256) void separate_bwd_kernel(
+    int act, int C_, int64_t N, int E, const float* __restrict__ mix_pwr,
+    const float* __restrict__ attr, const float* __restrict__ embed,
+    const float* __restrict__ dout, float* __restrict__ dembed,
+    float* __restrict__ partial /* [B][chunks][C][EP] */) {
+  constexpr int C = CP;
+  (void)C_;
+  __shared__ float tab[CP * EP];
+  __shared__ float red[4 * EP];
+  const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  for (int i = threadIdx.x; i < C * EP; i += 256) {
+    const int c = i / EP, e = i % EP;
+    tab[i] = (e < E) ? attr[((int64_t)b * C + c) * E + e] : 0.f;
+  }
+  __syncthreads();
+  const int64_t n0 = (int64_t)ch * CHUNK_N, n1 = min(N, n0 + CHUNK_N);
+  const float* eb = embed + (int64_t)b * N * E;
+  float* db = dembed + (int64_t)b * N * E;
+  float accs[CP][EP];
+#pragma unroll
+  for (int c = 0; c < CP; ++c)
+#pragma unroll
+    for (int e = 0; e < EP; ++e) accs[c][e] = 0.f;
+
+  for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
+    float x[EP];
+    load_row<EP>(eb + n * E, E, x);
+    float m[CP], dl[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      float s = 0.f;
+      if (c < C) {
+#pragma unroll
+        for (int e = 0; e < EP; ++e) s += x[e] * tab[c * EP + e];
+      }
+      m[c] = s;
+    }
+    const float mp = mix_pwr[(int64_t)b * N + n];
+    if (act == 0) {
+      float mx = m[0];
+#pragma unroll
+      for (int c = 1; c < CP; ++c) if (c < C) mx = fmaxf(mx, m[c]);
+      float den = 0.f;
+#pragma unroll
+      for (int c = 0; c < CP; ++c) if (c < C) { m[c] = expf(m[c] - mx); den += m[c]; }
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < CP; ++c)
+        if (c < C) {
+          m[c] = m[c] / den;
+          dl[c] = dout[((int64_t)b * C + c) * N + n] * mp;   // dL/dmask
+          dot += m[c] * dl[c];
+        }
+#pragma unroll
+      for (int c = 0; c < CP; ++c) if (c < C) dl[c] = m[c] * (dl[c] - dot);
+    } else {
+#pragma unroll
+      for (int c = 0; c < CP; ++c)
+        if (c < C) {
+          m[c] = sigmoid_acc(m[c]);
+          dl[c] = dout[((int64_t)b * C + c) * N + n] * mp * m[c] * (1.f - m[c]);
+        }
+    }
+    float dx[EP];
+#pragma unroll
+    for (int e = 0; e < EP; ++e) dx[e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CP; ++c)
+      if (c < C) {
+#pragma unroll
+        for (int e = 0; e < EP; ++e) {
+          dx[e] += dl[c] * tab[c * EP + e];
+          accs[c][e] += dl[c] * x[e];
+        }
+      }
+    store_row<EP>(db + n * E, E, dx);
+  }
+  float* out = partial + ((int64_t)b * nch + ch) * C * EP;
+#pragma unroll
+  for (int c = 0; c < CP; ++c)
+    if (c < C) block_reduce_store<EP>(accs[c], EP, red, out + c * EP);
+}
+
+__global__ void sum_chunks_kernel(int nch, int cnt_out, int C, int E, int EP,
+                                  const float* __restrict__ partial, float* __restrict__ out) {
+  // out[b][c][e] = sum_ch partial[b][ch][c][e(EP)]
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < C * E; i += blockDim.x) {
+    const int c = i / E, e = i % E;
+    float s = 0.f;
+    for (int ch = 0; ch < nch; ++ch)
+      s += partial[(((int64_t)b * nch + ch) * C + c) * EP + e];
+    out[((int64_t)b * C + c) * E + e] = s;
+  }
+  (void)cnt_out;
+}
+
+// =========================================================================
+// anchor estimator (app/modules.py:501-545)
+// =========================================================================
+#define ANCH_TN 128   // bins per LDS tile
+
+struct AnchorCombos { int P; int idx[MAXP][MAXC]; };
+
+static void make_combos(int A, int C, AnchorCombos& cb) {
+  // itertools.combinations(range(A), C): lexicographic (app/ops.py:287-292)
+  int cur[MAXC];
+  for (int i = 0; i < C; ++i) cur[i] = i;
+  cb.P = 0;
+  for (;;) {
+    for (int i = 0; i < C; ++i) cb.idx[cb.P][i] = cur[i];
+    ++cb.P;
+    int i = C - 1;
+    while (i >= 0 && cur[i] == A - C + i) --i;
+    if (i < 0) break;
+    ++cur[i];
+    for (int j = i + 1; j < C; ++j) cur[j] = cur[j - 1] + 1;
+  }
+}
+
+// LDS: Xs[ANCH_TN][EPA] (embedding tile + ones column), Ss[ANCH_TN][PC+1]
+template <int EP>
+__global__ __launch_bounds__(256) void anchor_fwd_kernel(
+    int C, int64_t N, int E, int A, AnchorCombos cb, const float* __restrict__ embed,
+    const float* __restrict__ anchors, float* __restrict__ partial /* [B][chunks][PC][EPA] */) {
+  constexpr int EPA = EP + 4;           // + ones column, padded to a float4
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int PC = cb.P * C;
+  const int lds = PC + 1;               // odd-ish stride for the assignment tile
+  float* Xs = smem;                     // [ANCH_TN][EPA]
+  float* Ss = Xs + ANCH_TN * EPA;       // [ANCH_TN][lds]
+  float* An = Ss + ANCH_TN * lds;       // [A][EP]
+  const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < A * EP; i += 256) {
+    const int a = i / EP, e = i % EP;
+    An[i] = (e < E) ? anchors[a * E + e] : 0.f;
+  }
+  const int64_t n0 = (int64_t)ch * CHUNK_N, n1 = min(N, n0 + CHUNK_N);
+  const float* eb = embed + (int64_t)b * N * E;
+
+  // work items: (pc, quad) -> 4 accumulators; up to 4 items per thread
+  constexpr int EQ = EPA / 4;
+  const int nitems = PC * EQ;
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  for (int64_t base = n0; base < n1; base += ANCH_TN) {
+    // phase 1: one thread per bin builds its row and its soft assignments
+    if (tid < ANCH_TN) {
+      const int64_t n = base + tid;
+      float x[EP];
+      float* xr = Xs + tid * EPA;
+      if (n < n1) {
+        load_row<EP>(eb + n * E, E, x);
+#pragma unroll
+        for (int e = 0; e < EP; ++e) xr[e] = x[e];
+        xr[EP] = 1.f; xr[EP + 1] = 0.f; xr[EP + 2] = 0.f; xr[EP + 3] = 0.f;
+        float d[MAXA];
+#pragma unroll
+        for (int a = 0; a < MAXA; ++a) {
+          float s = 0.f;
+          if (a < A) {
+#pragma unroll
+            for (int e = 0; e < EP; ++e) s += x[e] * An[a * EP + e];   // modules.py:513-515
+          }
+          d[a] = s;
+        }
+        for (int p = 0; p < cb.P; ++p) {
+          float lg[MAXC];
+          float mx = -INFINITY;
+#pragma unroll
+          for (int c = 0; c < MAXC; ++c)
+            if (c < C) {
+              const int a = cb.idx[p][c];
+              float v = d[0];
+#pragma unroll
+              for (int q = 1; q < MAXA; ++q) v = (a == q) ? d[q] : v;
+              lg[c] = v;
+              mx = fmaxf(mx, v);
+            }
+          float den = 0.f;
+#pragma unroll
+          for (int c = 0; c < MAXC; ++c) if (c < C) { lg[c] = expf(lg[c] - mx); den += lg[c]; }
+#pragma unroll
+          for (int c = 0; c < MAXC; ++c)
+            if (c < C) Ss[tid * lds + p * C + c] = lg[c] / den;        // modules.py:516
+        }
+      } else {
+        for (int e = 0; e < EPA; ++e) xr[e] = 0.f;
+        for (int i = 0; i < PC; ++i) Ss[tid * lds + i] = 0.f;
+      }
+    }
+    __syncthreads();
+    // phase 2: contract assignments against [x | 1]  (modules.py:519-523)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int item = tid + it * 256;
+      if (item < nitems) {
+        const int pc = item / EQ, q = item % EQ;
+        f32x4 a4 = acc[it];
+        for (int r = 0; r < ANCH_TN; ++r) {
+          const float sv = Ss[r * lds + pc];
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(&Xs[r * EPA + q * 4]);
+          a4 += sv * xv;
+        }
+        acc[it] = a4;
+      }
+    }
+    __syncthreads();
+  }
+  float* out = partial + ((int64_t)b * nch + ch) * PC * EPA;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int item = tid + it * 256;
+    if (item < nitems) {
+      const int pc = item / EQ, q = item % EQ;
+      *reinterpret_cast<f32x4*>(&out[pc * EPA + q * 4]) = acc[it];
+    }
+  }
+}
+
+// one block per utterance: sum chunks, normalise, Gram max incl. diagonal,
+// argmin (first index on ties), gather (modules.py:522-537)
+__global__ void anchor_final_kernel(int C, int E, int EPA, int P, int nch,
+                                    const float* __restrict__ partial,
+                                    float* __restrict__ attr, float* __restrict__ asets,
+                                    float* __restrict__ asum, int32_t* __restrict__ choice) {
+  extern __shared__ float sm[];
+  const int PC = P * C;
+  float* S = sm;                 // [PC][EPA] summed
+  float* sim = S + PC * EPA;     // [P]
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < PC * EPA; i += blockDim.x) {
+    float s = 0.f;
+    for (int ch = 0; ch < nch; ++ch) s += partial[((int64_t)b * nch + ch) * PC * EPA + i];
+    S[i] = s;
+  }
+  __syncthreads();
+  const int EP = EPA - 4;
+  for (int i = threadIdx.x; i < PC * E; i += blockDim.x) {
+    const int pc = i / E, e = i % E;
+    const float v = S[pc * EPA + e] / S[pc * EPA + EP];      // modules.py:522-523
+    asets[((int64_t)b * PC + pc) * E + e] = v;
+  }
+  for (int i = threadIdx.x; i < PC; i += blockDim.x) asum[(int64_t)b * PC + i] = S[i * EPA + EP];
+  __syncthreads();
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    float mx = -INFINITY;
+    for (int c1 = 0; c1 < C; ++c1)
+      for (int c2 = 0; c2 < C; ++c2) {                        // full CxC incl. diagonal (K7)
+        float dot = 0.f;
+        const float d1 = S[(p * C + c1) * EPA + EP], d2 = S[(p * C + c2) * EPA + EP];
+        for (int e = 0; e < E; ++e)
+          dot += (S[(p * C + c1) * EPA + e] / d1) * (S[(p * C + c2) * EPA + e] / d2);
+        mx = fmaxf(mx, dot);
+      }
+    sim[p] = mx;                                              // modules.py:526-530
+  }
+  __syncthreads();
+  __shared__ int best_s;
+  if (threadIdx.x == 0) {
+    int best = 0;
+    for (int p = 1; p < P; ++p) if (sim[p] < sim[best]) best = p;   // modules.py:533
+    choice[b] = best;
+    best_s = best;
+  }
+  __syncthreads();
+  const int best = best_s;
+  for (int i = threadIdx.x; i < C * E; i += blockDim.x) {
+    const int c = i / E, e = i % E;
+    attr[((int64_t)b * C + c) * E + e] =
+        S[(best * C + c) * EPA + e] / S[(best * C + c) * EPA + EP];   // modules.py:534-537
+  }
+}
+
+// backward through the chosen subset only (argmin has no gradient)
+template <int EP, int CP>
+__global__ __launch_bounds__(256) void anchor_bwd_kernel(
+    int C_, int64_t N, int E, int A, AnchorCombos cb, const float* __restrict__ dattr,
+    const float* __restrict__ embed, const float* __restrict__ anchors,
+    const float* __restrict__ attr, const float* __restrict__ asum,
+    const int32_t* __restrict__ choice, float* __restrict__ dembed,
+    float* __restrict__ partial /* [B][chunks][C][EP] */) {
+  constexpr int C = CP;
+  (void)C_;
+  __shared__ float An[MAXC * EP];   // chosen anchors
+  __shared__ float G[MAXC * EP];    // dL/dSnum[c][e]
+  __shared__ float g0[MAXC];        // dL/dSden[c]
+  __shared__ float red[4 * EP];
+  const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  const int pstar = choice[b];
+  for (int i = threadIdx.x; i < C * EP; i += 256) {
+    const int c = i / EP, e = i % EP;
+    const int a = cb.idx[pstar][c];
+    const float den = asum[((int64_t)b * cb.P + pstar) * C + c];
+    An[i] = (e < E) ? anchors[a * E + e] : 0.f;
+    G[i] = (e < E) ? dattr[((int64_t)b * C + c) * E + e] / den : 0.f;
+  }
+  if (threadIdx.x < C) {
+    const int c = threadIdx.x;
+    const float den = asum[((int64_t)b * cb.P + pstar) * C + c];
+    float s = 0.f;
+    for (int e = 0; e < E; ++e)
+      s += dattr[((int64_t)b * C + c) * E + e] * attr[((int64_t)b * C + c) * E + e];
+    g0[c] = -s / den;
+  }
+  __syncthreads();
+  const int64_t n0 = (int64_t)ch * CHUNK_N, n1 = min(N, n0 + CHUNK_N);
+  const float* eb = embed + (int64_t)b * N * E;
+  float* db = dembed + (int64_t)b * N * E;
+  float accs[CP][EP];
+#pragma unroll
+  for (int c = 0; c < CP; ++c)
+#pragma unroll
+    for (int e = 0; e < EP; ++e) accs[c][e] = 0.f;
+  for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
+    float x[EP];
+    load_row<EP>(eb + n * E, E, x);
+    float s[CP], ds[CP];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CP; ++c)
+      if (c < C) {
+        float v = 0.f, w = 0.f;
+#pragma unroll
+        for (int e = 0; e < EP; ++e) { v += x[e] * An[c * EP + e]; w += x[e] * G[c * EP + e]; }
+        s[c] = v; ds[c] = w + g0[c];
+        mx = fmaxf(mx, v);
+      }
+    float den = 0.f;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) if (c < C) { s[c] = expf(s[c] - mx); den += s[c]; }
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) if (c < C) { s[c] /= den; dot += s[c] * ds[c]; }
+    float dx[EP];
+    load_row<EP>(db + n * E, E, dx);
+#pragma unroll
+    for (int c = 0; c < CP; ++c)
+      if (c < C) {
+        const float dl = s[c] * (ds[c] - dot);
+#pragma unroll
+        for (int e = 0; e < EP; ++e) {
+          dx[e] += s[c] * G[c * EP + e] + dl * An[c * EP + e];
+          accs[c][e] += dl * x[e];
+        }
+      }
+    store_row<EP>(db + n * E, E, dx);
+  }
+  float* out = partial + ((int64_t)b * nch + ch) * C * EP;
+#pragma unroll
+  for (int c = 0; c < CP; ++c)
+    if (c < C) block_reduce_store<EP>(accs[c], EP, red, out + c * EP);
+}
+
+__global__ void anchor_bwd_final_kernel(int B, int C, int E, int EP, int A, int nch,
+                                        AnchorCombos cb, const float* __restrict__ partial,
+                                        const int32_t* __restrict__ choice,
+                                        float* __restrict__ danchors) {
+  // single block; deterministic scatter over utterances
+  for (int i = threadIdx.x; i < A * E; i += blockDim.x) {
+    const int a = i / E, e = i % E;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const int p = choice[b];
+      for (int c = 0; c < C; ++c) {
+        if (cb.idx[p][c] != a) continue;
+        for (int ch = 0; ch < nch; ++ch)
+          s += partial[(((int64_t)b * nch + ch) * C + c) * EP + e];
+      }
+    }
+    danchors[i] = s;
+  }
+}
+
+// =========================================================================
+// host entry points
+// =========================================================================
+static int pick_ep(int E) {
+  if (E <= 4) return 4;
+  if (E <= 8) return 8;
+  if (E <= 20) return 20;
+  if (E <= 40) return 40;
+  if (E <= 64) return 64;
+  return 0;
+}
+
+#define DISPATCH_EP(EPV, ...)                     \
+  switch (EPV) {                                   \
+    case 4: { constexpr int EP = 4; __VA_ARGS__; } break;   \
+    case 8: { constexpr int EP = 8; __VA_ARGS__; } break;   \
+    case 20: { constexpr int EP = 20; __VA_ARGS__; } break; \
+    case 40: { constexpr int EP = 40; __VA_ARGS__; } break; \
+    case 64: { constexpr int EP = 64; __VA_ARGS__; } break; \
+    default: break;                                \
+  }
+
+#define DISPATCH_CP(CV, ...)                      \
+  switch (CV) {                                    \
+    case 1: { constexpr int CP = 1; __VA_ARGS__; } break;   \
+    case 2: { constexpr int CP = 2; __VA_ARGS__; } break;   \
+    case 3: { constexpr int CP = 3; __VA_ARGS__; } break;   \
+    case 4: { constexpr int CP = 4; __VA_ARGS__; } break;   \
+    default: break;                                \
+  }
+
+static int check_common(const char* who, int B, int C, int64_t N, int E) {
+  if (!(B > 0 && C > 0 && C <= MAXC && N > 0 && E > 0)) {
+    danet_set_error("%s: bad shape B=%d C=%d N=%lld E=%d", who, B, C, (long long)N, E);
+    return DANET_ERR_ARG;
+  }
+  if (pick_ep(E) == 0) {
+    danet_set_error("%s: E=%d > 64 unsupported", who, E);
+    return DANET_ERR_UNSUPPORTED;
+  }
+  if (B > 65535) {
+    danet_set_error("%s: B > 65535", who);
+    return DANET_ERR_UNSUPPORTED;
+  }
+  return DANET_OK;
+}
+
+extern "C" size_t danet_attractor_truth_workspace_bytes(int B, int C, int64_t N, int E) {
+  const int EP = pick_ep(E);
+  return (size_t)B * n_chunks(N) * C * (EP + 1) * sizeof(float);
+}
+
+extern "C" int danet_attractor_truth_fwd(danet_stream_t stream_, int mode, int B, int C,
+                                         int64_t N, int E, const float* embed,
+                                         const float* src_pwr, const float* mix_pwr, float eps,
+                                         float* attr, float* denom, void* ws, size_t ws_bytes) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_common("attractor_truth_fwd", B, C, N, E);
+  if (rc) return rc;
+  DANET_CHECK_ARG(mode >= 0 && mode <= 2, "attractor_truth_fwd: mode");
+  DANET_CHECK_ARG(embed && src_pwr && attr && denom && (mode == 0 || mix_pwr),
+                  "attractor_truth_fwd: null pointer");
+  if (!ws || ws_bytes < danet_attractor_truth_workspace_bytes(B, C, N, E)) {
+    danet_set_error("attractor_truth_fwd: workspace too small");
+    return DANET_ERR_WORKSPACE;
+  }
+  if (mode == 0 && !mix_pwr) mix_pwr = src_pwr;  // never read for its value
+  const int nch = n_chunks(N), EPV = pick_ep(E);
+  dim3 grid(nch, B);
+  DISPATCH_EP(EPV, (truth_fwd_kernel<EP><<<grid, 256, 0, stream>>>(
+                       mode, C, N, E, embed, src_pwr, mix_pwr, (float*)ws)));
+  DANET_CHECK_LAUNCH();
+  truth_final_kernel<<<B, 128, 0, stream>>>(mode, C, E, EPV, nch, eps, (const float*)ws, attr,
+                                            denom);
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
+
+extern "C" int danet_attractor_truth_bwd(danet_stream_t stream_, int mode, int B, int C,
+                                         int64_t N, int E, const float* dattr,
+                                         const float* src_pwr, const float* mix_pwr,
+                                         const float* denom, float eps, float* dembed) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_common("attractor_truth_bwd", B, C, N, E);
+  if (rc) return rc;
+  DANET_CHECK_ARG(dattr && src_pwr && denom && dembed && (mode == 0 || mix_pwr),
+                  "attractor_truth_bwd: null pointer");
+  if (mode == 0 && !mix_pwr) mix_pwr = src_pwr;
+  const int EPV = pick_ep(E);
+  dim3 grid((unsigned)min((int64_t)64, cdiv64(N, 256)), B);
+  DISPATCH_EP(EPV, (truth_bwd_kernel<EP><<<grid, 256, 0, stream>>>(
+                       mode, C, N, E, dattr, src_pwr, mix_pwr, denom, eps, dembed)));
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
+
+extern "C" int danet_separate_fwd(danet_stream_t stream_, int act, int B, int C, int64_t N,
+                                  int E, const float* mix_pwr, const float* attr,
+                                  const float* embed, float* out, float* masks) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_common("separate_fwd", B, C, N, E);
+  if (rc) return rc;
+  DANET_CHECK_ARG(act == 0 || act == 1, "separate_fwd: act");
+  DANET_CHECK_ARG(mix_pwr && attr && embed && out, "separate_fwd: null pointer");
+  const int EPV = pick_ep(E);
+  dim3 grid((unsigned)min((int64_t)64, cdiv64(N, 256)), B);
+  DISPATCH_EP(EPV, (separate_fwd_kernel<EP><<<grid, 256, 0, stream>>>(
+                       act, C, N, E, mix_pwr, attr, embed, out, masks)));
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
+
+extern "C" size_t danet_separate_bwd_workspace_bytes(int B, int C, int64_t N, int E) {
+  return (size_t)B * n_chunks(N) * C * pick_ep(E) * sizeof(float);
+}
+
+extern "C" int danet_separate_bwd(danet_stream_t stream_, int act, int B, int C, int64_t N,
+                                  int E, const float* mix_pwr, const float* attr,
+                                  const float* embed, const float* dout, float* dembed,
+                                  float* dattr, void* ws, size_t ws_bytes) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_common("separate_bwd", B, C, N, E);
+  if (rc) return rc;
+  DANET_CHECK_ARG(act == 0 || act == 1, "separate_bwd: act");
+  DANET_CHECK_ARG(mix_pwr && attr && embed && dout && dembed && dattr, "separate_bwd: null pointer");
+  if (!ws || ws_bytes < danet_separate_bwd_workspace_bytes(B, C, N, E)) {
+    danet_set_error("separate_bwd: workspace too small");
+    return DANET_ERR_WORKSPACE;
+  }
+  const int nch = n_chunks(N), EPV = pick_ep(E);
+  dim3 grid(nch, B);
+  DISPATCH_EP(EPV, DISPATCH_CP(C, (separate_bwd_kernel<EP, CP><<<grid, 256, 0, stream>>>(
+                       act, C, N, E, mix_pwr, attr, embed, dout, dembed, (float*)ws))));
+  DANET_CHECK_LAUNCH();
+  sum_chunks_kernel<<<B, 128, 0, stream>>>(nch, 0, C, E, EPV, (const float*)ws, dattr);
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
+
+static int anchor_check(const char* who, int B, int C, int64_t N, int E, int A) {
+  int rc = check_common(who, B, C, N, E);
+  if (rc) return rc;
+  if (!(A >= C && A <= MAXA)) {
+    danet_set_error("%s: need C <= A <= %d (A=%d)", who, MAXA, A);
+    return DANET_ERR_UNSUPPORTED;
+  }
+  return DANET_OK;
+}
+
+static int n_combos(int A, int C) {
+  long r = 1;
+  for (int i = 1; i <= C; ++i) r = r * (A - C + i) / i;
+  return (int)r;
+}
+
+extern "C" size_t danet_attractor_anchor_workspace_bytes(int B, int C, int64_t N, int E, int A) {
+  const int EP = pick_ep(E), P = n_combos(A, C);
+  const size_t fwd = (size_t)B * n_chunks(N) * P * C * (EP + 4) * sizeof(float);
+  const size_t bwd = (size_t)B * n_chunks(N) * C * EP * sizeof(float);
+  return fwd > bwd ? fwd : bwd;
+}
+
+extern "C" int danet_attractor_anchor_fwd(danet_stream_t stream_, int B, int C, int64_t N, int E,
+                                          int A, const float* embed, const float* anchors,
+                                          float* attr, float* asets, float* asum,
+                                          int32_t* choice, void* ws, size_t ws_bytes) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = anchor_check("attractor_anchor_fwd", B, C, N, E, A);
+  if (rc) return rc;
+  DANET_CHECK_ARG(embed && anchors && attr && asets && asum && choice,
+                  "attractor_anchor_fwd: null pointer");
+  if (!ws || ws_bytes < danet_attractor_anchor_workspace_bytes(B, C, N, E, A)) {
+    danet_set_error("attractor_anchor_fwd: workspace too small");
+    return DANET_ERR_WORKSPACE;
+  }
+  AnchorCombos cb;
+  make_combos(A, C, cb);
+  const int PC = cb.P * C, EPV = pick_ep(E), EPA = EPV + 4;
+  if (PC * (EPA / 4) > 1024) {
+    danet_set_error("attractor_anchor_fwd: P*C*E too large");
+    return DANET_ERR_UNSUPPORTED;
+  }
+  const int nch = n_chunks(N);
+  const size_t lds = ((size_t)ANCH_TN * EPA + (size_t)ANCH_TN * (PC + 1) + (size_t)A * EPV) * sizeof(float);
+  dim3 grid(nch, B);
+  DISPATCH_EP(EPV, {
+    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)anchor_fwd_kernel<EP>,
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    anchor_fwd_kernel<EP><<<grid, 256, lds, stream>>>(C, N, E, A, cb, embed, anchors, (float*)ws);
+  });
+  DANET_CHECK_LAUNCH();
+  const size_t lds2 = ((size_t)PC * EPA + cb.P) * sizeof(float);
+  anchor_final_kernel<<<B, 128, lds2, stream>>>(C, E, EPA, cb.P, nch, (const float*)ws, attr,
+                                                asets, asum, choice);
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
+
+extern "C" int danet_attractor_anchor_bwd(danet_stream_t stream_, int B, int C, int64_t N, int E,
+                                          int A, const float* dattr, const float* embed,
+                                          const float* anchors, const float* attr,
+                                          const float* asum, const int32_t* choice,
+                                          float* dembed, float* danchors, void* ws,
+                                          size_t ws_bytes) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = anchor_check("attractor_anchor_bwd", B, C, N, E, A);
+  if (rc) return rc;
+  DANET_CHECK_ARG(dattr && embed && anchors && attr && asum && choice && dembed && danchors,
+                  "attractor_anchor_bwd: null pointer");
+  if (!ws || ws_bytes < danet_attractor_anchor_workspace_bytes(B, C, N, E, A)) {
+    danet_set_error("attractor_anchor_bwd: workspace too small");
+    return DANET_ERR_WORKSPACE;
+  }
+  AnchorCombos cb;
+  make_combos(A, C, cb);
+  const int nch = n_chunks(N), EPV = pick_ep(E);
+  dim3 grid(nch, B);
+  DISPATCH_EP(EPV, DISPATCH_CP(C, (anchor_bwd_kernel<EP, CP><<<grid, 256, 0, stream>>>(
+                       C, N, E, A, cb, dattr, embed, anchors, attr, asum, choice, dembed,
+                       (float*)ws))));
+  DANET_CHECK_LAUNCH();
+  anchor_bwd_final_kernel<<<1, 256, 0, stream>>>(B, C, E, EPV, A, nch, cb, (const float*)ws,
+                                                 choice, danchors);
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}

@@ -1,0 +1,72 @@
+// Shared helpers for libdanet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "danet_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define DANET_WAVE 64
+
+extern "C" void danet_set_error(const char* fmt, ...);
+
+#define DANET_CHECK_ARG(cond, ...)                         \
+  do {                                                     \
+    if (!(cond)) {                                         \
+      danet_set_error(__VA_ARGS__);                        \
+      return DANET_ERR_ARG;                                \
+    }                                                      \
+  } while (0)
+
+#define DANET_CHECK_HIP(expr)                                               \
+  do {                                                                      \
+    hipError_t e__ = (expr);                                                \
+    if (e__ != hipSuccess) {                                                \
+      danet_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                      __FILE__, __LINE__);                                  \
+      return DANET_ERR_LAUNCH;                                              \
+    }                                                                       \
+  } while (0)
+
+#define DANET_CHECK_LAUNCH() DANET_CHECK_HIP(hipGetLastError())
+
+__host__ __device__ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- wave64 reductions -----------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum for blockDim.x multiple of 64 (<= 1024); result valid in all
+// threads.  `red` = LDS scratch of >= 16 floats.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int i = 0; i < nw; ++i) s += red[i];
+  return s;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) {
+  return 1.0f / (1.0f + __expf(-x));
+}
+// accurate variants used on the parity path (1e-4 relative through T steps)
+__device__ __forceinline__ float sigmoid_acc(float x) {
+  return 1.0f / (1.0f + expf(-x));
+}

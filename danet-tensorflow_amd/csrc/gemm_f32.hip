@@ -1,0 +1,266 @@
+// fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32,
+// k-ordered fmaf chain) -- replaces the tf.matmul inside ops.lyr_linear
+// (reference app/ops.py:66-68,72-78) for the hoisted LSTM input projections,
+// the encoder output projection and every backward product of both.
+//
+// Tiling: 128x128x16 block tile, 256 threads = 4 waves in 2x2, each wave owns a
+// 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 acc VGPRs).  Operands are
+// staged global -> registers -> LDS as [k][mn] (ld 132: conflict-free
+// ds_read_b32 fragment reads, 2-way-at-most transposing writes), double
+// buffered so the next tile's global loads fly under the current tile's 32
+// MFMAs.  Small-output / long-K products (weight gradients) use a
+// deterministic split-K: per-slice slabs in `ws`, summed by a second kernel.
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 16
+#define LDT 132  // BM + 4
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  float* slab;  // split-K partials [splitk][M][N] (or null)
+  int M, N, K;
+  int lda, ldb, ldc;
+  int kchunk;   // K range per z-slice (multiple of BK)
+  int splitk;
+  int vecA, vecB;
+  float beta;
+};
+
+// Load this thread's share of one operand tile into registers.
+// KCONTIG: element (mn, k) at P[mn*ld + k]; else at P[k*ld + mn].
+template <bool KCONTIG>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld,
+                                          int mn0, int mn_lim, int k0, int k_lim,
+                                          int vec, int tid, f32x4 (&r)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + i * 256;
+    int mn, k;
+    if (KCONTIG) { mn = mn0 + (idx >> 2); k = k0 + (idx & 3) * 4; }
+    else         { k = k0 + (idx >> 5);  mn = mn0 + (idx & 31) * 4; }
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (KCONTIG) {
+      if (mn < mn_lim) {
+        const float* p = P + (size_t)mn * ld + k;
+        if (vec && k + 3 < k_lim) {
+          v = *reinterpret_cast<const f32x4*>(p);
+        } else {
+          if (k + 0 < k_lim) v.x = p[0];
+          if (k + 1 < k_lim) v.y = p[1];
+          if (k + 2 < k_lim) v.z = p[2];
+          if (k + 3 < k_lim) v.w = p[3];
+        }
+      }
+    } else {
+      if (k < k_lim) {
+        const float* p = P + (size_t)k * ld + mn;
+        if (vec && mn + 3 < mn_lim) {
+          v = *reinterpret_cast<const f32x4*>(p);
+        } else {
+          if (mn + 0 < mn_lim) v.x = p[0];
+          if (mn + 1 < mn_lim) v.y = p[1];
+          if (mn + 2 < mn_lim) v.z = p[2];
+          if (mn + 3 < mn_lim) v.w = p[3];
+        }
+      }
+    }
+    r[i] = v;
+  }
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ void store_tile(float* __restrict__ S, int tid,
+                                           const f32x4 (&r)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + i * 256;
+    if (KCONTIG) {
+      const int mn = idx >> 2, k = (idx & 3) * 4;
+      S[(k + 0) * LDT + mn] = r[i].x;
+      S[(k + 1) * LDT + mn] = r[i].y;
+      S[(k + 2) * LDT + mn] = r[i].z;
+      S[(k + 3) * LDT + mn] = r[i].w;
+    } else {
+      const int k = idx >> 5, mn = (idx & 31) * 4;
+      *reinterpret_cast<f32x4*>(&S[k * LDT + mn]) = r[i];
+    }
+  }
+}
+
+template <bool A_KCONTIG, bool B_KCONTIG>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * LDT];
+  // layout: [A buf0 | A buf1 | B buf0 | B buf1], each BK*LDT floats
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs
+  // (private L2 each); give each XCD a contiguous band of N-tiles of one
+  // M-row-band so neighbours share the A panel in that XCD's L2.
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  int bid = blockIdx.x;
+  const int nwg = tiles_m * tiles_n;
+  if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int z = blockIdx.z;
+  const int kbeg = z * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[2], rb[2];
+  if (nk > 0) {
+    load_tile<A_KCONTIG>(g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, tid, ra);
+    load_tile<B_KCONTIG>(g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid, rb);
+    store_tile<A_KCONTIG>(smem, tid, ra);
+    store_tile<B_KCONTIG>(smem + 2 * BK * LDT, tid, rb);
+  }
+  __syncthreads();
+
+  const int fa = wm * 64 + (lane & 31);  // fragment column within the tile
+  const int fb = wn * 64 + (lane & 31);
+  const int fk = lane >> 5;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      const int k0 = kbeg + (kt + 1) * BK;
+      load_tile<A_KCONTIG>(g.A, g.lda, m0, g.M, k0, kend, g.vecA, tid, ra);
+      load_tile<B_KCONTIG>(g.B, g.ldb, n0, g.N, k0, kend, g.vecB, tid, rb);
+    }
+    const float* as = smem + cur * (BK * LDT);
+    const float* bs = smem + (2 + cur) * (BK * LDT);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int k = kk * 2 + fk;
+      const float a0 = as[k * LDT + fa], a1 = as[k * LDT + fa + 32];
+      const float b0 = bs[k * LDT + fb], b1 = bs[k * LDT + fb + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      store_tile<A_KCONTIG>(smem + (cur ^ 1) * (BK * LDT), tid, ra);
+      store_tile<B_KCONTIG>(smem + (2 + (cur ^ 1)) * (BK * LDT), tid, rb);
+    }
+    __syncthreads();
+  }
+
+  // epilogue.  D layout (32x32): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = n0 + wn * 64 + nt * 32 + col_l;
+      if (col >= g.N) continue;
+      const float bv = (g.bias && g.splitk == 1) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+        if (row >= g.M) continue;
+        float v = acc[mt][nt][r];
+        if (g.splitk == 1) {
+          float* c = g.C + (size_t)row * g.ldc + col;
+          v += bv;
+          if (g.beta != 0.f) v += *c;
+          *c = v;
+        } else {
+          g.slab[((size_t)z * g.M + row) * g.N + col] = v;
+        }
+      }
+    }
+}
+
+__global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slab,
+                                          float* __restrict__ C,
+                                          const float* __restrict__ bias, int M,
+                                          int N, int ldc, int splitk, float beta) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)M * N;
+  if (i >= total) return;
+  const int row = (int)(i / N), col = (int)(i % N);
+  float s = 0.f;
+  for (int z = 0; z < splitk; ++z) s += slab[(size_t)z * total + i];
+  if (bias) s += bias[col];
+  float* c = C + (size_t)row * ldc + col;
+  if (beta != 0.f) s += *c;
+  *c = s;
+}
+
+static int choose_splitk(int M, int N, int K) {
+  const int tiles = cdiv(M, BM) * cdiv(N, BN);
+  if (tiles >= 192 || K < 512) return 1;
+  int s = cdiv(512, tiles);
+  const int maxs = K / 128;
+  if (s > maxs) s = maxs;
+  if (s > 32) s = 32;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" size_t danet_gemm_f32_workspace_bytes(int M, int N, int K) {
+  const int s = choose_splitk(M, N, K);
+  return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
+extern "C" int danet_gemm_f32(danet_stream_t stream_, int transA, int transB,
+                              int M, int N, int K, const float* A, int lda,
+                              const float* B, int ldb, float* C, int ldc,
+                              const float* bias, float beta, void* ws,
+                              size_t ws_bytes) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DANET_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: non-positive shape %d %d %d", M, N, K);
+  DANET_CHECK_ARG(A && B && C, "gemm: null operand");
+  DANET_CHECK_ARG(beta == 0.f || beta == 1.f, "gemm: beta must be 0 or 1");
+  DANET_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N,
+                  "gemm: leading dimension too small");
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.bias = bias;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.beta = beta;
+  g.vecA = (((uintptr_t)A & 15) == 0) && (lda % 4 == 0);
+  g.vecB = (((uintptr_t)B & 15) == 0) && (ldb % 4 == 0);
+  int splitk = choose_splitk(M, N, K);
+  int kchunk = cdiv(cdiv(K, splitk), BK) * BK;
+  splitk = cdiv(K, kchunk);
+  g.splitk = splitk; g.kchunk = kchunk; g.slab = nullptr;
+  if (splitk > 1) {
+    const size_t need = (size_t)splitk * M * N * sizeof(float);
+    if (!ws || ws_bytes < need) {
+      danet_set_error("gemm: workspace %zu < %zu", ws_bytes, need);
+      return DANET_ERR_WORKSPACE;
+    }
+    g.slab = (float*)ws;
+  }
+  dim3 grid(cdiv(M, BM) * cdiv(N, BN), 1, splitk), block(256);
+  const bool ak = !transA, bk = (transB != 0);
+  if (ak && !bk) gemm_f32_kernel<true, false><<<grid, block, 0, stream>>>(g);
+  else if (ak && bk) gemm_f32_kernel<true, true><<<grid, block, 0, stream>>>(g);
+  else if (!ak && !bk) gemm_f32_kernel<false, false><<<grid, block, 0, stream>>>(g);
+  else gemm_f32_kernel<false, true><<<grid, block, 0, stream>>>(g);
+  DANET_CHECK_LAUNCH();
+  if (splitk > 1) {
+    const int64_t total = (int64_t)M * N;
+    gemm_splitk_reduce_kernel<<<(unsigned)cdiv64(total, 256), 256, 0, stream>>>(
+        g.slab, C, bias, M, N, ldc, splitk, beta);
+    DANET_CHECK_LAUNCH();
+  }
+  return DANET_OK;
+}

@@ -1,0 +1,477 @@
+// Persistent recurrent LSTM kernels for gfx950: the sequential half of
+// Model.lyr_lstm / _lyr_bilstm (reference main.py:76-132, app/modules.py:120-137,
+// cell math app/ops.py:139-147: a=[x,h]W+b, g linear, i/f/o sigmoid,
+// c'=i*g+f*c, h'=o*tanh(c')).  The input half (x_t*Wx+b for all t) is hoisted
+// into one MFMA GEMM by the host; these kernels run all T dependent steps of
+// both directions in ONE launch.
+//
+// Decomposition.  The recurrent matmul h[B,H] x Wh[H,4H] is latency-bound
+// (T dependent steps), so Wh must not move: workgroup (dir, g, p) keeps the
+// 4 gate columns of its 8 hidden units stationary in LDS for the whole
+// sequence ([K/4][32][4] layout -> one conflict-free ds_read_b128 feeds four
+// v_mfma_f32_16x16x4_f32), holds the cell state of its (batch row, unit)
+// pairs in registers, and per step only all-gathers h_{t-1} (B x H fp32) from
+// the other workgroups of its direction through the layer's own output buffer
+// (each step writes a distinct row block, so there is no WAR hazard and no
+// extra exchange buffer).  A fragments come straight from global memory with
+// 16-B sc1 (L1-bypassing) loads: lane (r,q) loads h[r][k0+4q..k0+4q+3] and
+// the j-th MFMA of the group pairs element j with weight row k0+4q+j -- a
+// permutation of the contraction index that both operands share, so no LDS
+// staging or shuffles are needed.  K is split over the 4 waves (one per
+// SIMD); partial tiles are reduced through LDS.
+//
+// Inter-workgroup hand-off (MI355X_MICROARCH "visibility", guide G16 R1):
+// payload stored write-through (sc1), every storing wave drains vmcnt(0),
+// __syncthreads, ONE lane stores the per-producer step flag (relaxed, agent
+// scope); consumers poll the flag words relaxed (sc1) and read the payload with
+// sc1 loads -- placement-independent, no per-step cache invalidate.  Flags are
+// zeroed by a memset node before every launch; every spin is bounded and a
+// timeout sets the status word instead of hanging.
+#include "common.h"
+
+#define LSTM_UNITS_FWD 8    // hidden units per workgroup (x4 gates = 32 columns)
+#define LSTM_UNITS_BWD 16   // hidden units per workgroup in BPTT
+#define SPIN_LIMIT (1u << 21)
+
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+struct LstmFwdArgs {
+  const float* gx[2];
+  const float* Wh[2];
+  float* gates[2];
+  float* cell[2];
+  float* ypad;
+  unsigned* flags;  // [ndir][G][P]
+  int* status;
+  int T, B, H, ndir, ldy, ldw, P, G, KP;  // KP = H padded to 16
+};
+
+struct LstmBwdArgs {
+  const float* dy;
+  const float* Wh[2];
+  const float* gates[2];
+  const float* cell[2];
+  float* da[2];
+  unsigned* flags;
+  int* status;
+  int T, B, H, ndir, lddy, ldw, P, G;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+// wait until all `n` producer flags are >= target (wave-level; every wave of
+// the block polls for itself so no block barrier is needed on the wait side)
+__device__ __forceinline__ void wait_flags(unsigned* flags, int n, unsigned target,
+                                           int* status, int lane) {
+  unsigned spins = 0;
+  for (;;) {
+    bool ok = true;
+    for (int i = lane; i < n; i += 64)
+      ok &= (__hip_atomic_load(flags + i, RLX_AGENT) >= target);
+    if (__all(ok)) break;
+    __builtin_amdgcn_s_sleep(1);
+    ++spins;
+    if ((spins & 1023u) == 0) {
+      // another workgroup already gave up -> do not wait either
+      if (__hip_atomic_load(status, RLX_AGENT) != 0) break;
+      if (spins >= SPIN_LIMIT) {
+        if (lane == 0) __hip_atomic_store(status, 1, RLX_AGENT);
+        break;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // smem: weights [KP/4][32][4] | red [4 waves][16*MT][33]
+  float* Wl = smem;
+  float* red = smem + (size_t)a.KP * 32;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bid = blockIdx.x;
+  const int dir = bid / (a.G * a.P);
+  const int grp = (bid / a.P) % a.G;
+  const int p = bid % a.P;
+  const int H = a.H, B = a.B, T = a.T;
+  const int u0 = p * LSTM_UNITS_FWD;
+  const int b0 = grp * (16 * MT);
+
+  // ---- stationary weights: Wl[(k/4)*32 + n][k%4], n = gate*8 + u ----------
+  {
+    const float* W = a.Wh[dir];
+    for (int idx = tid; idx < a.KP * 32; idx += 256) {
+      const int k = idx >> 5, n = idx & 31;
+      const int gate = n >> 3, u = u0 + (n & 7);
+      float v = 0.f;
+      if (k < H && u < H) v = W[(size_t)k * a.ldw + gate * H + u];
+      Wl[((k >> 2) * 32 + n) * 4 + (k & 3)] = v;
+    }
+  }
+  __syncthreads();
+
+  const unsigned ybytes = (unsigned)((size_t)(T + 2) * B * a.ldy * sizeof(float));
+  const __amdgpu_buffer_rsrc_t yres = make_rsrc(a.ypad, ybytes);
+  unsigned* myflags = a.flags + (size_t)(dir * a.G + grp) * a.P;
+
+  // gate-math ownership: thread -> (batch row bl, unit u)
+  const int bl = tid >> 3, ul = tid & 7;
+  const bool owner = (bl < 16 * MT) && (b0 + bl < B) && (u0 + ul < H);
+  const int bg = b0 + bl, unit = u0 + ul;
+  float c_state = 0.f;
+
+  // A-fragment addressing: lane (r = lane&15, q = lane>>4)
+  const int fr = lane & 15, fq = lane >> 4;
+  const int NG = a.KP / 16;
+
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? (T - 1 - s) : s;
+    const int blk_prev = dir ? (t + 2) : t;  // ypad block holding h_{prev}
+
+    // prefetch this step's hoisted input projections (independent of h)
+    float gxv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (owner) {
+      const float* gp = a.gx[dir] + ((size_t)t * B + bg) * (4 * H) + unit;
+#pragma unroll
+      for (int gte = 0; gte < 4; ++gte) gxv[gte] = gp[gte * H];
+    }
+
+    if (s > 0) wait_flags(myflags, a.P, (unsigned)s, a.status, lane);
+
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kg = wave; kg < NG; kg += 4) {
+      const int k = kg * 16 + fq * 4;
+      u32x4 av[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = b0 + mt * 16 + fr;
+        unsigned off = ybytes;  // == num_records: out of range -> load returns 0
+        if (row < B && k < H)
+          off = (unsigned)((((size_t)blk_prev * B + row) * a.ldy + dir * H + k) * 4);
+        av[mt] = __builtin_amdgcn_raw_buffer_load_b128(yres, off, 0, 16 /*sc1*/);
+      }
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(&Wl[(((k >> 2)) * 32 + fr) * 4]);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(&Wl[(((k >> 2)) * 32 + 16 + fr) * 4]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float av_j = __builtin_bit_cast(float, av[mt][j]);
+          acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_j, w0[j], acc[mt][0], 0, 0, 0);
+          acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_j, w1[j], acc[mt][1], 0, 0, 0);
+        }
+      }
+    }
+
+    // cross-wave reduction.  D layout 16x16: col = lane&15, row = 4*(lane>>4)+r
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          red[(wave * 16 * MT + mt * 16 + 4 * fq + r) * 33 + nt * 16 + fr] = acc[mt][nt][r];
+    __syncthreads();
+
+    if (owner) {
+      float pre[4];
+#pragma unroll
+      for (int gte = 0; gte < 4; ++gte) {
+        float v = gxv[gte];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += red[(w * 16 * MT + bl) * 33 + gte * 8 + ul];
+        pre[gte] = v;
+      }
+      const float g = pre[0];                 // linear candidate (ops.py:143)
+      const float ig = sigmoid_acc(pre[1]);
+      const float fg = sigmoid_acc(pre[2]);
+      const float og = sigmoid_acc(pre[3]);
+      c_state = ig * g + fg * c_state;        // ops.py:146
+      const float h = og * tanhf(c_state);    // ops.py:147
+      // exchange payload: write-through store of h_t
+      __hip_atomic_store(a.ypad + ((size_t)(t + 1) * B + bg) * a.ldy + dir * H + unit,
+                         h, RLX_AGENT);
+      float* gs = a.gates[dir] + ((size_t)t * B + bg) * (4 * H) + unit;
+      gs[0] = g; gs[H] = ig; gs[2 * H] = fg; gs[3 * H] = og;
+      a.cell[dir][((size_t)t * B + bg) * H + unit] = c_state;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains
+    __syncthreads();                                    // also protects `red`
+    if (tid == 0) __hip_atomic_store(myflags + p, (unsigned)(s + 1), RLX_AGENT);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// backward (BPTT)
+// ---------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // smem: weights^T [4H/4][16][4] | red [4 waves][16*MT][17]
+  const int H = a.H, B = a.B, T = a.T, H4 = 4 * a.H;
+  float* Wl = smem;
+  float* red = smem + (size_t)H4 * 16;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bid = blockIdx.x;
+  const int dir = bid / (a.G * a.P);
+  const int grp = (bid / a.P) % a.G;
+  const int p = bid % a.P;
+  const int u0 = p * LSTM_UNITS_BWD;
+  const int b0 = grp * (16 * MT);
+
+  // stationary Wh^T slice: element (n, j) = Wh[u0+j][n] at ((n/4)*16 + j)*4 + n%4
+  {
+    const float* W = a.Wh[dir];
+    for (int idx = tid; idx < H4 * 16; idx += 256) {
+      const int j = idx / H4, n = idx % H4;   // n fastest -> coalesced row reads
+      float v = 0.f;
+      if (u0 + j < H) v = W[(size_t)(u0 + j) * a.ldw + n];
+      Wl[((n >> 2) * 16 + j) * 4 + (n & 3)] = v;
+    }
+  }
+  __syncthreads();
+
+  const unsigned dbytes = (unsigned)((size_t)T * B * H4 * sizeof(float));
+  const __amdgpu_buffer_rsrc_t dres = make_rsrc(a.da[dir], dbytes);
+  unsigned* myflags = a.flags + (size_t)(dir * a.G + grp) * a.P;
+
+  // ownership: thread -> pairs (bl = tid/16 + 16*i, unit j = tid%16), i < MT
+  const int jl = tid & 15, unit = u0 + jl;
+  float dc_state[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) dc_state[i] = 0.f;
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int NG = H4 / 16;
+
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? s : (T - 1 - s);          // BPTT order per direction
+    const int t_done = dir ? (t - 1) : (t + 1);   // step processed just before
+    const int t_cprev = dir ? (t + 1) : (t - 1);  // time of c_{prev} in scan order
+
+    // prefetch everything that does not depend on the exchange
+    float gv[MT][4], cv[MT], cpv[MT], dyv[MT];
+    bool own[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int bl = (tid >> 4) + 16 * i, bg = b0 + bl;
+      own[i] = (bg < B) && (unit < H);
+      cv[i] = cpv[i] = dyv[i] = 0.f;
+      gv[i][0] = gv[i][1] = gv[i][2] = gv[i][3] = 0.f;
+      if (own[i]) {
+        const float* gp = a.gates[dir] + ((size_t)t * B + bg) * H4 + unit;
+        gv[i][0] = gp[0]; gv[i][1] = gp[H]; gv[i][2] = gp[2 * H]; gv[i][3] = gp[3 * H];
+        cv[i] = a.cell[dir][((size_t)t * B + bg) * H + unit];
+        if (t_cprev >= 0 && t_cprev < T)
+          cpv[i] = a.cell[dir][((size_t)t_cprev * B + bg) * H + unit];
+        dyv[i] = a.dy[((size_t)t * B + bg) * a.lddy + dir * H + unit];
+      }
+    }
+
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      acc[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    if (s > 0) {
+      wait_flags(myflags, a.P, (unsigned)s, a.status, lane);
+      for (int kg = wave; kg < NG; kg += 4) {
+        const int n = kg * 16 + fq * 4;
+        u32x4 av[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int row = b0 + mt * 16 + fr;
+          unsigned off = dbytes;  // == num_records: out of range -> 0
+          if (row < B) off = (unsigned)((((size_t)t_done * B + row) * H4 + n) * 4);
+          av[mt] = __builtin_amdgcn_raw_buffer_load_b128(dres, off, 0, 16 /*sc1*/);
+        }
+        const f32x4 w = *reinterpret_cast<const f32x4*>(&Wl[((n >> 2) * 16 + fr) * 4]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                __builtin_bit_cast(float, av[mt][j]), w[j], acc[mt][j & 1], 0, 0, 0);
+      }
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        red[(wave * 16 * MT + mt * 16 + 4 * fq + r) * 17 + fr] = acc[mt][0][r] + acc[mt][1][r];
+    __syncthreads();
+
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if (!own[i]) continue;
+      const int bl = (tid >> 4) + 16 * i, bg = b0 + bl;
+      float dh = dyv[i];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) dh += red[(w * 16 * MT + bl) * 17 + jl];
+      const float g = gv[i][0], ig = gv[i][1], fg = gv[i][2], og = gv[i][3];
+      const float tc = tanhf(cv[i]);
+      const float dc = dc_state[i] + dh * og * (1.f - tc * tc);
+      const float da_g = dc * ig;
+      const float da_i = dc * g * ig * (1.f - ig);
+      const float da_f = dc * cpv[i] * fg * (1.f - fg);
+      const float da_o = dh * tc * og * (1.f - og);
+      dc_state[i] = dc * fg;
+      float* dp = a.da[dir] + ((size_t)t * B + bg) * H4 + unit;
+      __hip_atomic_store(dp, da_g, RLX_AGENT);
+      __hip_atomic_store(dp + H, da_i, RLX_AGENT);
+      __hip_atomic_store(dp + 2 * H, da_f, RLX_AGENT);
+      __hip_atomic_store(dp + 3 * H, da_o, RLX_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(myflags + p, (unsigned)(s + 1), RLX_AGENT);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct LstmPlan { int MT, G, Pf, Pb, KP; size_t lds_f, lds_b; };
+
+static LstmPlan make_plan(int B, int H) {
+  LstmPlan pl;
+  pl.MT = (B <= 16) ? 1 : 2;
+  pl.G = cdiv(B, 16 * pl.MT);
+  pl.Pf = cdiv(H, LSTM_UNITS_FWD);
+  pl.Pb = cdiv(H, LSTM_UNITS_BWD);
+  pl.KP = cdiv(H, 16) * 16;
+  pl.lds_f = ((size_t)pl.KP * 32 + (size_t)4 * 16 * pl.MT * 33) * sizeof(float);
+  pl.lds_b = ((size_t)4 * H * 16 + (size_t)4 * 16 * pl.MT * 17) * sizeof(float);
+  return pl;
+}
+
+#define LSTM_FLAG_OFFSET 64  // bytes; word 0 of ws is the status
+
+extern "C" size_t danet_lstm_workspace_bytes(int T, int B, int H, int ndir) {
+  (void)T;
+  LstmPlan pl = make_plan(B, H);
+  const int pmax = pl.Pf > pl.Pb ? pl.Pf : pl.Pb;
+  return LSTM_FLAG_OFFSET + align_up((size_t)ndir * pl.G * pmax * sizeof(unsigned), 64);
+}
+
+static int lstm_check_common(int T, int B, int H, int ndir, void* ws, size_t ws_bytes) {
+  DANET_CHECK_ARG(T > 0 && B > 0 && H > 0, "lstm: non-positive shape");
+  DANET_CHECK_ARG(ndir == 1 || ndir == 2, "lstm: ndir must be 1 or 2");
+  if (H % 4 != 0) {
+    danet_set_error("lstm: H=%d must be a multiple of 4", H);
+    return DANET_ERR_UNSUPPORTED;
+  }
+  if (!ws || ws_bytes < danet_lstm_workspace_bytes(T, B, H, ndir)) {
+    danet_set_error("lstm: workspace too small");
+    return DANET_ERR_WORKSPACE;
+  }
+  return DANET_OK;
+}
+
+extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int ndir,
+                              const float* gx_f, const float* gx_b,
+                              const float* Wh_f, const float* Wh_b, int ldw,
+                              float* ypad, int ldy, float* gates_f, float* gates_b,
+                              float* cell_f, float* cell_b, void* ws, size_t ws_bytes) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = lstm_check_common(T, B, H, ndir, ws, ws_bytes);
+  if (rc) return rc;
+  DANET_CHECK_ARG(gx_f && Wh_f && ypad && gates_f && cell_f, "lstm_fwd: null pointer");
+  DANET_CHECK_ARG(ndir == 1 || (gx_b && Wh_b && gates_b && cell_b), "lstm_fwd: null bwd pointer");
+  DANET_CHECK_ARG(ldy >= ndir * H && ldy % 4 == 0 && ldw >= 4 * H, "lstm_fwd: bad ld");
+  DANET_CHECK_ARG(((uintptr_t)ypad & 15) == 0, "lstm_fwd: ypad must be 16-B aligned");
+  DANET_CHECK_ARG((size_t)(T + 2) * B * ldy * 4 < 0xFFFFFFF0ull, "lstm_fwd: ypad > 4 GiB");
+  LstmPlan pl = make_plan(B, H);
+  if (pl.lds_f > 160 * 1024) {
+    danet_set_error("lstm_fwd: H=%d needs %zu B LDS", H, pl.lds_f);
+    return DANET_ERR_UNSUPPORTED;
+  }
+  const int nblk = ndir * pl.G * pl.Pf;
+  if (nblk > 256) {  // 1 workgroup per CU must be co-resident
+    danet_set_error("lstm_fwd: %d workgroups exceed the 256 CUs", nblk);
+    return DANET_ERR_UNSUPPORTED;
+  }
+  LstmFwdArgs a;
+  a.gx[0] = gx_f; a.gx[1] = gx_b; a.Wh[0] = Wh_f; a.Wh[1] = Wh_b;
+  a.gates[0] = gates_f; a.gates[1] = gates_b; a.cell[0] = cell_f; a.cell[1] = cell_b;
+  a.ypad = ypad; a.status = (int*)ws;
+  a.flags = (unsigned*)((char*)ws + LSTM_FLAG_OFFSET);
+  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.ldy = ldy; a.ldw = ldw;
+  a.P = pl.Pf; a.G = pl.G; a.KP = pl.KP;
+  DANET_CHECK_HIP(hipMemsetAsync(ws, 0, danet_lstm_workspace_bytes(T, B, H, ndir), stream));
+  // zero initial state: pad blocks 0 and T+1 (main.py:108-123)
+  const size_t blk = (size_t)B * ldy * sizeof(float);
+  DANET_CHECK_HIP(hipMemsetAsync(ypad, 0, blk, stream));
+  DANET_CHECK_HIP(hipMemsetAsync((char*)ypad + (size_t)(T + 1) * blk, 0, blk, stream));
+  if (pl.MT == 1) {
+    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_kernel<1>,
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_f));
+    lstm_fwd_kernel<1><<<nblk, 256, pl.lds_f, stream>>>(a);
+  } else {
+    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_kernel<2>,
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_f));
+    lstm_fwd_kernel<2><<<nblk, 256, pl.lds_f, stream>>>(a);
+  }
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
+
+extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int ndir,
+                              const float* dy, int lddy,
+                              const float* Wh_f, const float* Wh_b, int ldw,
+                              const float* gates_f, const float* gates_b,
+                              const float* cell_f, const float* cell_b,
+                              float* da_f, float* da_b, void* ws, size_t ws_bytes) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = lstm_check_common(T, B, H, ndir, ws, ws_bytes);
+  if (rc) return rc;
+  DANET_CHECK_ARG(dy && Wh_f && gates_f && cell_f && da_f, "lstm_bwd: null pointer");
+  DANET_CHECK_ARG(ndir == 1 || (Wh_b && gates_b && cell_b && da_b), "lstm_bwd: null bwd pointer");
+  DANET_CHECK_ARG(lddy >= ndir * H && ldw >= 4 * H, "lstm_bwd: bad ld");
+  DANET_CHECK_ARG(((uintptr_t)da_f & 15) == 0 && ((uintptr_t)da_b & 15) == 0,
+                  "lstm_bwd: da must be 16-B aligned");
+  DANET_CHECK_ARG((size_t)T * B * 4 * H * 4 < 0xFFFFFFF0ull, "lstm_bwd: da > 4 GiB");
+  LstmPlan pl = make_plan(B, H);
+  if (pl.lds_b > 160 * 1024) {
+    danet_set_error("lstm_bwd: H=%d needs %zu B LDS", H, pl.lds_b);
+    return DANET_ERR_UNSUPPORTED;
+  }
+  const int nblk = ndir * pl.G * pl.Pb;
+  if (nblk > 256) {
+    danet_set_error("lstm_bwd: %d workgroups exceed the 256 CUs", nblk);
+    return DANET_ERR_UNSUPPORTED;
+  }
+  LstmBwdArgs a;
+  a.dy = dy; a.lddy = lddy; a.Wh[0] = Wh_f; a.Wh[1] = Wh_b; a.ldw = ldw;
+  a.gates[0] = gates_f; a.gates[1] = gates_b; a.cell[0] = cell_f; a.cell[1] = cell_b;
+  a.da[0] = da_f; a.da[1] = da_b; a.status = (int*)ws;
+  a.flags = (unsigned*)((char*)ws + LSTM_FLAG_OFFSET);
+  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.P = pl.Pb; a.G = pl.G;
+  DANET_CHECK_HIP(hipMemsetAsync(ws, 0, danet_lstm_workspace_bytes(T, B, H, ndir), stream));
+  if (pl.MT == 1) {
+    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_bwd_kernel<1>,
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_b));
+    lstm_bwd_kernel<1><<<nblk, 256, pl.lds_b, stream>>>(a);
+  } else {
+    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_bwd_kernel<2>,
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_b));
+    lstm_bwd_kernel<2><<<nblk, 256, pl.lds_b, stream>>>(a);
+  }
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}

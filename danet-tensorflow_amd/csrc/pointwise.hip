@@ -1,0 +1,238 @@
+// HBM-bound elementwise / reduction kernels of the DANet hot path (gfx950):
+// in-graph front-end (reference main.py:233-240), phase re-attach
+// (main.py:281-284,330-335), per-utterance mean-centre (app/modules.py:209-210,
+// 244-245), column sums (bias gradients) and the clip + TF1-Adam update
+// (main.py:359-363, app/ozers.py:15-18).  All are coalesced grid-stride streams;
+// the complex spectra are read as interleaved (re,im) float2.
+#include "common.h"
+
+// ------------------------------------------------------------------ front-end
+__global__ void frontend_kernel(int B, int C, int64_t N, const float2* __restrict__ src,
+                                float* __restrict__ mix_pwr, float* __restrict__ mix_log,
+                                float2* __restrict__ phasor, float* __restrict__ phase,
+                                float* __restrict__ src_pwr, float2* __restrict__ mix) {
+  const int64_t total = (int64_t)B * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / N, n = i % N;
+    float re = 0.f, im = 0.f;
+    for (int c = 0; c < C; ++c) {                      // main.py:233-234
+      const float2 s = src[((int64_t)b * C + c) * N + n];
+      re += s.x; im += s.y;
+      if (src_pwr) src_pwr[((int64_t)b * C + c) * N + n] = hypotf(s.x, s.y);  // main.py:236
+    }
+    const float mag = hypotf(re, im);                  // main.py:239
+    if (mix) mix[i] = make_float2(re, im);
+    if (mix_pwr) mix_pwr[i] = mag;
+    if (mix_log) mix_log[i] = log1pf(mag);             // main.py:240
+    const float ph = atan2f(im, re);                   // main.py:237-238
+    if (phase) phase[i] = ph;
+    if (phasor) phasor[i] = make_float2(cosf(ph), sinf(ph));   // main.py:283-284
+  }
+}
+
+extern "C" int danet_frontend_fwd(danet_stream_t stream, int B, int C, int64_t N,
+                                  const float* src_c64, float* mix_pwr, float* mix_log,
+                                  float* phasor, float* phase, float* src_pwr,
+                                  float* mix_c64) {
+  DANET_CHECK_ARG(B > 0 && C > 0 && N > 0 && src_c64, "frontend: bad args");
+  const int64_t total = (int64_t)B * N;
+  const int grid = (int)min((int64_t)2048, cdiv64(total, 256));
+  frontend_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(
+      B, C, N, (const float2*)src_c64, mix_pwr, mix_log, (float2*)phasor, phase, src_pwr,
+      (float2*)mix_c64);
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
+
+// ------------------------------------------------------------- phase re-attach
+// permutation p of C elements in itertools.permutations (lexicographic) order
+__device__ __forceinline__ void nth_permutation(int C, int p, int* out) {
+  int avail[4] = {0, 1, 2, 3};
+  int fact = 1;
+  for (int i = 2; i < C; ++i) fact *= i;  // (C-1)!
+  int n = C;
+  for (int i = 0; i < C; ++i) {
+    const int q = p / fact;
+    p -= q * fact;
+    out[i] = avail[q];
+    for (int j = q; j < n - 1; ++j) avail[j] = avail[j + 1];
+    --n;
+    if (n > 1) fact /= n;
+  }
+}
+
+__global__ void reattach_kernel(int B, int C, int64_t N, const float* __restrict__ sep_pwr,
+                                const float2* __restrict__ phasor,
+                                const int32_t* __restrict__ perm_idx,
+                                float2* __restrict__ out) {
+  const int64_t total = (int64_t)B * C * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i % N;
+    const int c = (int)((i / N) % C);
+    const int b = (int)(i / (N * C));
+    int src_c = c;
+    if (perm_idx) {
+      int perm[4];
+      nth_permutation(C, perm_idx[b], perm);
+      src_c = perm[c];                                 // main.py:293-306
+    }
+    const float pw = sep_pwr[((int64_t)b * C + src_c) * N + n];
+    const float2 ph = phasor[(int64_t)b * N + n];
+    out[i] = make_float2(ph.x * pw, ph.y * pw);        // main.py:282-284
+  }
+}
+
+extern "C" int danet_reattach_phase(danet_stream_t stream, int B, int C, int64_t N,
+                                    const float* sep_pwr, const float* phasor,
+                                    const int32_t* perm_idx, float* out_c64) {
+  DANET_CHECK_ARG(B > 0 && C > 0 && C <= 4 && N > 0 && sep_pwr && phasor && out_c64,
+                  "reattach: bad args");
+  const int64_t total = (int64_t)B * C * N;
+  const int grid = (int)min((int64_t)2048, cdiv64(total, 256));
+  reattach_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(
+      B, C, N, sep_pwr, (const float2*)phasor, perm_idx, (float2*)out_c64);
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
+
+// ---------------------------------------------------------------- mean-centre
+// One workgroup per (utterance, T-slice) pair would need a second pass; the
+// tensors here are a few MB, so: kernel 1 = per-utterance sums with CH chunks
+// per utterance (deterministic two-level reduce), kernel 2 = subtract + layout
+// change + zero padding.
+#define CENTER_CHUNKS 32
+
+__device__ __forceinline__ int64_t center_index(int layout, int B, int T, int ld, int b, int t) {
+  return layout == 0 ? ((int64_t)b * T + t) * ld : ((int64_t)t * B + b) * ld;
+}
+
+__global__ void center_sum_kernel(int B, int T, int D, const float* __restrict__ in,
+                                  int layout, int ld, float* __restrict__ partial) {
+  __shared__ float red[16];
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const int64_t total = (int64_t)T * D;
+  const int64_t per = cdiv64(total, CENTER_CHUNKS);
+  const int64_t beg = ch * per, end = min(total, beg + per);
+  float s = 0.f;
+  for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+    const int t = (int)(i / D), d = (int)(i % D);
+    s += in[center_index(layout, B, T, ld, b, t) + d];
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partial[b * CENTER_CHUNKS + ch] = s;
+}
+
+__global__ void center_apply_kernel(int B, int T, int D, const float* __restrict__ in,
+                                    int in_layout, int ld_in, float* __restrict__ out,
+                                    int out_layout, int ld_out,
+                                    const float* __restrict__ partial,
+                                    float* __restrict__ mean_out) {
+  const int b = blockIdx.y;
+  float s = 0.f;
+  for (int i = 0; i < CENTER_CHUNKS; ++i) s += partial[b * CENTER_CHUNKS + i];
+  const float mean = s / (float)((int64_t)T * D);
+  if (mean_out && blockIdx.x == 0 && threadIdx.x == 0) mean_out[b] = mean;
+  const int64_t total = (int64_t)T * ld_out;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i / ld_out), d = (int)(i % ld_out);
+    float v = 0.f;
+    if (d < D) v = in[center_index(in_layout, B, T, ld_in, b, t) + d] - mean;
+    out[center_index(out_layout, B, T, ld_out, b, t) + d] = v;
+  }
+}
+
+// `mean` doubles as scratch: [B] means followed by [B][CENTER_CHUNKS] partial
+// sums (keeps the ABI allocation-free and re-entrant).
+extern "C" int danet_center_mean_elems(int B) { return B * (1 + CENTER_CHUNKS); }
+
+extern "C" int danet_center(danet_stream_t stream, int B, int T, int D, const float* in,
+                            int in_layout, int ld_in, float* out, int out_layout,
+                            int ld_out, float* mean) {
+  DANET_CHECK_ARG(B > 0 && T > 0 && D > 0 && in && out && mean, "center: bad args (mean scratch is required)");
+  DANET_CHECK_ARG(ld_in >= D && ld_out >= D, "center: ld < D");
+  DANET_CHECK_ARG((in_layout | 1) == 1 && (out_layout | 1) == 1, "center: layout must be 0/1");
+  float* partial = mean + B;
+  dim3 g1(CENTER_CHUNKS, B);
+  center_sum_kernel<<<g1, 256, 0, (hipStream_t)stream>>>(B, T, D, in, in_layout, ld_in, partial);
+  DANET_CHECK_LAUNCH();
+  const int gx = (int)min((int64_t)64, cdiv64((int64_t)T * ld_out, 256));
+  dim3 g2(gx, B);
+  center_apply_kernel<<<g2, 256, 0, (hipStream_t)stream>>>(
+      B, T, D, in, in_layout, ld_in, out, out_layout, ld_out, partial, mean);
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
+
+// -------------------------------------------------------------------- colsum
+#define COLSUM_ROWS 256  // rows per partial block
+
+__global__ void colsum_partial_kernel(int M, int N, const float* __restrict__ A, int lda,
+                                      float* __restrict__ partial) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= N) return;
+  const int r0 = blockIdx.y * COLSUM_ROWS, r1 = min(M, r0 + COLSUM_ROWS);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += A[(size_t)r * lda + col];
+  partial[(size_t)blockIdx.y * N + col] = s;
+}
+
+__global__ void colsum_final_kernel(int nparts, int N, const float* __restrict__ partial,
+                                    float* __restrict__ out, float beta) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= N) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * N + col];
+  out[col] = (beta != 0.f) ? out[col] + s : s;
+}
+
+extern "C" size_t danet_colsum_f32_workspace_bytes(int M, int N) {
+  return (size_t)cdiv(M, COLSUM_ROWS) * N * sizeof(float);
+}
+
+extern "C" int danet_colsum_f32(danet_stream_t stream, int M, int N, const float* A, int lda,
+                                float* out, float beta, void* ws, size_t ws_bytes) {
+  DANET_CHECK_ARG(M > 0 && N > 0 && A && out && lda >= N, "colsum: bad args");
+  if (!ws || ws_bytes < danet_colsum_f32_workspace_bytes(M, N)) {
+    danet_set_error("colsum: workspace too small");
+    return DANET_ERR_WORKSPACE;
+  }
+  const int nparts = cdiv(M, COLSUM_ROWS);
+  dim3 g(cdiv(N, 256), nparts);
+  colsum_partial_kernel<<<g, 256, 0, (hipStream_t)stream>>>(M, N, A, lda, (float*)ws);
+  DANET_CHECK_LAUNCH();
+  colsum_final_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(nparts, N, (const float*)ws,
+                                                                     out, beta);
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
+
+// ---------------------------------------------------------- clip + TF1 Adam
+__global__ void adam_clip_kernel(int64_t n, float* __restrict__ theta,
+                                 const float* __restrict__ grad, float* __restrict__ m,
+                                 float* __restrict__ v, float lr_t, float b1, float b2,
+                                 float eps, float clip, float gscale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float g = grad[i] * gscale;
+    if (clip > 0.f) g = fminf(fmaxf(g, -clip), clip);          // main.py:359-362
+    const float mi = b1 * m[i] + (1.f - b1) * g;
+    const float vi = b2 * v[i] + (1.f - b2) * g * g;
+    m[i] = mi; v[i] = vi;
+    theta[i] -= lr_t * mi / (sqrtf(vi) + eps);                 // eps outside the root (TF1)
+  }
+}
+
+extern "C" int danet_adam_clip_step(danet_stream_t stream, int64_t n, float* theta,
+                                    const float* grad, float* m, float* v, float lr_t,
+                                    float beta1, float beta2, float eps, float clip,
+                                    float grad_scale) {
+  DANET_CHECK_ARG(n > 0 && theta && grad && m && v, "adam: bad args");
+  const int grid = (int)min((int64_t)2048, cdiv64(n, 256));
+  adam_clip_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(n, theta, grad, m, v, lr_t, beta1,
+                                                          beta2, eps, clip, grad_scale);
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}

@@ -1,0 +1,63 @@
+'''
+Datasets.  Only the reference's data-free `toy` generator
+(app/datasets/dataset.py:43-63) is re-stated; `timit` / `wsj0` need licensed
+corpora and are out of scope.  `synth` is the speech-shaped 8 kHz
+2-speaker generator the benchmarks use.
+'''
+import numpy as np
+
+from .hparams import hparams
+
+
+class Dataset(object):
+    '''base class (app/datasets/dataset.py:12-35)'''
+    def __init__(self):
+        self.is_loaded = False
+
+    def epoch(self, subset, batch_size, shuffle=False):
+        raise NotImplementedError()
+
+    def install_and_load(self):
+        raise NotImplementedError()
+
+
+@hparams.register_dataset('toy')
+class WhiteNoiseData(Dataset):
+    '''always generates uniform noise rand(batch, 128, FEATURE_SIZE), 10 batches
+    per epoch (app/datasets/dataset.py:43-63)'''
+    def epoch(self, subset, batch_size, shuffle=False):
+        if not self.is_loaded:
+            raise RuntimeError('Dataset is not loaded.')
+        for _ in range(10):
+            signal = np.random.rand(
+                batch_size, 128, hparams.FEATURE_SIZE).astype(hparams.FLOATX)
+            yield (signal,)
+
+    def install_and_load(self):
+        self.is_loaded = True
+        return
+
+
+def speech_shaped_wave(rng, n_samples, smprate=8000, rms=1000.0, phase=0.0):
+    '''white N(0,1) -> one-pole low-pass (0.95) -> 3 Hz amplitude envelope ->
+    int16-like RMS; the reference feeds un-normalised int16-scale waveforms
+    (app/datasets/TIMIT/process.py:44-46)'''
+    import scipy.signal
+    x = rng.randn(n_samples).astype(np.float32)
+    y = scipy.signal.lfilter([1.0], [1.0, -0.95], x)
+    t = np.arange(n_samples) / float(smprate)
+    y = y * (0.5 * (1.0 + np.sin(2 * np.pi * 3.0 * t + phase)))
+    y = y * (rms / (np.sqrt(np.mean(y ** 2)) + 1e-12))
+    return y.astype(np.float32)
+
+
+def synth_waves(seed, n_utt, n_frames, smprate=None):
+    '''[n_utt, Ls] float32 waveforms whose STFT has exactly `n_frames` frames
+    (T = 1 + ceil(Ls/S))'''
+    rng = np.random.RandomState(seed)
+    S = hparams.FFT_STRIDE
+    Ls = (n_frames - 1) * S
+    smprate = smprate or hparams.SMPRATE
+    return np.stack([
+        speech_shaped_wave(rng, Ls, smprate, phase=rng.uniform(0, 2 * np.pi))
+        for _ in range(n_utt)])

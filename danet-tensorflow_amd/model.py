@@ -1,0 +1,246 @@
+'''
+Model: the forward graph of the reference's `Model.build()` (main.py:208-399)
+re-stated eagerly over the HIP ops, plus the train / valid / infer steps the
+reference runs through `g_sess.run` (main.py:402-532, :685-690).
+
+Host code is Python + PyTorch-ROCm (autograd engine, device memory, streams,
+torch.distributed); every tensor op on the path is a libdanet_hip.so kernel.
+
+Data parallelism (new; the reference is single-GPU, README.md:226): one process
+per GPU, `hparams.BATCH_SIZE` is the per-GPU batch, parameters live in one flat
+fp32 buffer broadcast from rank 0, gradients accumulate into one flat fp32
+bucket that is all-reduced ONCE per step over RCCL, then
+value-clipped (main.py:359-362) and applied by the TF1-style Adam kernel.
+'''
+import math
+import os
+
+import numpy as np
+import torch
+
+from .hparams import hparams
+from . import ops
+from . import modules  # noqa: F401  (registers the plugins)
+from . import ozers    # noqa: F401  (registers the optimisers)
+
+
+class Model(object):
+    '''Base class for a fully trainable model (main.py:61-548)'''
+
+    def __init__(self, name='BaseModel', device=None, seed=1337):
+        self.name = name
+        self.device = torch.device(device if device is not None else
+                                   'cuda:%d' % torch.cuda.current_device())
+        self.s_states_di = {}
+        self.vars = {}
+        self._order = []
+        self._gen = torch.Generator().manual_seed(seed)
+        self._flat = None
+        self.learn_rate = float(hparams.LR)
+        self.step_count = 0
+        self.built = False
+
+    # ------------------------------------------------------------ variables
+    def get_variable(self, name, shape, init):
+        '''tf.get_variable under scope "global/" (main.py:229).  `init(shape,
+        generator)` returns a CPU float32 tensor.'''
+        full = 'global/' + name
+        v = self.vars.get(full)
+        if v is None:
+            if self._flat is not None:
+                raise KeyError('variable %s requested after build()' % full)
+            v = init(list(shape), self._gen).to(self.device).requires_grad_(True)
+            assert list(v.shape) == list(shape), (full, v.shape, shape)
+            self.vars[full] = v
+            self._order.append(full)
+        return v
+
+    def lyr_lstm(self, name, s_x, hdim, axis=-1, t_axis=0, op_linear=None,
+                 w_init=None, b_init=None):
+        '''single unidirectional LSTM layer (main.py:76-132); s_x [B,T,D]
+        (t_axis=-2/1) or [T,B,D] (t_axis=0) -> same layout with D -> hdim.
+        Zero initial state; state variables are never carried across calls
+        (main.py:108-123, :538-540).'''
+        assert s_x.dim() == 3 and axis in (-1, 2)
+        t_axis = t_axis % 3
+        assert t_axis in (0, 1)
+        if t_axis == 0:
+            s_x = s_x.transpose(0, 1)
+        D = s_x.shape[-1]
+        W = self.get_variable(name + '/LSTM/linear/W', [D + hdim, 4 * hdim], w_init)
+        b = self.get_variable(name + '/LSTM/linear/B', [4 * hdim], b_init)
+        y = ops.LstmLayerFn.apply(s_x, hdim, W, b)
+        return y.transpose(0, 1) if t_axis == 0 else y
+
+    def parameter_count(self):
+        return sum(v.numel() for v in self.vars.values())
+
+    # ---------------------------------------------------------------- build
+    def build(self):
+        '''create sub-modules (main.py:210-211, 249-250, 263-270), materialise
+        variables with one dry forward, then flatten them for the optimiser.'''
+        self.encoder = hparams.get_encoder()(self, 'encoder')
+        self.estimator = hparams.get_estimator(
+            hparams.TRAIN_ESTIMATOR_METHOD)(self, 'train_estimator')
+        self.using_same_method = (
+            hparams.INFER_ESTIMATOR_METHOD == hparams.TRAIN_ESTIMATOR_METHOD)
+        if self.using_same_method:
+            self.valid_estimator = self.estimator
+        else:
+            self.valid_estimator = hparams.get_estimator(
+                hparams.INFER_ESTIMATOR_METHOD)(self, 'infer_estimator')
+            assert not self.valid_estimator.USE_TRUTH           # main.py:266
+        self.separator = hparams.get_separator(hparams.SEPARATOR_TYPE)(self, 'separator')
+        B, C, F = hparams.BATCH_SIZE, hparams.MAX_N_SIGNAL, hparams.FEATURE_SIZE
+        dry = torch.zeros(B, C, 4, F, dtype=torch.complex64, device=self.device)
+        with torch.no_grad():
+            self.forward(dry, with_valid=True)
+        self._flatten()
+        self.ozer = hparams.get_optimizer()(
+            learn_rate=self.learn_rate, lr_decay=hparams.LR_DECAY)
+        self.ozer.bind(self._flat, self._flat_grad)
+        self.built = True
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.broadcast(self._flat, src=0)
+        return self
+
+    def _flatten(self):
+        n = sum(self.vars[k].numel() for k in self._order)
+        flat = torch.empty(n, device=self.device)
+        grad = torch.zeros(n, device=self.device)
+        off = 0
+        for k in self._order:
+            v = self.vars[k]
+            m = v.numel()
+            flat[off:off + m].copy_(v.detach().reshape(-1))
+            nv = flat[off:off + m].view(v.shape).requires_grad_(True)
+            nv.grad = grad[off:off + m].view(v.shape)
+            self.vars[k] = nv
+            off += m
+        self._flat, self._flat_grad = flat, grad
+
+    # -------------------------------------------------------------- forward
+    def forward(self, s_src_signals, with_valid=False, with_train=True):
+        '''main.py:215-337.  s_src_signals complex64 [B, C, T, F].'''
+        B, E = hparams.BATCH_SIZE, hparams.EMBED_SIZE
+        eps = float(hparams.EPS)
+        fe = ops.frontend(s_src_signals)                       # main.py:233-240
+        s_embed = self.encoder(fe['mix_log'])                  # main.py:243
+        s_embed_flat = s_embed.reshape(B, -1, E)               # main.py:244-246
+        out = dict(embed=s_embed, input=s_src_signals)
+        phasor = fe['phasor']
+        if with_train:
+            s_attractors = self.estimator(                     # main.py:251-254
+                s_embed, s_src_pwr=fe['src_pwr'], s_mix_pwr=fe['mix_pwr'])
+            s_sep_pwr = self.separator(fe['mix_pwr'], s_attractors, s_embed_flat)  # :271-272
+            loss, perms, idx, snr = ops.pit_mse_loss(          # main.py:289-290, 308-309
+                s_src_signals, s_sep_pwr, phasor, mode=0, eps=eps)
+            out.update(attrs=s_attractors, sep_pwr=s_sep_pwr, loss=loss, SNR=snr,
+                       perm_idx=idx, perms=perms)
+        if with_valid:
+            if self.using_same_method and with_train:
+                s_vattr, s_vsep = out['attrs'], out['sep_pwr']
+            else:
+                if self.valid_estimator.USE_TRUTH:
+                    s_vattr = self.valid_estimator(
+                        s_embed, s_src_pwr=fe['src_pwr'], s_mix_pwr=fe['mix_pwr'])
+                else:
+                    s_vattr = self.valid_estimator(s_embed)    # main.py:267
+                s_vsep = self.separator(fe['mix_pwr'], s_vattr, s_embed_flat)  # :277-278
+            vloss, perms, vidx, vsnr = ops.pit_mse_loss(       # main.py:312-313, 336-337
+                s_src_signals, s_vsep, phasor, mode=1, eps=eps)
+            out.update(valid_attrs=s_vattr, sep_pwr_valid=s_vsep, valid_loss=vloss,
+                       valid_SNR=vsnr, valid_perm_idx=vidx, perms=perms)
+        out['phasor'] = phasor
+        out['mix_pwr'] = fe['mix_pwr']
+        return out
+
+    def debug_fetch(self, s_src_signals):
+        '''the `-m debug` fetch list (main.py:387-397): embed, attrs, input,
+        output (+ module debug_fetches when hparams.DEBUG)'''
+        with torch.no_grad():
+            o = self.forward(s_src_signals)
+            res = dict(embed=o['embed'], attrs=o['attrs'], input=s_src_signals,
+                       output=ops.reattach_phase(o['sep_pwr'], o['phasor'], o['perm_idx']))
+            for mod in (self.encoder, self.separator, self.estimator):
+                res.update(getattr(mod, 'debug_fetches', {}) or {})
+        return res
+
+    # ------------------------------------------------------------ train step
+    def train_step(self, s_src_signals, sync_metrics=True):
+        '''one `g_sess.run(train_fetches)` (main.py:430-431): forward, backward,
+        gradient all-reduce, value clip, Adam.  Returns dict(loss, SNR, LR) of
+        device scalars (no host sync unless the caller reads them).'''
+        self._flat_grad.zero_()
+        out = self.forward(s_src_signals)
+        out['loss'].backward()
+        world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size()
+            if world > 1:
+                torch.distributed.all_reduce(self._flat_grad)  # SUM over xGMI
+        self.step_count += 1
+        self.ozer.step(self.step_count, self.learn_rate,
+                       clip=hparams.GRAD_CLIP_THRES, grad_scale=1.0 / world)
+        return dict(loss=out['loss'].detach(), SNR=out['SNR'], LR=self.learn_rate)
+
+    def valid_step(self, s_src_signals):
+        '''`g_sess.run(valid_fetches)` (main.py:499-500)'''
+        with torch.no_grad():
+            out = self.forward(s_src_signals, with_valid=True, with_train=False)
+        return dict(loss=out['valid_loss'], SNR=out['valid_SNR'])
+
+    def infer(self, s_mixed_signals):
+        '''`g_sess.run(infer_fetches, {s_mixed_signals: ...})` (main.py:384-385,
+        685-690): complex mixture [B,T,F] -> separated complex [B,C,T,F] using
+        the inference estimator and the mixture phase (main.py:333-335).'''
+        B, E = hparams.BATCH_SIZE, hparams.EMBED_SIZE
+        with torch.no_grad():
+            fe = ops.frontend(s_mixed_signals[:, None].contiguous())
+            s_embed = self.encoder(fe['mix_log'])
+            s_attr = self.valid_estimator(s_embed)
+            s_sep = self.separator(fe['mix_pwr'], s_attr, s_embed.reshape(B, -1, E))
+            return ops.reattach_phase(s_sep, fe['phasor'])
+
+    # ------------------------------------------------------- misc (main.py)
+    def set_learn_rate(self, lr):
+        self.learn_rate = float(lr)
+
+    def get_learn_rate(self):
+        return self.learn_rate
+
+    def reset_state(self):
+        '''RNN states are never carried (main.py:538-540 re-zeros zeros)'''
+        return
+
+    def save_params(self, filename, step=None):
+        '''trainable variables only, like tf.train.Saver(var_list=trainables)
+        (main.py:357,399); stored as .npz keyed by the reference's TF variable
+        names (a TF1 checkpoint cannot be written without TF).'''
+        save_dir = os.path.dirname(os.path.abspath(filename))
+        if not os.path.exists(save_dir):
+            os.makedirs(save_dir)
+        if step is not None:
+            filename = '%s-%d' % (filename, step)
+        np.savez(filename, **{k: v.detach().cpu().numpy() for k, v in self.vars.items()})
+
+    def load_params(self, filename):
+        if not filename.endswith('.npz'):
+            filename = filename + '.npz'
+        data = np.load(filename)
+        with torch.no_grad():
+            for k, v in self.vars.items():
+                v.copy_(torch.as_tensor(data[k]).to(self.device))
+        return True
+
+    def load_param_dict(self, di):
+        '''set variables from {tf_variable_name: ndarray} (tests / oracle parity)'''
+        with torch.no_grad():
+            for k, a in di.items():
+                self.vars[k].copy_(torch.as_tensor(np.asarray(a, dtype=np.float32)).to(self.device))
+
+    def param_dict(self):
+        return {k: v.detach().cpu().numpy() for k, v in self.vars.items()}
+
+    def grad_dict(self):
+        return {k: v.grad.detach().cpu().numpy() for k, v in self.vars.items()}

@@ -1,0 +1,545 @@
+'''
+Ops of the DANet hot path, MI355X-native: thin tensor-level wrappers over the
+C ABI (include/danet_hip.h) plus the `torch.autograd.Function`s that let
+PyTorch-ROCm drive backward.  Mirrors the roles of the reference's
+`app/ops.py` (lyr_linear, lyr_lstm_flat, combinations, pit_mse_loss,
+batch_snr) and of `Model.lyr_lstm` (main.py:76-132); names and argument meaning
+follow the reference where a counterpart exists.
+
+Everything here requires the HIP library and a GPU; nothing falls back to CPU.
+'''
+import itertools
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ptr, check
+
+
+def _L():
+    return _lib.load()
+
+
+def _f32(t):
+    assert t.is_cuda and t.dtype == torch.float32, (t.device, t.dtype)
+    return t
+
+
+def _ws(nbytes, dev):
+    w = _lib.workspace(nbytes, dev)
+    return w, w.numel()
+
+
+# ---------------------------------------------------------------------------
+# raw wrappers (no autograd)
+# ---------------------------------------------------------------------------
+def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, beta=0.0):
+    '''C[M,N] = op(A) op(B) (+bias) (+beta*C) on the fp32 matrix cores.
+    A, B, C are tensors whose data_ptr() is element (0,0); ld* in elements.'''
+    L = _L()
+    need = L.danet_gemm_f32_workspace_bytes(M, N, K)
+    w, wn = _ws(need, C.device)
+    check(L.danet_gemm_f32(_lib.stream(), int(transA), int(transB), M, N, K,
+                           ptr(_f32(A)), lda, ptr(_f32(B)), ldb, ptr(_f32(C)), ldc,
+                           ptr(bias), float(beta), ptr(w), wn))
+    return C
+
+
+def colsum(A, M, N, lda, out, beta=0.0):
+    L = _L()
+    w, wn = _ws(L.danet_colsum_f32_workspace_bytes(M, N), out.device)
+    check(L.danet_colsum_f32(_lib.stream(), M, N, ptr(_f32(A)), lda, ptr(out), float(beta),
+                             ptr(w), wn))
+    return out
+
+
+def center(x, B, T, D, in_layout, ld_in, out, out_layout, ld_out):
+    '''out[b] = x[b] - mean(x[b]) with an optional layout switch; returns means [B]'''
+    L = _L()
+    scratch = torch.empty(L.danet_center_mean_elems(B), dtype=torch.float32, device=x.device)
+    check(L.danet_center(_lib.stream(), B, T, D, ptr(_f32(x)), in_layout, ld_in,
+                         ptr(out), out_layout, ld_out, ptr(scratch)))
+    return scratch[:B]
+
+
+def frontend(src, want_phase=False, want_mix=False):
+    '''main.py:233-240.  src complex64 [B,C,T,F] ->
+    dict(src_pwr [B,C,T,F], mix_pwr, mix_log [B,T,F], phasor [B,T,F,2], ...)'''
+    assert src.is_cuda and src.dtype == torch.complex64
+    src = src.contiguous()
+    B, C, T, F = src.shape
+    N = T * F
+    dev = src.device
+    out = dict(
+        src_pwr=torch.empty(B, C, T, F, device=dev),
+        mix_pwr=torch.empty(B, T, F, device=dev),
+        mix_log=torch.empty(B, T, F, device=dev),
+        phasor=torch.empty(B, T, F, 2, device=dev))
+    phase = torch.empty(B, T, F, device=dev) if want_phase else None
+    mix = torch.empty(B, T, F, dtype=torch.complex64, device=dev) if want_mix else None
+    check(_L().danet_frontend_fwd(
+        _lib.stream(), B, C, N, ptr(torch.view_as_real(src)), ptr(out['mix_pwr']),
+        ptr(out['mix_log']), ptr(out['phasor']), ptr(phase), ptr(out['src_pwr']),
+        ptr(torch.view_as_real(mix)) if mix is not None else None))
+    if want_phase:
+        out['phase'] = phase
+    if want_mix:
+        out['mix'] = mix
+    return out
+
+
+def reattach_phase(sep_pwr, phasor, perm_idx=None):
+    '''main.py:281-284 / :330-335 (with the permutation gather of :293-306)'''
+    B, C, T, F = sep_pwr.shape
+    out = torch.empty(B, C, T, F, dtype=torch.complex64, device=sep_pwr.device)
+    check(_L().danet_reattach_phase(
+        _lib.stream(), B, C, T * F, ptr(_f32(sep_pwr.contiguous())), ptr(phasor),
+        ptr(perm_idx), ptr(torch.view_as_real(out))))
+    return out
+
+
+def combinations(s_data, subset_size, total_size=None, name=None):
+    '''reference app/ops.py:273-292: gather rows by itertools.combinations'''
+    if total_size is None:
+        total_size = s_data.shape[0]
+    combs = torch.tensor(list(itertools.combinations(range(total_size), subset_size)),
+                         device=s_data.device)
+    return s_data[combs]
+
+
+def stft(x, window, fft_size, fft_stride):
+    '''x float32 [n_sig, Ls] (or [Ls]) -> complex64 [n_sig, T, F]
+    (app/utils.py:117-122).  Raises ValueError when Ls < fft_size like scipy.'''
+    squeeze = x.dim() == 1
+    if squeeze:
+        x = x[None]
+    x = _f32(x.contiguous())
+    n_sig, Ls = x.shape
+    L = _L()
+    T = L.danet_stft_num_frames(Ls, fft_size, fft_stride)
+    if T < 0:
+        raise ValueError('window is longer than input signal')
+    F = fft_size // 2 + 1
+    out = torch.empty(n_sig, T, F, dtype=torch.complex64, device=x.device)
+    check(L.danet_stft(_lib.stream(), n_sig, Ls, fft_size, fft_stride, ptr(x),
+                       ptr(_f32(window)), ptr(torch.view_as_real(out))))
+    return out[0] if squeeze else out
+
+
+def istft(X, stride, window):
+    '''utils.istft (app/utils.py:53-75).  X complex64 [n_sig, T, F] or [T, F]
+    -> float64 [n_sig, T*stride]'''
+    squeeze = X.dim() == 2
+    if squeeze:
+        X = X[None]
+    assert X.dtype == torch.complex64 and X.is_cuda
+    X = X.contiguous()
+    n_sig, T, F = X.shape
+    N = (F - 1) * 2
+    L = _L()
+    out = torch.empty(n_sig, T * stride, dtype=torch.float64, device=X.device)
+    w, wn = _ws(L.danet_istft_workspace_bytes(n_sig, T, N, stride), X.device)
+    check(L.danet_istft(_lib.stream(), n_sig, T, N, stride, ptr(torch.view_as_real(X)),
+                        ptr(_f32(window)), ptr(out), ptr(w), wn))
+    return out[0] if squeeze else out
+
+
+# ---------------------------------------------------------------------------
+# LSTM layer (both directions), raw forward / backward on time-major tensors
+# ---------------------------------------------------------------------------
+class _LayerCtx(object):
+    __slots__ = ('x', 'ldx', 'D', 'T', 'B', 'H', 'ndir', 'ypad', 'gates', 'cells',
+                 'Ws', 'status')
+
+
+_pending_status = []
+
+
+def lstm_status_ok():
+    '''True when no persistent-LSTM launch since the last call reported an
+    inter-workgroup timeout.  Synchronises.'''
+    ok = True
+    for s in _pending_status:
+        ok = ok and int(s.item()) == 0
+    del _pending_status[:]
+    return ok
+
+
+def _lstm_ws(T, B, H, ndir, dev):
+    n = _L().danet_lstm_workspace_bytes(T, B, H, ndir)
+    return torch.empty(n, dtype=torch.uint8, device=dev), n
+
+
+def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs):
+    '''x: time-major [T*B rows, ldx] tensor (data_ptr = row 0), D valid columns.
+    Ws[d]: [D+H, 4H] (reference layout, rows 0..D-1 input, D.. recurrent),
+    bs[d]: [4H].  Returns ctx with ypad [T+2, B, ndir*H].'''
+    ndir = len(Ws)
+    dev = x.device
+    gates, cells = [], []
+    for d in range(ndir):
+        gx = torch.empty(T * B, 4 * H, device=dev)
+        # hoisted input half of ops.lyr_lstm_flat's [x,h]W+b (app/ops.py:139-142)
+        gemm(x, Ws[d], gx, T * B, 4 * H, D, ldx, 4 * H, 4 * H, bias=bs[d])
+        gates.append(gx)                       # overwritten in place by g,i,f,o
+        cells.append(torch.empty(T * B, H, device=dev))
+    ypad = torch.empty(T + 2, B, ndir * H, device=dev)
+    ws, wn = _lstm_ws(T, B, H, ndir, dev)
+    Whs = [W[D:] for W in Ws]
+    L = _L()
+    check(L.danet_lstm_fwd(
+        _lib.stream(), T, B, H, ndir, ptr(gates[0]), ptr(gates[-1]),
+        ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(ypad), ndir * H,
+        ptr(gates[0]), ptr(gates[-1]), ptr(cells[0]), ptr(cells[-1]), ptr(ws), wn))
+    c = _LayerCtx()
+    c.x, c.ldx, c.D, c.T, c.B, c.H, c.ndir = x, ldx, D, T, B, H, ndir
+    c.ypad, c.gates, c.cells, c.Ws = ypad, gates, cells, Ws
+    c.status = ws[:4].view(torch.int32)
+    _pending_status.append(c.status)
+    return c
+
+
+def lstm_layer_bwd(c, dy, need_dx):
+    '''dy: [T, B, ndir*H] contiguous.  Returns (dx [T*B, D] or None, dWs, dbs).'''
+    T, B, H, D, ndir = c.T, c.B, c.H, c.D, c.ndir
+    dev = dy.device
+    das = [torch.empty(T * B, 4 * H, device=dev) for _ in range(ndir)]
+    ws, wn = _lstm_ws(T, B, H, ndir, dev)
+    Whs = [W[D:] for W in c.Ws]
+    L = _L()
+    check(L.danet_lstm_bwd(
+        _lib.stream(), T, B, H, ndir, ptr(_f32(dy)), ndir * H,
+        ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(c.gates[0]), ptr(c.gates[-1]),
+        ptr(c.cells[0]), ptr(c.cells[-1]), ptr(das[0]), ptr(das[-1]), ptr(ws), wn))
+    _pending_status.append(ws[:4].view(torch.int32))
+    dWs, dbs = [], []
+    ldy = ndir * H
+    for d in range(ndir):
+        dW = torch.empty(D + H, 4 * H, device=dev)
+        # dWx = X^T da
+        gemm(c.x, das[d], dW, D, 4 * H, T * B, c.ldx, 4 * H, 4 * H, transA=True)
+        # dWh = Hprev^T da; Hprev(t) = ypad block t (fwd) / block t+2 (bwd)
+        hprev = c.ypad.view(-1)[(0 if d == 0 else 2 * B * ldy + H):]
+        gemm(hprev, das[d], dW[D:], H, 4 * H, T * B, ldy, 4 * H, 4 * H, transA=True)
+        db = torch.empty(4 * H, device=dev)
+        colsum(das[d], T * B, 4 * H, 4 * H, db)
+        dWs.append(dW)
+        dbs.append(db)
+    dx = None
+    if need_dx:
+        dx = torch.empty(T * B, D, device=dev)
+        for d in range(ndir):
+            # dX += da Wx^T
+            gemm(das[d], c.Ws[d], dx, T * B, D, 4 * H, 4 * H, 4 * H, D, transB=True,
+                 beta=0.0 if d == 0 else 1.0)
+    return dx, dWs, dbs
+
+
+class LstmLayerFn(torch.autograd.Function):
+    '''One (bi)LSTM layer on batch-major input: Model.lyr_lstm / _lyr_bilstm
+    (main.py:76-132, app/modules.py:120-137).  x [B,T,D] -> [B,T,ndir*H]'''
+
+    @staticmethod
+    def forward(ctx, x, H, *params):
+        ndir = len(params) // 2
+        Ws, bs = list(params[0::2]), list(params[1::2])
+        B, T, D = x.shape
+        xt = x.transpose(0, 1).contiguous()         # tf.transpose, main.py:98-104
+        c = lstm_layer_fwd(xt, D, D, T, B, H, Ws, bs)
+        ctx.c = c
+        ctx.xt = xt
+        return c.ypad[1:T + 1].transpose(0, 1).contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        c = ctx.c
+        dyt = dy.transpose(0, 1).contiguous()
+        dx, dWs, dbs = lstm_layer_bwd(c, dyt, ctx.needs_input_grad[0])
+        out = [None, None]
+        if dx is not None:
+            out[0] = dx.view(c.T, c.B, c.D).transpose(0, 1).contiguous()
+        for dW, db in zip(dWs, dbs):
+            out += [dW, db]
+        return tuple(out)
+
+
+class RnnEncoderFn(torch.autograd.Function):
+    '''Whole `bilstm-orig` / `lstm-orig` encoder (app/modules.py:148-260):
+    mean-centre -> L stacked (bi)LSTM layers -> mean-centre -> bias-free output
+    projection.  x [B,T,F] -> embed [B,T,F*E].
+    params = (W_0f, b_0f, [W_0b, b_0b], W_1f, ..., W_out)'''
+
+    @staticmethod
+    def forward(ctx, x, H, L, ndir, *params):
+        x = _f32(x.contiguous())
+        B, T, F = x.shape
+        dev = x.device
+        Wout = params[-1]
+        Fp = (F + 3) // 4 * 4
+        # x - mean_{t,f}(x), switched to time-major, zero-padded to a float4 row
+        xc = torch.empty(T, B, Fp, device=dev)
+        center(x, B, T, F, 0, F, xc, 1, Fp)                  # modules.py:209-210
+        ctxs = []
+        cur, ld, D = xc, Fp, F
+        for l in range(L):                                    # modules.py:223-242
+            Ws = [params[(l * ndir + d) * 2] for d in range(ndir)]
+            bs = [params[(l * ndir + d) * 2 + 1] for d in range(ndir)]
+            c = lstm_layer_fwd(cur, ld, D, T, B, H, Ws, bs)
+            ctxs.append(c)
+            cur, ld, D = c.ypad[1:], ndir * H, ndir * H
+        # y - mean_{t,h}(y), back to batch-major                modules.py:244-245
+        yc = torch.empty(B, T, D, device=dev)
+        center(cur, B, T, D, 1, D, yc, 0, D)
+        O = Wout.shape[1]
+        embed = torch.empty(B, T, O, device=dev)
+        gemm(yc, Wout, embed, B * T, O, D, D, O, O)           # modules.py:249-255
+        ctx.ctxs, ctx.yc, ctx.Wout = ctxs, yc, Wout
+        ctx.dims = (B, T, F, H, L, ndir, D, O)
+        return embed
+
+    @staticmethod
+    def backward(ctx, dembed):
+        B, T, F, H, L, ndir, D, O = ctx.dims
+        dembed = _f32(dembed.contiguous())
+        dev = dembed.device
+        dWout = torch.empty(D, O, device=dev)
+        gemm(ctx.yc, dembed, dWout, D, O, B * T, D, O, O, transA=True)
+        dyc = torch.empty(B, T, D, device=dev)
+        gemm(dembed, ctx.Wout, dyc, B * T, D, O, O, O, D, transB=True)
+        dy = torch.empty(T, B, D, device=dev)
+        center(dyc, B, T, D, 0, D, dy, 1, D)                 # centre is self-adjoint
+        grads = [None] * (2 * L * ndir)
+        for l in reversed(range(L)):
+            dx, dWs, dbs = lstm_layer_bwd(ctx.ctxs[l], dy, need_dx=(l > 0))
+            for d in range(ndir):
+                grads[(l * ndir + d) * 2] = dWs[d]
+                grads[(l * ndir + d) * 2 + 1] = dbs[d]
+            dy = dx
+        ctx.ctxs = None
+        return (None, None, None, None) + tuple(grads) + (dWout,)
+
+
+class LinearFn(torch.autograd.Function):
+    '''ops.lyr_linear on the last axis (app/ops.py:72-78,81-89)'''
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        shp = x.shape
+        x2 = _f32(x.contiguous()).view(-1, shp[-1])
+        M, K = x2.shape
+        N = W.shape[1]
+        y = torch.empty(M, N, device=x.device)
+        gemm(x2, W, y, M, N, K, K, N, N, bias=b)
+        ctx.save_for_backward(x2, W)
+        ctx.has_b = b is not None
+        ctx.shp = shp
+        return y.view(*shp[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W = ctx.saved_tensors
+        M, K = x2.shape
+        N = W.shape[1]
+        dy2 = _f32(dy.contiguous()).view(M, N)
+        dW = torch.empty(K, N, device=dy.device)
+        gemm(x2, dy2, dW, K, N, M, K, N, N, transA=True)
+        db = None
+        if ctx.has_b:
+            db = torch.empty(N, device=dy.device)
+            colsum(dy2, M, N, N, db)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, device=dy.device)
+            gemm(dy2, W, dx, M, K, N, N, N, K, transB=True)
+            dx = dx.view(ctx.shp)
+        return dx, dW, db
+
+
+def lyr_linear(x, W, b=None):
+    return LinearFn.apply(x, W, b)
+
+
+def relu(s_x, alpha=0.):
+    '''app/ops.py:93-107 (toy encoder only; elementwise torch op)'''
+    if alpha == 0.:
+        return torch.relu(s_x)
+    return torch.maximum(s_x * alpha, s_x)
+
+
+# ---------------------------------------------------------------------------
+# estimators / separators / loss
+# ---------------------------------------------------------------------------
+TRUTH_MODES = {'truth': 0, 'truth-threshold': 1, 'truth-weighted': 2}
+
+
+class TruthAttractorFn(torch.autograd.Function):
+    '''app/modules.py:382-487'''
+
+    @staticmethod
+    def forward(ctx, embed, src_pwr, mix_pwr, mode, eps):
+        B, T, F, E = embed.shape
+        C = src_pwr.shape[1]
+        N = T * F
+        dev = embed.device
+        embed = _f32(embed.contiguous())
+        src_pwr = _f32(src_pwr.contiguous())
+        mix_pwr = _f32(mix_pwr.contiguous())
+        attr = torch.empty(B, C, E, device=dev)
+        denom = torch.empty(B, C, device=dev)
+        L = _L()
+        w, wn = _ws(L.danet_attractor_truth_workspace_bytes(B, C, N, E), dev)
+        check(L.danet_attractor_truth_fwd(_lib.stream(), mode, B, C, N, E, ptr(embed),
+                                          ptr(src_pwr), ptr(mix_pwr), eps, ptr(attr),
+                                          ptr(denom), ptr(w), wn))
+        ctx.save_for_backward(src_pwr, mix_pwr, denom)
+        ctx.args = (mode, eps, B, C, N, E, T, F)
+        return attr
+
+    @staticmethod
+    def backward(ctx, dattr):
+        src_pwr, mix_pwr, denom = ctx.saved_tensors
+        mode, eps, B, C, N, E, T, F = ctx.args
+        dembed = torch.zeros(B, T, F, E, device=dattr.device)
+        check(_L().danet_attractor_truth_bwd(
+            _lib.stream(), mode, B, C, N, E, ptr(_f32(dattr.contiguous())), ptr(src_pwr),
+            ptr(mix_pwr), ptr(denom), eps, ptr(dembed)))
+        return dembed, None, None, None, None
+
+
+class AnchorAttractorFn(torch.autograd.Function):
+    '''app/modules.py:490-545.  Returns (attr, asets, subset_choice)'''
+
+    @staticmethod
+    def forward(ctx, embed, anchors, C):
+        B, T, F, E = embed.shape
+        A = anchors.shape[0]
+        N = T * F
+        dev = embed.device
+        embed = _f32(embed.contiguous())
+        anchors = _f32(anchors.contiguous())
+        P = math.comb(A, C)
+        attr = torch.empty(B, C, E, device=dev)
+        asets = torch.empty(B, P, C, E, device=dev)
+        asum = torch.empty(B, P, C, device=dev)
+        choice = torch.empty(B, dtype=torch.int32, device=dev)
+        L = _L()
+        w, wn = _ws(L.danet_attractor_anchor_workspace_bytes(B, C, N, E, A), dev)
+        check(L.danet_attractor_anchor_fwd(_lib.stream(), B, C, N, E, A, ptr(embed),
+                                           ptr(anchors), ptr(attr), ptr(asets), ptr(asum),
+                                           ptr(choice), ptr(w), wn))
+        ctx.save_for_backward(embed, anchors, attr, asum, choice)
+        ctx.args = (B, C, N, E, A, T, F)
+        ctx.mark_non_differentiable(asets, choice)
+        return attr, asets, choice
+
+    @staticmethod
+    def backward(ctx, dattr, _dasets, _dchoice):
+        embed, anchors, attr, asum, choice = ctx.saved_tensors
+        B, C, N, E, A, T, F = ctx.args
+        dev = dattr.device
+        dembed = torch.zeros(B, T, F, E, device=dev)
+        danchors = torch.empty(A, E, device=dev)
+        L = _L()
+        w, wn = _ws(L.danet_attractor_anchor_workspace_bytes(B, C, N, E, A), dev)
+        check(L.danet_attractor_anchor_bwd(
+            _lib.stream(), B, C, N, E, A, ptr(_f32(dattr.contiguous())), ptr(embed),
+            ptr(anchors), ptr(attr), ptr(asum), ptr(choice), ptr(dembed), ptr(danchors),
+            ptr(w), wn))
+        return dembed, danchors, None
+
+
+class SeparateFn(torch.autograd.Function):
+    '''app/modules.py:548-603.  act 0 softmax / 1 sigmoid.
+    (mix_pwr [B,T,F], attr [B,C,E], embed_flat [B,N,E]) -> (sep [B,C,T,F], masks)'''
+
+    @staticmethod
+    def forward(ctx, mix_pwr, attr, embed_flat, act, want_masks):
+        B, T, F = mix_pwr.shape
+        C, E = attr.shape[1], attr.shape[2]
+        N = T * F
+        dev = mix_pwr.device
+        mix_pwr = _f32(mix_pwr.contiguous())
+        attr = _f32(attr.contiguous())
+        embed_flat = _f32(embed_flat.contiguous())
+        out = torch.empty(B, C, T, F, device=dev)
+        masks = torch.empty(B, T, F, C, device=dev) if want_masks else None
+        check(_L().danet_separate_fwd(_lib.stream(), act, B, C, N, E, ptr(mix_pwr), ptr(attr),
+                                      ptr(embed_flat), ptr(out), ptr(masks)))
+        ctx.save_for_backward(mix_pwr, attr, embed_flat)
+        ctx.args = (act, B, C, N, E)
+        if masks is None:
+            masks = torch.empty(0, device=dev)
+        ctx.mark_non_differentiable(masks)
+        return out, masks
+
+    @staticmethod
+    def backward(ctx, dout, _dmasks):
+        mix_pwr, attr, embed_flat = ctx.saved_tensors
+        act, B, C, N, E = ctx.args
+        dev = dout.device
+        dembed = torch.empty(B, N, E, device=dev)
+        dattr = torch.empty(B, C, E, device=dev)
+        L = _L()
+        w, wn = _ws(L.danet_separate_bwd_workspace_bytes(B, C, N, E), dev)
+        check(L.danet_separate_bwd(_lib.stream(), act, B, C, N, E, ptr(mix_pwr), ptr(attr),
+                                   ptr(embed_flat), ptr(_f32(dout.contiguous())), ptr(dembed),
+                                   ptr(dattr), ptr(w), wn))
+        return None, dattr, dembed, None, None
+
+
+class PitMseFn(torch.autograd.Function):
+    '''ops.pit_mse_loss (app/ops.py:374-431) fused with the phase re-attach
+    (main.py:281-284) and batch_snr (app/ops.py:191-222).
+    mode 0: complex MSE (train, main.py:289-290); mode 1: magnitude MSE
+    (valid, main.py:312-313).  Returns (loss, snr, perm_idx)'''
+
+    @staticmethod
+    def forward(ctx, src, sep_pwr, phasor, mode, eps):
+        assert src.dtype == torch.complex64
+        B, C, T, F = sep_pwr.shape
+        N = T * F
+        dev = sep_pwr.device
+        src = src.contiguous()
+        sep_pwr = _f32(sep_pwr.contiguous())
+        phasor = _f32(phasor.contiguous())
+        out = torch.empty(2, device=dev)
+        perm_idx = torch.empty(B, dtype=torch.int32, device=dev)
+        L = _L()
+        w, wn = _ws(L.danet_pit_mse_workspace_bytes(B, C, N), dev)
+        check(L.danet_pit_mse_fwd(_lib.stream(), mode, B, C, N, ptr(torch.view_as_real(src)),
+                                  ptr(sep_pwr), ptr(phasor), eps, ptr(out[0:]), ptr(out[1:]),
+                                  ptr(perm_idx), ptr(w), wn))
+        ctx.save_for_backward(src, sep_pwr, phasor, perm_idx)
+        ctx.args = (mode, B, C, N)
+        loss, snr = out[0].clone(), out[1].clone()
+        ctx.mark_non_differentiable(snr, perm_idx)
+        return loss, snr, perm_idx
+
+    @staticmethod
+    def backward(ctx, dloss, _dsnr, _dperm):
+        src, sep_pwr, phasor, perm_idx = ctx.saved_tensors
+        mode, B, C, N = ctx.args
+        dsep = torch.empty_like(sep_pwr)
+        # dloss is a device scalar; fold it in afterwards to avoid a host sync
+        check(_L().danet_pit_mse_bwd(_lib.stream(), mode, B, C, N,
+                                     ptr(torch.view_as_real(src)), ptr(sep_pwr), ptr(phasor),
+                                     ptr(perm_idx), 1.0, ptr(dsep)))
+        return None, dsep * dloss, None, None, None
+
+
+def pit_mse_loss(s_x, s_y_pwr, phasor, mode=0, eps=1e-7):
+    '''returns (s_loss, v_perms, s_loss_sets_idx, snr) like app/ops.py:374-431'''
+    C = s_y_pwr.shape[1]
+    loss, snr, idx = PitMseFn.apply(s_x, s_y_pwr, phasor, mode, eps)
+    v_perms = torch.tensor(list(itertools.permutations(range(C))), dtype=torch.int32)
+    return loss, v_perms, idx, snr
+
+
+def adam_clip_step(theta, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, clip=100.0,
+                   grad_scale=1.0):
+    '''flat fp32 buffers; tf.train.AdamOptimizer + clip_by_value
+    (main.py:359-363, app/ozers.py:15-18)'''
+    check(_L().danet_adam_clip_step(_lib.stream(), theta.numel(), ptr(_f32(theta)),
+                                    ptr(_f32(grad)), ptr(_f32(m)), ptr(_f32(v)), lr_t, beta1,
+                                    beta2, eps, clip if clip else 0.0, grad_scale))

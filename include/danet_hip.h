@@ -1,0 +1,246 @@
+/*
+ * libdanet_hip.so -- C ABI of the MI355X-native (gfx950) Deep Attractor
+ * Network hot path.
+ *
+ * The reference (khaotik/DaNet-Tensorflow) has NO native boundary: its hot
+ * path is TF1 graph ops built by pure-Python plugin classes
+ * (app/modules.py:11-93, registries app/hparams.py:72-100).  This header is
+ * therefore the boundary a maintainer would bind from those plugin classes
+ * (ctypes stub shown in INTEGRATION.md); each entry point cites the reference
+ * op sequence it replaces (file:line under the reference root).
+ *
+ * Conventions
+ *  - every pointer is a caller-owned DEVICE pointer (the library never
+ *    allocates or frees), dense row-major, fp32 unless the name says
+ *    otherwise; `stream` is a hipStream_t passed as void*.
+ *  - `ws` is caller-provided device scratch of at least
+ *    `*_workspace_bytes(...)` bytes; contents are clobbered.
+ *  - return value: 0 = DANET_OK, negative = error (no exceptions cross the
+ *    ABI); `danet_last_error()` returns a thread-local message.
+ *  - all launches are asynchronous on `stream`; no global state, re-entrant
+ *    per stream (each concurrent call needs its own `ws`).
+ *  - symbols: B batch (mixtures), C speakers, T frames, F bins, E embedding,
+ *    H hidden units per LSTM direction, N = T*F time-frequency bins,
+ *    A anchors, P = C(A,C) anchor subsets.
+ *  - "time-major" = [T][B][.], "batch-major" = [B][T][.].
+ */
+#ifndef DANET_HIP_H
+#define DANET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DANET_OK 0
+#define DANET_ERR_ARG (-1)          /* bad shape / null pointer / misalignment */
+#define DANET_ERR_LAUNCH (-2)       /* hipLaunch / hipMemset failure           */
+#define DANET_ERR_UNSUPPORTED (-3)  /* shape outside the compiled envelope     */
+#define DANET_ERR_WORKSPACE (-4)    /* ws too small                            */
+
+#define DANET_ABI_VERSION 1
+
+typedef void* danet_stream_t;
+
+int danet_abi_version(void);
+const char* danet_last_error(void);
+
+/* ---------------------------------------------------------------- a1 / a2
+ * STFT: replaces scipy.signal.stft(x, window=FFT_WND, nperseg=N,
+ * noverlap=N-S)[2].astype(complex64).T  (app/utils.py:117-122,
+ * app/datasets/TIMIT/process.py:93-97, app/datasets/WSJ0/process.py:175-179).
+ * boundary='zeros', padded=True, scaling 1/sum(window).  N in {64..1024},
+ * power of two.  x[n_sig][Ls] -> out[n_sig][T][N/2+1] (re,im interleaved).
+ * danet_stft_num_frames returns T = 1+ceil(Ls/S) or DANET_ERR_ARG if Ls < N
+ * (scipy raises ValueError there).                                        */
+int danet_stft_num_frames(int64_t Ls, int N, int S);
+int danet_stft(danet_stream_t stream, int n_sig, int64_t Ls, int N, int S,
+               const float* x, const float* window, float* out_c64);
+
+/* iSTFT: replaces utils.istft (app/utils.py:53-75): overlap-add of
+ * irfft(X[n])*w over frames n < len(range(0, T*S-N, S)), divided by the
+ * overlap-added w^2 where non-zero; float64 accumulators and output
+ * [n_sig][T*S]; does NOT undo the 1/sum(w) STFT scaling (neither does the
+ * reference).                                                              */
+size_t danet_istft_workspace_bytes(int n_sig, int T, int N, int S);
+int danet_istft(danet_stream_t stream, int n_sig, int T, int N, int S,
+                const float* X_c64, const float* window, double* out,
+                void* ws, size_t ws_bytes);
+
+/* ---------------------------------------------------------------- a3 / a13
+ * In-graph front-end (main.py:233-240): mix = sum_c src; |src|; atan2;
+ * |mix|; log1p(|mix|).  src complex64 [B][C][N].  Optional outputs may be
+ * NULL.  `phasor` [B][N][2] = (cos phi, sin phi) of the mixture phase
+ * ((1,0) where mix == 0, matching atan2(0,0)=0).                            */
+int danet_frontend_fwd(danet_stream_t stream, int B, int C, int64_t N,
+                       const float* src_c64, float* mix_pwr, float* mix_log,
+                       float* phasor, float* phase, float* src_pwr,
+                       float* mix_c64);
+
+/* Phase re-attach (main.py:281-284, :330-335): out[b][c] =
+ * phasor[b] * sep_pwr[b][perm(c)], perm = perms[perm_idx[b]] in
+ * itertools.permutations order, identity when perm_idx == NULL.            */
+int danet_reattach_phase(danet_stream_t stream, int B, int C, int64_t N,
+                         const float* sep_pwr, const float* phasor,
+                         const int32_t* perm_idx, float* out_c64);
+
+/* ---------------------------------------------------------------- a4
+ * Per-utterance mean-centre (app/modules.py:209-210, :244-245):
+ * out[b] = in[b] - mean_{t,d}(in[b]).  Layout 0 = batch-major [B][T][ld],
+ * 1 = time-major [T][B][ld]; in/out layouts are independent (this is where
+ * the encoder switches between the API's batch-major tensors and the LSTM
+ * stack's time-major ones).  Columns D..ld_out-1 of `out` are zero-filled.
+ * `mean` is REQUIRED scratch+output of danet_center_mean_elems(B) floats: the
+ * first B hold the per-utterance means, the rest per-chunk partial sums.
+ * The same call is its own backward.                                        */
+int danet_center_mean_elems(int B);
+int danet_center(danet_stream_t stream, int B, int T, int D,
+                 const float* in, int in_layout, int ld_in,
+                 float* out, int out_layout, int ld_out, float* mean);
+
+/* ---------------------------------------------------------------- a4 / a7
+ * fp32 GEMM on MFMA (v_mfma_f32_32x32x2_f32, exact fp32):
+ *   C[M][N] = op(A)[M][K] * op(B)[K][N] (+ bias[N]) (+ beta * C), beta in {0,1}
+ * transA=0: A stored [M][lda];  transA=1: A stored [K][lda] (op(A)=A^T)
+ * transB=0: B stored [K][ldb];  transB=1: B stored [N][ldb] (op(B)=B^T)
+ * Replaces the tf.matmul inside ops.lyr_linear (app/ops.py:66-68,72-78) for
+ * the hoisted LSTM input projections and the encoder output projection, and
+ * all their backward products.  `ws` is used for deterministic split-K.    */
+size_t danet_gemm_f32_workspace_bytes(int M, int N, int K);
+int danet_gemm_f32(danet_stream_t stream, int transA, int transB,
+                   int M, int N, int K,
+                   const float* A, int lda, const float* B, int ldb,
+                   float* C, int ldc, const float* bias, float beta,
+                   void* ws, size_t ws_bytes);
+
+/* out[N] = sum_m A[m][n] (+ beta*out): bias gradients.                     */
+int danet_colsum_f32(danet_stream_t stream, int M, int N, const float* A,
+                     int lda, float* out, float beta, void* ws,
+                     size_t ws_bytes);
+size_t danet_colsum_f32_workspace_bytes(int M, int N);
+
+/* ---------------------------------------------------------------- a5-a7
+ * Recurrent half of Model.lyr_lstm / _lyr_bilstm (main.py:76-132,
+ * app/modules.py:120-137, app/ops.py:110-148) as ONE persistent launch for
+ * all T steps and both directions.
+ *   gx_d   [T][B][4H]  hoisted x_t*Wx + b (gate column blocks g|i|f|o)
+ *   Wh_d   [H][ldw]    recurrent rows of the reference's W[D+H][4H]
+ *   ypad   [T+2][B][ldy] layer output, time t in block t+1; blocks 0 and T+1
+ *          are zeroed by the call (zero initial state, main.py:108-123).
+ *          direction 0 (fwd) writes columns [0,H), direction 1 (bwd, the
+ *          reversed scan of app/modules.py:132-136) writes [H,2H).
+ *   gates_d[T][B][4H]  saved post-activation g,i,f,o (may alias gx_d)
+ *   cell_d [T][B][H]   saved c_t
+ * ndir = 1 (lstm-orig) or 2 (bilstm-orig); *_b pointers ignored if ndir=1.
+ * After the call, ws word 0 (int32) is 0 on success, non-zero if an
+ * inter-workgroup wait timed out (see danet_lstm_status).                  */
+size_t danet_lstm_workspace_bytes(int T, int B, int H, int ndir);
+int danet_lstm_fwd(danet_stream_t stream, int T, int B, int H, int ndir,
+                   const float* gx_f, const float* gx_b,
+                   const float* Wh_f, const float* Wh_b, int ldw,
+                   float* ypad, int ldy,
+                   float* gates_f, float* gates_b,
+                   float* cell_f, float* cell_b,
+                   void* ws, size_t ws_bytes);
+
+/* BPTT of the above.  dy [T][B][lddy] (dir d uses columns [d*H,(d+1)*H)).
+ * Outputs da_d [T][B][4H] = dL/d(pre-activation); the caller finishes with
+ * GEMMs: dWx = X^T da, dWh = Hprev^T da, db = colsum(da), dX = da Wx^T.    */
+int danet_lstm_bwd(danet_stream_t stream, int T, int B, int H, int ndir,
+                   const float* dy, int lddy,
+                   const float* Wh_f, const float* Wh_b, int ldw,
+                   const float* gates_f, const float* gates_b,
+                   const float* cell_f, const float* cell_b,
+                   float* da_f, float* da_b,
+                   void* ws, size_t ws_bytes);
+
+/* ---------------------------------------------------------------- a8-a10
+ * Truth-family attractor estimators (app/modules.py:382-487).
+ * mode 0 'truth' (w=1, denom count+1), 1 'truth-threshold' (w=[|mix|>5],
+ * denom +eps), 2 'truth-weighted' (w=|mix|, denom +eps).
+ * embed [B][N][E], src_pwr [B][C][N], mix_pwr [B][N] -> attr [B][C][E],
+ * denom [B][C] (sum of weights, before the +1 / +eps; saved for bwd).      */
+size_t danet_attractor_truth_workspace_bytes(int B, int C, int64_t N, int E);
+int danet_attractor_truth_fwd(danet_stream_t stream, int mode, int B, int C,
+                              int64_t N, int E, const float* embed,
+                              const float* src_pwr, const float* mix_pwr,
+                              float eps, float* attr, float* denom,
+                              void* ws, size_t ws_bytes);
+/* dembed [B][N][E] += w[b][n] * dattr[b][idx(b,n)][:] / (denom + add)      */
+int danet_attractor_truth_bwd(danet_stream_t stream, int mode, int B, int C,
+                              int64_t N, int E, const float* dattr,
+                              const float* src_pwr, const float* mix_pwr,
+                              const float* denom, float eps, float* dembed);
+
+/* ---------------------------------------------------------------- a11
+ * Anchor estimator (app/modules.py:490-545, app/ops.py:273-292), fused: one
+ * read of the embedding instead of the reference's [B][P][T][F][C] tensors.
+ * anchors [A][E]; outputs attr [B][C][E], asets [B][P][C][E] (attractor per
+ * subset), asum [B][P][C] (sum of soft assignments), choice int32 [B].     */
+size_t danet_attractor_anchor_workspace_bytes(int B, int C, int64_t N, int E,
+                                              int A);
+int danet_attractor_anchor_fwd(danet_stream_t stream, int B, int C, int64_t N,
+                               int E, int A, const float* embed,
+                               const float* anchors, float* attr,
+                               float* asets, float* asum, int32_t* choice,
+                               void* ws, size_t ws_bytes);
+/* dembed [B][N][E] += ..., danchors [A][E] = ... (through the chosen subset) */
+int danet_attractor_anchor_bwd(danet_stream_t stream, int B, int C, int64_t N,
+                               int E, int A, const float* dattr,
+                               const float* embed, const float* anchors,
+                               const float* attr, const float* asum,
+                               const int32_t* choice, float* dembed,
+                               float* danchors, void* ws, size_t ws_bytes);
+
+/* ---------------------------------------------------------------- a12
+ * Dot-product separators (app/modules.py:548-603). act 0 = softmax over C
+ * ('dot-softmax-orig'), 1 = sigmoid ('dot-sigmoid-orig').
+ * out [B][C][N] = mix_pwr * act(embed . attr^T); masks [B][N][C] optional. */
+int danet_separate_fwd(danet_stream_t stream, int act, int B, int C,
+                       int64_t N, int E, const float* mix_pwr,
+                       const float* attr, const float* embed, float* out,
+                       float* masks);
+size_t danet_separate_bwd_workspace_bytes(int B, int C, int64_t N, int E);
+/* dembed [B][N][E] = (overwritten), dattr [B][C][E] = (overwritten)        */
+int danet_separate_bwd(danet_stream_t stream, int act, int B, int C,
+                       int64_t N, int E, const float* mix_pwr,
+                       const float* attr, const float* embed,
+                       const float* dout, float* dembed, float* dattr,
+                       void* ws, size_t ws_bytes);
+
+/* ---------------------------------------------------------------- a14/a15
+ * PIT-MSE loss + SNR (app/ops.py:374-431, :191-222; main.py:289-337).
+ * src is always the complex64 truth [B][C][N].
+ * mode 0: MSE between src and phasor*sep_pwr (train loss, main.py:281-290);
+ * mode 1: MSE between |src| and sep_pwr (valid loss, main.py:312-313).
+ * Outputs: loss[1]; perm_idx[B] (index into itertools.permutations(range(C)),
+ * first on ties); snr[1] (optional) = mean batch_snr of src vs the complex
+ * estimate permuted by perm_idx (main.py:308-309, :336-337).  C <= 4.       */
+size_t danet_pit_mse_workspace_bytes(int B, int C, int64_t N);
+int danet_pit_mse_fwd(danet_stream_t stream, int mode, int B, int C,
+                      int64_t N, const float* src_c64, const float* sep_pwr,
+                      const float* phasor, float eps, float* loss,
+                      float* snr, int32_t* perm_idx, void* ws,
+                      size_t ws_bytes);
+/* dsep_pwr [B][C][N] = dloss * dL/dsep_pwr                                  */
+int danet_pit_mse_bwd(danet_stream_t stream, int mode, int B, int C,
+                      int64_t N, const float* src_c64, const float* sep_pwr,
+                      const float* phasor, const int32_t* perm_idx,
+                      float dloss, float* dsep_pwr);
+
+/* ---------------------------------------------------------------- a16
+ * clip_by_value + tf.train.AdamOptimizer update (main.py:359-363,
+ * app/ozers.py:15-18): g = clamp(grad*grad_scale, +-clip);
+ * m,v EMA; theta -= lr_t * m / (sqrt(v) + eps), lr_t precomputed by host
+ * as lr*sqrt(1-b2^t)/(1-b1^t).  clip <= 0 disables clipping.              */
+int danet_adam_clip_step(danet_stream_t stream, int64_t n, float* theta,
+                         const float* grad, float* m, float* v, float lr_t,
+                         float beta1, float beta2, float eps, float clip,
+                         float grad_scale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DANET_HIP_H */

@@ -1,0 +1,571 @@
+'''
+GPU parity tests (run with `-m gpu` on an MI355X): every entry point of
+libdanet_hip.so, through the Python boundary, against the CPU oracle
+(oracle/danet_oracle.py, oracle/torch_ref.py) on identical seeded inputs.
+
+Tolerance: 1e-4 relative to the tensor's max magnitude (north_star: "within
+1e-4 relative fp32"; relative-to-max because saturated masks / exact zeros make
+per-element relative error meaningless); integer outputs (frame counts,
+argmin / permutation indices) must be exact.
+'''
+import os
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import danet_oracle as O
+from oracle import torch_ref as R
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'frontend_ref.npz')
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.complex128 if np.iscomplexobj(a) or np.iscomplexobj(b) else np.float64)
+    b = np.asarray(b, dtype=a.dtype)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def cu(x, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(x)).to('cuda', dtype)
+
+
+@pytest.fixture(autouse=True)
+def _lstm_status():
+    yield
+    from danet_amd import ops
+    torch.cuda.synchronize()
+    assert ops.lstm_status_ok(), 'persistent LSTM kernel reported a hand-off timeout'
+
+
+def test_single_hip_runtime_loaded():
+    '''libdanet_hip.so must share torch's libamdhip64 (one HIP runtime)'''
+    from danet_amd import _lib
+    _lib.load()
+    torch.zeros(1, device='cuda')
+    libs = set()
+    with open('/proc/self/maps') as f:
+        for line in f:
+            if 'libamdhip64' in line:
+                libs.add(line.split()[-1])
+    assert len(libs) == 1, libs
+    assert any('libdanet_hip.so' in l for l in open('/proc/self/maps'))
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize('M,N,K', [(1, 1, 1), (7, 5, 3), (128, 128, 16), (130, 260, 33),
+                                   (257, 129, 129), (64, 1200, 132), (300, 1200, 4096),
+                                   (600, 2580, 1024), (4096, 600, 64)])
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm(M, N, K, ta, tb):
+    from danet_amd import ops
+    rng = np.random.RandomState(M * 31 + N * 7 + K + ta * 2 + tb)
+    A = rng.randn(K, M) if ta else rng.randn(M, K)
+    Bm = rng.randn(N, K) if tb else rng.randn(K, N)
+    bias = rng.randn(N)
+    C0 = rng.randn(M, N)
+    ref = (A.T if ta else A) @ (Bm.T if tb else Bm)
+    dA, dB = cu(A), cu(Bm)
+    C = torch.empty(M, N, device='cuda')
+    ops.gemm(dA, dB, C, M, N, K, dA.shape[1], dB.shape[1], N, transA=ta, transB=tb)
+    assert relerr(C.cpu().numpy(), ref) < 2e-5
+    C = cu(C0)
+    ops.gemm(dA, dB, C, M, N, K, dA.shape[1], dB.shape[1], N, transA=ta, transB=tb,
+             bias=cu(bias), beta=1.0)
+    assert relerr(C.cpu().numpy(), ref + bias + C0) < 2e-5
+
+
+def test_gemm_strided_views_and_asymmetric():
+    '''sub-matrix operands with ld > width; asymmetric operands catch a
+    transposed fragment/epilogue mapping'''
+    from danet_amd import ops
+    M, N, K = 96, 72, 40
+    A = np.zeros((M, K)); A[np.arange(min(M, K)), np.arange(min(M, K))] = 1.0
+    Bm = np.arange(K * N, dtype=np.float64).reshape(K, N) / 100.0
+    big_a = torch.zeros(M, K + 12, device='cuda'); big_a[:, 4:4 + K] = cu(A)
+    big_b = torch.zeros(K, N + 8, device='cuda'); big_b[:, 8:8 + N] = cu(Bm)
+    big_c = torch.full((M, N + 4), -7.0, device='cuda')
+    ops.gemm(big_a[:, 4:], big_b[:, 8:], big_c[:, 4:], M, N, K, K + 12, N + 8, N + 4)
+    got = big_c.cpu().numpy()
+    assert relerr(got[:, 4:], A @ Bm) < 1e-6
+    assert np.all(got[:, :4] == -7.0)
+
+
+# ------------------------------------------------------------------ centre
+@pytest.mark.parametrize('B,T,D', [(2, 3, 5), (4, 16, 129), (32, 8, 600)])
+def test_center_layouts(B, T, D):
+    from danet_amd import ops
+    rng = np.random.RandomState(0)
+    x = rng.randn(B, T, D) + 3.0
+    ref = x - x.mean(axis=(1, 2), keepdims=True)
+    ldo = (D + 3) // 4 * 4
+    out = torch.full((T, B, ldo), 9.0, device='cuda')
+    mean = ops.center(cu(x), B, T, D, 0, D, out, 1, ldo)
+    got = out.cpu().numpy()
+    assert relerr(got[:, :, :D].transpose(1, 0, 2), ref) < 1e-5
+    assert np.all(got[:, :, D:] == 0.0)
+    assert relerr(mean.cpu().numpy(), x.mean(axis=(1, 2))) < 1e-5
+    back = torch.empty(B, T, D, device='cuda')
+    ops.center(out, B, T, D, 1, ldo, back, 0, D)
+    assert relerr(back.cpu().numpy(), ref) < 1e-5
+
+
+# ---------------------------------------------------------------- frontend
+def test_frontend_and_reattach():
+    from danet_amd import ops
+    rng = np.random.RandomState(1)
+    B, C, T, F = 3, 2, 7, 33
+    src = (rng.randn(B, C, T, F) + 1j * rng.randn(B, C, T, F)).astype(np.complex64) * 50
+    src[0, :, 0, :4] = 0                       # atan2(0,0) / log1p(0) / |0|
+    fe = ops.frontend(torch.as_tensor(src).cuda(), want_phase=True, want_mix=True)
+    ref = O.frontend(src)
+    for k in ('src_pwr', 'mix_pwr', 'mix_log', 'phase', 'mix'):
+        assert relerr(fe[k].cpu().numpy(), ref[k]) < 1e-5, k
+    ph = fe['phasor'].cpu().numpy()
+    assert relerr(ph[..., 0], np.cos(ref['phase'])) < 1e-5
+    assert relerr(ph[..., 1], np.sin(ref['phase'])) < 1e-5
+    pw = rng.rand(B, C, T, F).astype(np.float32)
+    idx = np.array([1, 0, 1], dtype=np.int32)
+    got = ops.reattach_phase(cu(pw), fe['phasor'], torch.as_tensor(idx).cuda()).cpu().numpy()
+    perms = O.permutations(C)
+    want = O.reattach_phase(O.perm_gather(pw.astype(np.float64), perms, idx), ref['phase'])
+    assert relerr(got, want) < 1e-5
+
+
+# ------------------------------------------------------------------- LSTM
+def _lstm_ref(x, Ws, bs, H, dy):
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    Wt = [torch.tensor(W, dtype=torch.float64, requires_grad=True) for W in Ws]
+    bt = [torch.tensor(b, dtype=torch.float64, requires_grad=True) for b in bs]
+    outs = [R.lstm_scan(xt, Wt[0], bt[0], H)]
+    if len(Ws) == 2:
+        outs.append(R.lstm_scan(xt, Wt[1], bt[1], H, reverse=True))
+    y = torch.cat(outs, dim=-1)
+    (y * torch.tensor(dy)).sum().backward()
+    return y.detach().numpy(), xt.grad.numpy(), [w.grad.numpy() for w in Wt], [b.grad.numpy() for b in bt]
+
+
+@pytest.mark.parametrize('B,T,D,H,ndir', [
+    (2, 5, 7, 4, 2), (1, 9, 5, 8, 1), (4, 16, 129, 12, 2), (17, 6, 20, 36, 2),
+    (32, 12, 64, 300, 2), (33, 4, 16, 16, 2), (16, 8, 24, 600, 1)])
+def test_lstm_layer_fwd_bwd(B, T, D, H, ndir):
+    from danet_amd import ops
+    rng = np.random.RandomState(B * 100 + T * 10 + H)
+    r = 0.75 / np.sqrt(H)
+    x = rng.randn(B, T, D) * 0.7
+    Ws = [rng.uniform(-r, r, size=(D + H, 4 * H)) * 2 for _ in range(ndir)]
+    bs = [O.lstm_bias_init(H) + rng.randn(4 * H) * 0.1 for _ in range(ndir)]
+    dy = rng.randn(B, T, ndir * H)
+    ry, rdx, rdW, rdb = _lstm_ref(x, Ws, bs, H, dy)
+    xc = cu(x).requires_grad_(True)
+    params = []
+    for W, b in zip(Ws, bs):
+        params += [cu(W).requires_grad_(True), cu(b).requires_grad_(True)]
+    y = ops.LstmLayerFn.apply(xc, H, *params)
+    assert relerr(y.detach().cpu().numpy(), ry) < TOL
+    y.backward(cu(dy))
+    assert relerr(xc.grad.cpu().numpy(), rdx) < TOL
+    for d in range(ndir):
+        assert relerr(params[2 * d].grad.cpu().numpy(), rdW[d]) < TOL
+        assert relerr(params[2 * d + 1].grad.cpu().numpy(), rdb[d]) < TOL
+
+
+def test_lstm_kat_gate_order_no_tanh():
+    '''K1/K2: W=0, b=[1|1.5|-1|1] => c1=sigma(1.5), h1=sigma(1)tanh(c1),
+    c2=sigma(1.5)+sigma(-1)c1; with the reference bias init (g bias 0) h == 0'''
+    from danet_amd import ops
+    H, D, B, T = 4, 3, 2, 2
+    x = torch.randn(B, T, D, device='cuda')
+    W = torch.zeros(D + H, 4 * H, device='cuda')
+    b = cu(np.concatenate([np.full(H, 1.0), np.full(H, 1.5), np.full(H, -1.0), np.full(H, 1.0)]))
+    y = ops.LstmLayerFn.apply(x, H, W, b).cpu().numpy()
+    sig = lambda v: 1 / (1 + np.exp(-v))
+    c1 = sig(1.5); h1 = sig(1.0) * np.tanh(c1)
+    c2 = sig(1.5) + sig(-1.0) * c1; h2 = sig(1.0) * np.tanh(c2)
+    assert np.allclose(y[:, 0], h1, atol=1e-6) and abs(h1 - 0.492549) < 1e-6
+    assert np.allclose(y[:, 1], h2, atol=1e-6)
+    y0 = ops.LstmLayerFn.apply(x, H, W, cu(O.lstm_bias_init(H))).cpu().numpy()
+    assert np.all(y0 == 0.0)
+
+
+# -------------------------------------------------------------- estimators
+def _embed_case(rng, B, C, T, F, E):
+    embed = rng.randn(B, T, F, E)
+    src = (rng.randn(B, C, T, F) + 1j * rng.randn(B, C, T, F)) * 4
+    src[0, :, 0] = 0                                       # argmax ties -> index 0 (K9)
+    fe = O.frontend(src)
+    return embed, fe['src_pwr'], fe['mix_pwr']
+
+
+@pytest.mark.parametrize('mode', ['truth', 'truth-threshold', 'truth-weighted'])
+@pytest.mark.parametrize('B,C,T,F,E', [(2, 2, 5, 7, 3), (3, 3, 40, 129, 20), (2, 2, 33, 65, 40)])
+def test_truth_estimators(mode, B, C, T, F, E):
+    from danet_amd import ops
+    rng = np.random.RandomState(5)
+    embed, src_pwr, mix_pwr = _embed_case(rng, B, C, T, F, E)
+    ref = {'truth': O.est_truth, 'truth-threshold': O.est_truth_threshold,
+           'truth-weighted': O.est_truth_weighted}[mode](embed, src_pwr, mix_pwr)
+    e = cu(embed).requires_grad_(True)
+    attr = ops.TruthAttractorFn.apply(e, cu(src_pwr), cu(mix_pwr), ops.TRUTH_MODES[mode], 1e-7)
+    assert relerr(attr.detach().cpu().numpy(), ref) < TOL
+    dattr = rng.randn(B, C, E)
+    attr.backward(cu(dattr))
+    et = torch.tensor(embed, requires_grad=True)
+    fn = {'truth': R.est_truth, 'truth-threshold': R.est_truth_threshold,
+          'truth-weighted': R.est_truth_weighted}[mode]
+    (fn(et, torch.tensor(src_pwr), torch.tensor(mix_pwr), 1e-7) * torch.tensor(dattr)).sum().backward()
+    assert relerr(e.grad.cpu().numpy(), et.grad.numpy()) < TOL
+
+
+def test_truth_kats():
+    '''K5: one bin => attr = embed/2 ('truth' divides by count+1);
+    K6: |mix| == 5.0 excluded, next float above included'''
+    from danet_amd import ops
+    embed = cu(np.array([[[[2.0, 4.0, 6.0, 8.0]]]]))                      # B=T=F=1, E=4
+    src_pwr = cu(np.array([[[[1.0]], [[0.5]]]]).reshape(1, 2, 1, 1))
+    mix = cu(np.array([[[1.0]]]))
+    a = ops.TruthAttractorFn.apply(embed, src_pwr, mix, 0, 1e-7).cpu().numpy()
+    assert np.allclose(a[0, 0], [1, 2, 3, 4]) and np.all(a[0, 1] == 0)
+    five = np.float32(5.0)
+    mixv = np.array([[[five, np.nextafter(five, np.float32(10))]]], dtype=np.float32)   # [1,1,2]
+    emb = cu(np.array([[[[1.0, 0, 0, 0], [0, 1.0, 0, 0]]]]))              # [1,1,2,4]
+    sp = cu(np.ones((1, 2, 1, 2))); sp[0, 1] = 0.5
+    a = ops.TruthAttractorFn.apply(emb, sp, cu(mixv), 1, 1e-7).cpu().numpy()
+    assert abs(a[0, 0, 0]) < 1e-6 and abs(a[0, 0, 1] - 1.0) < 1e-5
+
+
+@pytest.mark.parametrize('B,C,T,F,E,A', [(2, 2, 5, 7, 3, 4), (3, 2, 40, 129, 20, 6),
+                                         (2, 3, 17, 65, 20, 5), (1, 2, 300, 129, 20, 6)])
+def test_anchor_estimator(B, C, T, F, E, A):
+    from danet_amd import ops
+    rng = np.random.RandomState(11)
+    embed = rng.randn(B, T, F, E) * 0.5
+    anchors = rng.randn(A, E)
+    ref, info = O.est_anchor(embed, anchors, C, return_all=True)
+    e = cu(embed).requires_grad_(True)
+    an = cu(anchors).requires_grad_(True)
+    attr, asets, choice = ops.AnchorAttractorFn.apply(e, an, C)
+    assert np.array_equal(choice.cpu().numpy(), info['subset_choice'])
+    assert relerr(asets.cpu().numpy(), info['asets']) < TOL
+    assert relerr(attr.detach().cpu().numpy(), ref) < TOL
+    dattr = rng.randn(B, C, E)
+    attr.backward(cu(dattr))
+    et = torch.tensor(embed, requires_grad=True)
+    at = torch.tensor(anchors, requires_grad=True)
+    (R.est_anchor(et, at, C) * torch.tensor(dattr)).sum().backward()
+    assert relerr(e.grad.cpu().numpy(), et.grad.numpy()) < TOL
+    assert relerr(an.grad.cpu().numpy(), at.grad.numpy()) < TOL
+
+
+def test_anchor_kat_diagonal_in_max():
+    '''K7: the similarity max runs over the full CxC Gram matrix, diagonal
+    included: a subset with a long attractor loses even if its attractors are
+    orthogonal'''
+    from danet_amd import ops
+    rng = np.random.RandomState(3)
+    embed = rng.randn(1, 6, 9, 3) * np.array([3.0, 0.2, 0.2])
+    anchors = np.array([[4.0, 0, 0], [-4.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]])
+    ref, info = O.est_anchor(embed, anchors, 2, return_all=True)
+    gram = info['asets'] @ np.swapaxes(info['asets'], -1, -2)
+    offdiag = np.array([[g[0, 1] for g in gb] for gb in gram])
+    assert np.argmin(offdiag[0]) != info['subset_choice'][0]   # the KAT is discriminating
+    _, _, choice = ops.AnchorAttractorFn.apply(cu(embed), cu(anchors), 2)
+    assert int(choice[0]) == int(info['subset_choice'][0])
+
+
+# --------------------------------------------------------------- separators
+@pytest.mark.parametrize('act', [0, 1])
+@pytest.mark.parametrize('B,C,T,F,E', [(2, 2, 5, 7, 3), (3, 3, 40, 129, 20), (2, 2, 20, 65, 40)])
+def test_separators(act, B, C, T, F, E):
+    from danet_amd import ops
+    rng = np.random.RandomState(7)
+    embed = rng.randn(B, T * F, E)
+    attr = rng.randn(B, C, E)
+    mix = rng.rand(B, T, F) * 10
+    name = 'softmax' if act == 0 else 'sigmoid'
+    ref, rmask = O.sep_dot(mix, attr, embed, name, return_masks=True)
+    e = cu(embed).requires_grad_(True)
+    a = cu(attr).requires_grad_(True)
+    sep, masks = ops.SeparateFn.apply(cu(mix), a, e, act, True)
+    assert relerr(sep.detach().cpu().numpy(), ref) < TOL
+    assert relerr(masks.cpu().numpy(), rmask) < TOL
+    dout = rng.randn(B, C, T, F)
+    sep.backward(cu(dout))
+    et = torch.tensor(embed, requires_grad=True)
+    at = torch.tensor(attr, requires_grad=True)
+    (R.sep_dot(torch.tensor(mix), at, et, name)[0] * torch.tensor(dout)).sum().backward()
+    assert relerr(e.grad.cpu().numpy(), et.grad.numpy()) < TOL
+    assert relerr(a.grad.cpu().numpy(), at.grad.numpy()) < TOL
+
+
+def test_separator_kat_equal_attractors():
+    '''K4: equal attractors => softmax masks 1/C; zero logits => sigmoid 0.5'''
+    from danet_amd import ops
+    B, C, T, F, E = 1, 3, 2, 5, 4
+    embed = torch.randn(B, T * F, E, device='cuda')
+    attr = torch.randn(B, 1, E, device='cuda').expand(B, C, E).contiguous()
+    mix = torch.rand(B, T, F, device='cuda') + 1
+    sep, _ = ops.SeparateFn.apply(mix, attr, embed, 0, False)
+    assert torch.allclose(sep, (mix / C)[:, None].expand(B, C, T, F), rtol=1e-6)
+    sep, _ = ops.SeparateFn.apply(mix, torch.zeros(B, C, E, device='cuda'), embed, 1, False)
+    assert torch.allclose(sep, (mix * 0.5)[:, None].expand(B, C, T, F), rtol=1e-6)
+
+
+# --------------------------------------------------------------------- loss
+@pytest.mark.parametrize('mode', [0, 1])
+@pytest.mark.parametrize('B,C,T,F', [(2, 2, 5, 7), (5, 3, 40, 129), (32, 2, 16, 129), (3, 1, 4, 9)])
+def test_pit_mse(mode, B, C, T, F):
+    from danet_amd import ops
+    rng = np.random.RandomState(13)
+    src = (rng.randn(B, C, T, F) + 1j * rng.randn(B, C, T, F)) * 3
+    fe = O.frontend(src)
+    # estimates close to a random permutation of the truth so every perm is hit
+    pick = rng.randint(0, len(O.permutations(C)), size=B)
+    sep = np.abs(src)[np.arange(B)[:, None], O.permutations(C)[pick]] * (0.8 + 0.4 * rng.rand(B, C, T, F))
+    phasor = np.stack([np.cos(fe['phase']), np.sin(fe['phase'])], -1)
+    if mode == 0:
+        est = O.reattach_phase(sep, fe['phase'])
+        rloss, perms, ridx, _ = O.pit_mse_loss(src, est)
+    else:
+        rloss, perms, ridx, _ = O.pit_mse_loss(fe['src_pwr'], sep)
+    rsnr = O.batch_snr(src, O.reattach_phase(O.perm_gather(sep, perms, ridx), fe['phase'])).mean()
+    s = cu(sep).requires_grad_(True)
+    loss, snr, idx = ops.PitMseFn.apply(torch.as_tensor(src.astype(np.complex64)).cuda(), s,
+                                        cu(phasor), mode, 1e-7)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert relerr(float(loss), rloss) < TOL
+    assert relerr(float(snr), rsnr) < TOL
+    (loss * 1.7).backward()
+    st = torch.tensor(sep, requires_grad=True)
+    if mode == 0:
+        ph = torch.tensor(fe['phase'])[:, None]
+        est = torch.complex(torch.cos(ph) * st, torch.sin(ph) * st)
+        tl = R.pit_mse_loss(torch.tensor(src), est)[0]
+    else:
+        tl = R.pit_mse_loss(torch.tensor(fe['src_pwr']), st)[0]
+    (tl * 1.7).backward()
+    assert relerr(s.grad.cpu().numpy(), st.grad.numpy()) < TOL
+
+
+def test_pit_kat_swap_and_order():
+    '''K8: swapping the sources flips idx 0 -> 1 with the same loss; 3-speaker
+    permutations follow itertools.permutations order'''
+    from danet_amd import ops
+    rng = np.random.RandomState(2)
+    B, C, T, F = 1, 2, 3, 5
+    src = (rng.randn(B, C, T, F) + 1j * rng.randn(B, C, T, F)).astype(np.complex64)
+    fe = O.frontend(src)
+    phasor = cu(np.stack([np.cos(fe['phase']), np.sin(fe['phase'])], -1))
+    sep = np.abs(src).astype(np.float32)
+    l0, _, i0 = ops.PitMseFn.apply(torch.as_tensor(src).cuda(), cu(sep), phasor, 1, 1e-7)
+    l1, _, i1 = ops.PitMseFn.apply(torch.as_tensor(src).cuda(), cu(sep[:, ::-1].copy()), phasor, 1, 1e-7)
+    assert int(i0[0]) == 0 and int(i1[0]) == 1 and abs(float(l0) - float(l1)) < 1e-7
+    C = 3
+    src = (rng.randn(1, C, T, F) + 1j * rng.randn(1, C, T, F)).astype(np.complex64) * np.array([1, 5, 25]).reshape(1, 3, 1, 1)
+    fe = O.frontend(src)
+    phasor = cu(np.stack([np.cos(fe['phase']), np.sin(fe['phase'])], -1))
+    for p, perm in enumerate(itertools.permutations(range(C))):
+        # estimate j = |src_i| for perm[i] = j
+        sep = np.zeros((1, C, T, F), np.float32)
+        for i, j in enumerate(perm):
+            sep[:, j] = np.abs(src[:, i])
+        _, _, idx = ops.PitMseFn.apply(torch.as_tensor(src).cuda(), cu(sep), phasor, 1, 1e-7)
+        assert int(idx[0]) == p
+
+
+# ---------------------------------------------------------------- STFT/iSTFT
+def test_stft_against_reference_golden(hp):
+    from danet_amd import ops
+    g = np.load(GOLD)
+    w256 = O.fft_window(256)
+    assert np.array_equal(w256.view(np.uint32), g['wnd256_bits'])            # G1
+    for L in (256, 257, 319, 320, 8000, 8001, 8063, 8064):                   # G2
+        x = np.random.RandomState(0).randn(L).astype(np.float32)
+        X = ops.stft(cu(x), cu(w256), 256, 64).cpu().numpy()
+        ref = g['stft256_L%d' % L]
+        assert X.shape == ref.shape == (1 + -(-L // 64), 129)                # K10, exact
+        assert relerr(X, ref) < 1e-5
+    X = ops.stft(cu(g['stft256_int16scale_x']), cu(w256), 256, 64).cpu().numpy()
+    assert relerr(X, g['stft256_int16scale']) < 1e-5
+    with pytest.raises(ValueError):                                           # K10: Ls < N
+        ops.stft(cu(np.zeros(255, np.float32)), cu(w256), 256, 64)
+    assert int(g['stft256_short_raises']) == 1
+    # batched call == per-signal calls
+    xs = np.random.RandomState(4).randn(3, 1000).astype(np.float32)
+    Xb = ops.stft(cu(xs), cu(w256), 256, 64).cpu().numpy()
+    for i in range(3):
+        assert relerr(Xb[i], O.stft(xs[i], w256, 256, 64)) < 1e-5
+
+
+def test_stft_512_long_utterance_golden():
+    from danet_amd import ops
+    g = np.load(GOLD)
+    w = O.fft_window(512)
+    assert np.array_equal(w.view(np.uint32), g['wnd512_bits'])
+    x = np.random.RandomState(0).randn(160000).astype(np.float32)
+    X = ops.stft(cu(x), cu(w), 512, 128)
+    assert tuple(X.shape) == tuple(g['stft512_L160000_shape']) == (1251, 257)
+    Xn = X.cpu().numpy()
+    scale = np.abs(Xn).max()
+    assert np.abs(Xn[:2] - g['stft512_L160000_head']).max() / scale < 1e-5
+    assert np.abs(Xn[-2:] - g['stft512_L160000_tail']).max() / scale < 1e-5
+    assert np.abs(Xn[600:602] - g['stft512_L160000_mid']).max() / scale < 1e-5
+    assert abs(np.abs(Xn.astype(np.complex128)).sum() - g['stft512_L160000_abs_sum']) \
+        < 1e-5 * g['stft512_L160000_abs_sum']
+    y = ops.istft(X, 128, cu(w)).cpu().numpy()
+    assert len(y) == int(g['istft512_L160000_len'])
+    sc = np.abs(g['istft512_L160000_head']).max()
+    assert np.abs(y[:1024] - g['istft512_L160000_head']).max() / sc < 1e-5
+    assert np.abs(y[-1024:] - g['istft512_L160000_tail']).max() / sc < 1e-5
+    assert abs(np.abs(y).sum() - g['istft512_L160000_abs_sum']) < 1e-5 * g['istft512_L160000_abs_sum']
+
+
+def test_istft_against_reference_golden():
+    from danet_amd import ops
+    g = np.load(GOLD)
+    w = O.fft_window(256)
+    for L in (256, 257, 320, 8000, 8064):                                    # G3
+        X = g['stft256_L%d' % L]
+        ref = g['istft256_L%d' % L]
+        y = ops.istft(torch.as_tensor(X).cuda(), 64, cu(w)).cpu().numpy()
+        assert y.shape == ref.shape and y.dtype == np.float64
+        assert np.abs(y - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-30)
+        # frame truncation: the tail the reference never writes stays exactly 0
+        used = O.istft_num_frames_used(X.shape[0], 256, 64)
+        assert np.all(y[(used - 1) * 64 + 256:] == 0) if used > 0 else np.all(y == 0)
+
+
+def test_stft_istft_round_trip_property():
+    '''size-independent property: istft(stft(x)) * sum(w) == x on the samples
+    the reference's istft covers with full window overlap'''
+    from danet_amd import ops
+    w = O.fft_window(256)
+    x = np.random.RandomState(9).randn(4, 40000).astype(np.float32)
+    X = ops.stft(cu(x), cu(w), 256, 64)
+    y = ops.istft(X, 64, cu(w)).cpu().numpy() * float(w.astype(np.float64).sum())
+    # stft sample i sits at extended index i+128; covered region: full overlap
+    T = X.shape[1]
+    used = O.istft_num_frames_used(T, 256, 64)
+    lo, hi = 256, (used - 1) * 64
+    assert np.abs(y[:, lo:hi] - x[:, lo - 128:hi - 128]).max() < 2e-4 * np.abs(x).max()
+
+
+# --------------------------------------------------------------- whole model
+def _model_case(hp, cfg, B, C, T, seed=0):
+    from danet_amd.model import Model
+    hp.load(dict(BATCH_SIZE=B, MAX_N_SIGNAL=C, FFT_SIZE=cfg['FFT'], FFT_STRIDE=cfg['FFT'] // 4,
+                 EMBED_SIZE=cfg['E'], NUM_LSTM_LAYERS=cfg['L'], LSTM_HDIM=cfg['H'],
+                 NUM_ANCHOR=cfg['A'], ENCODER_TYPE=cfg.get('encoder', 'bilstm-orig'),
+                 TRAIN_ESTIMATOR_METHOD=cfg['train_est'],
+                 INFER_ESTIMATOR_METHOD=cfg['infer_est'], SEPARATOR_TYPE=cfg['separator']))
+    hp.digest()
+    F = hp.FEATURE_SIZE
+    rng = np.random.RandomState(seed)
+    src = ((rng.randn(B, C, T, F) + 1j * rng.randn(B, C, T, F)) * 6).astype(np.complex64)
+    model = Model('t', device='cuda').build()
+    return model, src
+
+
+@pytest.mark.parametrize('train_est,sepn', [('truth-weighted', 'dot-sigmoid-orig'),
+                                            ('anchor', 'dot-softmax-orig'),
+                                            ('truth', 'dot-softmax-orig'),
+                                            ('truth-threshold', 'dot-sigmoid-orig')])
+def test_model_forward_backward_tiny(hp, train_est, sepn):
+    '''G5-style: every debug_fetches intermediate + loss/SNR/perm + all
+    parameter gradients vs the oracle at B=2,C=2,T=8,F=5,E=3,H=4,L=2,A=4'''
+    cfg = dict(FFT=8, H=4, L=2, E=3, C=2, A=4, train_est=train_est, infer_est='anchor',
+               separator=sepn, with_valid=True)
+    model, src = _model_case(hp, cfg, B=2, C=2, T=8)
+    params = model.param_dict()
+    model._flat_grad.zero_()
+    out = model.forward(torch.as_tensor(src).cuda(), with_valid=True)
+    out['loss'].backward()
+    ref = O.model_forward(src.astype(np.complex128), params, cfg)
+    for k in ('embed', 'attrs', 'sep_pwr', 'valid_attrs', 'sep_pwr_valid'):
+        assert relerr(out[k].detach().cpu().numpy(), ref[k]) < TOL, k
+    for k in ('loss', 'SNR', 'valid_loss', 'valid_SNR'):
+        assert relerr(float(out[k]), ref[k]) < TOL, k
+    assert np.array_equal(out['perm_idx'].cpu().numpy(), ref['perm_idx'])
+    assert np.array_equal(out['valid_perm_idx'].cpu().numpy(), ref['valid_perm_idx'])
+    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params.items()}
+    r = R.model_forward(torch.tensor(src.astype(np.complex128)), tp, cfg)
+    r['loss'].backward()
+    g = model.grad_dict()
+    for k in params:
+        if tp[k].grad is None:
+            assert np.all(g[k] == 0), k                    # e.g. unused infer anchors
+        else:
+            assert relerr(g[k], tp[k].grad.numpy()) < 2 * TOL, k
+
+
+def test_model_cfg1_toy_data(hp):
+    '''BASELINE cfg 1: toy white-noise batch (reference generator), B=4, C=2,
+    F=129, 1-layer BiLSTM H=300, truth-weighted + anchor, softmax separator'''
+    cfg = dict(FFT=256, H=300, L=1, E=20, C=2, A=6, train_est='truth-weighted',
+               infer_est='anchor', separator='dot-softmax-orig', with_valid=True)
+    model, _ = _model_case(hp, cfg, B=4, C=2, T=4)
+    src = O.toy_batch(np.random.RandomState(1337), 4, 2, hp.FEATURE_SIZE, T=128)
+    params = model.param_dict()
+    model._flat_grad.zero_()
+    out = model.forward(torch.as_tensor(src).cuda(), with_valid=True)
+    out['loss'].backward()
+    ref = O.model_forward(src.astype(np.complex128), params, cfg)
+    for k in ('embed', 'attrs', 'sep_pwr', 'sep_pwr_valid'):
+        assert relerr(out[k].detach().cpu().numpy(), ref[k]) < TOL, k
+    for k in ('loss', 'SNR', 'valid_loss', 'valid_SNR'):
+        assert relerr(float(out[k]), ref[k]) < TOL, k
+    assert np.array_equal(out['valid_perm_idx'].cpu().numpy(), ref['valid_perm_idx'])
+    mask_mse = float(np.mean((out['sep_pwr'].detach().cpu().numpy() - ref['sep_pwr']) ** 2))
+    assert mask_mse < 1e-8 * float(np.mean(ref['sep_pwr'] ** 2)) + 1e-12
+
+
+def test_train_step_matches_tf_adam(hp):
+    '''two optimiser steps == oracle TF1-Adam (eps outside the root) + clip'''
+    cfg = dict(FFT=8, H=4, L=1, E=3, C=2, A=4, train_est='truth-weighted', infer_est='anchor',
+               separator='dot-sigmoid-orig')
+    model, src = _model_case(hp, cfg, B=2, C=2, T=6)
+    p0 = model.param_dict()
+    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p0.items()}
+    m = {k: torch.zeros_like(v) for k, v in tp.items()}
+    v = {k: torch.zeros_like(v_) for k, v_ in tp.items()}
+    for t in (1, 2):
+        model.train_step(torch.as_tensor(src).cuda())
+        for k in tp:
+            tp[k].grad = None
+        R.model_forward(torch.tensor(src.astype(np.complex128)), tp, cfg)['loss'].backward()
+        R.tf_adam_step_(tp, {k: tp[k].grad for k in tp}, m, v, t, hp.LR, clip=hp.GRAD_CLIP_THRES)
+    p2 = model.param_dict()
+    for k in p0:
+        moved = np.abs(tp[k].detach().numpy() - p0[k]).max()
+        assert np.abs(p2[k] - tp[k].detach().numpy()).max() <= 2e-3 * moved + 1e-7, k
+
+
+def test_lstm_orig_encoder_and_lyr_lstm_api(hp):
+    '''unidirectional `lstm-orig` plugin and the Model.lyr_lstm entry point'''
+    cfg = dict(FFT=8, H=8, L=2, E=3, C=2, A=4, train_est='truth-weighted', infer_est='anchor',
+               separator='dot-sigmoid-orig', encoder='lstm-orig')
+    model, src = _model_case(hp, cfg, B=2, C=2, T=7)
+    params = model.param_dict()
+    out = model.forward(torch.as_tensor(src).cuda())
+    ref = O.model_forward(src.astype(np.complex128), params, cfg)
+    assert relerr(out['embed'].detach().cpu().numpy(), ref['embed']) < TOL
+    assert relerr(float(out['loss']), ref['loss']) < TOL
+
+
+def test_infer_and_debug_fetches(hp):
+    cfg = dict(FFT=8, H=4, L=1, E=3, C=2, A=4, train_est='truth-weighted', infer_est='anchor',
+               separator='dot-softmax-orig')
+    hp.load(dict(DEBUG=True))
+    model, src = _model_case(hp, cfg, B=2, C=2, T=8)
+    params = model.param_dict()
+    mix = src.sum(axis=1)
+    got = model.infer(torch.as_tensor(mix).cuda()).cpu().numpy()
+    ref = O.model_forward(src.astype(np.complex128), params, dict(cfg, with_valid=True))
+    assert relerr(got, ref['signals_infer']) < TOL
+    dbg = model.debug_fetch(torch.as_tensor(src).cuda())
+    assert relerr(dbg['output'].cpu().numpy(), ref['output']) < TOL
+    assert relerr(dbg['masks'].cpu().numpy(), ref['masks']) < TOL
