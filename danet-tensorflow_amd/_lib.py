@@ -128,3 +128,46 @@ def workspace(nbytes, device):
         t = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws[key] = t
     return t
+
+
+# ---- optional per-kernel timing (HIP events on the launch stream) ------------
+_prof = None
+
+
+def profile_start():
+    global _prof
+    _prof = {}
+
+
+def profile_stop():
+    '''-> {label: (n_launches, total_ms)}; synchronises'''
+    global _prof
+    p, _prof = _prof, None
+    torch.cuda.synchronize()
+    out = {}
+    for label, evs in (p or {}).items():
+        out[label] = (len(evs), sum(a.elapsed_time(b) for a, b in evs))
+    return out
+
+
+class timed(object):
+    '''with timed('label'): <one library call>  -- records a start/end event pair
+    on the current stream (the stream the kernels are launched on) when
+    profiling is enabled; free otherwise.'''
+    __slots__ = ('label', 'a')
+
+    def __init__(self, label):
+        self.label = label
+
+    def __enter__(self):
+        if _prof is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _prof is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            _prof.setdefault(self.label, []).append((self.a, b))
+        return False

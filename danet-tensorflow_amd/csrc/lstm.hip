@@ -35,6 +35,18 @@
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
+// NB: the b128 buffer-load builtin must be assigned to a GCC-style
+// __vector_size__ vector; assigning it to an ext_vector_type silently lowers to
+// a single-dword load (hipcc 7.2).
+typedef unsigned v4u __attribute__((__vector_size__(16)));
+
+// 16-B L1-bypassing (sc1) load through a buffer descriptor; out-of-range
+// offsets return 0.
+__device__ __forceinline__ f32x4 load_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16 /*sc1*/);
+  return __builtin_bit_cast(f32x4, v);
+}
+
 struct LstmFwdArgs {
   const float* gx[2];
   const float* Wh[2];
@@ -82,6 +94,9 @@ __device__ __forceinline__ void wait_flags(unsigned* flags, int n, unsigned targ
       }
     }
   }
+  // relaxed polls order nothing at the language level: keep the payload loads
+  // below the poll loop (the hardware issues loads in order)
+  asm volatile("" ::: "memory");
 }
 
 // ---------------------------------------------------------------------------
@@ -152,14 +167,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
 
     for (int kg = wave; kg < NG; kg += 4) {
       const int k = kg * 16 + fq * 4;
-      u32x4 av[MT];
+      f32x4 av[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int row = b0 + mt * 16 + fr;
         unsigned off = ybytes;  // == num_records: out of range -> load returns 0
         if (row < B && k < H)
           off = (unsigned)((((size_t)blk_prev * B + row) * a.ldy + dir * H + k) * 4);
-        av[mt] = __builtin_amdgcn_raw_buffer_load_b128(yres, off, 0, 16 /*sc1*/);
+        av[mt] = load_sc1_b128(yres, off);
       }
       const f32x4 w0 = *reinterpret_cast<const f32x4*>(&Wl[(((k >> 2)) * 32 + fr) * 4]);
       const f32x4 w1 = *reinterpret_cast<const f32x4*>(&Wl[(((k >> 2)) * 32 + 16 + fr) * 4]);
@@ -167,7 +182,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const float av_j = __builtin_bit_cast(float, av[mt][j]);
+          const float av_j = av[mt][j];
           acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_j, w0[j], acc[mt][0], 0, 0, 0);
           acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_j, w1[j], acc[mt][1], 0, 0, 0);
         }
@@ -291,13 +306,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
       wait_flags(myflags, a.P, (unsigned)s, a.status, lane);
       for (int kg = wave; kg < NG; kg += 4) {
         const int n = kg * 16 + fq * 4;
-        u32x4 av[MT];
+        f32x4 av[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const int row = b0 + mt * 16 + fr;
           unsigned off = dbytes;  // == num_records: out of range -> 0
           if (row < B) off = (unsigned)((((size_t)t_done * B + row) * H4 + n) * 4);
-          av[mt] = __builtin_amdgcn_raw_buffer_load_b128(dres, off, 0, 16 /*sc1*/);
+          av[mt] = load_sc1_b128(dres, off);
         }
         const f32x4 w = *reinterpret_cast<const f32x4*>(&Wl[((n >> 2) * 16 + fr) * 4]);
 #pragma unroll
@@ -305,7 +320,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
             acc[mt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                __builtin_bit_cast(float, av[mt][j]), w[j], acc[mt][j & 1], 0, 0, 0);
+                av[mt][j], w[j], acc[mt][j & 1], 0, 0, 0);
       }
     }
 

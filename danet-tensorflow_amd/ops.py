@@ -40,9 +40,10 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None,
     L = _L()
     need = L.danet_gemm_f32_workspace_bytes(M, N, K)
     w, wn = _ws(need, C.device)
-    check(L.danet_gemm_f32(_lib.stream(), int(transA), int(transB), M, N, K,
-                           ptr(_f32(A)), lda, ptr(_f32(B)), ldb, ptr(_f32(C)), ldc,
-                           ptr(bias), float(beta), ptr(w), wn))
+    with _lib.timed('gemm_f32'):
+        check(L.danet_gemm_f32(_lib.stream(), int(transA), int(transB), M, N, K,
+                               ptr(_f32(A)), lda, ptr(_f32(B)), ldb, ptr(_f32(C)), ldc,
+                               ptr(bias), float(beta), ptr(w), wn))
     return C
 
 
@@ -188,10 +189,11 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs):
     ws, wn = _lstm_ws(T, B, H, ndir, dev)
     Whs = [W[D:] for W in Ws]
     L = _L()
-    check(L.danet_lstm_fwd(
-        _lib.stream(), T, B, H, ndir, ptr(gates[0]), ptr(gates[-1]),
-        ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(ypad), ndir * H,
-        ptr(gates[0]), ptr(gates[-1]), ptr(cells[0]), ptr(cells[-1]), ptr(ws), wn))
+    with _lib.timed('lstm_fwd'):
+        check(L.danet_lstm_fwd(
+            _lib.stream(), T, B, H, ndir, ptr(gates[0]), ptr(gates[-1]),
+            ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(ypad), ndir * H,
+            ptr(gates[0]), ptr(gates[-1]), ptr(cells[0]), ptr(cells[-1]), ptr(ws), wn))
     c = _LayerCtx()
     c.x, c.ldx, c.D, c.T, c.B, c.H, c.ndir = x, ldx, D, T, B, H, ndir
     c.ypad, c.gates, c.cells, c.Ws = ypad, gates, cells, Ws
@@ -208,10 +210,11 @@ def lstm_layer_bwd(c, dy, need_dx):
     ws, wn = _lstm_ws(T, B, H, ndir, dev)
     Whs = [W[D:] for W in c.Ws]
     L = _L()
-    check(L.danet_lstm_bwd(
-        _lib.stream(), T, B, H, ndir, ptr(_f32(dy)), ndir * H,
-        ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(c.gates[0]), ptr(c.gates[-1]),
-        ptr(c.cells[0]), ptr(c.cells[-1]), ptr(das[0]), ptr(das[-1]), ptr(ws), wn))
+    with _lib.timed('lstm_bwd'):
+        check(L.danet_lstm_bwd(
+            _lib.stream(), T, B, H, ndir, ptr(_f32(dy)), ndir * H,
+            ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(c.gates[0]), ptr(c.gates[-1]),
+            ptr(c.cells[0]), ptr(c.cells[-1]), ptr(das[0]), ptr(das[-1]), ptr(ws), wn))
     _pending_status.append(ws[:4].view(torch.int32))
     dWs, dbs = [], []
     ldy = ndir * H
