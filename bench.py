@@ -65,7 +65,8 @@ def cpu_baseline(hp, params_np, sample_b, n_steps=3):
     from oracle import torch_ref as R
     from danet_amd import datasets
     from oracle import danet_oracle as O
-    cores = os.cpu_count() or 1
+    # tiny per-timestep matmuls stop scaling (and thrash) beyond a few threads
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     C, T = hp.MAX_N_SIGNAL, hp.MAX_TRAIN_LEN
     waves = datasets.synth_waves(4242, sample_b * C, T)
@@ -78,6 +79,7 @@ def cpu_baseline(hp, params_np, sample_b, n_steps=3):
     m = {k: torch.zeros_like(v) for k, v in tp.items()}
     v = {k: torch.zeros_like(x) for k, x in tp.items()}
     times = []
+    budget_s, t_start = 20.0, time.time()
     for t in range(1, n_steps + 2):
         t0 = time.time()
         for k in tp:
@@ -85,6 +87,10 @@ def cpu_baseline(hp, params_np, sample_b, n_steps=3):
         R.model_forward(src, tp, cfg)['loss'].backward()
         R.tf_adam_step_(tp, {k: tp[k].grad for k in tp}, m, v, t, hp.LR, clip=hp.GRAD_CLIP_THRES)
         times.append(time.time() - t0)
+        print('[bench] cpu_baseline step %d: %.2f s' % (t, times[-1]), file=sys.stderr, flush=True)
+        if len(times) >= 2 and time.time() - t_start > budget_s:
+            break
+    n_steps = len(times) - 1
     dt = float(np.mean(times[1:]))
     mix_s = sample_b * T * hp.FFT_STRIDE / hp.SMPRATE
     return dict(value=mix_s / dt, unit='mixture-seconds/s', cores=cores, kind='port',
@@ -139,6 +145,8 @@ def main():
     hp = setup_hparams(args)
     batches = make_batches(hp, rank, 4, device)
     model = Model('bench', device=device, seed=1337).build()
+    log = lambda *a: print('[bench r%d]' % rank, *a, file=sys.stderr, flush=True)
+    log('built: %d params' % model.parameter_count())
 
     def barrier():
         torch.cuda.synchronize()
@@ -149,6 +157,7 @@ def main():
     for i in range(args.warmup):
         model.train_step(batches[i % len(batches)])
     barrier()
+    log('warmup done')
     _lib.profile_start()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -157,6 +166,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = _lib.profile_stop()
     ok = ops.lstm_status_ok()
+    log('timed region: %.3f s for %d steps; lstm status ok=%s' % (dt, args.steps, ok))
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -193,7 +203,9 @@ def main():
                                grad_allreduce_bytes=int(model._flat_grad.numel() * 4)),
                    roofline=roofline, kernels=kern)
         if world == 1:
+            torch.set_num_threads(min(os.cpu_count() or 1, 16))
             mse, mx = mask_mse_vs_oracle(hp, model, batches[0])
+            log('mask mse vs oracle %.3e (max abs %.3e)' % (mse, mx))
             res['mask_mse_vs_oracle'] = mse
             res['mask_max_abs_err_vs_oracle'] = mx
             if not args.no_cpu_baseline:
