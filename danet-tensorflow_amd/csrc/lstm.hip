@@ -10,28 +10,37 @@
 // 4 gate columns of its 8 hidden units stationary in LDS for the whole
 // sequence ([K/4][32][4] layout -> one conflict-free ds_read_b128 feeds four
 // v_mfma_f32_16x16x4_f32), holds the cell state of its (batch row, unit)
-// pairs in registers, and per step only all-gathers h_{t-1} (B x H fp32) from
-// the other workgroups of its direction through the layer's own output buffer
-// (each step writes a distinct row block, so there is no WAR hazard and no
-// extra exchange buffer).  A fragments come straight from global memory with
-// 16-B sc1 (L1-bypassing) loads: lane (r,q) loads h[r][k0+4q..k0+4q+3] and
-// the j-th MFMA of the group pairs element j with weight row k0+4q+j -- a
-// permutation of the contraction index that both operands share, so no LDS
-// staging or shuffles are needed.  K is split over the 4 waves (one per
-// SIMD); partial tiles are reduced through LDS.
+// pairs in registers, and per step only all-gathers h_{t-1} from the other
+// workgroups of its cluster through the layer's own output buffer.  Batch rows
+// are independent recurrences, so they are split into clusters (dir, g) of
+// 16*MT rows that never synchronise with each other.  A fragments come
+// straight from global memory with 16-B sc1 (L1-bypassing) loads: lane (r,q)
+// loads h[r][k0+4q..k0+4q+3] and the j-th MFMA of the group pairs element j
+// with weight row k0+4q+j -- a permutation of the contraction index that both
+// operands share, so no LDS staging or shuffles are needed.  K is split over
+// the 4 waves (one per SIMD); partial tiles are reduced through LDS.  BPTT is
+// the mirror image: stationary Wh^T slice, all-gather of da_{t+-1}.
 //
-// Inter-workgroup hand-off (MI355X_MICROARCH "visibility", guide G16 R1):
-// payload stored write-through (sc1), every storing wave drains vmcnt(0),
-// __syncthreads, ONE lane stores the per-producer step flag (relaxed, agent
-// scope); consumers poll the flag words relaxed (sc1) and read the payload with
-// sc1 loads -- placement-independent, no per-step cache invalidate.  Flags are
-// zeroed by a memset node before every launch; every spin is bounded and a
-// timeout sets the status word instead of hanging.
+// Inter-workgroup hand-off: THE PAYLOAD IS THE FLAG.  Every exchanged word
+// (h_t[b][j] / da_t[b][n]) is written exactly ONCE per launch, to its own
+// address.  The host call pre-fills the exchange buffer with the bit pattern
+// 0xFFFFFFFF (a NaN no arithmetic here produces: hardware NaNs are canonical
+// 0x7FC00000), producers publish with 4-byte write-through (sc1) stores, and
+// consumers simply re-issue their sc1 fragment loads until no word equals the
+// sentinel.  Each 4-byte word validates itself, so nothing depends on store
+// ordering, dispatch order or XCD placement (guide G16, form R2 "the data IS
+// the flag"), and the step pays one store->load latency instead of
+// drain + barrier + flag + poll + load.  Every spin is bounded; a timeout sets
+// the status word (ws word 0) instead of hanging.
 #include "common.h"
+#include <stdlib.h>
 
 #define LSTM_UNITS_FWD 8    // hidden units per workgroup (x4 gates = 32 columns)
 #define LSTM_UNITS_BWD 16   // hidden units per workgroup in BPTT
-#define SPIN_LIMIT (1u << 21)
+#define SPIN_LIMIT (1u << 20)
+#define FWD_CH 5            // k-groups (16 k each) per wave whose loads fly together
+#define BWD_CH 19
+#define SENTINEL 0xFFFFFFFFu
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
@@ -41,10 +50,12 @@
 typedef unsigned v4u __attribute__((__vector_size__(16)));
 
 // 16-B L1-bypassing (sc1) load through a buffer descriptor; out-of-range
-// offsets return 0.
-__device__ __forceinline__ f32x4 load_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned off) {
-  const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16 /*sc1*/);
-  return __builtin_bit_cast(f32x4, v);
+// offsets return 0 (which is != SENTINEL, i.e. "valid").
+__device__ __forceinline__ v4u load_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16 /*sc1*/);
+}
+__device__ __forceinline__ bool has_sentinel(v4u v) {
+  return v[0] == SENTINEL || v[1] == SENTINEL || v[2] == SENTINEL || v[3] == SENTINEL;
 }
 
 struct LstmFwdArgs {
@@ -53,7 +64,6 @@ struct LstmFwdArgs {
   float* gates[2];
   float* cell[2];
   float* ypad;
-  unsigned* flags;  // [ndir][G][P]
   int* status;
   int T, B, H, ndir, ldy, ldw, P, G, KP;  // KP = H padded to 16
 };
@@ -64,7 +74,6 @@ struct LstmBwdArgs {
   const float* gates[2];
   const float* cell[2];
   float* da[2];
-  unsigned* flags;
   int* status;
   int T, B, H, ndir, lddy, ldw, P, G;
 };
@@ -73,30 +82,22 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
-// wait until all `n` producer flags are >= target (wave-level; every wave of
-// the block polls for itself so no block barrier is needed on the wait side)
-__device__ __forceinline__ void wait_flags(unsigned* flags, int n, unsigned target,
-                                           int* status, int lane) {
-  unsigned spins = 0;
-  for (;;) {
-    bool ok = true;
-    for (int i = lane; i < n; i += 64)
-      ok &= (__hip_atomic_load(flags + i, RLX_AGENT) >= target);
-    if (__all(ok)) break;
-    __builtin_amdgcn_s_sleep(1);
-    ++spins;
-    if ((spins & 1023u) == 0) {
-      // another workgroup already gave up -> do not wait either
-      if (__hip_atomic_load(status, RLX_AGENT) != 0) break;
-      if (spins >= SPIN_LIMIT) {
-        if (lane == 0) __hip_atomic_store(status, 1, RLX_AGENT);
-        break;
-      }
+// one failed validation pass: back off, and give up (once, for everybody) when
+// the bound is hit.  Returns true when the caller must stop waiting.
+__device__ __forceinline__ bool spin_fail(unsigned& spins, int* status, int lane) {
+  // the fragment loads are ordinary (non-volatile) reads to the compiler: this
+  // clobber is what forces them to be re-issued on the next pass
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_sleep(2);
+  ++spins;
+  if ((spins & 255u) == 0) {
+    if (__hip_atomic_load(status, RLX_AGENT) != 0) return true;   // someone gave up
+    if (spins >= SPIN_LIMIT) {
+      if (lane == 0) __hip_atomic_store(status, 1, RLX_AGENT);
+      return true;
     }
   }
-  // relaxed polls order nothing at the language level: keep the payload loads
-  // below the poll loop (the hardware issues loads in order)
-  asm volatile("" ::: "memory");
+  return false;
 }
 
 // ---------------------------------------------------------------------------
@@ -133,7 +134,6 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
 
   const unsigned ybytes = (unsigned)((size_t)(T + 2) * B * a.ldy * sizeof(float));
   const __amdgpu_buffer_rsrc_t yres = make_rsrc(a.ypad, ybytes);
-  unsigned* myflags = a.flags + (size_t)(dir * a.G + grp) * a.P;
 
   // gate-math ownership: thread -> (batch row bl, unit u)
   const int bl = tid >> 3, ul = tid & 7;
@@ -157,34 +157,61 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
       for (int gte = 0; gte < 4; ++gte) gxv[gte] = gp[gte * H];
     }
 
-    if (s > 0) wait_flags(myflags, a.P, (unsigned)s, a.status, lane);
-
     f32x4 acc[MT][2];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int kg = wave; kg < NG; kg += 4) {
-      const int k = kg * 16 + fq * 4;
-      f32x4 av[MT];
+    // step 0 multiplies the zero initial state (main.py:108-123): skip it.
+    // This wave's k-groups are wave, wave+4, ...; all of a chunk's 16-B loads
+    // are issued together and re-issued until every word has been published.
+    if (s > 0) {
+      for (int g0 = 0; g0 * 4 + wave < NG; g0 += FWD_CH) {
+        v4u av[FWD_CH][MT];
+        unsigned spins = 0;
+        for (;;) {
+          bool ok = true;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int row = b0 + mt * 16 + fr;
-        unsigned off = ybytes;  // == num_records: out of range -> load returns 0
-        if (row < B && k < H)
-          off = (unsigned)((((size_t)blk_prev * B + row) * a.ldy + dir * H + k) * 4);
-        av[mt] = load_sc1_b128(yres, off);
-      }
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(&Wl[(((k >> 2)) * 32 + fr) * 4]);
-      const f32x4 w1 = *reinterpret_cast<const f32x4*>(&Wl[(((k >> 2)) * 32 + 16 + fr) * 4]);
+          for (int g = 0; g < FWD_CH; ++g) {
+            const int k = ((g0 + g) * 4 + wave) * 16 + fq * 4;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+            for (int mt = 0; mt < MT; ++mt) {
+              const int row = b0 + mt * 16 + fr;
+              unsigned off = ybytes;  // == num_records: out of range -> 0 (valid)
+              if (row < B && k < H)
+                off = (unsigned)((((size_t)blk_prev * B + row) * a.ldy + dir * H + k) * 4);
+              av[g][mt] = load_sc1_b128(yres, off);
+            }
+          }
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const float av_j = av[mt][j];
-          acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_j, w0[j], acc[mt][0], 0, 0, 0);
-          acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_j, w1[j], acc[mt][1], 0, 0, 0);
+          for (int g = 0; g < FWD_CH; ++g)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) ok &= !has_sentinel(av[g][mt]);
+          if (__all(ok)) break;
+          if (spin_fail(spins, a.status, lane)) break;
+        }
+#pragma unroll
+        for (int g = 0; g < FWD_CH; ++g) {
+          const int kg = (g0 + g) * 4 + wave;
+          if (kg < NG) {   // wave-uniform
+            const int k4 = kg * 4 + fq;
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + fr) * 4]);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + 16 + fr) * 4]);
+            // NB: bit_cast the WHOLE vector -- __builtin_bit_cast(float, vec[j])
+            // on a vector element reads element 0 for every j (hipcc 7.2)
+            f32x4 af[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = __builtin_bit_cast(f32x4, av[g][mt]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) {
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], w0[j], acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], w1[j], acc[mt][1], 0, 0, 0);
+              }
+            }
+          }
         }
       }
     }
@@ -214,16 +241,19 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
       const float og = sigmoid_acc(pre[3]);
       c_state = ig * g + fg * c_state;        // ops.py:146
       const float h = og * tanhf(c_state);    // ops.py:147
-      // exchange payload: write-through store of h_t
+      // publish h_t: one write-through 4-byte store, no drain, no flag
       __hip_atomic_store(a.ypad + ((size_t)(t + 1) * B + bg) * a.ldy + dir * H + unit,
                          h, RLX_AGENT);
+      // saved activations are only read by later kernels (plain stores)
       float* gs = a.gates[dir] + ((size_t)t * B + bg) * (4 * H) + unit;
       gs[0] = g; gs[H] = ig; gs[2 * H] = fg; gs[3 * H] = og;
       a.cell[dir][((size_t)t * B + bg) * H + unit] = c_state;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains
-    __syncthreads();                                    // also protects `red`
-    if (tid == 0) __hip_atomic_store(myflags + p, (unsigned)(s + 1), RLX_AGENT);
+    // `red` is rewritten only after this wave has seen every h_t word of its
+    // cluster, i.e. after every owner thread (in every wave) has finished
+    // reading `red` for this step -- but waves without owners never publish,
+    // so a block barrier keeps the reuse safe in all shapes.
+    __syncthreads();
   }
 }
 
@@ -260,7 +290,6 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
 
   const unsigned dbytes = (unsigned)((size_t)T * B * H4 * sizeof(float));
   const __amdgpu_buffer_rsrc_t dres = make_rsrc(a.da[dir], dbytes);
-  unsigned* myflags = a.flags + (size_t)(dir * a.G + grp) * a.P;
 
   // ownership: thread -> pairs (bl = tid/16 + 16*i, unit j = tid%16), i < MT
   const int jl = tid & 15, unit = u0 + jl;
@@ -303,24 +332,46 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
     }
 
     if (s > 0) {
-      wait_flags(myflags, a.P, (unsigned)s, a.status, lane);
-      for (int kg = wave; kg < NG; kg += 4) {
-        const int n = kg * 16 + fq * 4;
-        f32x4 av[MT];
+      for (int g0 = 0; g0 * 4 + wave < NG; g0 += BWD_CH) {
+        v4u av[BWD_CH][MT];
+        unsigned spins = 0;
+        for (;;) {
+          bool ok = true;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const int row = b0 + mt * 16 + fr;
-          unsigned off = dbytes;  // == num_records: out of range -> 0
-          if (row < B) off = (unsigned)((((size_t)t_done * B + row) * H4 + n) * 4);
-          av[mt] = load_sc1_b128(dres, off);
+          for (int g = 0; g < BWD_CH; ++g) {
+            const int kg = (g0 + g) * 4 + wave;
+            const int n = kg * 16 + fq * 4;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              const int row = b0 + mt * 16 + fr;
+              unsigned off = dbytes;  // == num_records: out of range -> 0 (valid)
+              if (row < B && kg < NG) off = (unsigned)((((size_t)t_done * B + row) * H4 + n) * 4);
+              av[g][mt] = load_sc1_b128(dres, off);
+            }
+          }
+#pragma unroll
+          for (int g = 0; g < BWD_CH; ++g)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) ok &= !has_sentinel(av[g][mt]);
+          if (__all(ok)) break;
+          if (spin_fail(spins, a.status, lane)) break;
         }
-        const f32x4 w = *reinterpret_cast<const f32x4*>(&Wl[((n >> 2) * 16 + fr) * 4]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int g = 0; g < BWD_CH; ++g) {
+          const int kg = (g0 + g) * 4 + wave;
+          if (kg < NG) {   // wave-uniform
+            const f32x4 w = *reinterpret_cast<const f32x4*>(&Wl[((kg * 4 + fq) * 16 + fr) * 4]);
+            f32x4 af[MT];   // whole-vector bit_cast (see forward kernel)
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            acc[mt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                av[mt][j], w[j], acc[mt][j & 1], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) af[mt] = __builtin_bit_cast(f32x4, av[g][mt]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt)
+                acc[mt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                    af[mt][j], w[j], acc[mt][j & 1], 0, 0, 0);
+          }
+        }
       }
     }
 
@@ -346,42 +397,42 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
       const float da_f = dc * cpv[i] * fg * (1.f - fg);
       const float da_o = dh * tc * og * (1.f - og);
       dc_state[i] = dc * fg;
+      // publish da_t (also the kernel's output): write-through 4-byte stores
       float* dp = a.da[dir] + ((size_t)t * B + bg) * H4 + unit;
       __hip_atomic_store(dp, da_g, RLX_AGENT);
       __hip_atomic_store(dp + H, da_i, RLX_AGENT);
       __hip_atomic_store(dp + 2 * H, da_f, RLX_AGENT);
       __hip_atomic_store(dp + 3 * H, da_o, RLX_AGENT);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(myflags + p, (unsigned)(s + 1), RLX_AGENT);
+    __syncthreads();   // `red` reuse (see forward kernel)
   }
 }
 
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-struct LstmPlan { int MT, G, Pf, Pb, KP; size_t lds_f, lds_b; };
+struct LstmPlan { int MT, G, P, KP; size_t lds; };
 
-static LstmPlan make_plan(int B, int H) {
+// MT=1 (16-row clusters) halves the per-step MFMA time and the payload per
+// workgroup at the price of twice the workgroups; it is used whenever one
+// workgroup per CU still fits.  DANET_LSTM_FWD_MT / DANET_LSTM_BWD_MT = 1|2
+// override the choice (A/B experiments).
+static LstmPlan make_plan(int B, int H, int ndir, bool bwd) {
   LstmPlan pl;
-  pl.MT = (B <= 16) ? 1 : 2;
-  pl.G = cdiv(B, 16 * pl.MT);
-  pl.Pf = cdiv(H, LSTM_UNITS_FWD);
-  pl.Pb = cdiv(H, LSTM_UNITS_BWD);
+  pl.P = cdiv(H, bwd ? LSTM_UNITS_BWD : LSTM_UNITS_FWD);
   pl.KP = cdiv(H, 16) * 16;
-  pl.lds_f = ((size_t)pl.KP * 32 + (size_t)4 * 16 * pl.MT * 33) * sizeof(float);
-  pl.lds_b = ((size_t)4 * H * 16 + (size_t)4 * 16 * pl.MT * 17) * sizeof(float);
+  pl.MT = (ndir * cdiv(B, 16) * pl.P > 256) ? 2 : 1;
+  const char* force = getenv(bwd ? "DANET_LSTM_BWD_MT" : "DANET_LSTM_FWD_MT");
+  if (force && (force[0] == '1' || force[0] == '2')) pl.MT = force[0] - '0';
+  pl.G = cdiv(B, 16 * pl.MT);
+  pl.lds = bwd ? ((size_t)4 * H * 16 + (size_t)4 * 16 * pl.MT * 17) * sizeof(float)
+               : ((size_t)pl.KP * 32 + (size_t)4 * 16 * pl.MT * 33) * sizeof(float);
   return pl;
 }
 
-#define LSTM_FLAG_OFFSET 64  // bytes; word 0 of ws is the status
-
 extern "C" size_t danet_lstm_workspace_bytes(int T, int B, int H, int ndir) {
-  (void)T;
-  LstmPlan pl = make_plan(B, H);
-  const int pmax = pl.Pf > pl.Pb ? pl.Pf : pl.Pb;
-  return LSTM_FLAG_OFFSET + align_up((size_t)ndir * pl.G * pmax * sizeof(unsigned), 64);
+  (void)T; (void)B; (void)H; (void)ndir;
+  return 64;   // status word (+ padding)
 }
 
 static int lstm_check_common(int T, int B, int H, int ndir, void* ws, size_t ws_bytes) {
@@ -411,12 +462,12 @@ extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int n
   DANET_CHECK_ARG(ldy >= ndir * H && ldy % 4 == 0 && ldw >= 4 * H, "lstm_fwd: bad ld");
   DANET_CHECK_ARG(((uintptr_t)ypad & 15) == 0, "lstm_fwd: ypad must be 16-B aligned");
   DANET_CHECK_ARG((size_t)(T + 2) * B * ldy * 4 < 0xFFFFFFF0ull, "lstm_fwd: ypad > 4 GiB");
-  LstmPlan pl = make_plan(B, H);
-  if (pl.lds_f > 160 * 1024) {
-    danet_set_error("lstm_fwd: H=%d needs %zu B LDS", H, pl.lds_f);
+  LstmPlan pl = make_plan(B, H, ndir, false);
+  if (pl.lds > 160 * 1024) {
+    danet_set_error("lstm_fwd: H=%d needs %zu B LDS", H, pl.lds);
     return DANET_ERR_UNSUPPORTED;
   }
-  const int nblk = ndir * pl.G * pl.Pf;
+  const int nblk = ndir * pl.G * pl.P;
   if (nblk > 256) {  // 1 workgroup per CU must be co-resident
     danet_set_error("lstm_fwd: %d workgroups exceed the 256 CUs", nblk);
     return DANET_ERR_UNSUPPORTED;
@@ -425,22 +476,23 @@ extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int n
   a.gx[0] = gx_f; a.gx[1] = gx_b; a.Wh[0] = Wh_f; a.Wh[1] = Wh_b;
   a.gates[0] = gates_f; a.gates[1] = gates_b; a.cell[0] = cell_f; a.cell[1] = cell_b;
   a.ypad = ypad; a.status = (int*)ws;
-  a.flags = (unsigned*)((char*)ws + LSTM_FLAG_OFFSET);
   a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.ldy = ldy; a.ldw = ldw;
-  a.P = pl.Pf; a.G = pl.G; a.KP = pl.KP;
+  a.P = pl.P; a.G = pl.G; a.KP = pl.KP;
   DANET_CHECK_HIP(hipMemsetAsync(ws, 0, danet_lstm_workspace_bytes(T, B, H, ndir), stream));
-  // zero initial state: pad blocks 0 and T+1 (main.py:108-123)
+  // "not yet published" sentinel everywhere, then the zero initial state in pad
+  // blocks 0 and T+1 (main.py:108-123)
   const size_t blk = (size_t)B * ldy * sizeof(float);
+  DANET_CHECK_HIP(hipMemsetAsync((char*)ypad + blk, 0xFF, (size_t)T * blk, stream));
   DANET_CHECK_HIP(hipMemsetAsync(ypad, 0, blk, stream));
   DANET_CHECK_HIP(hipMemsetAsync((char*)ypad + (size_t)(T + 1) * blk, 0, blk, stream));
   if (pl.MT == 1) {
     DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_kernel<1>,
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_f));
-    lstm_fwd_kernel<1><<<nblk, 256, pl.lds_f, stream>>>(a);
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+    lstm_fwd_kernel<1><<<nblk, 256, pl.lds, stream>>>(a);
   } else {
     DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_kernel<2>,
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_f));
-    lstm_fwd_kernel<2><<<nblk, 256, pl.lds_f, stream>>>(a);
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+    lstm_fwd_kernel<2><<<nblk, 256, pl.lds, stream>>>(a);
   }
   DANET_CHECK_LAUNCH();
   return DANET_OK;
@@ -461,12 +513,12 @@ extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int n
   DANET_CHECK_ARG(((uintptr_t)da_f & 15) == 0 && ((uintptr_t)da_b & 15) == 0,
                   "lstm_bwd: da must be 16-B aligned");
   DANET_CHECK_ARG((size_t)T * B * 4 * H * 4 < 0xFFFFFFF0ull, "lstm_bwd: da > 4 GiB");
-  LstmPlan pl = make_plan(B, H);
-  if (pl.lds_b > 160 * 1024) {
-    danet_set_error("lstm_bwd: H=%d needs %zu B LDS", H, pl.lds_b);
+  LstmPlan pl = make_plan(B, H, ndir, true);
+  if (pl.lds > 160 * 1024) {
+    danet_set_error("lstm_bwd: H=%d needs %zu B LDS", H, pl.lds);
     return DANET_ERR_UNSUPPORTED;
   }
-  const int nblk = ndir * pl.G * pl.Pb;
+  const int nblk = ndir * pl.G * pl.P;
   if (nblk > 256) {
     danet_set_error("lstm_bwd: %d workgroups exceed the 256 CUs", nblk);
     return DANET_ERR_UNSUPPORTED;
@@ -475,17 +527,19 @@ extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int n
   a.dy = dy; a.lddy = lddy; a.Wh[0] = Wh_f; a.Wh[1] = Wh_b; a.ldw = ldw;
   a.gates[0] = gates_f; a.gates[1] = gates_b; a.cell[0] = cell_f; a.cell[1] = cell_b;
   a.da[0] = da_f; a.da[1] = da_b; a.status = (int*)ws;
-  a.flags = (unsigned*)((char*)ws + LSTM_FLAG_OFFSET);
-  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.P = pl.Pb; a.G = pl.G;
+  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.P = pl.P; a.G = pl.G;
   DANET_CHECK_HIP(hipMemsetAsync(ws, 0, danet_lstm_workspace_bytes(T, B, H, ndir), stream));
+  const size_t dbytes = (size_t)T * B * 4 * H * sizeof(float);
+  DANET_CHECK_HIP(hipMemsetAsync(da_f, 0xFF, dbytes, stream));
+  if (ndir == 2) DANET_CHECK_HIP(hipMemsetAsync(da_b, 0xFF, dbytes, stream));
   if (pl.MT == 1) {
     DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_bwd_kernel<1>,
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_b));
-    lstm_bwd_kernel<1><<<nblk, 256, pl.lds_b, stream>>>(a);
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+    lstm_bwd_kernel<1><<<nblk, 256, pl.lds, stream>>>(a);
   } else {
     DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_bwd_kernel<2>,
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_b));
-    lstm_bwd_kernel<2><<<nblk, 256, pl.lds_b, stream>>>(a);
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+    lstm_bwd_kernel<2><<<nblk, 256, pl.lds, stream>>>(a);
   }
   DANET_CHECK_LAUNCH();
   return DANET_OK;

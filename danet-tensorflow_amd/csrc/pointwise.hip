@@ -167,7 +167,7 @@ extern "C" int danet_center(danet_stream_t stream, int B, int T, int D, const fl
 }
 
 // -------------------------------------------------------------------- colsum
-#define COLSUM_ROWS 256  // rows per partial block
+#define COLSUM_ROWS 32   // rows per partial block
 
 __global__ void colsum_partial_kernel(int M, int N, const float* __restrict__ A, int lda,
                                       float* __restrict__ partial) {
