@@ -22,6 +22,7 @@ from .hparams import hparams
 from . import ops
 from . import modules  # noqa: F401  (registers the plugins)
 from . import ozers    # noqa: F401  (registers the optimisers)
+from . import dist
 
 
 class Model(object):
@@ -100,8 +101,7 @@ class Model(object):
             learn_rate=self.learn_rate, lr_decay=hparams.LR_DECAY)
         self.ozer.bind(self._flat, self._flat_grad)
         self.built = True
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            torch.distributed.broadcast(self._flat, src=0)
+        dist.broadcast_params_(self._flat)
         return self
 
     def _flatten(self):
@@ -174,14 +174,10 @@ class Model(object):
         self._flat_grad.zero_()
         out = self.forward(s_src_signals)
         out['loss'].backward()
-        world = 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            world = torch.distributed.get_world_size()
-            if world > 1:
-                torch.distributed.all_reduce(self._flat_grad)  # SUM over xGMI
+        grad_scale = dist.allreduce_grads_(self._flat_grad)    # ONE RCCL all-reduce / step
         self.step_count += 1
         self.ozer.step(self.step_count, self.learn_rate,
-                       clip=hparams.GRAD_CLIP_THRES, grad_scale=1.0 / world)
+                       clip=hparams.GRAD_CLIP_THRES, grad_scale=grad_scale)
         return dict(loss=out['loss'].detach(), SNR=out['SNR'], LR=self.learn_rate)
 
     def valid_step(self, s_src_signals):

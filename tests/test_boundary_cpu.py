@@ -1,0 +1,239 @@
+'''
+CPU tests (run with -m "not gpu") of the drop-in boundary: the C-ABI library
+loads and exports every symbol include/danet_hip.h declares (no compute calls
+without a GPU), the hparams / registry surface matches the reference's
+(app/hparams.py, default.json), the product path fails loudly instead of
+falling back, and the N>1 data-parallel path (gloo, world_size 2).
+'''
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'danet_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(danet_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from danet_amd import _lib
+    lib = _lib.load()                       # dlopen + resolves every PROTOTYPES entry
+    syms = _header_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(lib, s), 'missing export: ' + s
+    assert set(_lib.PROTOTYPES) == set(syms), set(_lib.PROTOTYPES) ^ set(syms)
+    assert lib.danet_abi_version() == 1
+    # pure host-side helpers are callable without a GPU
+    assert lib.danet_stft_num_frames(8000, 256, 64) == 126
+    assert lib.danet_stft_num_frames(160000, 512, 128) == 1251
+    assert lib.danet_stft_num_frames(255, 256, 64) < 0
+    assert lib.danet_center_mean_elems(4) >= 4
+    assert lib.danet_gemm_f32_workspace_bytes(300, 1200, 4096) > 0
+    assert lib.danet_gemm_f32_workspace_bytes(4096, 1200, 600) == 0
+
+
+def test_abi_has_no_torch_types():
+    txt = open(os.path.join(ROOT, 'include', 'danet_hip.h')).read()
+    assert 'extern "C"' in txt
+    code = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)          # declarations only
+    assert 'torch' not in code.lower() and 'at::' not in code and 'Tensor' not in code
+    assert '#include <torch' not in txt and '#include <ATen' not in txt
+
+
+def test_bad_arguments_return_error_codes_not_crashes():
+    from danet_amd import _lib
+    lib = _lib.load()
+    rc = lib.danet_gemm_f32(None, 0, 0, 0, 4, 4, None, 4, None, 4, None, 4, None, 0.0, None, 0)
+    assert rc == -1 and b'gemm' in lib.danet_last_error()
+    rc = lib.danet_lstm_fwd(None, 4, 2, 6, 2, None, None, None, None, 24, None, 12,
+                            None, None, None, None, ctypes.c_void_p(8), 64)
+    assert rc == -3 and b'multiple of 4' in lib.danet_last_error()
+    with pytest.raises(_lib.DanetHipError):
+        _lib.check(rc)
+
+
+def test_product_path_fails_loudly_without_gpu_or_extension(tmp_path):
+    '''no CPU fallback: CPU tensors are rejected, and a missing .so is a hard error'''
+    from danet_amd import ops, _lib
+    with pytest.raises(AssertionError):
+        ops.frontend(torch.zeros(1, 2, 3, 5, dtype=torch.complex64))       # CPU tensor
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as g; g.load_package()\n"
+        "from danet_amd import _lib\n"
+        "_lib.LIB_PATH = %r\n"
+        "try:\n"
+        "    _lib.load()\n"
+        "except _lib.DanetHipError as e:\n"
+        "    print('LOUD:', 'no CPU fallback' in str(e))\n"
+    ) % (ROOT, str(tmp_path / 'nope.so'))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert 'LOUD: True' in out.stdout, out.stdout + out.stderr
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'danet-tensorflow_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                txt = open(os.path.join(dirpath, f)).read()
+                for pat in (r'^\s*(from|import)\s+oracle', r'import_module\([\'"]oracle',
+                            r'danet_oracle', r'torch_ref', r'oracle/'):
+                    assert not re.search(pat, txt, flags=re.M), (os.path.join(dirpath, f), pat)
+
+
+# ------------------------------------------------------------------ hparams
+def test_hparams_surface_matches_reference_default_json(hp):
+    # the reference's key list (default.json:2-40) with its values
+    ref = dict(FLOATX='float32', INTX='int32', FFT_SIZE=256, FFT_STRIDE=64, SMPRATE=8000,
+               BATCH_SIZE=32, MAX_N_SIGNAL=2, LENGTH_ALIGN=4, MAX_TRAIN_LEN=128, EMBED_SIZE=20,
+               RELU_LEAKAGE=0.3, EPS=1e-7, DROPOUT_KEEP_PROB=1.0, REG_SCALE=1e-2, REG_TYPE='L2',
+               LR=3e-4, LR_DECAY=0.8, LR_DECAY_TYPE=None, NUM_EPOCH_PER_LR_DECAY=10,
+               GRAD_CLIP_THRES=100.0, TRAIN_ESTIMATOR_METHOD='truth-weighted',
+               INFER_ESTIMATOR_METHOD='anchor', NUM_ANCHOR=6, ENCODER_TYPE='toy',
+               SEPARATOR_TYPE='dot-sigmoid-orig', OPTIMIZER_TYPE='adam', DATASET_TYPE='toy',
+               SUMMARY_DIR='./logs', SUMMARY_TITLE='Test 1', DEBUG=False)
+    for k, v in ref.items():
+        assert getattr(hp, k) == v, k
+    assert hp.NUM_LSTM_LAYERS == 4 and hp.LSTM_HDIM == 300      # reference hard-codes these
+    hp.digest()
+    assert hp.COMPLEXX == 'complex64' and hp.FEATURE_SIZE == 129
+    assert hp.FFT_WND.dtype == np.float32 and hp.FFT_WND.shape == (256,)
+    hp.load(dict(FFT_SIZE=512))
+    hp.digest()                                                # re-derives from the expression
+    assert hp.FEATURE_SIZE == 257 and hp.FFT_WND.shape == (512,)
+    with pytest.raises(NameError):
+        hp.load({'lower_case': 1})
+    with pytest.raises(AssertionError):
+        hp.load({'BAD': [1, 2]})
+
+
+def test_hparams_load_json(hp, tmp_path):
+    f = tmp_path / 'c.json'
+    f.write_text(json.dumps(dict(BATCH_SIZE=8, ENCODER_TYPE='bilstm-orig')))
+    hp.load_json(str(f))
+    assert hp.BATCH_SIZE == 8 and hp.ENCODER_TYPE == 'bilstm-orig'
+
+
+def test_plugin_registries_and_class_contracts(hp):
+    from danet_amd import modules
+    assert set(hp.encoder_registry) >= {'toy', 'lstm-orig', 'bilstm-orig'}
+    assert set(hp.estimator_registry) == {'truth', 'truth-threshold', 'truth-weighted', 'anchor'}
+    assert set(hp.separator_registry) == {'dot-sigmoid-orig', 'dot-softmax-orig'}
+    assert set(hp.ozer_registry) == {'sgd', 'adam'}
+    assert 'toy' in hp.dataset_registry
+    hp.load(dict(ENCODER_TYPE='bilstm-orig'))
+    assert hp.get_encoder() is modules.BiLstmEncoder
+    assert hp.get_estimator('anchor') is modules.AnchoredEstimator
+    assert hp.get_separator('dot-softmax-orig') is modules.DotSeparatorSoftmax
+    assert modules.AnchoredEstimator.USE_TRUTH is False
+    for n in ('truth', 'truth-threshold', 'truth-weighted'):
+        assert hp.get_estimator(n).USE_TRUTH is True
+    with pytest.raises(KeyError):
+        hp.get_estimator('kmeans-not-registered')
+    for cls in (modules.Encoder, modules.Estimator, modules.Separator):
+        with pytest.raises(NotImplementedError):
+            cls(None, 'x')(None) if cls is not modules.Separator else cls(None, 'x')(None, None, None)
+    m = modules.BiLstmEncoder('model', 'encoder')
+    assert m.model == 'model' and m.name == 'encoder'
+
+
+def test_user_plugin_registration(hp):
+    from danet_amd.hparams import hparams
+    from danet_amd import modules
+
+    @hparams.register_estimator('my-est')
+    class MyEst(modules.Estimator):
+        USE_TRUTH = False
+    try:
+        assert hp.get_estimator('my-est') is MyEst
+    finally:
+        del type(hp).estimator_registry['my-est']
+
+
+def test_toy_dataset_matches_reference_shape(hp):
+    from danet_amd import datasets
+    hp.digest()
+    ds = hp.get_dataset()()
+    with pytest.raises(RuntimeError):
+        next(ds.epoch('train', 8))
+    ds.install_and_load()
+    batches = list(ds.epoch('train', 8))
+    assert len(batches) == 10
+    sig, = batches[0]
+    assert sig.shape == (8, 128, 129) and sig.dtype == np.float32
+    assert 0.0 <= sig.min() and sig.max() < 1.0
+    waves = datasets.synth_waves(1337, 3, 128)
+    assert waves.shape == (3, 127 * 64) and waves.dtype == np.float32
+    assert abs(np.sqrt(np.mean(waves[0] ** 2)) - 1000.0) < 1.0
+
+
+# -------------------------------------------------- data parallel (gloo, N=2)
+_DP_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+import __graft_entry__ as g; g.load_package()
+from danet_amd import dist
+from oracle import danet_oracle as O, torch_ref as R
+dist.init_from_env('gloo')
+rank, world = dist.rank(), dist.world_size()
+assert world == 2
+rng = np.random.RandomState(0)
+Bg, C, T, F, E, H, L, A = 4, 2, 6, 5, 3, 4, 1, 4
+src = (rng.randn(Bg, C, T, F) + 1j * rng.randn(Bg, C, T, F)) * 3
+p = O.init_bilstm_params(rng, F, E, H, L)
+p['global/train_estimator/anchors'] = rng.randn(A, E)
+cfg = dict(H=H, L=L, E=E, C=C, A=A, train_est='anchor', infer_est='anchor', separator='dot-softmax-orig')
+names = sorted(p)
+def flat_grad(batch, pd):
+    tp = {k: torch.tensor(v, requires_grad=True) for k, v in pd.items()}
+    R.model_forward(torch.tensor(batch), tp, cfg)['loss'].backward()
+    return torch.cat([tp[k].grad.reshape(-1) for k in names])
+# rank-dependent garbage params, then broadcast from rank 0
+flat_p = torch.cat([torch.tensor(p[k]).reshape(-1) for k in names]) + (0.0 if rank == 0 else 7.0)
+dist.broadcast_params_(flat_p)
+off = 0
+pd = {}
+for k in names:
+    n = p[k].size
+    pd[k] = flat_p[off:off + n].reshape(p[k].shape).numpy().copy(); off += n
+shard = src[rank * 2:(rank + 1) * 2]            # BATCH_SIZE = 2 per rank
+gbuf = flat_grad(shard, pd)
+scale = dist.allreduce_grads_(gbuf)              # ONE collective per step
+gbuf *= scale
+full = flat_grad(src, p)                         # global-batch gradient, rank-0 params
+err = float((gbuf - full).abs().max() / full.abs().max())
+mx = dist.allreduce_max_scalar(float(rank + 1), 'cpu')
+print('RANK', rank, 'ERR', err, 'MAX', mx, 'SEED', dist.shard_seed(1337), flush=True)
+'''
+
+
+def test_data_parallel_gloo_world2(tmp_path):
+    '''sharding by batch + ONE summed all-reduce + 1/world == global-batch gradient'''
+    script = tmp_path / 'dp_worker.py'
+    script.write_text(_DP_WORKER % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    out = subprocess.run(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+         '--master-addr', '127.0.0.1', '--master-port', '29533', str(script)],
+        capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('RANK')]
+    assert len(lines) == 2, out.stdout
+    for l in lines:
+        tok = l.split()
+        assert float(tok[3]) < 1e-12, l
+        assert float(tok[5]) == 2.0
+        assert int(tok[7]) == 1337 + int(tok[1])
