@@ -172,19 +172,89 @@ def _lstm_ws(T, B, H, ndir, dev):
     return torch.empty(n, dtype=torch.uint8, device=dev), n
 
 
+# ---- concurrent chains on side HIP streams ---------------------------------
+# The GEMMs of the two scan directions (and dWx / dWh / dX in backward) are
+# independent and individually too small to fill 256 CUs evenly (e.g. 320 tiles);
+# issued on separate streams their tiles co-schedule.  All tensors are allocated
+# on the main stream and the main stream joins the side streams before anything
+# is returned, so the caching allocator never recycles memory still in use.
+_side = {}
+SIDE_STREAMS = int(__import__('os').environ.get('DANET_SIDE_STREAMS', '2'))
+
+
+def _side_streams(dev, n):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    pool = _side.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:n]
+
+
+class _Fork(object):
+    '''with _Fork(dev, n) as f:  f.run(i, fn)  -> fn runs on chain i
+    (chain 0 = the current stream, chain i>0 = side stream i-1); join on exit.'''
+
+    def __init__(self, dev, nchains, defer=False, keep=()):
+        '''defer=True: do not join on exit -- the side chains keep running under
+        whatever the main stream does next (e.g. weight-gradient GEMMs under the
+        next layer's latency-bound BPTT kernel, which leaves most CUs idle);
+        `join_deferred()` joins them.  `keep` = tensors the chains read that the
+        caller is about to drop (kept alive until the join).'''
+        self.main = torch.cuda.current_stream(dev)
+        n = min(nchains - 1, SIDE_STREAMS)
+        self.sides = _side_streams(dev, n) if n > 0 else []
+        self.used = set()
+        self.defer, self.keep = defer, keep
+
+    def __enter__(self):
+        if self.sides:
+            ev = self.main.record_event()
+            for s in self.sides:
+                s.wait_event(ev)
+        return self
+
+    def run(self, chain, fn):
+        if not self.sides or chain == 0:
+            return fn()
+        s = self.sides[(chain - 1) % len(self.sides)]
+        self.used.add(s)
+        with torch.cuda.stream(s):
+            return fn()
+
+    def __exit__(self, *exc):
+        if self.defer and self.used:
+            _deferred.append((self.main, tuple(self.used), self.keep))
+        else:
+            for s in self.used:
+                self.main.wait_stream(s)
+        return False
+
+
+_deferred = []
+
+
+def join_deferred():
+    '''main stream waits for every deferred side chain'''
+    while _deferred:
+        main, used, _keep = _deferred.pop()
+        for s in used:
+            main.wait_stream(s)
+
+
 def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs):
     '''x: time-major [T*B rows, ldx] tensor (data_ptr = row 0), D valid columns.
     Ws[d]: [D+H, 4H] (reference layout, rows 0..D-1 input, D.. recurrent),
     bs[d]: [4H].  Returns ctx with ypad [T+2, B, ndir*H].'''
     ndir = len(Ws)
     dev = x.device
-    gates, cells = [], []
-    for d in range(ndir):
-        gx = torch.empty(T * B, 4 * H, device=dev)
-        # hoisted input half of ops.lyr_lstm_flat's [x,h]W+b (app/ops.py:139-142)
-        gemm(x, Ws[d], gx, T * B, 4 * H, D, ldx, 4 * H, 4 * H, bias=bs[d])
-        gates.append(gx)                       # overwritten in place by g,i,f,o
-        cells.append(torch.empty(T * B, H, device=dev))
+    gates = [torch.empty(T * B, 4 * H, device=dev) for _ in range(ndir)]
+    cells = [torch.empty(T * B, H, device=dev) for _ in range(ndir)]
+    with _Fork(dev, ndir) as f:
+        for d in range(ndir):
+            # hoisted input half of ops.lyr_lstm_flat's [x,h]W+b (app/ops.py:139-142);
+            # `gates[d]` is later overwritten in place by g,i,f,o
+            f.run(d, lambda d=d: gemm(x, Ws[d], gates[d], T * B, 4 * H, D, ldx, 4 * H, 4 * H,
+                                      bias=bs[d]))
     ypad = torch.empty(T + 2, B, ndir * H, device=dev)
     ws, wn = _lstm_ws(T, B, H, ndir, dev)
     Whs = [W[D:] for W in Ws]
@@ -216,26 +286,32 @@ def lstm_layer_bwd(c, dy, need_dx):
             ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(c.gates[0]), ptr(c.gates[-1]),
             ptr(c.cells[0]), ptr(c.cells[-1]), ptr(das[0]), ptr(das[-1]), ptr(ws), wn))
     _pending_status.append(ws[:4].view(torch.int32))
-    dWs, dbs = [], []
     ldy = ndir * H
-    for d in range(ndir):
-        dW = torch.empty(D + H, 4 * H, device=dev)
+    dWs = [torch.empty(D + H, 4 * H, device=dev) for _ in range(ndir)]
+    dbs = [torch.empty(4 * H, device=dev) for _ in range(ndir)]
+    dx = torch.empty(T * B, D, device=dev) if need_dx else None
+
+    def weight_grads(d):
         # dWx = X^T da
-        gemm(c.x, das[d], dW, D, 4 * H, T * B, c.ldx, 4 * H, 4 * H, transA=True)
+        gemm(c.x, das[d], dWs[d], D, 4 * H, T * B, c.ldx, 4 * H, 4 * H, transA=True)
         # dWh = Hprev^T da; Hprev(t) = ypad block t (fwd) / block t+2 (bwd)
         hprev = c.ypad.view(-1)[(0 if d == 0 else 2 * B * ldy + H):]
-        gemm(hprev, das[d], dW[D:], H, 4 * H, T * B, ldy, 4 * H, 4 * H, transA=True)
-        db = torch.empty(4 * H, device=dev)
-        colsum(das[d], T * B, 4 * H, 4 * H, db)
-        dWs.append(dW)
-        dbs.append(db)
-    dx = None
-    if need_dx:
-        dx = torch.empty(T * B, D, device=dev)
+        gemm(hprev, das[d], dWs[d][D:], H, 4 * H, T * B, ldy, 4 * H, 4 * H, transA=True)
+        colsum(das[d], T * B, 4 * H, 4 * H, dbs[d])
+
+    def input_grad():
         for d in range(ndir):
             # dX += da Wx^T
             gemm(das[d], c.Ws[d], dx, T * B, D, 4 * H, 4 * H, 4 * H, D, transB=True,
                  beta=0.0 if d == 0 else 1.0)
+
+    # chain 0 (main stream) carries dX, which the next layer's BPTT waits for; the
+    # weight-gradient chains are joined by the caller (`join_deferred`)
+    with _Fork(dev, ndir + 1, defer=True, keep=(das, c.x, c.ypad, dy)) as f:
+        if need_dx:
+            f.run(0, input_grad)
+        for d in range(ndir):
+            f.run(d + 1, lambda d=d: weight_grads(d))
     return dx, dWs, dbs
 
 
@@ -259,6 +335,7 @@ class LstmLayerFn(torch.autograd.Function):
         c = ctx.c
         dyt = dy.transpose(0, 1).contiguous()
         dx, dWs, dbs = lstm_layer_bwd(c, dyt, ctx.needs_input_grad[0])
+        join_deferred()
         out = [None, None]
         if dx is not None:
             out[0] = dx.view(c.T, c.B, c.D).transpose(0, 1).contiguous()
@@ -307,9 +384,10 @@ class RnnEncoderFn(torch.autograd.Function):
         dembed = _f32(dembed.contiguous())
         dev = dembed.device
         dWout = torch.empty(D, O, device=dev)
-        gemm(ctx.yc, dembed, dWout, D, O, B * T, D, O, O, transA=True)
         dyc = torch.empty(B, T, D, device=dev)
-        gemm(dembed, ctx.Wout, dyc, B * T, D, O, O, O, D, transB=True)
+        with _Fork(dev, 2, defer=True, keep=(dembed, ctx.yc)) as f:
+            f.run(0, lambda: gemm(dembed, ctx.Wout, dyc, B * T, D, O, O, O, D, transB=True))
+            f.run(1, lambda: gemm(ctx.yc, dembed, dWout, D, O, B * T, D, O, O, transA=True))
         dy = torch.empty(T, B, D, device=dev)
         center(dyc, B, T, D, 0, D, dy, 1, D)                 # centre is self-adjoint
         grads = [None] * (2 * L * ndir)
@@ -319,6 +397,7 @@ class RnnEncoderFn(torch.autograd.Function):
                 grads[(l * ndir + d) * 2] = dWs[d]
                 grads[(l * ndir + d) * 2 + 1] = dbs[d]
             dy = dx
+        join_deferred()
         ctx.ctxs = None
         return (None, None, None, None) + tuple(grads) + (dWout,)
 
