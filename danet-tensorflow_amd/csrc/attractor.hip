@@ -322,7 +322,7 @@ __global__ void sum_chunks_kernel(int nch, int cnt_out, int C, int E, int EP,
 // =========================================================================
 // anchor estimator (app/modules.py:501-545)
 // =========================================================================
-#define ANCH_TN 128   // bins per LDS tile
+#define ANCH_TN 256   // bins per LDS tile (one per thread in phase 1)
 
 struct AnchorCombos { int P; int idx[MAXP][MAXC]; };
 
@@ -392,22 +392,38 @@ __global__ __launch_bounds__(256) void anchor_fwd_kernel(
           }
           d[a] = s;
         }
+        // softmax over a subset is invariant to a common shift, so the A
+        // exponentials are taken once against the global max instead of C per
+        // subset (P*C = 30 -> A = 6 expf per bin at A=6, C=2)
+        float dmax = d[0];
+#pragma unroll
+        for (int a = 1; a < MAXA; ++a) if (a < A) dmax = fmaxf(dmax, d[a]);
+        float ea[MAXA];
+#pragma unroll
+        for (int a = 0; a < MAXA; ++a) ea[a] = (a < A) ? expf(d[a] - dmax) : 0.f;
         for (int p = 0; p < cb.P; ++p) {
-          float lg[MAXC];
-          float mx = -INFINITY;
+          float lg[MAXC], dl[MAXC];
+          float den = 0.f;
 #pragma unroll
           for (int c = 0; c < MAXC; ++c)
             if (c < C) {
               const int a = cb.idx[p][c];
-              float v = d[0];
+              float v = ea[0], w = d[0];
 #pragma unroll
-              for (int q = 1; q < MAXA; ++q) v = (a == q) ? d[q] : v;
-              lg[c] = v;
-              mx = fmaxf(mx, v);
+              for (int q = 1; q < MAXA; ++q) { v = (a == q) ? ea[q] : v; w = (a == q) ? d[q] : w; }
+              lg[c] = v; dl[c] = w;
+              den += v;
             }
-          float den = 0.f;
+          if (den < 1e-30f) {
+            // every member underflowed against the global max: redo this subset
+            // against its own max (exactly tf.nn.softmax's formulation)
+            float mx = -INFINITY;
 #pragma unroll
-          for (int c = 0; c < MAXC; ++c) if (c < C) { lg[c] = expf(lg[c] - mx); den += lg[c]; }
+            for (int c = 0; c < MAXC; ++c) if (c < C) mx = fmaxf(mx, dl[c]);
+            den = 0.f;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) if (c < C) { lg[c] = expf(dl[c] - mx); den += lg[c]; }
+          }
 #pragma unroll
           for (int c = 0; c < MAXC; ++c)
             if (c < C) Ss[tid * lds + p * C + c] = lg[c] / den;        // modules.py:516
@@ -580,15 +596,18 @@ __global__ __launch_bounds__(256) void anchor_bwd_kernel(
     if (c < C) block_reduce_store<EP>(accs[c], EP, red, out + c * EP);
 }
 
-__global__ void anchor_bwd_final_kernel(int B, int C, int E, int EP, int A, int nch,
-                                        AnchorCombos cb, const float* __restrict__ partial,
-                                        const int32_t* __restrict__ choice,
-                                        float* __restrict__ danchors) {
-  // single block; deterministic scatter over utterances
-  for (int i = threadIdx.x; i < A * E; i += blockDim.x) {
-    const int a = i / E, e = i % E;
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) {
+__global__ __launch_bounds__(256) void anchor_bwd_final_kernel(
+    int B, int C, int E, int EP, int A, int nch, AnchorCombos cb,
+    const float* __restrict__ partial, const int32_t* __restrict__ choice,
+    float* __restrict__ danchors) {
+  // one block per anchor; thread = (e, 1 of 4 utterance lanes); fixed summation
+  // order => deterministic scatter over utterances
+  __shared__ float red[4][64];
+  const int a = blockIdx.x;
+  const int e = threadIdx.x & 63, bl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (e < E) {
+    for (int b = bl; b < B; b += 4) {
       const int p = choice[b];
       for (int c = 0; c < C; ++c) {
         if (cb.idx[p][c] != a) continue;
@@ -596,8 +615,11 @@ __global__ void anchor_bwd_final_kernel(int B, int C, int E, int EP, int A, int 
           s += partial[(((int64_t)b * nch + ch) * C + c) * EP + e];
       }
     }
-    danchors[i] = s;
   }
+  red[bl][e] = s;
+  __syncthreads();
+  if (bl == 0 && e < E)
+    danchors[a * E + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
 // =========================================================================
@@ -821,7 +843,7 @@ extern "C" int danet_attractor_anchor_bwd(danet_stream_t stream_, int B, int C, 
                        C, N, E, A, cb, dattr, embed, anchors, attr, asum, choice, dembed,
                        (float*)ws))));
   DANET_CHECK_LAUNCH();
-  anchor_bwd_final_kernel<<<1, 256, 0, stream>>>(B, C, E, EPV, A, nch, cb, (const float*)ws,
+  anchor_bwd_final_kernel<<<A, 256, 0, stream>>>(B, C, E, EPV, A, nch, cb, (const float*)ws,
                                                  choice, danchors);
   DANET_CHECK_LAUNCH();
   return DANET_OK;

@@ -11,6 +11,7 @@
 // MFMAs.  Small-output / long-K products (weight gradients) use a
 // deterministic split-K: per-slice slabs in `ws`, summed by a second kernel.
 #include "common.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -207,11 +208,15 @@ __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slab,
 
 static int choose_splitk(int M, int N, int K) {
   const int tiles = cdiv(M, BM) * cdiv(N, BN);
-  if (tiles >= 192 || K < 512) return 1;
-  int s = cdiv(512, tiles);
-  const int maxs = K / 128;
+  if (tiles >= 160 || K < 512) return 1;
+  // aim at ~one workgroup per CU: every extra slice costs a full M*N slab
+  // write + read in the reduce kernel (it was 8% of the train step at s=18)
+  static int target = 0;
+  if (!target) { const char* e = getenv("DANET_SPLITK_TARGET"); target = e ? atoi(e) : 256; }
+  int s = cdiv(target, tiles);
+  const int maxs = K / 256;
   if (s > maxs) s = maxs;
-  if (s > 32) s = 32;
+  if (s > 16) s = 16;
   return s < 1 ? 1 : s;
 }
 

@@ -167,16 +167,31 @@ extern "C" int danet_center(danet_stream_t stream, int B, int T, int D, const fl
 }
 
 // -------------------------------------------------------------------- colsum
-#define COLSUM_ROWS 32   // rows per partial block
+// Two-level deterministic reduction.  Level 1: workgroup (64 columns x 4 row
+// lanes) sums a band of COLSUM_ROWS rows -- 64 consecutive floats per row lane
+// keep the loads coalesced while 4 independent row lanes (and many bands) keep
+// enough loads in flight; level 2 sums the <= M/COLSUM_ROWS band partials.
+#define COLSUM_ROWS 128
 
-__global__ void colsum_partial_kernel(int M, int N, const float* __restrict__ A, int lda,
-                                      float* __restrict__ partial) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= N) return;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(
+    int M, int N, const float* __restrict__ A, int lda, float* __restrict__ partial) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
   const int r0 = blockIdx.y * COLSUM_ROWS, r1 = min(M, r0 + COLSUM_ROWS);
-  float s = 0.f;
-  for (int r = r0; r < r1; ++r) s += A[(size_t)r * lda + col];
-  partial[(size_t)blockIdx.y * N + col] = s;
+  float s0 = 0.f, s1 = 0.f;
+  if (col < N) {
+    int r = r0 + rl;
+    for (; r + 4 < r1; r += 8) {
+      s0 += A[(size_t)r * lda + col];
+      s1 += A[(size_t)(r + 4) * lda + col];
+    }
+    if (r < r1) s0 += A[(size_t)r * lda + col];
+  }
+  red[rl][cl] = s0 + s1;
+  __syncthreads();
+  if (rl == 0 && col < N)
+    partial[(size_t)blockIdx.y * N + col] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
 __global__ void colsum_final_kernel(int nparts, int N, const float* __restrict__ partial,
@@ -200,11 +215,11 @@ extern "C" int danet_colsum_f32(danet_stream_t stream, int M, int N, const float
     return DANET_ERR_WORKSPACE;
   }
   const int nparts = cdiv(M, COLSUM_ROWS);
-  dim3 g(cdiv(N, 256), nparts);
+  dim3 g(cdiv(N, 64), nparts);
   colsum_partial_kernel<<<g, 256, 0, (hipStream_t)stream>>>(M, N, A, lda, (float*)ws);
   DANET_CHECK_LAUNCH();
-  colsum_final_kernel<<<cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(nparts, N, (const float*)ws,
-                                                                     out, beta);
+  colsum_final_kernel<<<cdiv(N, 64), 64, 0, (hipStream_t)stream>>>(nparts, N, (const float*)ws,
+                                                                   out, beta);
   DANET_CHECK_LAUNCH();
   return DANET_OK;
 }

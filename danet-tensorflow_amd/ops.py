@@ -151,7 +151,7 @@ def istft(X, stride, window):
 # ---------------------------------------------------------------------------
 class _LayerCtx(object):
     __slots__ = ('x', 'ldx', 'D', 'T', 'B', 'H', 'ndir', 'ypad', 'gates', 'cells',
-                 'Ws', 'status')
+                 'Ws', 'bs', 'status')
 
 
 _pending_status = []
@@ -232,6 +232,19 @@ class _Fork(object):
 
 _deferred = []
 
+DIRECT_GRADS = __import__('os').environ.get('DANET_DIRECT_GRADS', '1') == '1'
+
+
+def _grad_target(param, shape, dev):
+    """(tensor to accumulate the gradient of `param` into, is_direct).  Direct =
+    the parameter already owns a dense .grad (e.g. a view of Model's flat
+    gradient bucket): kernels add into it (beta=1) and autograd is handed None,
+    which saves one elementwise accumulate kernel per parameter per step."""
+    g = param.grad if (DIRECT_GRADS and torch.is_tensor(param)) else None
+    if g is not None and g.is_contiguous() and tuple(g.shape) == tuple(shape):
+        return g, True
+    return torch.empty(*shape, device=dev), False
+
 
 def join_deferred():
     '''main stream waits for every deferred side chain'''
@@ -266,7 +279,7 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs):
             ptr(gates[0]), ptr(gates[-1]), ptr(cells[0]), ptr(cells[-1]), ptr(ws), wn))
     c = _LayerCtx()
     c.x, c.ldx, c.D, c.T, c.B, c.H, c.ndir = x, ldx, D, T, B, H, ndir
-    c.ypad, c.gates, c.cells, c.Ws = ypad, gates, cells, Ws
+    c.ypad, c.gates, c.cells, c.Ws, c.bs = ypad, gates, cells, Ws, bs
     c.status = ws[:4].view(torch.int32)
     _pending_status.append(c.status)
     return c
@@ -287,17 +300,23 @@ def lstm_layer_bwd(c, dy, need_dx):
             ptr(c.cells[0]), ptr(c.cells[-1]), ptr(das[0]), ptr(das[-1]), ptr(ws), wn))
     _pending_status.append(ws[:4].view(torch.int32))
     ldy = ndir * H
-    dWs = [torch.empty(D + H, 4 * H, device=dev) for _ in range(ndir)]
-    dbs = [torch.empty(4 * H, device=dev) for _ in range(ndir)]
+    # gradients accumulate straight into the parameters' .grad (the model's flat
+    # all-reduce bucket) when there is one; autograd then gets None for them
+    dWs, dbs, direct = [], [], []
+    for d in range(ndir):
+        gW, okW = _grad_target(c.Ws[d], (D + H, 4 * H), dev)
+        gb, okb = _grad_target(c.bs[d], (4 * H,), dev)
+        dWs.append(gW); dbs.append(gb); direct.append((okW, okb))
     dx = torch.empty(T * B, D, device=dev) if need_dx else None
 
     def weight_grads(d):
+        bW, bb = (1.0 if direct[d][0] else 0.0), (1.0 if direct[d][1] else 0.0)
         # dWx = X^T da
-        gemm(c.x, das[d], dWs[d], D, 4 * H, T * B, c.ldx, 4 * H, 4 * H, transA=True)
+        gemm(c.x, das[d], dWs[d], D, 4 * H, T * B, c.ldx, 4 * H, 4 * H, transA=True, beta=bW)
         # dWh = Hprev^T da; Hprev(t) = ypad block t (fwd) / block t+2 (bwd)
         hprev = c.ypad.view(-1)[(0 if d == 0 else 2 * B * ldy + H):]
-        gemm(hprev, das[d], dWs[d][D:], H, 4 * H, T * B, ldy, 4 * H, 4 * H, transA=True)
-        colsum(das[d], T * B, 4 * H, 4 * H, dbs[d])
+        gemm(hprev, das[d], dWs[d][D:], H, 4 * H, T * B, ldy, 4 * H, 4 * H, transA=True, beta=bW)
+        colsum(das[d], T * B, 4 * H, 4 * H, dbs[d], beta=bb)
 
     def input_grad():
         for d in range(ndir):
@@ -312,6 +331,8 @@ def lstm_layer_bwd(c, dy, need_dx):
             f.run(0, input_grad)
         for d in range(ndir):
             f.run(d + 1, lambda d=d: weight_grads(d))
+    dWs = [None if direct[d][0] else dWs[d] for d in range(ndir)]
+    dbs = [None if direct[d][1] else dbs[d] for d in range(ndir)]
     return dx, dWs, dbs
 
 
@@ -383,11 +404,12 @@ class RnnEncoderFn(torch.autograd.Function):
         B, T, F, H, L, ndir, D, O = ctx.dims
         dembed = _f32(dembed.contiguous())
         dev = dembed.device
-        dWout = torch.empty(D, O, device=dev)
+        dWout, direct_out = _grad_target(ctx.Wout, (D, O), dev)
         dyc = torch.empty(B, T, D, device=dev)
         with _Fork(dev, 2, defer=True, keep=(dembed, ctx.yc)) as f:
             f.run(0, lambda: gemm(dembed, ctx.Wout, dyc, B * T, D, O, O, O, D, transB=True))
-            f.run(1, lambda: gemm(ctx.yc, dembed, dWout, D, O, B * T, D, O, O, transA=True))
+            f.run(1, lambda: gemm(ctx.yc, dembed, dWout, D, O, B * T, D, O, O, transA=True,
+                                  beta=1.0 if direct_out else 0.0))
         dy = torch.empty(T, B, D, device=dev)
         center(dyc, B, T, D, 0, D, dy, 1, D)                 # centre is self-adjoint
         grads = [None] * (2 * L * ndir)
@@ -399,7 +421,7 @@ class RnnEncoderFn(torch.autograd.Function):
             dy = dx
         join_deferred()
         ctx.ctxs = None
-        return (None, None, None, None) + tuple(grads) + (dWout,)
+        return (None, None, None, None) + tuple(grads) + (None if direct_out else dWout,)
 
 
 class LinearFn(torch.autograd.Function):
