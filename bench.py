@@ -135,8 +135,11 @@ def main():
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get('DANET_FORCE_DIST') == '1'   # 1-rank RCCL smoke
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         torch.distributed.init_process_group('nccl', device_id=device)
 
     graft.load_package()
@@ -150,7 +153,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -167,7 +170,7 @@ def main():
     prof = _lib.profile_stop()
     ok = ops.lstm_status_ok()
     log('timed region: %.3f s for %d steps; lstm status ok=%s' % (dt, args.steps, ok))
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
@@ -211,7 +214,7 @@ def main():
             if not args.no_cpu_baseline:
                 res['cpu_baseline'] = cpu_baseline(hp, model.param_dict(), args.cpu_sample)
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         torch.distributed.destroy_process_group()
 
 

@@ -44,7 +44,7 @@ def init_from_env(backend='nccl', device=None):
 
 def broadcast_params_(flat, src=0):
     '''identical initial parameters on every rank'''
-    if world_size() > 1:
+    if is_dist():
         dist.broadcast(flat, src=src)
     return flat
 
@@ -53,7 +53,7 @@ def allreduce_grads_(flat_grad):
     '''SUM the flat gradient bucket over ranks (in place); returns the factor
     the caller must multiply by to get the global-batch mean gradient.'''
     w = world_size()
-    if w > 1:
+    if is_dist():          # also at w == 1 (keeps the RCCL path exercised)
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return 1.0 / w
 
