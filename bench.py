@@ -99,6 +99,23 @@ def cpu_baseline(hp, params_np, sample_b, n_steps=3):
                        % (sample_b, hp.BATCH_SIZE, n_steps, dt))
 
 
+def pmc_traffic_bytes(kernel):
+    '''HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/run_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate runs, KB units).
+    Correction per MI355X_MICROARCH.md "HBM": on gfx950 FETCH_SIZE reports half of
+    a 16-B/lane coalesced read stream, so reads = 2*FETCH_SIZE (calibrated here on
+    adam_clip_kernel: 2*52.7 MB vs 110.5 MB algorithmic); WRITE_SIZE as is.
+    None if no PMC summary was collected for this kernel (cfg 2 only).'''
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    for k, v in d.items():
+        if k.replace('void ', '').startswith(kernel) and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
+            return int((2.0 * v['FETCH_SIZE']['per_launch'] + v['WRITE_SIZE']['per_launch']) * 1024)
+    return None
+
+
 def mask_mse_vs_oracle(hp, model, src, n_check=2):
     '''SDR-proxy: MSE between the HIP path's masks and the float64 oracle's on
     the first `n_check` mixtures of the batch (mixtures are independent).'''
@@ -191,7 +208,8 @@ def main():
         achieved = lstm_flops / (ms / n * 1e-3) / 1e12
         roofline = dict(kernel=dom + '_kernel', bound='mfma', achieved=round(achieved, 3),
                         peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                        frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                        frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                        traffic=pmc_traffic_bytes(dom + '_kernel'),
                         us_per_timestep=round(1e3 * ms / n / T, 3),
                         note='latency-bound recurrence: T dependent steps per launch; '
                              'see DESIGN.md for the step-latency model')
