@@ -75,7 +75,7 @@ struct LstmBwdArgs {
   const float* cell[2];
   float* da[2];
   int* status;
-  int T, B, H, ndir, lddy, ldw, P, G;
+  int T, B, H, ndir, lddy, ldw, P, G, R;   // R = batch rows per cluster (<= 16*MT)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
   const int grp = (bid / a.P) % a.G;
   const int p = bid % a.P;
   const int u0 = p * LSTM_UNITS_BWD;
-  const int b0 = grp * (16 * MT);
+  const int b0 = grp * a.R;
 
   // stationary Wh^T slice: element (n, j) = Wh[u0+j][n] at ((n/4)*16 + j)*4 + n%4
   {
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int bl = (tid >> 4) + 16 * i, bg = b0 + bl;
-      own[i] = (bg < B) && (unit < H);
+      own[i] = (bl < a.R) && (bg < B) && (unit < H);
       cv[i] = cpv[i] = dyv[i] = 0.f;
       gv[i][0] = gv[i][1] = gv[i][2] = gv[i][3] = 0.f;
       if (own[i]) {
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
             for (int mt = 0; mt < MT; ++mt) {
               const int row = b0 + mt * 16 + fr;
               unsigned off = dbytes;  // == num_records: out of range -> 0 (valid)
-              if (row < B && kg < NG) off = (unsigned)((((size_t)t_done * B + row) * H4 + n) * 4);
+              if (row < B && kg < NG && mt * 16 + fr < a.R) off = (unsigned)((((size_t)t_done * B + row) * H4 + n) * 4);
               av[g][mt] = load_sc1_b128(dres, off);
             }
           }
@@ -518,7 +518,14 @@ extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int n
     danet_set_error("lstm_bwd: H=%d needs %zu B LDS", H, pl.lds);
     return DANET_ERR_UNSUPPORTED;
   }
-  const int nblk = ndir * pl.G * pl.P;
+  // rows per cluster: 8-row clusters halve the all-gather payload per workgroup
+  // (measured -7% on the BPTT launch at cfg 2) while the MFMA tile stays 16 rows;
+  // used whenever one workgroup per CU still fits.  DANET_LSTM_BWD_ROWS=16 overrides.
+  int R = 16 * pl.MT;
+  if (pl.MT == 1 && ndir * cdiv(B, 8) * pl.P <= 256) R = 8;
+  { const char* er = getenv("DANET_LSTM_BWD_ROWS"); if (er && pl.MT == 1 && atoi(er) == 16) R = 16; }
+  const int G = cdiv(B, R);
+  const int nblk = ndir * G * pl.P;
   if (nblk > 256) {
     danet_set_error("lstm_bwd: %d workgroups exceed the 256 CUs", nblk);
     return DANET_ERR_UNSUPPORTED;
@@ -527,7 +534,7 @@ extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int n
   a.dy = dy; a.lddy = lddy; a.Wh[0] = Wh_f; a.Wh[1] = Wh_b; a.ldw = ldw;
   a.gates[0] = gates_f; a.gates[1] = gates_b; a.cell[0] = cell_f; a.cell[1] = cell_b;
   a.da[0] = da_f; a.da[1] = da_b; a.status = (int*)ws;
-  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.P = pl.P; a.G = pl.G;
+  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.P = pl.P; a.G = G; a.R = R;
   DANET_CHECK_HIP(hipMemsetAsync(ws, 0, danet_lstm_workspace_bytes(T, B, H, ndir), stream));
   const size_t dbytes = (size_t)T * B * 4 * H * sizeof(float);
   DANET_CHECK_HIP(hipMemsetAsync(da_f, 0xFF, dbytes, stream));
