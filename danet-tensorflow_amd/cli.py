@@ -1,0 +1,214 @@
+'''
+Command-line driver: the reference's `main()` and train / valid / test / demo
+loops (main.py:402-532, :551-750) over the MI355X-native Model.
+
+Same flags (main.py:553-582): -n/--name -m/--mode -i/--input-pfile
+-o/--output-pfile -c/--config-file -ne/--num-epoch -if/--input-file
+-ds/--dataset -lr/--learn-rate -tl/--train-length -bs/--batch-size
+--no-save-on-epoch --no-valid-on-epoch; modes train | valid | test | demo | debug.
+Host-side Python like the reference (north_star: "host code stays Python").
+Not carried over: TensorBoard summaries, matplotlib plots, the interactive
+prompt mode (observability / UI, out of scope).  Checkpoints are .npz
+files keyed by the reference's TF variable names.
+'''
+from __future__ import print_function
+import argparse
+import os
+import sys
+from collections import OrderedDict
+from math import isnan
+from random import randint
+
+import numpy as np
+import torch
+
+from .hparams import hparams
+from . import datasets  # noqa: F401  (registers datasets)
+from . import dist
+from . import utils
+from .model import Model
+
+
+def _dict_add(dst, src):
+    for k, v in src.items():
+        dst[k] = dst.get(k, 0.) + float(v)
+
+
+def _dict_mul(di, coeff):
+    for k in di:
+        di[k] = di[k] * coeff
+
+
+def _dict_format(di):
+    return ' '.join('='.join((k, str(v))) for k, v in di.items())
+
+
+def _to_batch(data_pt, device):
+    '''dataset batch [B*C, T, F] (real or complex) -> complex64 [B, C, T, F] on the GPU
+    (main.py:417-421)'''
+    a = np.asarray(data_pt[0])
+    a = a.reshape(hparams.BATCH_SIZE, hparams.MAX_N_SIGNAL, -1, hparams.FEATURE_SIZE)
+    return torch.as_tensor(a.astype(np.complex64)).to(device)
+
+
+def train(model, n_epoch, dataset, args, out=sys.stdout):
+    '''Model.train (main.py:402-510)'''
+    best_loss, best_loss_time = float('+inf'), 0
+    model.set_learn_rate(hparams.LR)
+    out.write('Set learning rate to %f\n' % hparams.LR)
+    i_epoch = 0
+    while i_epoch < n_epoch:
+        cli_report = OrderedDict()
+        i_batch = 0
+        for i_batch, data_pt in enumerate(dataset.epoch(
+                'train', hparams.BATCH_SIZE * hparams.MAX_N_SIGNAL, shuffle=True)):
+            spectra = _to_batch(data_pt, model.device)
+            if hparams.MAX_TRAIN_LEN is not None and spectra.shape[2] > hparams.MAX_TRAIN_LEN:
+                beg = randint(0, spectra.shape[2] - hparams.MAX_TRAIN_LEN - 1)   # main.py:424-425
+                spectra = spectra[:, :, beg:beg + hparams.MAX_TRAIN_LEN].contiguous()
+            step_fetch = model.train_step(spectra)
+            model.reset_state()
+            out.write(':')
+            out.flush()
+            _dict_add(cli_report, step_fetch)
+        _dict_mul(cli_report, 1. / (i_batch + 1))
+        if hparams.LR_DECAY_TYPE == 'adaptive':                                  # main.py:439-451
+            if cli_report['loss'] < best_loss:
+                best_loss, best_loss_time = cli_report['loss'], 0
+            else:
+                best_loss_time += 1
+        elif hparams.LR_DECAY_TYPE == 'fixed':
+            best_loss_time += 1
+        elif hparams.LR_DECAY_TYPE is not None:
+            raise ValueError('Unknown LR_DECAY_TYPE "%s"' % hparams.LR_DECAY_TYPE)
+        if best_loss_time == hparams.NUM_EPOCH_PER_LR_DECAY:                     # main.py:453-459
+            best_loss_time = 0
+            old_lr = model.get_learn_rate()
+            new_lr = old_lr * hparams.LR_DECAY
+            model.set_learn_rate(new_lr)
+            out.write('[LR %f -> %f]' % (old_lr, new_lr))
+        if not args.no_save_on_epoch and dist.rank() == 0:
+            if any(map(isnan, cli_report.values())):                             # main.py:462-476
+                if i_epoch:
+                    out.write('\nEpoch %d/%d got NAN values, restoring last checkpoint ... '
+                              % (i_epoch + 1, n_epoch))
+                    model.load_params('saves/' + model.name + ('_e%d' % i_epoch))
+                    out.write('done')
+                    continue                  # redo this epoch from the restored parameters
+                out.write('\nRun into NAN during 1st epoch, exiting ...')
+                sys.exit(-1)
+            model.save_params('saves/' + model.name + ('_e%d' % (i_epoch + 1)))
+            out.write('S')
+        out.write('\nEpoch %d/%d %s\n' % (i_epoch + 1, n_epoch, _dict_format(cli_report)))
+        out.flush()
+        i_epoch += 1
+        if args.no_valid_on_epoch:
+            continue
+        rep = evaluate(model, dataset, 'valid', out)
+        out.write('\nValid  %d/%d %s\n' % (i_epoch, n_epoch, _dict_format(rep)))
+        out.flush()
+
+
+def evaluate(model, dataset, subset, out=sys.stdout):
+    '''validation / test sweep with valid_fetches (main.py:486-510, :512-532)'''
+    rep = OrderedDict()
+    i_batch = 0
+    for i_batch, data_pt in enumerate(dataset.epoch(
+            subset, hparams.BATCH_SIZE * hparams.MAX_N_SIGNAL, shuffle=False)):
+        _dict_add(rep, model.valid_step(_to_batch(data_pt, model.device)))
+        model.reset_state()
+        out.write('.')
+        out.flush()
+    _dict_mul(rep, 1. / (i_batch + 1))
+    return rep
+
+
+def demo(model, args, out=sys.stdout):
+    '''wav -> separated wavs (main.py:655-696)'''
+    feat = utils.load_wavfile(args.input_file)                       # [T, F] complex
+    x = torch.as_tensor(feat.astype(np.complex64)).to(model.device)[None]
+    sep = model.infer(x)[0].cpu().numpy()                            # [C, T, F]
+    base = os.path.splitext(args.input_file)[0]
+    for i, s in enumerate(sep):
+        fn = '%s_separated_%d.wav' % (base, i + 1)
+        utils.save_wavfile(fn, s)
+        out.write('wrote %s\n' % fn)
+
+
+def debug(model, dataset, out=sys.stdout):
+    '''dump the debug fetches to debug/debug_data.npz (main.py:717-737 writes a .mat)'''
+    data_pt = next(iter(dataset.epoch('train', hparams.BATCH_SIZE * hparams.MAX_N_SIGNAL)))
+    fetch = model.debug_fetch(_to_batch(data_pt, model.device))
+    os.makedirs('debug', exist_ok=True)
+    np.savez('debug/debug_data.npz',
+             **{k: v.detach().cpu().numpy() for k, v in fetch.items() if torch.is_tensor(v)})
+    out.write('wrote debug/debug_data.npz: %s\n' % ', '.join(sorted(fetch)))
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description='MI355X-native Deep Attractor Network')
+    p.add_argument('-n', '--name', default='UnnamedExperiment')
+    p.add_argument('-m', '--mode', default='train',
+                   help='train | valid | test | demo | debug')
+    p.add_argument('-i', '--input-pfile', help='path to input model parameter file')
+    p.add_argument('-o', '--output-pfile', help='path to output model parameters file')
+    p.add_argument('-c', '--config-file', help='JSON hyperparameter file (keys of default.json)')
+    p.add_argument('-ne', '--num-epoch', type=int, default=10)
+    p.add_argument('-if', '--input-file', help='input WAV file for "demo" mode')
+    p.add_argument('-ds', '--dataset', help='choose dataset to use, overrides hparams.DATASET_TYPE')
+    p.add_argument('-lr', '--learn-rate', type=float, help='overrides hparams.LR')
+    p.add_argument('-tl', '--train-length', type=int, help='overrides hparams.MAX_TRAIN_LEN')
+    p.add_argument('-bs', '--batch-size', type=int, help='overrides hparams.BATCH_SIZE')
+    p.add_argument('--no-save-on-epoch', action='store_true')
+    p.add_argument('--no-valid-on-epoch', action='store_true')
+    return p
+
+
+def main(argv=None, out=sys.stdout):
+    args = build_parser().parse_args(argv)
+    if args.config_file is not None:                                  # main.py:587-592
+        hparams.load_json(args.config_file)
+    if args.learn_rate is not None:                                   # main.py:594-604
+        hparams.LR = args.learn_rate
+    if args.train_length is not None:
+        hparams.MAX_TRAIN_LEN = args.train_length
+    if args.dataset is not None:
+        hparams.DATASET_TYPE = args.dataset
+    if args.batch_size is not None:
+        hparams.BATCH_SIZE = args.batch_size
+    if args.mode == 'demo':
+        hparams.BATCH_SIZE = 1                                        # main.py:623-627
+    hparams.digest()
+
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist.init_from_env('nccl', device)
+    np.random.seed(dist.shard_seed(1337))
+
+    dataset = None
+    if args.mode != 'demo':
+        out.write('Preparing dataset "%s" ... ' % hparams.DATASET_TYPE)
+        dataset = hparams.get_dataset()()
+        dataset.install_and_load()
+        out.write('done\n')
+    out.write('Building model ... ')
+    model = Model(name=args.name, device=device).build()
+    out.write('done (%d parameters)\n' % model.parameter_count())
+    if args.input_pfile is not None:
+        model.load_params(args.input_pfile)
+
+    if args.mode == 'train':
+        train(model, args.num_epoch, dataset, args, out)
+        if args.output_pfile is not None and dist.rank() == 0:
+            model.save_params(args.output_pfile)
+    elif args.mode in ('valid', 'test'):
+        rep = evaluate(model, dataset, args.mode, out)
+        out.write('\n%s: %s\n' % (args.mode.capitalize(), _dict_format(rep)))
+    elif args.mode == 'demo':
+        demo(model, args, out)
+    elif args.mode == 'debug':
+        debug(model, dataset, out)
+    else:
+        raise ValueError('Unknown mode "%s"' % args.mode)
+    return model

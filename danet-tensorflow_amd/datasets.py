@@ -61,3 +61,28 @@ def synth_waves(seed, n_utt, n_frames, smprate=None):
     return np.stack([
         speech_shaped_wave(rng, Ls, smprate, phase=rng.uniform(0, 2 * np.pi))
         for _ in range(n_utt)])
+
+
+@hparams.register_dataset('synth')
+class SynthSpeechData(Dataset):
+    '''speech-shaped synthetic 2..C-speaker data (SURVEY 8d cfg 2/3): yields
+    complex64 spectra [batch, T, FEATURE_SIZE] of independent single-speaker
+    utterances, like the reference's TIMIT / WSJ0 iterators
+    (app/datasets/timit.py, wsj0.py); mixing happens in the model (main.py:233).
+    The STFT runs on the GPU (danet_stft).'''
+    N_BATCH = {'train': 10, 'valid': 2, 'test': 2}
+    N_FRAMES = 160
+
+    def epoch(self, subset, batch_size, shuffle=False):
+        if not self.is_loaded:
+            raise RuntimeError('Dataset is not loaded.')
+        import torch
+        from . import utils
+        base = {'train': 0, 'valid': 10 ** 6, 'test': 2 * 10 ** 6}[subset]
+        for i in range(self.N_BATCH[subset]):
+            seed = base + i if not shuffle else base + int(np.random.randint(0, 10 ** 5))
+            waves = synth_waves(seed, batch_size, self.N_FRAMES)
+            yield (utils.stft(torch.as_tensor(waves)).cpu().numpy(),)
+
+    def install_and_load(self):
+        self.is_loaded = True

@@ -58,6 +58,8 @@ DEFAULTS = {
     # extensions (reference values hard-coded at app/modules.py:212,223-242)
     'NUM_LSTM_LAYERS': 4,
     'LSTM_HDIM': 300,
+    # k-means estimator (not in the reference, README.md:216; BASELINE cfg 5)
+    'KMEANS_ITERS': 10,
 }
 
 

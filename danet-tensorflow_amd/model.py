@@ -145,7 +145,10 @@ class Model(object):
                     s_vattr = self.valid_estimator(
                         s_embed, s_src_pwr=fe['src_pwr'], s_mix_pwr=fe['mix_pwr'])
                 else:
-                    s_vattr = self.valid_estimator(s_embed)    # main.py:267
+                    # main.py:267 passes only the embedding; the mixture magnitude is an
+                    # extra keyword the reference's estimator signature already has
+                    # (app/modules.py:501), used by the k-means extension as weights
+                    s_vattr = self.valid_estimator(s_embed, s_mix_pwr=fe['mix_pwr'])
                 s_vsep = self.separator(fe['mix_pwr'], s_vattr, s_embed_flat)  # :277-278
             vloss, perms, vidx, vsnr = ops.pit_mse_loss(       # main.py:312-313, 336-337
                 s_src_signals, s_vsep, phasor, mode=1, eps=eps)
@@ -194,7 +197,7 @@ class Model(object):
         with torch.no_grad():
             fe = ops.frontend(s_mixed_signals[:, None].contiguous())
             s_embed = self.encoder(fe['mix_log'])
-            s_attr = self.valid_estimator(s_embed)
+            s_attr = self.valid_estimator(s_embed, s_mix_pwr=fe['mix_pwr'])
             s_sep = self.separator(fe['mix_pwr'], s_attr, s_embed.reshape(B, -1, E))
             return ops.reattach_phase(s_sep, fe['phasor'])
 

@@ -246,6 +246,48 @@ class AnchoredEstimator(Estimator):
         return s_attractors
 
 
+@hparams.register_estimator('kmeans')
+class KMeansEstimator(Estimator):
+    '''k-means-style attractor estimation for inference (BASELINE cfg 5).  NOT in
+    the reference ("Only the favorable anchor method is implemented",
+    README.md:216) -- an extension with no reference behaviour to match.
+    Initialised from the anchor estimator's attractors (so it shares the
+    `anchors` variable name and shape, app/modules.py:503-506), then
+    hparams.KMEANS_ITERS Lloyd iterations: assign every time-frequency bin to its
+    nearest attractor by dot product (the separator's own similarity), recompute
+    each attractor as the |mix|-weighted mean of its bins (the reference's
+    truth-weighted formula, app/modules.py:476-482, with estimated instead of
+    ideal assignments).  Built entirely from the existing HIP kernels:
+    danet_separate_fwd -> argmax inside danet_attractor_truth_fwd.'''
+    USE_TRUTH = False
+
+    def __init__(self, model, name):
+        super(KMeansEstimator, self).__init__(model, name)
+        self.name = name
+
+    def __call__(self, s_embed, s_src_pwr=None, s_mix_pwr=None, s_embed_flat=None):
+        B, T, F, E = s_embed.shape
+        C = hparams.MAX_N_SIGNAL
+        v_anchors = self.model.get_variable(
+            self.name + '/anchors', [hparams.NUM_ANCHOR, hparams.EMBED_SIZE],
+            lambda shape, gen: torch.randn(shape, generator=gen, dtype=torch.float64).float())
+        with torch.no_grad():
+            s_embed_d = s_embed.detach()
+            if s_mix_pwr is None:
+                s_mix_pwr = torch.ones(B, T, F, device=s_embed.device)
+            s_attr, _, _ = ops.AnchorAttractorFn.apply(s_embed_d, v_anchors.detach(), C)
+            s_flat = s_embed_d.reshape(B, -1, E)
+            for _ in range(int(hparams.KMEANS_ITERS)):
+                # score[b,c,n] = |mix| * softmax_c(embed . attr): argmax_c = nearest attractor
+                s_score, _ = ops.SeparateFn.apply(s_mix_pwr, s_attr, s_flat, 0, False)
+                s_attr = ops.TruthAttractorFn.apply(
+                    s_embed_d, s_score, s_mix_pwr, ops.TRUTH_MODES['truth-weighted'],
+                    float(hparams.EPS))
+        if hparams.DEBUG:
+            self.debug_fetches = dict(anchors=v_anchors)
+        return s_attr
+
+
 class _DotSeparatorBase(Separator):
     ACT = None
 
