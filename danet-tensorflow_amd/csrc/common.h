@@ -70,3 +70,27 @@ __device__ __forceinline__ float sigmoidf_(float x) {
 __device__ __forceinline__ float sigmoid_acc(float x) {
   return 1.0f / (1.0f + expf(-x));
 }
+
+// Hardware-exponential variants for the latency-critical LSTM gate math
+// (v_exp_f32 / v_rcp_f32: ~1 ulp each; |relative error| of the results ~1e-6,
+// two orders below the 1e-4 parity bar -- checked by the GPU parity tests).
+// -DDANET_LSTM_ACCURATE_MATH restores libm expf/tanhf.
+__device__ __forceinline__ float sigmoid_hw(float x) {
+#ifdef DANET_LSTM_ACCURATE_MATH
+  return sigmoid_acc(x);
+#else
+  return __frcp_rn(1.0f + __expf(-x));
+#endif
+}
+__device__ __forceinline__ float tanh_hw(float x) {
+#ifdef DANET_LSTM_ACCURATE_MATH
+  return tanhf(x);
+#else
+  // tanh(x) = sign(x) * (1 - e) / (1 + e), e = exp(-2|x|) in (0, 1]: no overflow,
+  // no cancellation for large |x|; for tiny |x| the (1 - e) cancellation is
+  // absolute-error ~1e-8, relative to the O(1) tensor scale used by the bar
+  const float e = __expf(-2.0f * fabsf(x));
+  const float t = (1.0f - e) * __frcp_rn(1.0f + e);
+  return copysignf(t, x);
+#endif
+}

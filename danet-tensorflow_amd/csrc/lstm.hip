@@ -236,11 +236,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
         pre[gte] = v;
       }
       const float g = pre[0];                 // linear candidate (ops.py:143)
-      const float ig = sigmoid_acc(pre[1]);
-      const float fg = sigmoid_acc(pre[2]);
-      const float og = sigmoid_acc(pre[3]);
+      const float ig = sigmoid_hw(pre[1]);
+      const float fg = sigmoid_hw(pre[2]);
+      const float og = sigmoid_hw(pre[3]);
       c_state = ig * g + fg * c_state;        // ops.py:146
-      const float h = og * tanhf(c_state);    // ops.py:147
+      const float h = og * tanh_hw(c_state);   // ops.py:147
       // publish h_t: one write-through 4-byte store, no drain, no flag
       __hip_atomic_store(a.ypad + ((size_t)(t + 1) * B + bg) * a.ldy + dir * H + unit,
                          h, RLX_AGENT);
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
 #pragma unroll
       for (int w = 0; w < 4; ++w) dh += red[(w * 16 * MT + bl) * 17 + jl];
       const float g = gv[i][0], ig = gv[i][1], fg = gv[i][2], og = gv[i][3];
-      const float tc = tanhf(cv[i]);
+      const float tc = tanh_hw(cv[i]);
       const float dc = dc_state[i] + dh * og * (1.f - tc * tc);
       const float da_g = dc * ig;
       const float da_i = dc * g * ig * (1.f - ig);
