@@ -71,5 +71,22 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_trace():
+    '''diagnostic variant csrc/libdanet_hip_trace.so (-DDANET_LSTM_TRACE): the
+    persistent LSTM kernels time-stamp every step (tools/trace_lstm.py)'''
+    out = os.path.join(CSRC, 'libdanet_hip_trace.so')
+    srcs = [os.path.join(CSRC, f) for f in _sources()]
+    cmd = [HIPCC] + FLAGS + ['-DDANET_LSTM_TRACE', '-shared', '-o', out]
+    for sp in srcs:
+        cmd += (['-x', 'hip', sp] if sp.endswith('.hip') else ['-x', 'c++', sp])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('trace build failed:\n%s\n%s' % (r.stdout, r.stderr))
+    return out
+
+
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
+    if '--trace' in sys.argv:
+        print(build_trace())
+    else:
+        build(force='--force' in sys.argv)

@@ -100,6 +100,22 @@ __device__ __forceinline__ bool spin_fail(unsigned& spins, int* status, int lane
   return false;
 }
 
+// Optional diagnostic build (-DDANET_LSTM_TRACE, tools/trace_lstm.py): workgroup 0
+// wave 0 stamps the phases of every step with the 100 MHz wall clock into
+// ws[64 ...] as [T][8] u64 (A top, B exchange valid, C MFMA done, D barrier 1,
+// E published, F barrier 2, G retry count).
+#ifdef DANET_LSTM_TRACE
+#define TRACE(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) \
+    ((unsigned long long*)((char*)a.status + 64))[(size_t)s * 8 + (slot)] = wall_clock64(); } while (0)
+#define TRACE_VAL(slot, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) \
+    ((unsigned long long*)((char*)a.status + 64))[(size_t)s * 8 + (slot)] = (v); } while (0)
+#define TRACE_BYTES(T) ((size_t)(T) * 64)
+#else
+#define TRACE(slot) do {} while (0)
+#define TRACE_VAL(slot, v) do {} while (0)
+#define TRACE_BYTES(T) ((size_t)0)
+#endif
+
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
@@ -145,10 +161,24 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
   const int fr = lane & 15, fq = lane >> 4;
   const int NG = a.KP / 16;
 
+  // The weights are stationary: this lane's B fragments of the wave's first
+  // FWD_CH k-groups go to registers ONCE (2*FWD_CH float4), so the per-step MFMA
+  // chain never waits on an LDS read (measured: MFMA phase 0.93 -> see
+  // profiles/README.md); later chunks (H > 320) still read LDS.
+  f32x4 wreg[FWD_CH][2];
+#pragma unroll
+  for (int g = 0; g < FWD_CH; ++g) {
+    const int kg = g * 4 + wave;
+    const int k4 = (kg < NG ? kg : 0) * 4 + fq;
+    wreg[g][0] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + fr) * 4]);
+    wreg[g][1] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + 16 + fr) * 4]);
+  }
+
   for (int s = 0; s < T; ++s) {
     const int t = dir ? (T - 1 - s) : s;
     const int blk_prev = dir ? (t + 2) : t;  // ypad block holding h_{prev}
 
+    TRACE(0);
     // prefetch this step's hoisted input projections (independent of h)
     float gxv[4] = {0.f, 0.f, 0.f, 0.f};
     if (owner) {
@@ -191,13 +221,28 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
           if (__all(ok)) break;
           if (spin_fail(spins, a.status, lane)) break;
         }
+        TRACE(1); TRACE_VAL(6, spins);
+        // NO per-group branch here: a branch splits the accumulator chain into
+        // basic blocks and the compiler then moves the accumulators AGPR<->VGPR
+        // around every group (measured 2x on the MFMA phase).  Groups past NG
+        // multiply zeros (their loads were out of range) by finite weights.
+        f32x4 wq[FWD_CH][2];
+        if (g0 == 0) {
+#pragma unroll
+          for (int g = 0; g < FWD_CH; ++g) { wq[g][0] = wreg[g][0]; wq[g][1] = wreg[g][1]; }
+        } else {
+#pragma unroll
+          for (int g = 0; g < FWD_CH; ++g) {
+            const int kg = (g0 + g) * 4 + wave;
+            const int k4 = (kg < NG ? kg : 0) * 4 + fq;
+            wq[g][0] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + fr) * 4]);
+            wq[g][1] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + 16 + fr) * 4]);
+          }
+        }
 #pragma unroll
         for (int g = 0; g < FWD_CH; ++g) {
-          const int kg = (g0 + g) * 4 + wave;
-          if (kg < NG) {   // wave-uniform
-            const int k4 = kg * 4 + fq;
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + fr) * 4]);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + 16 + fr) * 4]);
+          {
+            const f32x4 w0 = wq[g][0], w1 = wq[g][1];
             // NB: bit_cast the WHOLE vector -- __builtin_bit_cast(float, vec[j])
             // on a vector element reads element 0 for every j (hipcc 7.2)
             f32x4 af[MT];
@@ -216,6 +261,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
       }
     }
 
+    TRACE(2);
     // cross-wave reduction.  D layout 16x16: col = lane&15, row = 4*(lane>>4)+r
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -225,6 +271,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
         for (int r = 0; r < 4; ++r)
           red[(wave * 16 * MT + mt * 16 + 4 * fq + r) * 33 + nt * 16 + fr] = acc[mt][nt][r];
     __syncthreads();
+    TRACE(3);
 
     if (owner) {
       float pre[4];
@@ -253,7 +300,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
     // cluster, i.e. after every owner thread (in every wave) has finished
     // reading `red` for this step -- but waves without owners never publish,
     // so a block barrier keeps the reuse safe in all shapes.
+    TRACE(4);
     __syncthreads();
+    TRACE(5);
   }
 }
 
@@ -300,11 +349,21 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
   const int fr = lane & 15, fq = lane >> 4;
   const int NG = H4 / 16;
 
+  // stationary Wh^T fragments of the wave's first BWD_CH k-groups in registers
+  // (see forward kernel); later chunks (H > 304) read LDS
+  f32x4 wreg[BWD_CH];
+#pragma unroll
+  for (int g = 0; g < BWD_CH; ++g) {
+    const int kg = g * 4 + wave;
+    wreg[g] = *reinterpret_cast<const f32x4*>(&Wl[(((kg < NG ? kg : 0) * 4 + fq) * 16 + fr) * 4]);
+  }
+
   for (int s = 0; s < T; ++s) {
     const int t = dir ? s : (T - 1 - s);          // BPTT order per direction
     const int t_done = dir ? (t - 1) : (t + 1);   // step processed just before
     const int t_cprev = dir ? (t + 1) : (t - 1);  // time of c_{prev} in scan order
 
+    TRACE(0);
     // prefetch everything that does not depend on the exchange
     float gv[MT][4], cv[MT], cpv[MT], dyv[MT];
     bool own[MT];
@@ -356,11 +415,22 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
           if (__all(ok)) break;
           if (spin_fail(spins, a.status, lane)) break;
         }
+        TRACE(1); TRACE_VAL(6, spins);
+        f32x4 wq[BWD_CH];     // straight-line MFMA chain (see forward kernel)
+        if (g0 == 0) {
+#pragma unroll
+          for (int g = 0; g < BWD_CH; ++g) wq[g] = wreg[g];
+        } else {
+#pragma unroll
+          for (int g = 0; g < BWD_CH; ++g) {
+            const int kg = (g0 + g) * 4 + wave;
+            wq[g] = *reinterpret_cast<const f32x4*>(&Wl[(((kg < NG ? kg : 0) * 4 + fq) * 16 + fr) * 4]);
+          }
+        }
 #pragma unroll
         for (int g = 0; g < BWD_CH; ++g) {
-          const int kg = (g0 + g) * 4 + wave;
-          if (kg < NG) {   // wave-uniform
-            const f32x4 w = *reinterpret_cast<const f32x4*>(&Wl[((kg * 4 + fq) * 16 + fr) * 4]);
+          {
+            const f32x4 w = wq[g];
             f32x4 af[MT];   // whole-vector bit_cast (see forward kernel)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) af[mt] = __builtin_bit_cast(f32x4, av[g][mt]);
@@ -375,12 +445,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
       }
     }
 
+    TRACE(2);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         red[(wave * 16 * MT + mt * 16 + 4 * fq + r) * 17 + fr] = acc[mt][0][r] + acc[mt][1][r];
     __syncthreads();
+    TRACE(3);
 
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -404,7 +476,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
       __hip_atomic_store(dp + 2 * H, da_f, RLX_AGENT);
       __hip_atomic_store(dp + 3 * H, da_o, RLX_AGENT);
     }
+    TRACE(4);
     __syncthreads();   // `red` reuse (see forward kernel)
+    TRACE(5);
   }
 }
 
@@ -431,8 +505,8 @@ static LstmPlan make_plan(int B, int H, int ndir, bool bwd) {
 }
 
 extern "C" size_t danet_lstm_workspace_bytes(int T, int B, int H, int ndir) {
-  (void)T; (void)B; (void)H; (void)ndir;
-  return 64;   // status word (+ padding)
+  (void)B; (void)H; (void)ndir;
+  return 64 + TRACE_BYTES(T);   // status word (+ padding) (+ trace records)
 }
 
 static int lstm_check_common(int T, int B, int H, int ndir, void* ws, size_t ws_bytes) {
