@@ -119,10 +119,13 @@ __device__ __forceinline__ bool spin_fail(unsigned& spins, int* status, int lane
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
-template <int MT>
-__global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
+// NW waves per workgroup split K (4 = one per SIMD; 8 / 16 shorten each wave's
+// chain of sc1 exchange loads, which is what bounds the exchange phase).
+template <int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
+  constexpr int CH = (FWD_CH * 4 + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // smem: weights [KP/4][32][4] | red [4 waves][16*MT][33]
+  // smem: weights [KP/4][32][4] | red [NW waves][16*MT][33]
   float* Wl = smem;
   float* red = smem + (size_t)a.KP * 32;
 
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
   // ---- stationary weights: Wl[(k/4)*32 + n][k%4], n = gate*8 + u ----------
   {
     const float* W = a.Wh[dir];
-    for (int idx = tid; idx < a.KP * 32; idx += 256) {
+    for (int idx = tid; idx < a.KP * 32; idx += 64 * NW) {
       const int k = idx >> 5, n = idx & 31;
       const int gate = n >> 3, u = u0 + (n & 7);
       float v = 0.f;
@@ -162,13 +165,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
   const int NG = a.KP / 16;
 
   // The weights are stationary: this lane's B fragments of the wave's first
-  // FWD_CH k-groups go to registers ONCE (2*FWD_CH float4), so the per-step MFMA
+  // CH k-groups go to registers ONCE (2*CH float4), so the per-step MFMA
   // chain never waits on an LDS read (measured: MFMA phase 0.93 -> see
   // profiles/README.md); later chunks (H > 320) still read LDS.
-  f32x4 wreg[FWD_CH][2];
+  f32x4 wreg[CH][2];
 #pragma unroll
-  for (int g = 0; g < FWD_CH; ++g) {
-    const int kg = g * 4 + wave;
+  for (int g = 0; g < CH; ++g) {
+    const int kg = g * NW + wave;
     const int k4 = (kg < NG ? kg : 0) * 4 + fq;
     wreg[g][0] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + fr) * 4]);
     wreg[g][1] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + 16 + fr) * 4]);
@@ -197,14 +200,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
     // This wave's k-groups are wave, wave+4, ...; all of a chunk's 16-B loads
     // are issued together and re-issued until every word has been published.
     if (s > 0) {
-      for (int g0 = 0; g0 * 4 + wave < NG; g0 += FWD_CH) {
-        v4u av[FWD_CH][MT];
+      for (int g0 = 0; g0 * NW + wave < NG; g0 += CH) {
+        v4u av[CH][MT];
         unsigned spins = 0;
         for (;;) {
           bool ok = true;
 #pragma unroll
-          for (int g = 0; g < FWD_CH; ++g) {
-            const int k = ((g0 + g) * 4 + wave) * 16 + fq * 4;
+          for (int g = 0; g < CH; ++g) {
+            const int k = ((g0 + g) * NW + wave) * 16 + fq * 4;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
               const int row = b0 + mt * 16 + fr;
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
             }
           }
 #pragma unroll
-          for (int g = 0; g < FWD_CH; ++g)
+          for (int g = 0; g < CH; ++g)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) ok &= !has_sentinel(av[g][mt]);
           if (__all(ok)) break;
@@ -226,21 +229,21 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
         // basic blocks and the compiler then moves the accumulators AGPR<->VGPR
         // around every group (measured 2x on the MFMA phase).  Groups past NG
         // multiply zeros (their loads were out of range) by finite weights.
-        f32x4 wq[FWD_CH][2];
+        f32x4 wq[CH][2];
         if (g0 == 0) {
 #pragma unroll
-          for (int g = 0; g < FWD_CH; ++g) { wq[g][0] = wreg[g][0]; wq[g][1] = wreg[g][1]; }
+          for (int g = 0; g < CH; ++g) { wq[g][0] = wreg[g][0]; wq[g][1] = wreg[g][1]; }
         } else {
 #pragma unroll
-          for (int g = 0; g < FWD_CH; ++g) {
-            const int kg = (g0 + g) * 4 + wave;
+          for (int g = 0; g < CH; ++g) {
+            const int kg = (g0 + g) * NW + wave;
             const int k4 = (kg < NG ? kg : 0) * 4 + fq;
             wq[g][0] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + fr) * 4]);
             wq[g][1] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + 16 + fr) * 4]);
           }
         }
 #pragma unroll
-        for (int g = 0; g < FWD_CH; ++g) {
+        for (int g = 0; g < CH; ++g) {
           {
             const f32x4 w0 = wq[g][0], w1 = wq[g][1];
             // NB: bit_cast the WHOLE vector -- __builtin_bit_cast(float, vec[j])
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
       for (int gte = 0; gte < 4; ++gte) {
         float v = gxv[gte];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) v += red[(w * 16 * MT + bl) * 33 + gte * 8 + ul];
+        for (int w = 0; w < NW; ++w) v += red[(w * 16 * MT + bl) * 33 + gte * 8 + ul];
         pre[gte] = v;
       }
       const float g = pre[0];                 // linear candidate (ops.py:143)
@@ -309,10 +312,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
 // ---------------------------------------------------------------------------
 // backward (BPTT)
 // ---------------------------------------------------------------------------
-template <int MT>
-__global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
+// NW waves per workgroup split K: 4 (one per SIMD) or 8 -- the MFMA pipe is per
+// SIMD so 8 waves do not speed the MFMA phase up, but each wave then issues half
+// the exchange loads, and sc1 reads of remotely written lines are bound per wave.
+template <int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void lstm_bwd_kernel(LstmBwdArgs a) {
+  constexpr int CH = (BWD_CH * 4 + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // smem: weights^T [4H/4][16][4] | red [4 waves][16*MT][17]
+  // smem: weights^T [4H/4][16][4] | red [NW waves][16*MT][17]
   const int H = a.H, B = a.B, T = a.T, H4 = 4 * a.H;
   float* Wl = smem;
   float* red = smem + (size_t)H4 * 16;
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
   // stationary Wh^T slice: element (n, j) = Wh[u0+j][n] at ((n/4)*16 + j)*4 + n%4
   {
     const float* W = a.Wh[dir];
-    for (int idx = tid; idx < H4 * 16; idx += 256) {
+    for (int idx = tid; idx < H4 * 16; idx += 64 * NW) {
       const int j = idx / H4, n = idx % H4;   // n fastest -> coalesced row reads
       float v = 0.f;
       if (u0 + j < H) v = W[(size_t)(u0 + j) * a.ldw + n];
@@ -349,12 +356,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
   const int fr = lane & 15, fq = lane >> 4;
   const int NG = H4 / 16;
 
-  // stationary Wh^T fragments of the wave's first BWD_CH k-groups in registers
+  // stationary Wh^T fragments of the wave's first CH k-groups in registers
   // (see forward kernel); later chunks (H > 304) read LDS
-  f32x4 wreg[BWD_CH];
+  f32x4 wreg[CH];
 #pragma unroll
-  for (int g = 0; g < BWD_CH; ++g) {
-    const int kg = g * 4 + wave;
+  for (int g = 0; g < CH; ++g) {
+    const int kg = g * NW + wave;
     wreg[g] = *reinterpret_cast<const f32x4*>(&Wl[(((kg < NG ? kg : 0) * 4 + fq) * 16 + fr) * 4]);
   }
 
@@ -391,14 +398,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
     }
 
     if (s > 0) {
-      for (int g0 = 0; g0 * 4 + wave < NG; g0 += BWD_CH) {
-        v4u av[BWD_CH][MT];
+      for (int g0 = 0; g0 * NW + wave < NG; g0 += CH) {
+        v4u av[CH][MT];
         unsigned spins = 0;
         for (;;) {
           bool ok = true;
 #pragma unroll
-          for (int g = 0; g < BWD_CH; ++g) {
-            const int kg = (g0 + g) * 4 + wave;
+          for (int g = 0; g < CH; ++g) {
+            const int kg = (g0 + g) * NW + wave;
             const int n = kg * 16 + fq * 4;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -409,26 +416,26 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
             }
           }
 #pragma unroll
-          for (int g = 0; g < BWD_CH; ++g)
+          for (int g = 0; g < CH; ++g)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) ok &= !has_sentinel(av[g][mt]);
           if (__all(ok)) break;
           if (spin_fail(spins, a.status, lane)) break;
         }
         TRACE(1); TRACE_VAL(6, spins);
-        f32x4 wq[BWD_CH];     // straight-line MFMA chain (see forward kernel)
+        f32x4 wq[CH];     // straight-line MFMA chain (see forward kernel)
         if (g0 == 0) {
 #pragma unroll
-          for (int g = 0; g < BWD_CH; ++g) wq[g] = wreg[g];
+          for (int g = 0; g < CH; ++g) wq[g] = wreg[g];
         } else {
 #pragma unroll
-          for (int g = 0; g < BWD_CH; ++g) {
-            const int kg = (g0 + g) * 4 + wave;
+          for (int g = 0; g < CH; ++g) {
+            const int kg = (g0 + g) * NW + wave;
             wq[g] = *reinterpret_cast<const f32x4*>(&Wl[(((kg < NG ? kg : 0) * 4 + fq) * 16 + fr) * 4]);
           }
         }
 #pragma unroll
-        for (int g = 0; g < BWD_CH; ++g) {
+        for (int g = 0; g < CH; ++g) {
           {
             const f32x4 w = wq[g];
             f32x4 af[MT];   // whole-vector bit_cast (see forward kernel)
@@ -460,7 +467,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
       const int bl = (tid >> 4) + 16 * i, bg = b0 + bl;
       float dh = dyv[i];
 #pragma unroll
-      for (int w = 0; w < 4; ++w) dh += red[(w * 16 * MT + bl) * 17 + jl];
+      for (int w = 0; w < NW; ++w) dh += red[(w * 16 * MT + bl) * 17 + jl];
       const float g = gv[i][0], ig = gv[i][1], fg = gv[i][2], og = gv[i][3];
       const float tc = tanh_hw(cv[i]);
       const float dc = dc_state[i] + dh * og * (1.f - tc * tc);
@@ -485,7 +492,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-struct LstmPlan { int MT, G, P, KP; size_t lds; };
+struct LstmPlan { int MT, G, P, KP, NW; size_t lds; };
 
 // MT=1 (16-row clusters) halves the per-step MFMA time and the payload per
 // workgroup at the price of twice the workgroups; it is used whenever one
@@ -499,8 +506,17 @@ static LstmPlan make_plan(int B, int H, int ndir, bool bwd) {
   const char* force = getenv(bwd ? "DANET_LSTM_BWD_MT" : "DANET_LSTM_FWD_MT");
   if (force && (force[0] == '1' || force[0] == '2')) pl.MT = force[0] - '0';
   pl.G = cdiv(B, 16 * pl.MT);
-  pl.lds = bwd ? ((size_t)4 * H * 16 + (size_t)4 * 16 * pl.MT * 17) * sizeof(float)
-               : ((size_t)pl.KP * 32 + (size_t)4 * 16 * pl.MT * 33) * sizeof(float);
+  // waves per workgroup: more waves = shorter per-wave exchange-load chains
+  pl.NW = bwd ? 8 : 4;
+  const char* fnw = getenv(bwd ? "DANET_LSTM_BWD_NW" : "DANET_LSTM_FWD_NW");
+  if (fnw && (atoi(fnw) == 4 || atoi(fnw) == 8 || atoi(fnw) == 16)) pl.NW = atoi(fnw);
+  if (pl.MT == 2 && pl.NW > 4) pl.NW = 4;          // ownership map assumes <= 256 threads
+  for (;;) {
+    pl.lds = bwd ? ((size_t)4 * H * 16 + (size_t)pl.NW * 16 * pl.MT * 17) * sizeof(float)
+                 : ((size_t)pl.KP * 32 + (size_t)pl.NW * 16 * pl.MT * 33) * sizeof(float);
+    if (pl.lds <= 160 * 1024 || pl.NW == 4) break;
+    pl.NW /= 2;
+  }
   return pl;
 }
 
@@ -559,15 +575,16 @@ extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int n
   DANET_CHECK_HIP(hipMemsetAsync((char*)ypad + blk, 0xFF, (size_t)T * blk, stream));
   DANET_CHECK_HIP(hipMemsetAsync(ypad, 0, blk, stream));
   DANET_CHECK_HIP(hipMemsetAsync((char*)ypad + (size_t)(T + 1) * blk, 0, blk, stream));
-  if (pl.MT == 1) {
-    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_kernel<1>,
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
-    lstm_fwd_kernel<1><<<nblk, 256, pl.lds, stream>>>(a);
-  } else {
-    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_kernel<2>,
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
-    lstm_fwd_kernel<2><<<nblk, 256, pl.lds, stream>>>(a);
-  }
+#define LAUNCH_FWD(MTV, NWV)                                                         \
+  do {                                                                               \
+    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_kernel<MTV, NWV>,       \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));                   \
+    lstm_fwd_kernel<MTV, NWV><<<nblk, 64 * NWV, pl.lds, stream>>>(a);                \
+  } while (0)
+  if (pl.MT == 2) LAUNCH_FWD(2, 4);
+  else if (pl.NW == 16) LAUNCH_FWD(1, 16);
+  else if (pl.NW == 8) LAUNCH_FWD(1, 8);
+  else LAUNCH_FWD(1, 4);
   DANET_CHECK_LAUNCH();
   return DANET_OK;
 }
@@ -613,15 +630,16 @@ extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int n
   const size_t dbytes = (size_t)T * B * 4 * H * sizeof(float);
   DANET_CHECK_HIP(hipMemsetAsync(da_f, 0xFF, dbytes, stream));
   if (ndir == 2) DANET_CHECK_HIP(hipMemsetAsync(da_b, 0xFF, dbytes, stream));
-  if (pl.MT == 1) {
-    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_bwd_kernel<1>,
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
-    lstm_bwd_kernel<1><<<nblk, 256, pl.lds, stream>>>(a);
-  } else {
-    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_bwd_kernel<2>,
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
-    lstm_bwd_kernel<2><<<nblk, 256, pl.lds, stream>>>(a);
-  }
+#define LAUNCH_BWD(MTV, NWV)                                                         \
+  do {                                                                               \
+    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_bwd_kernel<MTV, NWV>,       \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));                   \
+    lstm_bwd_kernel<MTV, NWV><<<nblk, 64 * NWV, pl.lds, stream>>>(a);                \
+  } while (0)
+  if (pl.MT == 2) LAUNCH_BWD(2, 4);
+  else if (pl.NW == 16) LAUNCH_BWD(1, 16);
+  else if (pl.NW == 8) LAUNCH_BWD(1, 8);
+  else LAUNCH_BWD(1, 4);
   DANET_CHECK_LAUNCH();
   return DANET_OK;
 }
