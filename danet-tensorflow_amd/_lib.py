@@ -32,6 +32,8 @@ PROTOTYPES = {
     'danet_gemm_f32_workspace_bytes': (c_sz, [c_int, c_int, c_int]),
     'danet_gemm_f32': (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_int,
                                c_p, c_int, c_p, c_f32, c_p, c_sz]),
+    'danet_gemm_f32_ex': (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_int,
+                                  c_p, c_int, c_p, c_f32, c_p, c_sz, c_int]),
     'danet_colsum_f32_workspace_bytes': (c_sz, [c_int, c_int]),
     'danet_colsum_f32': (c_int, [c_p, c_int, c_int, c_p, c_int, c_p, c_f32, c_p, c_sz]),
     'danet_lstm_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int]),

@@ -106,13 +106,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   // (private L2 each); give each XCD a contiguous band of N-tiles of one
   // M-row-band so neighbours share the A panel in that XCD's L2.
   const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
-  int bid = blockIdx.x;
   const int nwg = tiles_m * tiles_n;
+  // work item = (K slice z, tile); a capped grid (max_workgroups) walks the items
+  // persistently so an overlapped GEMM can be confined to a few CUs
+  for (int wi = blockIdx.x; wi < nwg * g.splitk; wi += gridDim.x) {
+  int bid = wi % nwg;
   if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
   const int tm = bid / tiles_n, tn = bid % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  const int z = blockIdx.z;
+  const int z = wi / nwg;
   const int kbeg = z * g.kchunk;
   const int kend = min(g.K, kbeg + g.kchunk);
   const int nk = (kend - kbeg + BK - 1) / BK;
@@ -188,6 +191,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         }
       }
     }
+  }  // work-item loop (the k-loop above ends with a barrier, so LDS reuse is safe)
 }
 
 __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slab,
@@ -225,11 +229,26 @@ extern "C" size_t danet_gemm_f32_workspace_bytes(int M, int N, int K) {
   return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
+extern "C" int danet_gemm_f32_ex(danet_stream_t stream_, int transA, int transB,
+                                 int M, int N, int K, const float* A, int lda,
+                                 const float* B, int ldb, float* C, int ldc,
+                                 const float* bias, float beta, void* ws,
+                                 size_t ws_bytes, int max_workgroups);
+
 extern "C" int danet_gemm_f32(danet_stream_t stream_, int transA, int transB,
                               int M, int N, int K, const float* A, int lda,
                               const float* B, int ldb, float* C, int ldc,
                               const float* bias, float beta, void* ws,
                               size_t ws_bytes) {
+  return danet_gemm_f32_ex(stream_, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, beta,
+                           ws, ws_bytes, 0);
+}
+
+extern "C" int danet_gemm_f32_ex(danet_stream_t stream_, int transA, int transB,
+                                 int M, int N, int K, const float* A, int lda,
+                                 const float* B, int ldb, float* C, int ldc,
+                                 const float* bias, float beta, void* ws,
+                                 size_t ws_bytes, int max_workgroups) {
   hipStream_t stream = (hipStream_t)stream_;
   DANET_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: non-positive shape %d %d %d", M, N, K);
   DANET_CHECK_ARG(A && B && C, "gemm: null operand");
@@ -254,7 +273,9 @@ extern "C" int danet_gemm_f32(danet_stream_t stream_, int transA, int transB,
     }
     g.slab = (float*)ws;
   }
-  dim3 grid(cdiv(M, BM) * cdiv(N, BN), 1, splitk), block(256);
+  int nblocks = cdiv(M, BM) * cdiv(N, BN) * splitk;
+  if (max_workgroups > 0 && nblocks > max_workgroups) nblocks = max_workgroups;
+  dim3 grid(nblocks, 1, 1), block(256);
   const bool ak = !transA, bk = (transB != 0);
   if (ak && !bk) gemm_f32_kernel<true, false><<<grid, block, 0, stream>>>(g);
   else if (ak && bk) gemm_f32_kernel<true, true><<<grid, block, 0, stream>>>(g);

@@ -34,16 +34,18 @@ def _ws(nbytes, dev):
 # ---------------------------------------------------------------------------
 # raw wrappers (no autograd)
 # ---------------------------------------------------------------------------
-def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, beta=0.0):
+def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, beta=0.0,
+         max_workgroups=0):
     '''C[M,N] = op(A) op(B) (+bias) (+beta*C) on the fp32 matrix cores.
-    A, B, C are tensors whose data_ptr() is element (0,0); ld* in elements.'''
+    A, B, C are tensors whose data_ptr() is element (0,0); ld* in elements.
+    max_workgroups > 0 caps the launch (persistent workgroups).'''
     L = _L()
     need = L.danet_gemm_f32_workspace_bytes(M, N, K)
     w, wn = _ws(need, C.device)
     with _lib.timed('gemm_f32'):
-        check(L.danet_gemm_f32(_lib.stream(), int(transA), int(transB), M, N, K,
-                               ptr(_f32(A)), lda, ptr(_f32(B)), ldb, ptr(_f32(C)), ldc,
-                               ptr(bias), float(beta), ptr(w), wn))
+        check(L.danet_gemm_f32_ex(_lib.stream(), int(transA), int(transB), M, N, K,
+                                  ptr(_f32(A)), lda, ptr(_f32(B)), ldb, ptr(_f32(C)), ldc,
+                                  ptr(bias), float(beta), ptr(w), wn, int(max_workgroups)))
     return C
 
 
@@ -180,6 +182,10 @@ def _lstm_ws(T, B, H, ndir, dev):
 # is returned, so the caching allocator never recycles memory still in use.
 _side = {}
 SIDE_STREAMS = int(__import__('os').environ.get('DANET_SIDE_STREAMS', '2'))
+# persistent-workgroup cap for GEMMs that run under a BPTT kernel (per chain; 0 = off).
+# Measured at cfg 2: caps of 32..96 all LOSE (5.4-7.1 ms/step vs 5.2 uncapped): the
+# interference is fabric contention on the exchange hops, not CU placement.
+OVERLAP_GEMM_WGS = int(__import__('os').environ.get('DANET_OVERLAP_GEMM_WGS', '0'))
 
 
 def _side_streams(dev, n):
@@ -309,13 +315,19 @@ def lstm_layer_bwd(c, dy, need_dx):
         dWs.append(gW); dbs.append(gb); direct.append((okW, okb))
     dx = torch.empty(T * B, D, device=dev) if need_dx else None
 
+    # the weight-gradient products overlap the NEXT layer's BPTT kernel (152 of
+    # 256 CUs at cfg 2): cap each chain so both together stay on the idle CUs
+    cap = OVERLAP_GEMM_WGS if need_dx else 0
+
     def weight_grads(d):
         bW, bb = (1.0 if direct[d][0] else 0.0), (1.0 if direct[d][1] else 0.0)
         # dWx = X^T da
-        gemm(c.x, das[d], dWs[d], D, 4 * H, T * B, c.ldx, 4 * H, 4 * H, transA=True, beta=bW)
+        gemm(c.x, das[d], dWs[d], D, 4 * H, T * B, c.ldx, 4 * H, 4 * H, transA=True, beta=bW,
+             max_workgroups=cap)
         # dWh = Hprev^T da; Hprev(t) = ypad block t (fwd) / block t+2 (bwd)
         hprev = c.ypad.view(-1)[(0 if d == 0 else 2 * B * ldy + H):]
-        gemm(hprev, das[d], dWs[d][D:], H, 4 * H, T * B, ldy, 4 * H, 4 * H, transA=True, beta=bW)
+        gemm(hprev, das[d], dWs[d][D:], H, 4 * H, T * B, ldy, 4 * H, 4 * H, transA=True, beta=bW,
+             max_workgroups=cap)
         colsum(das[d], T * B, 4 * H, 4 * H, dbs[d], beta=bb)
 
     def input_grad():
@@ -324,11 +336,14 @@ def lstm_layer_bwd(c, dy, need_dx):
             gemm(das[d], c.Ws[d], dx, T * B, D, 4 * H, 4 * H, 4 * H, D, transB=True,
                  beta=0.0 if d == 0 else 1.0)
 
-    # chain 0 (main stream) carries dX, which the next layer's BPTT waits for; the
-    # weight-gradient chains are joined by the caller (`join_deferred`)
+    # dX is what the next layer's BPTT waits for: it is issued first, alone, on
+    # the main stream.  The weight-gradient chains fork AFTER it (the fork event
+    # is recorded behind dX), so they do not compete with dX for CUs but overlap
+    # the next layer's latency-bound BPTT kernel instead; the caller joins them
+    # (`join_deferred`).
+    if need_dx:
+        input_grad()
     with _Fork(dev, ndir + 1, defer=True, keep=(das, c.x, c.ypad, dy)) as f:
-        if need_dx:
-            f.run(0, input_grad)
         for d in range(ndir):
             f.run(d + 1, lambda d=d: weight_grads(d))
     dWs = [None if direct[d][0] else dWs[d] for d in range(ndir)]
@@ -406,10 +421,11 @@ class RnnEncoderFn(torch.autograd.Function):
         dev = dembed.device
         dWout, direct_out = _grad_target(ctx.Wout, (D, O), dev)
         dyc = torch.empty(B, T, D, device=dev)
+        gemm(dembed, ctx.Wout, dyc, B * T, D, O, O, O, D, transB=True)   # critical path first
         with _Fork(dev, 2, defer=True, keep=(dembed, ctx.yc)) as f:
-            f.run(0, lambda: gemm(dembed, ctx.Wout, dyc, B * T, D, O, O, O, D, transB=True))
             f.run(1, lambda: gemm(ctx.yc, dembed, dWout, D, O, B * T, D, O, O, transA=True,
-                                  beta=1.0 if direct_out else 0.0))
+                                  beta=1.0 if direct_out else 0.0,
+                                  max_workgroups=2 * OVERLAP_GEMM_WGS))
         dy = torch.empty(T, B, D, device=dev)
         center(dyc, B, T, D, 0, D, dy, 1, D)                 # centre is self-adjoint
         grads = [None] * (2 * L * ndir)

@@ -114,6 +114,15 @@ int danet_gemm_f32(danet_stream_t stream, int transA, int transB,
                    const float* A, int lda, const float* B, int ldb,
                    float* C, int ldc, const float* bias, float beta,
                    void* ws, size_t ws_bytes);
+/* Same, with the launch capped at `max_workgroups` persistent workgroups
+ * (0 = one per tile): lets a product that is overlapped with a latency-bound
+ * kernel on another stream (weight gradients under the BPTT kernel) stay off the
+ * CUs that kernel occupies.                                                  */
+int danet_gemm_f32_ex(danet_stream_t stream, int transA, int transB,
+                      int M, int N, int K,
+                      const float* A, int lda, const float* B, int ldb,
+                      float* C, int ldc, const float* bias, float beta,
+                      void* ws, size_t ws_bytes, int max_workgroups);
 
 /* out[N] = sum_m A[m][n] (+ beta*out): bias gradients.                     */
 int danet_colsum_f32(danet_stream_t stream, int M, int N, const float* A,
