@@ -212,15 +212,16 @@ __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slab,
 
 static int choose_splitk(int M, int N, int K) {
   const int tiles = cdiv(M, BM) * cdiv(N, BN);
-  if (tiles >= 160 || K < 512) return 1;
-  // aim at ~one workgroup per CU: every extra slice costs a full M*N slab
-  // write + read in the reduce kernel (it was 8% of the train step at s=18)
+  if (tiles >= 192 || K < 512) return 1;
+  // Fill the 256 CUs ~twice over: 160-tile products (dX, dYc: N = 600) gain 1.4-1.9x
+  // from 4 slices; the cost is one M*N slab write + read per slice in the reduce
+  // kernel, so the slice count is capped (it was 8% of the train step at s = 18).
   static int target = 0;
-  if (!target) { const char* e = getenv("DANET_SPLITK_TARGET"); target = e ? atoi(e) : 256; }
+  if (!target) { const char* e = getenv("DANET_SPLITK_TARGET"); target = e ? atoi(e) : 512; }
   int s = cdiv(target, tiles);
   const int maxs = K / 256;
   if (s > maxs) s = maxs;
-  if (s > 16) s = 16;
+  if (s > 8) s = 8;
   return s < 1 ? 1 : s;
 }
 
