@@ -570,3 +570,44 @@ def test_infer_and_debug_fetches(hp):
     dbg = model.debug_fetch(torch.as_tensor(src).cuda())
     assert relerr(dbg['output'].cpu().numpy(), ref['output']) < TOL
     assert relerr(dbg['masks'].cpu().numpy(), ref['masks']) < TOL
+
+
+@pytest.mark.parametrize('B,T,D,H,ndir', [
+    (64, 6, 32, 300, 2),      # fwd: 32-row clusters (MT=2); bwd: 16-row clusters
+    (96, 3, 16, 300, 2),
+    (8, 5, 16, 600, 2),       # H=600 bidirectional: 150/76 workgroups, 154 KB LDS in BPTT
+    (3, 1, 9, 8, 2),          # T=1: no recurrent step at all
+    (40, 4, 12, 64, 1),
+])
+def test_lstm_layer_shape_envelope(B, T, D, H, ndir):
+    '''shapes outside the BASELINE configs that `-bs` / hparams can reach'''
+    from danet_amd import ops
+    rng = np.random.RandomState(B + T + H)
+    r = 0.75 / np.sqrt(H)
+    x = rng.randn(B, T, D) * 0.7
+    Ws = [rng.uniform(-r, r, size=(D + H, 4 * H)) * 2 for _ in range(ndir)]
+    bs = [O.lstm_bias_init(H) + rng.randn(4 * H) * 0.1 for _ in range(ndir)]
+    dy = rng.randn(B, T, ndir * H)
+    ry, rdx, rdW, rdb = _lstm_ref(x, Ws, bs, H, dy)
+    xc = cu(x).requires_grad_(True)
+    params = []
+    for W, b in zip(Ws, bs):
+        params += [cu(W).requires_grad_(True), cu(b).requires_grad_(True)]
+    y = ops.LstmLayerFn.apply(xc, H, *params)
+    assert relerr(y.detach().cpu().numpy(), ry) < TOL
+    y.backward(cu(dy))
+    assert relerr(xc.grad.cpu().numpy(), rdx) < TOL
+    for d in range(ndir):
+        assert relerr(params[2 * d].grad.cpu().numpy(), rdW[d]) < TOL
+        assert relerr(params[2 * d + 1].grad.cpu().numpy(), rdb[d]) < TOL
+
+
+def test_lstm_unsupported_shapes_fail_loudly():
+    '''outside the compiled envelope the library refuses (no silent fallback)'''
+    from danet_amd import ops, _lib
+    x = torch.randn(2, 3, 5, device='cuda')
+    H = 6                                           # not a multiple of 4
+    W = torch.randn(5 + H, 4 * H, device='cuda')
+    b = torch.zeros(4 * H, device='cuda')
+    with pytest.raises(_lib.DanetHipError):
+        ops.LstmLayerFn.apply(x, H, W, b)
