@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void separate_bwd_kernel(
     if (c < C) block_reduce_store<EP>(accs[c], EP, red, out + c * EP);
 }
 
-__global__ void sum_chunks_kernel(int nch, int cnt_out, int C, int E, int EP,
+__global__ void sum_chunks_kernel(int nch, int C, int E, int EP,
                                   const float* __restrict__ partial, float* __restrict__ out) {
   // out[b][c][e] = sum_ch partial[b][ch][c][e(EP)]
   const int b = blockIdx.x;
@@ -316,7 +316,6 @@ __global__ void sum_chunks_kernel(int nch, int cnt_out, int C, int E, int EP,
       s += partial[(((int64_t)b * nch + ch) * C + c) * EP + e];
     out[((int64_t)b * C + c) * E + e] = s;
   }
-  (void)cnt_out;
 }
 
 // =========================================================================
@@ -756,7 +755,7 @@ extern "C" int danet_separate_bwd(danet_stream_t stream_, int act, int B, int C,
   DISPATCH_EP(EPV, DISPATCH_CP(C, (separate_bwd_kernel<EP, CP><<<grid, 256, 0, stream>>>(
                        act, C, N, E, mix_pwr, attr, embed, dout, dembed, (float*)ws))));
   DANET_CHECK_LAUNCH();
-  sum_chunks_kernel<<<B, 128, 0, stream>>>(nch, 0, C, E, EPV, (const float*)ws, dattr);
+  sum_chunks_kernel<<<B, 128, 0, stream>>>(nch, C, E, EPV, (const float*)ws, dattr);
   DANET_CHECK_LAUNCH();
   return DANET_OK;
 }

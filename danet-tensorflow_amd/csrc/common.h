@@ -8,7 +8,6 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define DANET_WAVE 64
 
@@ -63,9 +62,6 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return s;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) {
-  return 1.0f / (1.0f + __expf(-x));
-}
 // accurate variants used on the parity path (1e-4 relative through T steps)
 __device__ __forceinline__ float sigmoid_acc(float x) {
   return 1.0f / (1.0f + expf(-x));

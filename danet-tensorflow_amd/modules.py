@@ -127,7 +127,6 @@ def _lyr_bilstm(name_, model_, s_input_, hdim_, t_axis_, axis_, w_init_, b_init_
 
 class _RnnEncoderBase(Encoder):
     NDIR = 1
-    DEFAULT_HDIM = 600
     INIT_SCALE = 1.15
 
     def _dims(self):

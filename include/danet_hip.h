@@ -143,8 +143,12 @@ size_t danet_colsum_f32_workspace_bytes(int M, int N);
  *   gates_d[T][B][4H]  saved post-activation g,i,f,o (may alias gx_d)
  *   cell_d [T][B][H]   saved c_t
  * ndir = 1 (lstm-orig) or 2 (bilstm-orig); *_b pointers ignored if ndir=1.
- * After the call, ws word 0 (int32) is 0 on success, non-zero if an
- * inter-workgroup wait timed out (see danet_lstm_status).                  */
+ * Requirements: H % 4 == 0, H <= 608, ypad 16-byte aligned, ldy % 4 == 0,
+ * all workgroups of the launch co-resident (checked: <= 256).  The call first
+ * fills ypad blocks 1..T with the bit pattern 0xFFFFFFFF ("not yet published":
+ * the exchanged state is its own flag), so ypad must not be read concurrently.
+ * After the launch, ws word 0 (int32) is 0 on success and non-zero if a bounded
+ * inter-workgroup wait timed out (the outputs are then invalid).            */
 size_t danet_lstm_workspace_bytes(int T, int B, int H, int ndir);
 int danet_lstm_fwd(danet_stream_t stream, int T, int B, int H, int ndir,
                    const float* gx_f, const float* gx_b,
@@ -155,8 +159,10 @@ int danet_lstm_fwd(danet_stream_t stream, int T, int B, int H, int ndir,
                    void* ws, size_t ws_bytes);
 
 /* BPTT of the above.  dy [T][B][lddy] (dir d uses columns [d*H,(d+1)*H)).
- * Outputs da_d [T][B][4H] = dL/d(pre-activation); the caller finishes with
- * GEMMs: dWx = X^T da, dWh = Hprev^T da, db = colsum(da), dX = da Wx^T.    */
+ * Outputs da_d [T][B][4H] = dL/d(pre-activation) (16-byte aligned; pre-filled
+ * with the 0xFFFFFFFF sentinel by the call); the caller finishes with GEMMs:
+ * dWx = X^T da, dWh = Hprev^T da, db = colsum(da), dX = da Wx^T.  Same status
+ * word convention as danet_lstm_fwd.                                        */
 int danet_lstm_bwd(danet_stream_t stream, int T, int B, int H, int ndir,
                    const float* dy, int lddy,
                    const float* Wh_f, const float* Wh_b, int ldw,
