@@ -11,6 +11,7 @@
 // assignment tensor (63 MB x2, app/modules.py:513-516): soft assignments for a
 // 128-bin tile are formed in LDS and contracted against the tile immediately.
 #include "common.h"
+#include <stdlib.h>
 
 #define CHUNK_N 2048       // bins per workgroup (reduction granularity)
 #define MAXC 4
@@ -341,11 +342,37 @@ static void make_combos(int A, int C, AnchorCombos& cb) {
   }
 }
 
+// itertools.combinations(range(A), C) at compile time: with (A, C) known the
+// subset loop indexes the exponential table with constants instead of two
+// 7-deep select chains per member (it was ~3/4 of the kernel's instructions).
+template <int A, int C>
+struct CombosCE {
+  int P;
+  int idx[MAXP][MAXC];
+  constexpr CombosCE() : P(0), idx() {
+    int cur[MAXC] = {0, 1, 2, 3};
+    bool more = true;
+    while (more) {
+      for (int i = 0; i < C; ++i) idx[P][i] = cur[i];
+      ++P;
+      int i = C - 1;
+      while (i >= 0 && cur[i] == A - C + i) --i;
+      if (i < 0) { more = false; }
+      else {
+        ++cur[i];
+        for (int j = i + 1; j < C; ++j) cur[j] = cur[j - 1] + 1;
+      }
+    }
+  }
+};
+
 // LDS: Xs[ANCH_TN][EPA] (embedding tile + ones column), Ss[ANCH_TN][PC+1]
-template <int EP>
+// AT, CTT > 0: (A, C) specialisation; AT = 0: generic (run-time table in `cb`)
+template <int EP, int AT, int CTT>
 __global__ __launch_bounds__(256) void anchor_fwd_kernel(
     int C, int64_t N, int E, int A, AnchorCombos cb, const float* __restrict__ embed,
-    const float* __restrict__ anchors, float* __restrict__ partial /* [B][chunks][PC][EPA] */) {
+    const float* __restrict__ anchors, float* __restrict__ partial /* [B][chunks][PC][EPA] */,
+    int RT, int CT /* MFMA tiling of the [PC][EPA] contraction; RT = 0: scalar path */) {
   constexpr int EPA = EP + 4;           // + ones column, padded to a float4
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int PC = cb.P * C;
@@ -368,6 +395,18 @@ __global__ __launch_bounds__(256) void anchor_fwd_kernel(
   f32x4 acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // MFMA path: out[pc][e] = sum_bins Ss[bin][pc] * Xs[bin][e] as RT x CT tiles of
+  // v_mfma_f32_32x32x2_f32, the tile's 256 bins split over the 4 waves.  Rows /
+  // columns past PC / EPA read whatever follows in LDS: they only ever reach
+  // accumulator entries that are never stored.
+  f32x16 macc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) macc[i][j][r] = 0.f;
+  const int mlane = tid & 63, mwave = tid >> 6;
   __syncthreads();
 
   for (int64_t base = n0; base < n1; base += ANCH_TN) {
@@ -400,6 +439,27 @@ __global__ __launch_bounds__(256) void anchor_fwd_kernel(
         float ea[MAXA];
 #pragma unroll
         for (int a = 0; a < MAXA; ++a) ea[a] = (a < A) ? expf(d[a] - dmax) : 0.f;
+        if constexpr (AT > 0) {
+          constexpr CombosCE<AT, CTT> tb{};
+#pragma unroll
+          for (int p = 0; p < tb.P; ++p) {
+            float lg[CTT];
+            float den = 0.f;
+#pragma unroll
+            for (int c = 0; c < CTT; ++c) { lg[c] = ea[tb.idx[p][c]]; den += lg[c]; }
+            if (den < 1e-30f) {      // all members underflowed: redo against the subset's own max
+              float mx = -INFINITY;
+#pragma unroll
+              for (int c = 0; c < CTT; ++c) mx = fmaxf(mx, d[tb.idx[p][c]]);
+              den = 0.f;
+#pragma unroll
+              for (int c = 0; c < CTT; ++c) { lg[c] = expf(d[tb.idx[p][c]] - mx); den += lg[c]; }
+            }
+            const float inv = 1.0f / den;
+#pragma unroll
+            for (int c = 0; c < CTT; ++c) Ss[tid * lds + p * CTT + c] = lg[c] * inv;   // modules.py:516
+          }
+        } else
         for (int p = 0; p < cb.P; ++p) {
           float lg[MAXC], dl[MAXC];
           float den = 0.f;
@@ -434,6 +494,25 @@ __global__ __launch_bounds__(256) void anchor_fwd_kernel(
     }
     __syncthreads();
     // phase 2: contract assignments against [x | 1]  (modules.py:519-523)
+    if (RT > 0) {
+      const int il = mlane & 31, kl = mlane >> 5;
+#pragma unroll 4
+      for (int ks = 0; ks < ANCH_TN / 8; ++ks) {
+        const int r = mwave * (ANCH_TN / 4) + ks * 2 + kl;
+        float av[2], bv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          av[i] = (i < RT) ? Ss[r * lds + i * 32 + il] : 0.f;
+          bv[i] = (i < CT) ? Xs[r * EPA + i * 32 + il] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (i < RT && j < CT)
+              macc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], macc[i][j], 0, 0, 0);
+      }
+    } else
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int item = tid + it * 256;
@@ -451,6 +530,32 @@ __global__ __launch_bounds__(256) void anchor_fwd_kernel(
     __syncthreads();
   }
   float* out = partial + ((int64_t)b * nch + ch) * PC * EPA;
+  if (RT > 0) {
+    // cross-wave reduction through LDS (tile buffers are dead now).
+    // D layout 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* red = smem;   // [4 waves][RT*32][CT*32]
+    const int ldr = CT * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (i < RT && j < CT) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (mlane >> 5);
+            red[(mwave * RT * 32 + row) * ldr + j * 32 + (mlane & 31)] = macc[i][j][r];
+          }
+        }
+    __syncthreads();
+    for (int idx = tid; idx < PC * EPA; idx += 256) {
+      const int pc = idx / EPA, e = idx % EPA;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += red[(w * RT * 32 + pc) * ldr + e];
+      out[idx] = v;
+    }
+    return;
+  }
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int item = tid + it * 256;
@@ -804,13 +909,23 @@ extern "C" int danet_attractor_anchor_fwd(danet_stream_t stream_, int B, int C, 
     return DANET_ERR_UNSUPPORTED;
   }
   const int nch = n_chunks(N);
-  const size_t lds = ((size_t)ANCH_TN * EPA + (size_t)ANCH_TN * (PC + 1) + (size_t)A * EPV) * sizeof(float);
+  // the [PC][EPA] contraction runs on the matrix cores when it fits 2 x 2 tiles of 32 x 32
+  int RT = 0, CT = 0;
+  if (PC <= 64 && EPA <= 64 && !getenv("DANET_ANCHOR_SCALAR")) { RT = cdiv(PC, 32); CT = cdiv(EPA, 32); }
+  size_t lds = ((size_t)ANCH_TN * EPA + (size_t)ANCH_TN * (PC + 1) + (size_t)A * EPV + 64) * sizeof(float);
+  const size_t lds_red = (size_t)4 * RT * 32 * CT * 32 * sizeof(float);
+  if (lds_red > lds) lds = lds_red;
   dim3 grid(nch, B);
-  DISPATCH_EP(EPV, {
-    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)anchor_fwd_kernel<EP>,
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    anchor_fwd_kernel<EP><<<grid, 256, lds, stream>>>(C, N, E, A, cb, embed, anchors, (float*)ws);
-  });
+#define LAUNCH_ANCHOR(AT_, CT_)                                                              \
+  DISPATCH_EP(EPV, {                                                                         \
+    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)anchor_fwd_kernel<EP, AT_, CT_>,         \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                              \
+    anchor_fwd_kernel<EP, AT_, CT_><<<grid, 256, lds, stream>>>(C, N, E, A, cb, embed,        \
+                                                                anchors, (float*)ws, RT, CT); \
+  })
+  if (A == 6 && C == 2) { LAUNCH_ANCHOR(6, 2); }          // default.json: NUM_ANCHOR 6, 2 speakers
+  else if (A == 6 && C == 3) { LAUNCH_ANCHOR(6, 3); }     // 3-speaker configs
+  else { LAUNCH_ANCHOR(0, 0); }
   DANET_CHECK_LAUNCH();
   const size_t lds2 = ((size_t)PC * EPA + cb.P) * sizeof(float);
   anchor_final_kernel<<<B, 128, lds2, stream>>>(C, E, EPA, cb.P, nch, (const float*)ws, attr,
