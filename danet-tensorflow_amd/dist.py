@@ -69,3 +69,49 @@ def allreduce_max_scalar(x, device):
 def shard_seed(base_seed):
     '''a different synthetic shard per rank (seed = 1337 + rank)'''
     return base_seed + rank()
+
+
+class GradBuckets(object):
+    '''Overlapped gradient reduction (opt-in: DANET_OVERLAP_ALLREDUCE=1).
+
+    The flat gradient bucket is reduced in contiguous pieces as backward produces
+    them -- output projection first, then the LSTM layers from the top down --
+    each as one asynchronous all-reduce launched behind that piece's
+    weight-gradient GEMMs (ops.GRAD_READY_HOOKS), so the collectives run under the
+    remaining BPTT kernels.  `finish()` reduces whatever was not covered (the tiny
+    estimator variables) and makes the current stream wait for every piece.
+    Every rank issues the same collectives in the same order.'''
+
+    def __init__(self, flat_grad, offsets):
+        '''offsets: {param data_ptr: (start, end)} element ranges in flat_grad'''
+        self.flat = flat_grad
+        self.offsets = offsets
+        self.works = []
+        self.covered = []
+
+    def hook(self, tag, params):
+        if not is_dist():
+            return
+        rng = [self.offsets[p.data_ptr()] for p in params if p.data_ptr() in self.offsets]
+        if len(rng) != len(params):
+            return                      # not ours (e.g. a stand-alone layer call)
+        lo, hi = min(r[0] for r in rng), max(r[1] for r in rng)
+        if sum(r[1] - r[0] for r in rng) != hi - lo:
+            return                      # not contiguous: leave it to finish()
+        self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        self.covered.append((lo, hi))
+
+    def finish(self):
+        '''returns the 1/world factor like allreduce_grads_'''
+        w = world_size()
+        if is_dist():
+            pos = 0
+            for lo, hi in sorted(self.covered) + [(self.flat.numel(), self.flat.numel())]:
+                if lo > pos:
+                    self.works.append(dist.all_reduce(self.flat[pos:lo], op=dist.ReduceOp.SUM,
+                                                      async_op=True))
+                pos = max(pos, hi)
+            for wk in self.works:
+                wk.wait()
+        self.works, self.covered = [], []
+        return 1.0 / w

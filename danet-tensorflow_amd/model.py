@@ -118,6 +118,15 @@ class Model(object):
             self.vars[k] = nv
             off += m
         self._flat, self._flat_grad = flat, grad
+        self._buckets = None
+        if os.environ.get('DANET_OVERLAP_ALLREDUCE', '0') == '1':
+            offs, off = {}, 0
+            for k in self._order:
+                v = self.vars[k]
+                offs[v.data_ptr()] = (off, off + v.numel())
+                off += v.numel()
+            self._buckets = dist.GradBuckets(grad, offs)
+            ops.GRAD_READY_HOOKS.append(self._buckets.hook)
 
     # -------------------------------------------------------------- forward
     def forward(self, s_src_signals, with_valid=False, with_train=True):
@@ -177,7 +186,10 @@ class Model(object):
         self._flat_grad.zero_()
         out = self.forward(s_src_signals)
         out['loss'].backward()
-        grad_scale = dist.allreduce_grads_(self._flat_grad)    # ONE RCCL all-reduce / step
+        if self._buckets is not None:
+            grad_scale = self._buckets.finish()                # pieces launched during backward
+        else:
+            grad_scale = dist.allreduce_grads_(self._flat_grad)    # ONE RCCL all-reduce / step
         self.step_count += 1
         self.ozer.step(self.step_count, self.learn_rate,
                        clip=hparams.GRAD_CLIP_THRES, grad_scale=grad_scale)

@@ -227,6 +227,20 @@ class _Fork(object):
         with torch.cuda.stream(s):
             return fn()
 
+    def after_all(self, fn):
+        '''run fn() on one of the used side streams once ALL side chains of this
+        fork have been issued (that stream first waits for the others) -- the
+        place to launch work that consumes everything the chains produce, e.g. a
+        gradient-bucket all-reduce.  With no side stream in use, fn runs in place.'''
+        used = list(self.used)
+        if not used:
+            return fn()
+        first = used[0]
+        for s in used[1:]:
+            first.wait_stream(s)
+        with torch.cuda.stream(first):
+            return fn()
+
     def __exit__(self, *exc):
         if self.defer and self.used:
             _deferred.append((self.main, tuple(self.used), self.keep))
@@ -237,6 +251,17 @@ class _Fork(object):
 
 
 _deferred = []
+
+# Called as hook(tag, params) when the gradients of `params` have been fully
+# issued (on the stream that is current during the call); tag = ('layer', l) /
+# ('out',).  Model uses it to launch per-bucket gradient all-reduces that overlap
+# the rest of backward (dist.GradBuckets).
+GRAD_READY_HOOKS = []
+
+
+def _fire_grad_ready(tag, params):
+    for h in GRAD_READY_HOOKS:
+        h(tag, params)
 
 DIRECT_GRADS = __import__('os').environ.get('DANET_DIRECT_GRADS', '1') == '1'
 
@@ -291,7 +316,7 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs):
     return c
 
 
-def lstm_layer_bwd(c, dy, need_dx):
+def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
     '''dy: [T, B, ndir*H] contiguous.  Returns (dx [T*B, D] or None, dWs, dbs).'''
     T, B, H, D, ndir = c.T, c.B, c.H, c.D, c.ndir
     dev = dy.device
@@ -346,6 +371,8 @@ def lstm_layer_bwd(c, dy, need_dx):
     with _Fork(dev, ndir + 1, defer=True, keep=(das, c.x, c.ypad, dy)) as f:
         for d in range(ndir):
             f.run(d + 1, lambda d=d: weight_grads(d))
+        if GRAD_READY_HOOKS and all(a and b for a, b in direct):
+            f.after_all(lambda: _fire_grad_ready(('layer', layer_tag), list(c.Ws) + list(c.bs)))
     dWs = [None if direct[d][0] else dWs[d] for d in range(ndir)]
     dbs = [None if direct[d][1] else dbs[d] for d in range(ndir)]
     return dx, dWs, dbs
@@ -426,11 +453,13 @@ class RnnEncoderFn(torch.autograd.Function):
             f.run(1, lambda: gemm(ctx.yc, dembed, dWout, D, O, B * T, D, O, O, transA=True,
                                   beta=1.0 if direct_out else 0.0,
                                   max_workgroups=2 * OVERLAP_GEMM_WGS))
+            if GRAD_READY_HOOKS and direct_out:
+                f.after_all(lambda: _fire_grad_ready(('out',), [ctx.Wout]))
         dy = torch.empty(T, B, D, device=dev)
         center(dyc, B, T, D, 0, D, dy, 1, D)                 # centre is self-adjoint
         grads = [None] * (2 * L * ndir)
         for l in reversed(range(L)):
-            dx, dWs, dbs = lstm_layer_bwd(ctx.ctxs[l], dy, need_dx=(l > 0))
+            dx, dWs, dbs = lstm_layer_bwd(ctx.ctxs[l], dy, need_dx=(l > 0), layer_tag=l)
             for d in range(ndir):
                 grads[(l * ndir + d) * 2] = dWs[d]
                 grads[(l * ndir + d) * 2 + 1] = dbs[d]

@@ -216,7 +216,8 @@ gbuf *= scale
 full = flat_grad(src, p)                         # global-batch gradient, rank-0 params
 err = float((gbuf - full).abs().max() / full.abs().max())
 mx = dist.allreduce_max_scalar(float(rank + 1), 'cpu')
-print('RANK', rank, 'ERR', err, 'MAX', mx, 'SEED', dist.shard_seed(1337), flush=True)
+open(os.path.join(os.environ['DP_OUT'], 'rank' + str(rank) + '.txt'), 'w').write(
+    ' '.join(['RANK', str(rank), 'ERR', repr(err), 'MAX', repr(mx), 'SEED', str(dist.shard_seed(1337))]))
 '''
 
 
@@ -224,14 +225,17 @@ def test_data_parallel_gloo_world2(tmp_path):
     '''sharding by batch + ONE summed all-reduce + 1/world == global-batch gradient'''
     script = tmp_path / 'dp_worker.py'
     script.write_text(_DP_WORKER % dict(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', DP_OUT=str(tmp_path))
+    import socket
+    with socket.socket() as sk:                     # a free port (a fixed one lingers in TIME_WAIT)
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
     out = subprocess.run(
         [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-         '--master-addr', '127.0.0.1', '--master-port', '29533', str(script)],
+         '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
         capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith('RANK')]
-    assert len(lines) == 2, out.stdout
+    lines = [(tmp_path / ('rank%d.txt' % r)).read_text() for r in range(2)]   # not stdout: it interleaves
     for l in lines:
         tok = l.split()
         assert float(tok[3]) < 1e-12, l

@@ -124,3 +124,19 @@ def test_cli_train_valid_test_debug_demo(hp, tmp_path, monkeypatch):
     for i in (1, 2):
         sr, y = scipy.io.wavfile.read('mix_separated_%d.wav' % i)
         assert sr == 8000 and len(y) == (1 + -(-4000 // 16)) * 16 and np.isfinite(y).all()
+
+
+def test_overlapped_allreduce_matches_single_allreduce_one_rank():
+    '''opt-in DANET_OVERLAP_ALLREDUCE path under a real (1-rank) RCCL group:
+    bit-identical parameters after 3 steps (own process: it owns a process group)'''
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_PORT=str(port), MASTER_ADDR='127.0.0.1', RANK='0', WORLD_SIZE='1')
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_overlap_allreduce.py')],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and 'OK' in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
