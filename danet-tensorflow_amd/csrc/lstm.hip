@@ -43,6 +43,7 @@
 #define SENTINEL 0xFFFFFFFFu
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define RLX_WG __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP
 
 // NB: the b128 buffer-load builtin must be assigned to a GCC-style
 // __vector_size__ vector; assigning it to an ext_vector_type silently lowers to
@@ -66,6 +67,7 @@ struct LstmFwdArgs {
   float* ypad;
   int* status;
   int T, B, H, ndir, ldy, ldw, P, G, KP;  // KP = H padded to 16
+  int xmap, plain;   // cluster = bid % nclusters placement; XCD-local plain publishes
 };
 
 struct LstmBwdArgs {
@@ -76,6 +78,7 @@ struct LstmBwdArgs {
   float* da[2];
   int* status;
   int T, B, H, ndir, lddy, ldw, P, G, R;   // R = batch rows per cluster (<= 16*MT)
+  int xmap, plain;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
@@ -131,9 +134,10 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bid = blockIdx.x;
-  const int dir = bid / (a.G * a.P);
-  const int grp = (bid / a.P) % a.G;
-  const int p = bid % a.P;
+  const int ncl = a.ndir * a.G;
+  const int cl = a.xmap ? bid % ncl : bid / a.P;   // xmap: members of a cluster share bid % 8
+  const int dir = cl / a.G, grp = cl % a.G;
+  const int p = a.xmap ? bid / ncl : bid % a.P;
   const int H = a.H, B = a.B, T = a.T;
   const int u0 = p * LSTM_UNITS_FWD;
   const int b0 = grp * (16 * MT);
@@ -292,8 +296,8 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
       c_state = ig * g + fg * c_state;        // ops.py:146
       const float h = og * tanh_hw(c_state);   // ops.py:147
       // publish h_t: one write-through 4-byte store, no drain, no flag
-      __hip_atomic_store(a.ypad + ((size_t)(t + 1) * B + bg) * a.ldy + dir * H + unit,
-                         h, RLX_AGENT);
+      float* hp = a.ypad + ((size_t)(t + 1) * B + bg) * a.ldy + dir * H + unit;
+      if (a.plain) __hip_atomic_store(hp, h, RLX_WG); else __hip_atomic_store(hp, h, RLX_AGENT);
       // saved activations are only read by later kernels (plain stores)
       float* gs = a.gates[dir] + ((size_t)t * B + bg) * (4 * H) + unit;
       gs[0] = g; gs[H] = ig; gs[2 * H] = fg; gs[3 * H] = og;
@@ -326,9 +330,10 @@ __global__ __launch_bounds__(64 * NW) void lstm_bwd_kernel(LstmBwdArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bid = blockIdx.x;
-  const int dir = bid / (a.G * a.P);
-  const int grp = (bid / a.P) % a.G;
-  const int p = bid % a.P;
+  const int ncl = a.ndir * a.G;
+  const int cl = a.xmap ? bid % ncl : bid / a.P;
+  const int dir = cl / a.G, grp = cl % a.G;
+  const int p = a.xmap ? bid / ncl : bid % a.P;
   const int u0 = p * LSTM_UNITS_BWD;
   const int b0 = grp * a.R;
 
@@ -478,13 +483,265 @@ __global__ __launch_bounds__(64 * NW) void lstm_bwd_kernel(LstmBwdArgs a) {
       dc_state[i] = dc * fg;
       // publish da_t (also the kernel's output): write-through 4-byte stores
       float* dp = a.da[dir] + ((size_t)t * B + bg) * H4 + unit;
-      __hip_atomic_store(dp, da_g, RLX_AGENT);
-      __hip_atomic_store(dp + H, da_i, RLX_AGENT);
-      __hip_atomic_store(dp + 2 * H, da_f, RLX_AGENT);
-      __hip_atomic_store(dp + 3 * H, da_o, RLX_AGENT);
+      if (a.plain) {
+        __hip_atomic_store(dp, da_g, RLX_WG);
+        __hip_atomic_store(dp + H, da_i, RLX_WG);
+        __hip_atomic_store(dp + 2 * H, da_f, RLX_WG);
+        __hip_atomic_store(dp + 3 * H, da_o, RLX_WG);
+      } else {
+        __hip_atomic_store(dp, da_g, RLX_AGENT);
+        __hip_atomic_store(dp + H, da_i, RLX_AGENT);
+        __hip_atomic_store(dp + 2 * H, da_f, RLX_AGENT);
+        __hip_atomic_store(dp + 3 * H, da_o, RLX_AGENT);
+      }
     }
     TRACE(4);
     __syncthreads();   // `red` reuse (see forward kernel)
+    TRACE(5);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// backward (BPTT), reduce-scatter form
+// ---------------------------------------------------------------------------
+// The all-gather kernel above makes every workgroup read its cluster's whole
+// da_t (R x 4H floats) each step.  Here the product dh_{prev} = da_t Wh^T is split
+// along K instead.  A cluster = 16 batch rows of one direction.  Producer group p
+// owns U units, i.e. the 4U columns {gate*H + u0 + j} of da_t, keeps the matching
+// Wh columns stationary IN REGISTERS and publishes its partial dh for all units
+//     part_p[r][i] = sum_{n in own 4U columns} da_t[r][n] * Wh[i][n]
+// The group is S "twin" workgroups that all redo the (cheap) exchange read + gate
+// math of the group's 16 x U elements and each compute 1/S of the 16-unit output
+// tiles, so the per-step MFMA chain is short and every MFMA row is a real batch
+// row.  A group then reads only the P partials of its own U units, sums them in a
+// fixed order (deterministic) and does the gate math.  da_t itself is no longer an
+// exchange medium: twin 0 writes it with plain stores, no prefill needed.
+//
+// Hand-off: the payload is the flag, with no sentinel to restore: bit 0 of every
+// published fp32 word carries the PHASE of its ring slot (use count & 1), i.e. a
+// partial keeps a 23-bit mantissa (<= 1 ulp of one partial, below the fp32
+// rounding of the P-term sum it feeds; NaNs stay NaNs).  A 16-byte chunk is valid
+// when all four words carry the expected phase: stale words of the slot's previous
+// use have the opposite phase, the host prefills phase 1 and the first use publishes
+// phase 0.  Ring depth 3: a workgroup Y publishes step n (slot n%3) only after the
+// twins owning ITS tiles published n-1 in every group, and each of those only after
+// the twins owning THEIR tiles published n-2 -- every twin class owns some group's
+// tile, so every workgroup has published n-2, i.e. finished reading step n-3 (all of
+// its waves passed the block barrier behind those reads), before slot n%3 is rewritten.
+// (Two slots are NOT enough with twins: a twin nobody in Y's tile class waits for
+// may lag two steps.)
+//
+// MFMA orientation: D[unit][batch row] = W-tile(16 units x 4 k) * da^T(4 k x 16
+// rows): each lane ends up with 4 CONSECUTIVE units of one batch row, and the ring
+// is laid out [slot][cluster][producer][tile][row][16 units] so that one store
+// instruction writes one contiguous 1 KB tile and a consumer reads whole rows.
+struct LstmBwdRsArgs {
+  const float* dy;
+  const float* Wh[2];
+  const float* gates[2];
+  const float* cell[2];
+  float* da[2];
+  float* ring;
+  int* status;
+  int T, B, H, ndir, lddy, ldw, P, G, S, NT, NI, D, xmap;
+};
+
+__device__ __forceinline__ void store_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned off, v4u v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16 /*sc1*/);
+}
+
+#define RS_NI_MAX 6
+
+template <int U, int NTW>
+__global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
+  constexpr int NW = 8;
+  constexpr int KG = U / 4;          // 16-wide k-groups of the 4U own columns
+  constexpr int OWN = 16 * U;        // (row, unit) elements of the group
+  constexpr int CPP = 4 * U;         // 16-byte chunks per producer
+  constexpr int PPR = 512 / CPP;     // producers covered by one round of loads
+  constexpr int LDA = 4 * U + 4;
+  __shared__ __attribute__((aligned(16))) float psum[PPR * OWN];  // 8 KB
+  __shared__ __attribute__((aligned(16))) float atile[16 * LDA];  // da_t own columns [row][k]
+
+  const int H = a.H, B = a.B, T = a.T, P = a.P, S = a.S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bid = blockIdx.x;
+  const int ncl = a.ndir * a.G;
+  // xmap: consecutive block ids cycle over the clusters (so a cluster's workgroups
+  // share their id modulo 8 = their XCD whenever ncl divides 8 or vice versa)
+  const int cl = a.xmap ? bid % ncl : bid / (P * S);
+  const int m = a.xmap ? bid / ncl : bid % (P * S);
+  const int p = m / S, tw = m % S;
+  const int dir = cl / a.G, grp = cl % a.G;
+  const int u0 = p * U, b0 = grp * 16;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // stationary weights: lane (fr, fq) of tile `tl` holds Wh[tl*16 + fr][own column
+  // k0 .. k0+3], k0 = kg*16 + fq*4 (the same K permutation as the B operand below)
+  f32x4 wreg[NTW][KG];
+  {
+    const float* W = a.Wh[dir];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      const int tl = tw + S * (wave + NW * i);
+      const int unit_i = tl * 16 + fr;
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg) {
+        const int k0 = kg * 16 + fq * 4;
+        const int gate = k0 / U, j0 = k0 % U;
+        f32x4 w = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (tl < a.NT && unit_i < H && u0 + j0 < H)
+          w = *reinterpret_cast<const f32x4*>(&W[(size_t)unit_i * a.ldw + gate * H + u0 + j0]);
+        wreg[i][kg] = w;
+      }
+    }
+  }
+
+  const size_t slot_floats = (size_t)ncl * P * a.NT * 256;
+  const unsigned rbytes = (unsigned)(slot_floats * a.D * sizeof(float));
+  const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.ring, rbytes);
+
+  // exchange-read mapping: chunk = 4 units of one (producer, row); this thread
+  // serves producers qq, qq+PPR, ... for a fixed (row, 4-unit quarter)
+  const int qq = tid / CPP, within = tid % CPP;
+  const int xr = within / (U / 4), xunit = u0 + (within % (U / 4)) * 4;
+  const unsigned xoff = (unsigned)((((xunit >> 4) * 16 + xr) * 16 + (xunit & 15)) * 4);
+
+  // gate-math ownership: threads 0..OWN-1 -> (row, unit)
+  const bool othr = tid < OWN;
+  const int orow = tid / U, oj = tid % U;
+  const int bg = b0 + orow, unit = u0 + oj;
+  const bool owner = othr && bg < B && unit < H;
+  float dc_state = 0.f;
+
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? s : (T - 1 - s);
+    const int t_cprev = dir ? (t + 1) : (t - 1);
+
+    TRACE(0);
+    float gv[4] = {0.f, 0.f, 0.f, 0.f}, cv = 0.f, cpv = 0.f, dyv = 0.f;
+    if (owner) {
+      const float* gp = a.gates[dir] + ((size_t)t * B + bg) * (4 * H) + unit;
+      gv[0] = gp[0]; gv[1] = gp[H]; gv[2] = gp[2 * H]; gv[3] = gp[3 * H];
+      cv = a.cell[dir][((size_t)t * B + bg) * H + unit];
+      if (t_cprev >= 0 && t_cprev < T) cpv = a.cell[dir][((size_t)t_cprev * B + bg) * H + unit];
+      dyv = a.dy[((size_t)t * B + bg) * a.lddy + dir * H + unit];
+    }
+
+    if (s > 0) {
+      const int slot = (s - 1) % a.D;
+      const unsigned par = (unsigned)(((s - 1) / a.D) & 1);
+      unsigned off[RS_NI_MAX];
+#pragma unroll
+      for (int i = 0; i < RS_NI_MAX; ++i) {
+        const int q = qq + PPR * i;
+        off[i] = rbytes;   // out of range: no such producer (contributes 0)
+        if (q < P)
+          off[i] = (unsigned)((((size_t)slot * ncl + cl) * P + q) * a.NT * 1024) + xoff;
+      }
+      v4u av[RS_NI_MAX];
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < RS_NI_MAX; ++i)
+          if (i < a.NI) av[i] = load_sc1_b128(rres, off[i]);
+#pragma unroll
+        for (int i = 0; i < RS_NI_MAX; ++i)
+          if (i < a.NI) {
+            const unsigned mm = par ? ~(av[i][0] & av[i][1] & av[i][2] & av[i][3])
+                                    : (av[i][0] | av[i][1] | av[i][2] | av[i][3]);
+            ok &= (off[i] == rbytes) || !(mm & 1u);
+          }
+        if (__all(ok)) break;
+        if (spin_fail(spins, a.status, lane)) break;
+      }
+      TRACE(1); TRACE_VAL(6, spins);
+      f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < RS_NI_MAX; ++i)
+        if (i < a.NI) {
+          v4u w = av[i];
+          if (off[i] == rbytes) w = (v4u){0u, 0u, 0u, 0u};
+          w[0] &= ~1u; w[1] &= ~1u; w[2] &= ~1u; w[3] &= ~1u;
+          sum += __builtin_bit_cast(f32x4, w);
+        }
+      *reinterpret_cast<f32x4*>(&psum[qq * OWN + within * 4]) = sum;
+    }
+    __syncthreads();
+    TRACE(2);
+
+    float dav[4] = {0.f, 0.f, 0.f, 0.f};
+    if (othr) {
+      float dh = dyv;
+      if (s > 0) {
+#pragma unroll
+        for (int k = 0; k < PPR; ++k) dh += psum[k * OWN + tid];
+      }
+      if (owner) {
+        const float g = gv[0], ig = gv[1], fg = gv[2], og = gv[3];
+        const float tc = tanh_hw(cv);
+        const float dc = dc_state + dh * og * (1.f - tc * tc);
+        dav[0] = dc * ig;
+        dav[1] = dc * g * ig * (1.f - ig);
+        dav[2] = dc * cpv * fg * (1.f - fg);
+        dav[3] = dh * tc * og * (1.f - og);
+        dc_state = dc * fg;
+      }
+      float* ap = &atile[orow * LDA + oj];
+      ap[0] = dav[0]; ap[U] = dav[1]; ap[2 * U] = dav[2]; ap[3 * U] = dav[3];
+    }
+    __syncthreads();
+    TRACE(3);
+
+    if (s + 1 < T) {
+      f32x4 bq[KG];
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg)
+        bq[kg] = *reinterpret_cast<const f32x4*>(&atile[fr * LDA + kg * 16 + fq * 4]);
+      // NACC independent accumulators per tile: a single dependent 16x16x4 chain
+      // cannot issue back to back
+      constexpr int NACC = 2;
+      f32x4 acc2[NTW][NACC];
+#pragma unroll
+      for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int c = 0; c < NACC; ++c) acc2[i][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < NTW; ++i)
+            acc2[i][j % NACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                wreg[i][kg][j], bq[kg][j], acc2[i][j % NACC], 0, 0, 0);
+      f32x4 acc[NTW];
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        acc[i] = acc2[i][0] + acc2[i][1];
+        if (NACC == 4) acc[i] += acc2[i][2] + acc2[i][3];
+      }
+      TRACE(4);
+      const int slot = s % a.D;
+      const unsigned ppub = (unsigned)((s / a.D) & 1);
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        const int tl = tw + S * (wave + NW * i);
+        unsigned o = rbytes;   // out of range: dropped
+        if (tl < a.NT)
+          o = (unsigned)(((((size_t)slot * ncl + cl) * P + p) * a.NT + tl) * 1024) +
+              (unsigned)((fr * 16 + fq * 4) * 4);
+        v4u w = __builtin_bit_cast(v4u, acc[i]);
+        w[0] = (w[0] & ~1u) | ppub; w[1] = (w[1] & ~1u) | ppub;
+        w[2] = (w[2] & ~1u) | ppub; w[3] = (w[3] & ~1u) | ppub;
+        store_sc1_b128(rres, o, w);
+      }
+    }
+    // da_t is only read by later kernels: plain stores, off the critical path
+    if (owner && tw == 0) {
+      float* dp = a.da[dir] + ((size_t)t * B + bg) * (4 * H) + unit;
+      dp[0] = dav[0]; dp[H] = dav[1]; dp[2 * H] = dav[2]; dp[3 * H] = dav[3];
+    }
     TRACE(5);
   }
 }
@@ -520,9 +777,60 @@ static LstmPlan make_plan(int B, int H, int ndir, bool bwd) {
   return pl;
 }
 
+// reduce-scatter BPTT geometry for U units per producer group; ok == false when
+// it does not fit one workgroup per CU
+struct RsPlan { bool ok; int U, G, P, S, NT, NTW, NI, D; size_t ring_bytes; };
+static RsPlan make_rs_plan(int B, int H, int ndir, int U) {
+  RsPlan r;
+  r.U = U; r.G = cdiv(B, 16); r.P = cdiv(H, U);
+  r.NT = cdiv(r.P * U, 16); r.D = 3;
+  r.NI = cdiv(r.P, 512 / (4 * U));
+  const int ncl = ndir * r.G;
+  int smax = 256 / (ncl * r.P);
+  if (smax > r.NT) smax = r.NT;
+  // twins: the fewest that leave at most two tiles per SIMD, else as many as fit
+  r.S = smax;
+  for (int sv = 1; sv <= smax; ++sv)
+    if (cdiv(r.NT, sv) <= 8) { r.S = sv; break; }
+  { const char* es = getenv("DANET_LSTM_BWD_S");
+    if (es && atoi(es) >= 1 && atoi(es) <= smax) r.S = atoi(es); }
+  r.NTW = r.S > 0 ? cdiv(cdiv(r.NT, r.S), 8) : 99;
+  r.ring_bytes = (size_t)r.D * ncl * r.P * r.NT * 1024;
+  r.ok = (H % 4 == 0) && smax >= 1 && r.NTW <= 3 && r.NI <= RS_NI_MAX &&
+         r.ring_bytes < 0xFFFFFFF0ull;
+  return r;
+}
+// DANET_LSTM_BWD_RS=0 selects the all-gather kernel; DANET_LSTM_BWD_U=8|16|32 pins U
+static RsPlan choose_rs_plan(int B, int H, int ndir) {
+  RsPlan none; none.ok = false; none.ring_bytes = 0;
+  const char* e = getenv("DANET_LSTM_BWD_RS");
+  if (e && atoi(e) == 0) return none;
+  const char* eu = getenv("DANET_LSTM_BWD_U");
+  const int pin = eu ? atoi(eu) : 0;
+  // fewest MFMAs per SIMD and step (tiles of a workgroup spread over 4 SIMDs, 4U/4
+  // k-steps each); ties go to the smaller U (shorter dependent chains).  Measured at
+  // cfg 2: U=16,S=3 2.4 us/step; U=32,S=5 2.8; U=8,S=1 3.0 (all-gather kernel: 3.5)
+  RsPlan best = none;
+  int best_cost = 1 << 30;
+  for (int U = 8; U <= 32; U *= 2) {
+    if (pin && pin != U) continue;
+    RsPlan r = make_rs_plan(B, H, ndir, U);
+    if (!r.ok) continue;
+    const int cost = cdiv(cdiv(r.NT, r.S), 4) * U;
+    if (cost < best_cost) { best = r; best_cost = cost; }
+  }
+  return best;
+}
+static size_t ring_offset(int T) { return (64 + TRACE_BYTES(T) + 255) / 256 * 256; }
+
 extern "C" size_t danet_lstm_workspace_bytes(int T, int B, int H, int ndir) {
-  (void)B; (void)H; (void)ndir;
-  return 64 + TRACE_BYTES(T);   // status word (+ padding) (+ trace records)
+  // status word (+ padding) (+ trace records) + partial-dh ring of the BPTT kernel
+  size_t ring = 0;
+  for (int U = 8; U <= 32; U *= 2) {
+    RsPlan r = make_rs_plan(B, H, ndir, U);
+    if (r.ok && r.ring_bytes > ring) ring = r.ring_bytes;
+  }
+  return ring_offset(T) + ring;
 }
 
 static int lstm_check_common(int T, int B, int H, int ndir, void* ws, size_t ws_bytes) {
@@ -568,7 +876,10 @@ extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int n
   a.ypad = ypad; a.status = (int*)ws;
   a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.ldy = ldy; a.ldw = ldw;
   a.P = pl.P; a.G = pl.G; a.KP = pl.KP;
-  DANET_CHECK_HIP(hipMemsetAsync(ws, 0, danet_lstm_workspace_bytes(T, B, H, ndir), stream));
+  a.xmap = getenv("DANET_LSTM_XMAP") ? atoi(getenv("DANET_LSTM_XMAP")) : 1;
+  a.plain = getenv("DANET_LSTM_PLAIN") ? atoi(getenv("DANET_LSTM_PLAIN")) : 0;
+  if (!(a.xmap && a.ndir * a.G == 8)) a.plain = 0;   // one cluster per XCD only
+  DANET_CHECK_HIP(hipMemsetAsync(ws, 0, 64 + TRACE_BYTES(T), stream));
   // "not yet published" sentinel everywhere, then the zero initial state in pad
   // blocks 0 and T+1 (main.py:108-123)
   const size_t blk = (size_t)B * ldy * sizeof(float);
@@ -604,6 +915,28 @@ extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int n
   DANET_CHECK_ARG(((uintptr_t)da_f & 15) == 0 && ((uintptr_t)da_b & 15) == 0,
                   "lstm_bwd: da must be 16-B aligned");
   DANET_CHECK_ARG((size_t)T * B * 4 * H * 4 < 0xFFFFFFF0ull, "lstm_bwd: da > 4 GiB");
+  const RsPlan rs = choose_rs_plan(B, H, ndir);
+  if (rs.ok) {
+    LstmBwdRsArgs a;
+    a.dy = dy; a.lddy = lddy; a.Wh[0] = Wh_f; a.Wh[1] = Wh_b; a.ldw = ldw;
+    a.gates[0] = gates_f; a.gates[1] = gates_b; a.cell[0] = cell_f; a.cell[1] = cell_b;
+    a.da[0] = da_f; a.da[1] = da_b; a.status = (int*)ws;
+    a.ring = (float*)((char*)ws + ring_offset(T));
+    a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.P = rs.P; a.G = rs.G; a.S = rs.S;
+    a.NT = rs.NT; a.NI = rs.NI; a.D = rs.D;
+    a.xmap = getenv("DANET_LSTM_XMAP") ? atoi(getenv("DANET_LSTM_XMAP")) : 1;
+    DANET_CHECK_HIP(hipMemsetAsync(ws, 0, 64 + TRACE_BYTES(T), stream));
+    DANET_CHECK_HIP(hipMemsetAsync(a.ring, 0x01, rs.ring_bytes, stream));   // phase 1
+    const int nblk = ndir * rs.G * rs.P * rs.S;
+#define LAUNCH_RS(UV, NTWV) lstm_bwd_rs_kernel<UV, NTWV><<<nblk, 512, 0, stream>>>(a)
+#define LAUNCH_RS_U(UV)                                          \
+    switch (rs.NTW) {                                            \
+      case 1: LAUNCH_RS(UV, 1); break; case 2: LAUNCH_RS(UV, 2); break; \
+      default: LAUNCH_RS(UV, 3); break; }
+    if (rs.U == 8) { LAUNCH_RS_U(8) } else if (rs.U == 16) { LAUNCH_RS_U(16) } else { LAUNCH_RS_U(32) }
+    DANET_CHECK_LAUNCH();
+    return DANET_OK;
+  }
   LstmPlan pl = make_plan(B, H, ndir, true);
   if (pl.lds > 160 * 1024) {
     danet_set_error("lstm_bwd: H=%d needs %zu B LDS", H, pl.lds);
@@ -626,7 +959,10 @@ extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int n
   a.gates[0] = gates_f; a.gates[1] = gates_b; a.cell[0] = cell_f; a.cell[1] = cell_b;
   a.da[0] = da_f; a.da[1] = da_b; a.status = (int*)ws;
   a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.P = pl.P; a.G = G; a.R = R;
-  DANET_CHECK_HIP(hipMemsetAsync(ws, 0, danet_lstm_workspace_bytes(T, B, H, ndir), stream));
+  a.xmap = getenv("DANET_LSTM_XMAP") ? atoi(getenv("DANET_LSTM_XMAP")) : 0;
+  a.plain = getenv("DANET_LSTM_PLAIN") ? atoi(getenv("DANET_LSTM_PLAIN")) : 0;
+  if (!(a.xmap && a.ndir * a.G == 8)) a.plain = 0;   // one cluster per XCD only
+  DANET_CHECK_HIP(hipMemsetAsync(ws, 0, 64 + TRACE_BYTES(T), stream));
   const size_t dbytes = (size_t)T * B * 4 * H * sizeof(float);
   DANET_CHECK_HIP(hipMemsetAsync(da_f, 0xFF, dbytes, stream));
   if (ndir == 2) DANET_CHECK_HIP(hipMemsetAsync(da_b, 0xFF, dbytes, stream));
