@@ -34,6 +34,9 @@ PROTOTYPES = {
                                c_p, c_int, c_p, c_f32, c_p, c_sz]),
     'danet_gemm_f32_ex': (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_int,
                                   c_p, c_int, c_p, c_f32, c_p, c_sz, c_int]),
+    'danet_gemm_f32_streamk_workspace_bytes': (c_sz, [c_int, c_int, c_int]),
+    'danet_gemm_f32_streamk': (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_int,
+                                       c_p, c_int, c_p, c_f32, c_p, c_sz]),
     'danet_colsum_f32_workspace_bytes': (c_sz, [c_int, c_int]),
     'danet_colsum_f32': (c_int, [c_p, c_int, c_int, c_p, c_int, c_p, c_f32, c_p, c_sz]),
     'danet_lstm_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int]),
@@ -119,15 +122,15 @@ def stream():
 _ws = {}
 
 
-def workspace(nbytes, device):
-    '''per-device grow-only scratch; safe because every library call is
-    stream-ordered on the current stream and finishes with `ws` before the next
-    call on that stream starts.'''
+def workspace(nbytes, device, tag=None):
+    '''per-(device, stream, tag) grow-only scratch, zero-initialised; safe because
+    every library call is stream-ordered on the current stream and finishes with
+    `ws` before the next call on that stream starts.'''
     key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream().cuda_stream)
+           torch.cuda.current_stream().cuda_stream, tag)
     t = _ws.get(key)
     if t is None or t.numel() < nbytes:
-        t = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        t = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws[key] = t
     return t
 

@@ -291,3 +291,273 @@ extern "C" int danet_gemm_f32_ex(danet_stream_t stream_, int transA, int transB,
   }
   return DANET_OK;
 }
+
+// ---------------------------------------------------------------------------
+// stream-K scheduling
+// ---------------------------------------------------------------------------
+// Alternative schedule for a product that has the GPU to itself (danet_gemm_f32_streamk):
+// one tile per workgroup leaves the last round of the 256 CUs mostly empty and
+// split-K needs a second kernel.  Here the launch is G persistent workgroups
+// (one per CU).  The tiles are dealt to the 8 XCDs in contiguous bands (workgroup b
+// runs on XCD b % 8: a band's A/B panels stay in that XCD's L2); within a band the
+// (tile, k-iteration) space is cut into G/8 EQUAL contiguous ranges, one per
+// workgroup, so every workgroup does the same number of MFMAs whatever the shape.
+// A tile whose k-range is cut is finished deterministically inside the kernel:
+//   - the workgroup holding a tile's LAST k-segment is its owner; the others
+//     publish their partial accumulators (write-through 16-byte stores, drained,
+//     then a flag carrying this launch's sequence number) and go on;
+//   - every workgroup walks its range from the END backwards, so what it owes a
+//     higher-numbered owner is computed first, and the tile it owns itself is
+//     computed last -- by then its contributors (all lower-numbered, dispatched
+//     earlier, and never waiting before they publish) are long done;
+//   - the owner adds the partials to its own segment in ascending workgroup order.
+// Same G + same shape => same summation order => bit-reproducible.
+// Measured (tools/bench_gemm.py, cfg-2 shapes): dYc 240 -> 137 us, dX 117 -> 78 us,
+// gx 106 -> 79 us alone on the GPU; but 2-3 such launches sharing the CUs with each
+// other and with a persistent LSTM kernel are SLOWER than the tile-per-workgroup
+// launches above (static equal ranges lose to the hardware's dynamic dispatch), so
+// the caller opts in per product.
+struct SkArgs {
+  float* slab;          // [G][16][256][4] partial accumulators
+  unsigned* flags;      // [G] launch sequence number when slab[w] is valid
+  unsigned seq;
+  int tiles_m, tiles_n, nk;   // nk = k-iterations (of BK) per tile
+};
+
+#define SK_SPIN_LIMIT (1u << 22)
+
+template <bool A_KCONTIG, bool B_KCONTIG>
+__device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* smem, int m0, int n0,
+                                             int kbeg, int kend, f32x16 (&acc)[2][2]) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  f32x4 ra[2], rb[2];
+  load_tile<A_KCONTIG>(g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, tid, ra);
+  load_tile<B_KCONTIG>(g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid, rb);
+  store_tile<A_KCONTIG>(smem, tid, ra);
+  store_tile<B_KCONTIG>(smem + 2 * BK * LDT, tid, rb);
+  __syncthreads();
+
+  const int fa = wm * 64 + (lane & 31);  // fragment column within the tile
+  const int fb = wn * 64 + (lane & 31);
+  const int fk = lane >> 5;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      const int k0 = kbeg + (kt + 1) * BK;
+      load_tile<A_KCONTIG>(g.A, g.lda, m0, g.M, k0, kend, g.vecA, tid, ra);
+      load_tile<B_KCONTIG>(g.B, g.ldb, n0, g.N, k0, kend, g.vecB, tid, rb);
+    }
+    const float* as = smem + cur * (BK * LDT);
+    const float* bs = smem + (2 + cur) * (BK * LDT);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int k = kk * 2 + fk;
+      const float a0 = as[k * LDT + fa], a1 = as[k * LDT + fa + 32];
+      const float b0 = bs[k * LDT + fb], b1 = bs[k * LDT + fb + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      store_tile<A_KCONTIG>(smem + (cur ^ 1) * (BK * LDT), tid, ra);
+      store_tile<B_KCONTIG>(smem + (2 + (cur ^ 1)) * (BK * LDT), tid, rb);
+    }
+    __syncthreads();   // also makes the LDS reusable by the next segment
+  }
+}
+
+typedef unsigned v4u __attribute__((__vector_size__(16)));   // see lstm.hip (b128 builtins)
+
+template <bool A_KCONTIG, bool B_KCONTIG>
+__global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(GemmArgs g, SkArgs sk) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * LDT];
+  // layout: [A buf0 | A buf1 | B buf0 | B buf1], each BK*LDT floats
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int G8 = gridDim.x >> 3;                 // workgroups per XCD band
+  const int band = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int tiles = sk.tiles_m * sk.tiles_n;
+  const int tb0 = (int)((int64_t)tiles * band / 8), tb1 = (int)((int64_t)tiles * (band + 1) / 8);
+  const int64_t I = (int64_t)(tb1 - tb0) * sk.nk;   // (tile, k-iteration) items of the band
+  const int64_t lo = I * j / G8, hi = I * (j + 1) / G8;
+
+  const unsigned slab_bytes = gridDim.x * 65536u;
+  const __amdgpu_buffer_rsrc_t sres =
+      __builtin_amdgcn_make_buffer_rsrc(sk.slab, 0, (int)slab_bytes, 0x00020000);
+
+  int64_t it = hi;
+  while (it > lo) {
+    const int tl = (int)((it - 1) / sk.nk);              // band-local tile
+    const int64_t tbase = (int64_t)tl * sk.nk;
+    const int kb = (int)((lo > tbase ? lo : tbase) - tbase), ke = (int)(it - tbase);
+    const int tile = tb0 + tl;
+    const int tm = tile / sk.tiles_n, tn = tile % sk.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+
+    gemm_segment<A_KCONTIG, B_KCONTIG>(g, smem, m0, n0, kb * BK, min(g.K, ke * BK), acc);
+
+    if (ke < sk.nk) {
+      // contributor: the tile's later k-segments belong to higher workgroups
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        f32x4 v;
+        v.x = acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 0];
+        v.y = acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 1];
+        v.z = acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 2];
+        v.w = acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 3];
+        __builtin_amdgcn_raw_buffer_store_b128(
+            __builtin_bit_cast(v4u, v), sres,
+            (unsigned)(((blockIdx.x * 16u + q) * 256u + tid) * 16u), 0, 16 /*sc1*/);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0)
+        __hip_atomic_store(&sk.flags[blockIdx.x], sk.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (kb > 0) {
+        // owner of a cut tile: add to the own segment the partials of the workgroups
+        // that hold k-iterations [0, kb) of it, in ascending workgroup order
+        const int jf = (int)((tbase * G8) / I);   // first candidate range
+        for (int jc = jf; jc < j; ++jc) {
+          const int64_t clo = I * jc / G8, chi = I * (jc + 1) / G8;
+          if (chi == clo || chi <= tbase || clo >= tbase + kb) continue;   // no share of this tile
+          const unsigned wsrc = (unsigned)(band + 8 * jc);
+          if (tid == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(&sk.flags[wsrc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
+                   sk.seq) {
+              __builtin_amdgcn_s_sleep(4);
+              if (++spins > SK_SPIN_LIMIT) __builtin_trap();   // contributor never ran: fail loudly
+            }
+          }
+          __syncthreads();
+#pragma unroll
+          for (int q0 = 0; q0 < 16; q0 += 4) {     // 4 loads in flight, 16 temporaries
+            v4u raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              raw[u] = __builtin_amdgcn_raw_buffer_load_b128(
+                  sres, (unsigned)(((wsrc * 16u + q0 + u) * 256u + tid) * 16u), 0, 16 /*sc1*/);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int q = q0 + u;
+              const f32x4 v = __builtin_bit_cast(f32x4, raw[u]);
+              acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 0] += v.x;
+              acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 1] += v.y;
+              acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 2] += v.z;
+              acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 3] += v.w;
+            }
+          }
+        }
+      }
+      // epilogue.  D layout (32x32): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+      const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int col = n0 + wn * 64 + nt * 32 + col_l;
+          if (col >= g.N) continue;
+          const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+            if (row >= g.M) continue;
+            float* c = g.C + (size_t)row * g.ldc + col;
+            float v = acc[mt][nt][r] + bv;
+            if (g.beta != 0.f) v += *c;
+            *c = v;
+          }
+        }
+    }
+    it = tbase + kb;
+  }
+}
+
+// Workgroups per launch (a multiple of 8, at most DANET_GEMM_WGS = 512 = two per CU):
+//   - short-K products with at least a tile per CU get one workgroup per tile (nothing
+//     is cut, nothing to fix up);
+//   - otherwise at most DANET_GEMM_MAXSPLIT (8) workgroups share a tile, so the owner's
+//     serial fix-up stays short; few-tile / long-K products (weight gradients) then run
+//     on fewer, longer workgroups -- they are overlapped with other kernels anyway.
+static int sk_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static int sk_grid(int M, int N, int K, int max_workgroups) {
+  static int gmax = 0, maxsplit = 0;
+  if (!gmax) {
+    gmax = sk_env("DANET_GEMM_WGS", 512) & ~7;
+    if (gmax < 8) gmax = 8;
+    if (gmax > 1024) gmax = 1024;
+    maxsplit = sk_env("DANET_GEMM_MAXSPLIT", 8);
+    if (maxsplit < 1) maxsplit = 1;
+  }
+  const int tiles = cdiv(M, BM) * cdiv(N, BN), nk = cdiv(K, BK);
+  int lim = gmax;
+  if (max_workgroups > 0 && max_workgroups < lim) lim = max_workgroups & ~7;
+  if (lim < 8) lim = 8;
+  int64_t gsz;
+  if (tiles >= 256 && (int64_t)tiles * nk < (int64_t)12 * lim) gsz = cdiv(tiles, 8) * 8;
+  else gsz = (int64_t)cdiv(tiles * maxsplit, 8) * 8;
+  if (gsz > lim) gsz = lim;
+  return (int)gsz;
+}
+#define SK_MAX_GRID 1024
+#define SK_HEADER (SK_MAX_GRID * sizeof(unsigned))
+
+extern "C" size_t danet_gemm_f32_streamk_workspace_bytes(int M, int N, int K) {
+  return SK_HEADER + (size_t)sk_grid(M, N, K, 0) * 65536;   // flags + one partial tile per workgroup
+}
+
+
+extern "C" int danet_gemm_f32_streamk(danet_stream_t stream_, int transA, int transB,
+                                      int M, int N, int K, const float* A, int lda,
+                                      const float* B, int ldb, float* C, int ldc,
+                                      const float* bias, float beta, void* ws,
+                                      size_t ws_bytes) {
+  static unsigned launch_seq = 0x5eed0000u;   // flag value of the next launch
+  hipStream_t stream = (hipStream_t)stream_;
+  DANET_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: non-positive shape %d %d %d", M, N, K);
+  DANET_CHECK_ARG(A && B && C, "gemm: null operand");
+  DANET_CHECK_ARG(beta == 0.f || beta == 1.f, "gemm: beta must be 0 or 1");
+  DANET_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N,
+                  "gemm: leading dimension too small");
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.bias = bias;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.beta = beta; g.slab = nullptr; g.splitk = 1; g.kchunk = K;
+  g.vecA = (((uintptr_t)A & 15) == 0) && (lda % 4 == 0);
+  g.vecB = (((uintptr_t)B & 15) == 0) && (ldb % 4 == 0);
+  const int gsz = sk_grid(M, N, K, 0);
+  const size_t need = SK_HEADER + (size_t)gsz * 65536;
+  if (!ws || ws_bytes < need || ((uintptr_t)ws & 15) != 0) {
+    danet_set_error("gemm: workspace %zu < %zu (or not 16-B aligned)", ws_bytes, need);
+    return DANET_ERR_WORKSPACE;
+  }
+  SkArgs sk;
+  sk.flags = (unsigned*)ws;
+  sk.slab = (float*)((char*)ws + SK_HEADER);
+  sk.seq = __atomic_add_fetch(&launch_seq, 1u, __ATOMIC_RELAXED);
+  sk.tiles_m = cdiv(M, BM); sk.tiles_n = cdiv(N, BN); sk.nk = cdiv(K, BK);
+  dim3 grid(gsz, 1, 1), block(256);
+  const bool ak = !transA, bk = (transB != 0);
+  if (ak && !bk) gemm_f32_sk_kernel<true, false><<<grid, block, 0, stream>>>(g, sk);
+  else if (ak && bk) gemm_f32_sk_kernel<true, true><<<grid, block, 0, stream>>>(g, sk);
+  else if (!ak && !bk) gemm_f32_sk_kernel<false, false><<<grid, block, 0, stream>>>(g, sk);
+  else gemm_f32_sk_kernel<false, true><<<grid, block, 0, stream>>>(g, sk);
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}

@@ -34,12 +34,30 @@ def _ws(nbytes, dev):
 # ---------------------------------------------------------------------------
 # raw wrappers (no autograd)
 # ---------------------------------------------------------------------------
+# stream-K schedule for the products on the backward critical path (dYc, dX): opt-in.
+# Alone on the GPU they gain 1.5-1.75x (tools/bench_gemm.py), in the train step the
+# weight-gradient chains on the side streams take most of that back (4.53 -> 4.50 ms),
+# which does not pay for an inter-workgroup hand-off on the critical path.
+STREAMK = int(__import__('os').environ.get('DANET_STREAMK', '0'))
+
+
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, beta=0.0,
-         max_workgroups=0):
+         max_workgroups=0, streamk=False):
     '''C[M,N] = op(A) op(B) (+bias) (+beta*C) on the fp32 matrix cores.
     A, B, C are tensors whose data_ptr() is element (0,0); ld* in elements.
-    max_workgroups > 0 caps the launch (persistent workgroups).'''
+    max_workgroups > 0 caps the launch (persistent workgroups); streamk selects the
+    stream-K schedule (for a product that has the GPU to itself).'''
     L = _L()
+    if streamk and STREAMK:
+        need = L.danet_gemm_f32_streamk_workspace_bytes(M, N, K)
+        # dedicated (zero-initialised, never shared) scratch: it holds the stream-K
+        # hand-off flags, which must only ever contain earlier launch sequence numbers
+        w = _lib.workspace(need, C.device, tag='gemm_sk')
+        with _lib.timed('gemm_f32'):
+            check(L.danet_gemm_f32_streamk(_lib.stream(), int(transA), int(transB), M, N, K,
+                                           ptr(_f32(A)), lda, ptr(_f32(B)), ldb, ptr(_f32(C)), ldc,
+                                           ptr(bias), float(beta), ptr(w), w.numel()))
+        return C
     need = L.danet_gemm_f32_workspace_bytes(M, N, K)
     w, wn = _ws(need, C.device)
     with _lib.timed('gemm_f32'):
@@ -359,7 +377,7 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
         for d in range(ndir):
             # dX += da Wx^T
             gemm(das[d], c.Ws[d], dx, T * B, D, 4 * H, 4 * H, 4 * H, D, transB=True,
-                 beta=0.0 if d == 0 else 1.0)
+                 beta=0.0 if d == 0 else 1.0, streamk=True)
 
     # dX is what the next layer's BPTT waits for: it is issued first, alone, on
     # the main stream.  The weight-gradient chains fork AFTER it (the fork event
@@ -448,7 +466,7 @@ class RnnEncoderFn(torch.autograd.Function):
         dev = dembed.device
         dWout, direct_out = _grad_target(ctx.Wout, (D, O), dev)
         dyc = torch.empty(B, T, D, device=dev)
-        gemm(dembed, ctx.Wout, dyc, B * T, D, O, O, O, D, transB=True)   # critical path first
+        gemm(dembed, ctx.Wout, dyc, B * T, D, O, O, O, D, transB=True, streamk=True)   # critical path first
         with _Fork(dev, 2, defer=True, keep=(dembed, ctx.yc)) as f:
             f.run(1, lambda: gemm(ctx.yc, dembed, dWout, D, O, B * T, D, O, O, transA=True,
                                   beta=1.0 if direct_out else 0.0,

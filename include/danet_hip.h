@@ -124,6 +124,20 @@ int danet_gemm_f32_ex(danet_stream_t stream, int transA, int transB,
                       float* C, int ldc, const float* bias, float beta,
                       void* ws, size_t ws_bytes, int max_workgroups);
 
+/* Same product, stream-K schedule: G persistent workgroups each take an equal
+ * share of the (tile, k-iteration) space of their XCD band; cut tiles are finished
+ * in-kernel in a fixed order (bit-reproducible, no second kernel).  Faster than
+ * danet_gemm_f32 for a product that has the GPU to itself (critical-path dX / dYc),
+ * slower when several products share the CUs.  `ws` (>= the _workspace_bytes value,
+ * 16-B aligned) must be zero-initialised once and then only ever be used by this
+ * function: it keeps the hand-off flags of earlier launches.                  */
+size_t danet_gemm_f32_streamk_workspace_bytes(int M, int N, int K);
+int danet_gemm_f32_streamk(danet_stream_t stream, int transA, int transB,
+                           int M, int N, int K,
+                           const float* A, int lda, const float* B, int ldb,
+                           float* C, int ldc, const float* bias, float beta,
+                           void* ws, size_t ws_bytes);
+
 /* out[N] = sum_m A[m][n] (+ beta*out): bias gradients.                     */
 int danet_colsum_f32(danet_stream_t stream, int M, int N, const float* A,
                      int lda, float* out, float beta, void* ws,

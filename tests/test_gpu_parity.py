@@ -79,6 +79,39 @@ def test_gemm(M, N, K, ta, tb):
     assert relerr(C.cpu().numpy(), ref + bias + C0) < 2e-5
 
 
+@pytest.mark.parametrize('M,N,K,ta,tb', [
+    (1, 1, 1, 0, 0), (130, 260, 33, 1, 0), (4096, 600, 1200, 0, 1), (600, 1200, 4096, 1, 0),
+    (129, 1200, 4096, 1, 0), (4096, 1200, 129, 0, 0), (300, 1200, 2000, 1, 1), (2100, 3000, 50, 0, 0)])
+def test_gemm_streamk_schedule(M, N, K, ta, tb, monkeypatch):
+    '''the opt-in stream-K schedule (danet_gemm_f32_streamk): correct, bit-reproducible
+    across launches, under a concurrent load on another stream'''
+    from danet_amd import ops
+    monkeypatch.setattr(ops, 'STREAMK', 1)
+    rng = np.random.RandomState(M + N + K)
+    A = rng.randn(K, M) if ta else rng.randn(M, K)
+    Bm = rng.randn(N, K) if tb else rng.randn(K, N)
+    bias, C0 = rng.randn(N), rng.randn(M, N)
+    ref = (A.T if ta else A) @ (Bm.T if tb else Bm)
+    dA, dB = cu(A), cu(Bm)
+    side = torch.cuda.Stream()
+    noise = torch.randn(1024, 1024, device='cuda')
+    outs = []
+    for it in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(4 * it):
+                noise @ noise
+        C = torch.empty(M, N, device='cuda')
+        ops.gemm(dA, dB, C, M, N, K, dA.shape[1], dB.shape[1], N, transA=ta, transB=tb, streamk=True)
+        outs.append(C)
+    torch.cuda.synchronize()
+    assert relerr(outs[0].cpu().numpy(), ref) < 2e-5
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    C = cu(C0)
+    ops.gemm(dA, dB, C, M, N, K, dA.shape[1], dB.shape[1], N, transA=ta, transB=tb,
+             bias=cu(bias), beta=1.0, streamk=True)
+    assert relerr(C.cpu().numpy(), ref + bias + C0) < 2e-5
+
+
 def test_gemm_strided_views_and_asymmetric():
     '''sub-matrix operands with ld > width; asymmetric operands catch a
     transposed fragment/epilogue mapping'''
@@ -611,3 +644,65 @@ def test_lstm_unsupported_shapes_fail_loudly():
     b = torch.zeros(4 * H, device='cuda')
     with pytest.raises(_lib.DanetHipError):
         ops.LstmLayerFn.apply(x, H, W, b)
+
+
+@pytest.mark.parametrize('B,T,H', [(2, 96, 300), (5, 40, 36), (16, 50, 128), (32, 128, 300),
+                                   (48, 33, 300), (32, 24, 600), (7, 25, 20), (64, 16, 300)])
+def test_lstm_bwd_handoff_under_uneven_load(B, T, H):
+    '''the BPTT kernel's inter-workgroup hand-off (phase-tagged partial-dh ring,
+    csrc/lstm.hip) repeated under an UNEVEN concurrent load (a GEMM stream that comes
+    and goes on another HIP stream), every output word compared with the independent
+    all-gather kernel (DANET_LSTM_BWD_RS=0) and the hand-off status word checked'''
+    from danet_amd import _lib
+    L = _lib.load()
+    ptr = _lib.ptr
+    dev = torch.device('cuda')
+    g = torch.Generator(device='cuda').manual_seed(B * 1000 + T * 10 + H)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    gx = [rnd(T * B, 4 * H) * 0.5 for _ in range(2)]
+    Wh = [rnd(H, 4 * H) * (0.75 / H ** 0.5) for _ in range(2)]
+    dy = rnd(T, B, 2 * H)
+    n = L.danet_lstm_workspace_bytes(T, B, H, 2)
+    st = torch.cuda.current_stream().cuda_stream
+    ypad = torch.empty(T + 2, B, 2 * H, device=dev)
+    gates = [x.clone() for x in gx]
+    cells = [torch.empty(T * B, H, device=dev) for _ in range(2)]
+    ws = torch.zeros(n, dtype=torch.uint8, device=dev)
+    _lib.check(L.danet_lstm_fwd(st, T, B, H, 2, ptr(gates[0]), ptr(gates[1]), ptr(Wh[0]), ptr(Wh[1]),
+                                4 * H, ptr(ypad), 2 * H, ptr(gates[0]), ptr(gates[1]),
+                                ptr(cells[0]), ptr(cells[1]), ptr(ws), n))
+    torch.cuda.synchronize()
+    assert int(ws[:4].view(torch.int32)[0]) == 0
+
+    def bwd():
+        das = [torch.full((T * B, 4 * H), float('nan'), device=dev) for _ in range(2)]
+        w = torch.zeros(n, dtype=torch.uint8, device=dev)
+        _lib.check(L.danet_lstm_bwd(st, T, B, H, 2, ptr(dy), 2 * H, ptr(Wh[0]), ptr(Wh[1]), 4 * H,
+                                    ptr(gates[0]), ptr(gates[1]), ptr(cells[0]), ptr(cells[1]),
+                                    ptr(das[0]), ptr(das[1]), ptr(w), n))
+        return das, w
+
+    old = os.environ.get('DANET_LSTM_BWD_RS')
+    os.environ['DANET_LSTM_BWD_RS'] = '0'
+    try:
+        ref, w = bwd()
+        torch.cuda.synchronize()
+        assert int(w[:4].view(torch.int32)[0]) == 0
+    finally:
+        if old is None:
+            del os.environ['DANET_LSTM_BWD_RS']
+        else:
+            os.environ['DANET_LSTM_BWD_RS'] = old
+    scale = max(float(r.abs().max()) for r in ref)
+    side = torch.cuda.Stream()
+    a = torch.randn(2048, 2048, device=dev)
+    for it in range(6):
+        with torch.cuda.stream(side):            # bursts of different length: uneven load
+            for _ in range(it * 3):
+                a @ a
+        das, w = bwd()
+        torch.cuda.synchronize()
+        assert int(w[:4].view(torch.int32)[0]) == 0, 'hand-off timeout (iteration %d)' % it
+        for d in range(2):
+            assert torch.isfinite(das[d]).all()
+            assert float((das[d] - ref[d]).abs().max()) < 2e-5 * scale
