@@ -206,13 +206,35 @@ def main():
         dom = max(('lstm_fwd', 'lstm_bwd'), key=lambda k: prof.get(k, (1, 0.0))[1])
         n, ms = prof[dom]
         achieved = lstm_flops / (ms / n * 1e-3) / 1e12
-        roofline = dict(kernel=dom + '_kernel', bound='mfma', achieved=round(achieved, 3),
+        # kernel symbol behind the label (csrc/lstm.hip): BPTT runs the reduce-scatter
+        # kernel unless DANET_LSTM_BWD_RS=0 selects the all-gather one
+        ksym = {'lstm_fwd': 'lstm_fwd_kernel',
+                'lstm_bwd': 'lstm_bwd_kernel' if os.environ.get('DANET_LSTM_BWD_RS') == '0'
+                else 'lstm_bwd_rs_kernel'}[dom]
+        roofline = dict(kernel=ksym, bound='mfma', achieved=round(achieved, 3),
                         peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
                         frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                        traffic=pmc_traffic_bytes(dom + '_kernel'),
+                        traffic=pmc_traffic_bytes(ksym),
                         us_per_timestep=round(1e3 * ms / n / T, 3),
                         note='latency-bound recurrence: T dependent steps per launch; '
                              'see DESIGN.md for the step-latency model')
+        # second-largest consumer: the fp32 MFMA GEMMs (all launches of one step together)
+        F, E = hp.FFT_SIZE // 2 + 1, hp.EMBED_SIZE
+        gemm_flops = 0.0
+        for l in range(L):
+            D = F if l == 0 else 2 * H
+            gemm_flops += 2 * (2.0 * B * T * D * 4 * H) * 3      # gx, dWx, dX per direction
+            gemm_flops += 2 * (2.0 * B * T * H * 4 * H)          # dWh per direction
+        gemm_flops -= 2 * (2.0 * B * T * F * 4 * H)              # layer 0 needs no dX
+        gemm_flops += 3 * 2.0 * B * T * 2 * H * F * E            # projection, dWout, dYc
+        if 'gemm_f32' in prof:
+            gn, gms = prof['gemm_f32']
+            gach = gemm_flops * args.steps / (gms * 1e-3) / 1e12
+            roofline['gemm_f32'] = dict(kernel='gemm_f32_kernel', bound='mfma',
+                                        achieved=round(gach, 2), peak=PEAK_F32_MFMA_TFLOPS,
+                                        unit='TFLOP/s', frac=round(gach / PEAK_F32_MFMA_TFLOPS, 4),
+                                        note='sum over the %d launches of a step, timed '
+                                             'in-step (2-3 of them run concurrently)' % (gn // args.steps))
         res = dict(metric='mixture-seconds/s (train step)', value=round(value, 2),
                    unit='mixture-seconds/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(1e3 * dt / args.steps, 3), higher_is_better=True,

@@ -199,7 +199,7 @@ def _lstm_ws(T, B, H, ndir, dev):
 # on the main stream and the main stream joins the side streams before anything
 # is returned, so the caching allocator never recycles memory still in use.
 _side = {}
-SIDE_STREAMS = int(__import__('os').environ.get('DANET_SIDE_STREAMS', '2'))
+SIDE_STREAMS = int(__import__('os').environ.get('DANET_SIDE_STREAMS', '1'))
 # persistent-workgroup cap for GEMMs that run under a BPTT kernel (per chain; 0 = off).
 # Measured at cfg 2: caps of 32..96 all LOSE (5.4-7.1 ms/step vs 5.2 uncapped): the
 # interference is fabric contention on the exchange hops, not CU placement.
