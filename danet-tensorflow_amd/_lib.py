@@ -17,6 +17,12 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libdanet_hip.so')
 c_int, c_i64, c_f32, c_sz, c_p = (ctypes.c_int, ctypes.c_int64, ctypes.c_float,
                                   ctypes.c_size_t, ctypes.c_void_p)
 
+class GemmProblem(ctypes.Structure):
+    '''danet_gemm_problem_t (include/danet_hip.h)'''
+    _fields_ = [('A', c_p), ('lda', c_int), ('B', c_p), ('ldb', c_int), ('C', c_p), ('ldc', c_int),
+                ('M', c_int), ('N', c_int), ('bias', c_p), ('beta', c_f32)]
+
+
 # name -> (restype, argtypes); mirrors include/danet_hip.h
 PROTOTYPES = {
     'danet_abi_version': (c_int, []),
@@ -37,6 +43,8 @@ PROTOTYPES = {
     'danet_gemm_f32_streamk_workspace_bytes': (c_sz, [c_int, c_int, c_int]),
     'danet_gemm_f32_streamk': (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_int,
                                        c_p, c_int, c_p, c_f32, c_p, c_sz]),
+    'danet_gemm_f32_streamk_grouped': (c_int, [c_p, c_int, c_int, c_int, c_int,
+                                               ctypes.POINTER(GemmProblem), c_int, c_p, c_sz]),
     'danet_colsum_f32_workspace_bytes': (c_sz, [c_int, c_int]),
     'danet_colsum_f32': (c_int, [c_p, c_int, c_int, c_p, c_int, c_p, c_f32, c_p, c_sz]),
     'danet_lstm_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int]),
@@ -159,10 +167,10 @@ class timed(object):
     '''with timed('label'): <one library call>  -- records a start/end event pair
     on the current stream (the stream the kernels are launched on) when
     profiling is enabled; free otherwise.'''
-    __slots__ = ('label', 'a')
+    __slots__ = ('label', 'tag', 'a')
 
-    def __init__(self, label):
-        self.label = label
+    def __init__(self, label, tag=None):
+        self.label, self.tag = label, tag
 
     def __enter__(self):
         if _prof is not None:
@@ -175,4 +183,6 @@ class timed(object):
             b = torch.cuda.Event(enable_timing=True)
             b.record()
             _prof.setdefault(self.label, []).append((self.a, b))
+            if self.tag:      # per-call-site breakdown next to the per-entry-point total
+                _prof.setdefault(self.label + ':' + self.tag, []).append((self.a, b))
         return False

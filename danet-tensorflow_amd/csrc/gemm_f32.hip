@@ -317,11 +317,21 @@ extern "C" int danet_gemm_f32_ex(danet_stream_t stream_, int transA, int transB,
 // other and with a persistent LSTM kernel are SLOWER than the tile-per-workgroup
 // launches above (static equal ranges lose to the hardware's dynamic dispatch), so
 // the caller opts in per product.
+#define SK_MAX_PROBLEMS 6
+struct SkProblem {
+  const float* A; const float* B; float* C; const float* bias;
+  int M, N, lda, ldb, ldc;
+  int vecA, vecB;
+  int tiles_n;     // N tiles of this problem
+  int tile0;       // first global tile index of this problem
+  float beta;
+};
 struct SkArgs {
+  SkProblem p[SK_MAX_PROBLEMS];   // a group shares K and the transpose flags
+  int nprob, K, nk, tiles;        // nk = k-iterations (of BK) per tile; tiles = total
   float* slab;          // [G][16][256][4] partial accumulators
   unsigned* flags;      // [G] launch sequence number when slab[w] is valid
   unsigned seq;
-  int tiles_m, tiles_n, nk;   // nk = k-iterations (of BK) per tile
 };
 
 #define SK_SPIN_LIMIT (1u << 22)
@@ -374,7 +384,7 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* smem, int
 typedef unsigned v4u __attribute__((__vector_size__(16)));   // see lstm.hip (b128 builtins)
 
 template <bool A_KCONTIG, bool B_KCONTIG>
-__global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(GemmArgs g, SkArgs sk) {
+__global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(SkArgs sk) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * LDT];
   // layout: [A buf0 | A buf1 | B buf0 | B buf1], each BK*LDT floats
   const int tid = threadIdx.x;
@@ -383,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(GemmArgs g, SkArgs 
 
   const int G8 = gridDim.x >> 3;                 // workgroups per XCD band
   const int band = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int tiles = sk.tiles_m * sk.tiles_n;
+  const int tiles = sk.tiles;
   const int tb0 = (int)((int64_t)tiles * band / 8), tb1 = (int)((int64_t)tiles * (band + 1) / 8);
   const int64_t I = (int64_t)(tb1 - tb0) * sk.nk;   // (tile, k-iteration) items of the band
   const int64_t lo = I * j / G8, hi = I * (j + 1) / G8;
@@ -398,7 +408,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(GemmArgs g, SkArgs 
     const int64_t tbase = (int64_t)tl * sk.nk;
     const int kb = (int)((lo > tbase ? lo : tbase) - tbase), ke = (int)(it - tbase);
     const int tile = tb0 + tl;
-    const int tm = tile / sk.tiles_n, tn = tile % sk.tiles_n;
+    int pi = sk.nprob - 1;
+    while (pi > 0 && tile < sk.p[pi].tile0) --pi;
+    const SkProblem& pr = sk.p[pi];
+    GemmArgs g;
+    g.A = pr.A; g.B = pr.B; g.C = pr.C; g.bias = pr.bias;
+    g.M = pr.M; g.N = pr.N; g.K = sk.K; g.lda = pr.lda; g.ldb = pr.ldb; g.ldc = pr.ldc;
+    g.vecA = pr.vecA; g.vecB = pr.vecB; g.beta = pr.beta;
+    g.slab = nullptr; g.splitk = 1; g.kchunk = sk.K;
+    const int ptile = tile - pr.tile0;
+    const int tm = ptile / pr.tiles_n, tn = ptile % pr.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
     f32x16 acc[2][2];
@@ -496,7 +515,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(GemmArgs g, SkArgs 
 //     serial fix-up stays short; few-tile / long-K products (weight gradients) then run
 //     on fewer, longer workgroups -- they are overlapped with other kernels anyway.
 static int sk_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-static int sk_grid(int M, int N, int K, int max_workgroups) {
+static int sk_grid(int tiles, int nk, int max_workgroups) {
   static int gmax = 0, maxsplit = 0;
   if (!gmax) {
     gmax = sk_env("DANET_GEMM_WGS", 512) & ~7;
@@ -505,7 +524,6 @@ static int sk_grid(int M, int N, int K, int max_workgroups) {
     maxsplit = sk_env("DANET_GEMM_MAXSPLIT", 8);
     if (maxsplit < 1) maxsplit = 1;
   }
-  const int tiles = cdiv(M, BM) * cdiv(N, BN), nk = cdiv(K, BK);
   int lim = gmax;
   if (max_workgroups > 0 && max_workgroups < lim) lim = max_workgroups & ~7;
   if (lim < 8) lim = 8;
@@ -519,45 +537,64 @@ static int sk_grid(int M, int N, int K, int max_workgroups) {
 #define SK_HEADER (SK_MAX_GRID * sizeof(unsigned))
 
 extern "C" size_t danet_gemm_f32_streamk_workspace_bytes(int M, int N, int K) {
-  return SK_HEADER + (size_t)sk_grid(M, N, K, 0) * 65536;   // flags + one partial tile per workgroup
+  (void)M; (void)N; (void)K;
+  return SK_HEADER + (size_t)SK_MAX_GRID * 65536;   // flags + one partial tile per workgroup
 }
 
+extern "C" int danet_gemm_f32_streamk_grouped(danet_stream_t stream_, int transA, int transB,
+                                              int K, int nprob, const danet_gemm_problem_t* probs,
+                                              int max_workgroups, void* ws, size_t ws_bytes) {
+  static unsigned launch_seq = 0x5eed0000u;   // flag value of the next launch
+  hipStream_t stream = (hipStream_t)stream_;
+  DANET_CHECK_ARG(probs && nprob >= 1 && nprob <= SK_MAX_PROBLEMS, "gemm group: 1..%d problems",
+                  SK_MAX_PROBLEMS);
+  DANET_CHECK_ARG(K > 0, "gemm: non-positive K %d", K);
+  SkArgs sk;
+  int tiles = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const danet_gemm_problem_t& q = probs[i];
+    DANET_CHECK_ARG(q.M > 0 && q.N > 0, "gemm: non-positive shape %d %d", q.M, q.N);
+    DANET_CHECK_ARG(q.A && q.B && q.C, "gemm: null operand");
+    DANET_CHECK_ARG(q.beta == 0.f || q.beta == 1.f, "gemm: beta must be 0 or 1");
+    DANET_CHECK_ARG(q.lda >= (transA ? q.M : K) && q.ldb >= (transB ? K : q.N) && q.ldc >= q.N,
+                    "gemm: leading dimension too small");
+    SkProblem& p = sk.p[i];
+    p.A = q.A; p.B = q.B; p.C = q.C; p.bias = q.bias;
+    p.M = q.M; p.N = q.N; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.beta = q.beta;
+    p.vecA = (((uintptr_t)q.A & 15) == 0) && (q.lda % 4 == 0);
+    p.vecB = (((uintptr_t)q.B & 15) == 0) && (q.ldb % 4 == 0);
+    p.tiles_n = cdiv(q.N, BN);
+    p.tile0 = tiles;
+    tiles += cdiv(q.M, BM) * p.tiles_n;
+  }
+  for (int i = nprob; i < SK_MAX_PROBLEMS; ++i) sk.p[i] = sk.p[0];
+  sk.nprob = nprob; sk.K = K; sk.nk = cdiv(K, BK); sk.tiles = tiles;
+  const int gsz = sk_grid(tiles, sk.nk, max_workgroups);
+  const size_t need = SK_HEADER + (size_t)gsz * 65536;
+  if (!ws || ws_bytes < need || ((uintptr_t)ws & 15) != 0) {
+    danet_set_error("gemm: workspace %zu < %zu (or not 16-B aligned)", ws_bytes, need);
+    return DANET_ERR_WORKSPACE;
+  }
+  sk.flags = (unsigned*)ws;
+  sk.slab = (float*)((char*)ws + SK_HEADER);
+  sk.seq = __atomic_add_fetch(&launch_seq, 1u, __ATOMIC_RELAXED);
+  dim3 grid(gsz, 1, 1), block(256);
+  const bool ak = !transA, bk = (transB != 0);
+  if (ak && !bk) gemm_f32_sk_kernel<true, false><<<grid, block, 0, stream>>>(sk);
+  else if (ak && bk) gemm_f32_sk_kernel<true, true><<<grid, block, 0, stream>>>(sk);
+  else if (!ak && !bk) gemm_f32_sk_kernel<false, false><<<grid, block, 0, stream>>>(sk);
+  else gemm_f32_sk_kernel<false, true><<<grid, block, 0, stream>>>(sk);
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
 
 extern "C" int danet_gemm_f32_streamk(danet_stream_t stream_, int transA, int transB,
                                       int M, int N, int K, const float* A, int lda,
                                       const float* B, int ldb, float* C, int ldc,
                                       const float* bias, float beta, void* ws,
                                       size_t ws_bytes) {
-  static unsigned launch_seq = 0x5eed0000u;   // flag value of the next launch
-  hipStream_t stream = (hipStream_t)stream_;
-  DANET_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: non-positive shape %d %d %d", M, N, K);
-  DANET_CHECK_ARG(A && B && C, "gemm: null operand");
-  DANET_CHECK_ARG(beta == 0.f || beta == 1.f, "gemm: beta must be 0 or 1");
-  DANET_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N,
-                  "gemm: leading dimension too small");
-  GemmArgs g;
-  g.A = A; g.B = B; g.C = C; g.bias = bias;
-  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-  g.beta = beta; g.slab = nullptr; g.splitk = 1; g.kchunk = K;
-  g.vecA = (((uintptr_t)A & 15) == 0) && (lda % 4 == 0);
-  g.vecB = (((uintptr_t)B & 15) == 0) && (ldb % 4 == 0);
-  const int gsz = sk_grid(M, N, K, 0);
-  const size_t need = SK_HEADER + (size_t)gsz * 65536;
-  if (!ws || ws_bytes < need || ((uintptr_t)ws & 15) != 0) {
-    danet_set_error("gemm: workspace %zu < %zu (or not 16-B aligned)", ws_bytes, need);
-    return DANET_ERR_WORKSPACE;
-  }
-  SkArgs sk;
-  sk.flags = (unsigned*)ws;
-  sk.slab = (float*)((char*)ws + SK_HEADER);
-  sk.seq = __atomic_add_fetch(&launch_seq, 1u, __ATOMIC_RELAXED);
-  sk.tiles_m = cdiv(M, BM); sk.tiles_n = cdiv(N, BN); sk.nk = cdiv(K, BK);
-  dim3 grid(gsz, 1, 1), block(256);
-  const bool ak = !transA, bk = (transB != 0);
-  if (ak && !bk) gemm_f32_sk_kernel<true, false><<<grid, block, 0, stream>>>(g, sk);
-  else if (ak && bk) gemm_f32_sk_kernel<true, true><<<grid, block, 0, stream>>>(g, sk);
-  else if (!ak && !bk) gemm_f32_sk_kernel<false, false><<<grid, block, 0, stream>>>(g, sk);
-  else gemm_f32_sk_kernel<false, true><<<grid, block, 0, stream>>>(g, sk);
-  DANET_CHECK_LAUNCH();
-  return DANET_OK;
+  danet_gemm_problem_t q;
+  q.A = A; q.lda = lda; q.B = B; q.ldb = ldb; q.C = C; q.ldc = ldc; q.M = M; q.N = N;
+  q.bias = bias; q.beta = beta;
+  return danet_gemm_f32_streamk_grouped(stream_, transA, transB, K, 1, &q, 0, ws, ws_bytes);
 }

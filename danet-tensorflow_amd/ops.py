@@ -42,7 +42,7 @@ STREAMK = int(__import__('os').environ.get('DANET_STREAMK', '0'))
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, beta=0.0,
-         max_workgroups=0, streamk=False):
+         max_workgroups=0, streamk=False, tag=None):
     '''C[M,N] = op(A) op(B) (+bias) (+beta*C) on the fp32 matrix cores.
     A, B, C are tensors whose data_ptr() is element (0,0); ld* in elements.
     max_workgroups > 0 caps the launch (persistent workgroups); streamk selects the
@@ -53,18 +53,45 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None,
         # dedicated (zero-initialised, never shared) scratch: it holds the stream-K
         # hand-off flags, which must only ever contain earlier launch sequence numbers
         w = _lib.workspace(need, C.device, tag='gemm_sk')
-        with _lib.timed('gemm_f32'):
+        with _lib.timed('gemm_f32', tag):
             check(L.danet_gemm_f32_streamk(_lib.stream(), int(transA), int(transB), M, N, K,
                                            ptr(_f32(A)), lda, ptr(_f32(B)), ldb, ptr(_f32(C)), ldc,
                                            ptr(bias), float(beta), ptr(w), w.numel()))
         return C
     need = L.danet_gemm_f32_workspace_bytes(M, N, K)
     w, wn = _ws(need, C.device)
-    with _lib.timed('gemm_f32'):
+    with _lib.timed('gemm_f32', tag):
         check(L.danet_gemm_f32_ex(_lib.stream(), int(transA), int(transB), M, N, K,
                                   ptr(_f32(A)), lda, ptr(_f32(B)), ldb, ptr(_f32(C)), ldc,
                                   ptr(bias), float(beta), ptr(w), wn, int(max_workgroups)))
     return C
+
+
+def gemm_group(problems, K, transA=False, transB=False, max_workgroups=0):
+    '''up to 6 products sharing K and the transpose flags as ONE stream-K launch.
+    problems: list of (A, lda, B, ldb, C, ldc, M, N, beta) with tensors whose data_ptr()
+    is element (0,0).'''
+    L = _L()
+    arr = (_lib.GemmProblem * len(problems))()
+    keep = []
+    for i, (A, lda, B, ldb, C, ldc, M, N, beta) in enumerate(problems):
+        A, B, C = _f32(A), _f32(B), _f32(C)
+        keep += [A, B, C]
+        arr[i].A, arr[i].lda, arr[i].B, arr[i].ldb = ptr(A), lda, ptr(B), ldb
+        arr[i].C, arr[i].ldc, arr[i].M, arr[i].N = ptr(C), ldc, M, N
+        arr[i].bias, arr[i].beta = None, float(beta)
+    dev = problems[0][4].device
+    w = _lib.workspace(L.danet_gemm_f32_streamk_workspace_bytes(0, 0, K), dev, tag='gemm_sk')
+    with _lib.timed('gemm_f32_group'):
+        check(L.danet_gemm_f32_streamk_grouped(_lib.stream(), int(transA), int(transB), K,
+                                               len(problems), arr, int(max_workgroups),
+                                               ptr(w), w.numel()))
+
+
+# weight gradients of a BiLSTM layer as one grouped stream-K launch (DANET_GROUPED_DW=0:
+# four split-K launches + reduce kernels)
+GROUPED_DW = int(__import__('os').environ.get('DANET_GROUPED_DW', '1'))
+GROUPED_DW_WGS = int(__import__('os').environ.get('DANET_GROUPED_DW_WGS', '256'))
 
 
 def colsum(A, M, N, lda, out, beta=0.0):
@@ -316,7 +343,7 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs):
             # hoisted input half of ops.lyr_lstm_flat's [x,h]W+b (app/ops.py:139-142);
             # `gates[d]` is later overwritten in place by g,i,f,o
             f.run(d, lambda d=d: gemm(x, Ws[d], gates[d], T * B, 4 * H, D, ldx, 4 * H, 4 * H,
-                                      bias=bs[d]))
+                                      bias=bs[d], tag='gx'))
     ypad = torch.empty(T + 2, B, ndir * H, device=dev)
     ws, wn = _lstm_ws(T, B, H, ndir, dev)
     Whs = [W[D:] for W in Ws]
@@ -373,11 +400,28 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
              max_workgroups=cap)
         colsum(das[d], T * B, 4 * H, 4 * H, dbs[d], beta=bb)
 
+    def hprev_of(d):
+        # Hprev(t) = ypad block t (fwd) / block t+2 (bwd)
+        return c.ypad.view(-1)[(0 if d == 0 else 2 * B * ldy + H):]
+
+    def weight_grads_grouped():
+        # dWx = X^T da and dWh = Hprev^T da of every direction: one stream-K launch
+        probs = []
+        for d in range(ndir):
+            bW = 1.0 if direct[d][0] else 0.0
+            probs.append((c.x, c.ldx, das[d], 4 * H, dWs[d], 4 * H, D, 4 * H, bW))
+            probs.append((hprev_of(d), ldy, das[d], 4 * H, dWs[d][D:], 4 * H, H, 4 * H, bW))
+        gemm_group(probs, T * B, transA=True, max_workgroups=GROUPED_DW_WGS)
+        # (the bias gradients as M = 1 members of the group were measured slower than
+        # the two column-sum kernels: +25 us on the group for 128-row tiles with one row)
+        for d in range(ndir):
+            colsum(das[d], T * B, 4 * H, 4 * H, dbs[d], beta=1.0 if direct[d][1] else 0.0)
+
     def input_grad():
         for d in range(ndir):
             # dX += da Wx^T
             gemm(das[d], c.Ws[d], dx, T * B, D, 4 * H, 4 * H, 4 * H, D, transB=True,
-                 beta=0.0 if d == 0 else 1.0, streamk=True)
+                 beta=0.0 if d == 0 else 1.0, streamk=True, tag='dX')
 
     # dX is what the next layer's BPTT waits for: it is issued first, alone, on
     # the main stream.  The weight-gradient chains fork AFTER it (the fork event
@@ -387,8 +431,13 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
     if need_dx:
         input_grad()
     with _Fork(dev, ndir + 1, defer=True, keep=(das, c.x, c.ypad, dy)) as f:
-        for d in range(ndir):
-            f.run(d + 1, lambda d=d: weight_grads(d))
+        if GROUPED_DW == 2:       # experiment: not overlapped at all
+            weight_grads_grouped()
+        elif GROUPED_DW:
+            f.run(1, weight_grads_grouped)
+        else:
+            for d in range(ndir):
+                f.run(d + 1, lambda d=d: weight_grads(d))
         if GRAD_READY_HOOKS and all(a and b for a, b in direct):
             f.after_all(lambda: _fire_grad_ready(('layer', layer_tag), list(c.Ws) + list(c.bs)))
     dWs = [None if direct[d][0] else dWs[d] for d in range(ndir)]
@@ -454,7 +503,7 @@ class RnnEncoderFn(torch.autograd.Function):
         center(cur, B, T, D, 1, D, yc, 0, D)
         O = Wout.shape[1]
         embed = torch.empty(B, T, O, device=dev)
-        gemm(yc, Wout, embed, B * T, O, D, D, O, O)           # modules.py:249-255
+        gemm(yc, Wout, embed, B * T, O, D, D, O, O, tag='proj')           # modules.py:249-255
         ctx.ctxs, ctx.yc, ctx.Wout = ctxs, yc, Wout
         ctx.dims = (B, T, F, H, L, ndir, D, O)
         return embed
@@ -466,11 +515,16 @@ class RnnEncoderFn(torch.autograd.Function):
         dev = dembed.device
         dWout, direct_out = _grad_target(ctx.Wout, (D, O), dev)
         dyc = torch.empty(B, T, D, device=dev)
-        gemm(dembed, ctx.Wout, dyc, B * T, D, O, O, O, D, transB=True, streamk=True)   # critical path first
+        gemm(dembed, ctx.Wout, dyc, B * T, D, O, O, O, D, transB=True, streamk=True, tag='dYc')   # critical path first
         with _Fork(dev, 2, defer=True, keep=(dembed, ctx.yc)) as f:
-            f.run(1, lambda: gemm(ctx.yc, dembed, dWout, D, O, B * T, D, O, O, transA=True,
-                                  beta=1.0 if direct_out else 0.0,
-                                  max_workgroups=2 * OVERLAP_GEMM_WGS))
+            if GROUPED_DW:    # alone on its stream under the top layer's BPTT kernel
+                f.run(1, lambda: gemm_group(
+                    [(ctx.yc, D, dembed, O, dWout, O, D, O, 1.0 if direct_out else 0.0)], B * T,
+                    transA=True, max_workgroups=GROUPED_DW_WGS))
+            else:
+                f.run(1, lambda: gemm(ctx.yc, dembed, dWout, D, O, B * T, D, O, O, transA=True,
+                                      beta=1.0 if direct_out else 0.0,
+                                      max_workgroups=2 * OVERLAP_GEMM_WGS, tag='dWout'))
             if GRAD_READY_HOOKS and direct_out:
                 f.after_all(lambda: _fire_grad_ready(('out',), [ctx.Wout]))
         dy = torch.empty(T, B, D, device=dev)

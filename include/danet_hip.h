@@ -137,6 +137,23 @@ int danet_gemm_f32_streamk(danet_stream_t stream, int transA, int transB,
                            const float* A, int lda, const float* B, int ldb,
                            float* C, int ldc, const float* bias, float beta,
                            void* ws, size_t ws_bytes);
+/* A GROUP of up to 6 products that share K and the transpose flags, as ONE stream-K
+ * launch over the union of their tiles: the four weight-gradient products of a BiLSTM
+ * layer (dWx, dWh per direction; K = T*B) then fill the GPU evenly in one kernel
+ * instead of 4 split-K launches + 4 reduce launches.  `max_workgroups` > 0 caps the
+ * persistent grid (256 = one per CU leaves room for a co-resident recurrent kernel).
+ * Workspace rules as for danet_gemm_f32_streamk.                                */
+typedef struct {
+  const float* A; int lda;
+  const float* B; int ldb;
+  float* C; int ldc;
+  int M, N;
+  const float* bias;   /* [N] or NULL */
+  float beta;          /* 0 or 1 */
+} danet_gemm_problem_t;
+int danet_gemm_f32_streamk_grouped(danet_stream_t stream, int transA, int transB,
+                                   int K, int nprob, const danet_gemm_problem_t* probs,
+                                   int max_workgroups, void* ws, size_t ws_bytes);
 
 /* out[N] = sum_m A[m][n] (+ beta*out): bias gradients.                     */
 int danet_colsum_f32(danet_stream_t stream, int M, int N, const float* A,

@@ -112,6 +112,40 @@ def test_gemm_streamk_schedule(M, N, K, ta, tb, monkeypatch):
     assert relerr(C.cpu().numpy(), ref + bias + C0) < 2e-5
 
 
+@pytest.mark.parametrize('K,shapes,ta,tb', [
+    (4096, [(600, 1200), (300, 1200), (600, 1200), (300, 1200)], 1, 0),   # a layer's dW group
+    (257, [(1, 1), (130, 260), (128, 128)], 0, 0),
+    (64, [(300, 70), (5, 900), (129, 129), (64, 64), (1, 7), (256, 384)], 1, 1),
+    (1000, [(2000, 40)], 0, 1)])
+def test_gemm_streamk_grouped(K, shapes, ta, tb):
+    '''danet_gemm_f32_streamk_grouped: several products in one launch, strided
+    outputs, beta in {0,1}, bit-reproducible, capped grid'''
+    from danet_amd import ops
+    rng = np.random.RandomState(K + len(shapes))
+    probs, refs, outs = [], [], []
+    for i, (M, N) in enumerate(shapes):
+        A = rng.randn(K, M) if ta else rng.randn(M, K)
+        Bm = rng.randn(N, K) if tb else rng.randn(K, N)
+        C0 = rng.randn(M, N + 3)                       # ldc > N
+        beta = float(i % 2)
+        ref = (A.T if ta else A) @ (Bm.T if tb else Bm) + beta * C0[:, :N]
+        dA, dB, dC = cu(A), cu(Bm), cu(C0)
+        probs.append((dA, dA.shape[1], dB, dB.shape[1], dC, N + 3, M, N, beta))
+        refs.append((ref, C0)); outs.append(dC)
+    for cap in (0, 64):
+        res = []
+        for rep in range(2):
+            for (ref, C0), dC in zip(refs, outs):
+                dC.copy_(cu(C0))
+            ops.gemm_group(probs, K, transA=ta, transB=tb, max_workgroups=cap)
+            res.append([dC.clone() for dC in outs])
+        for (ref, C0), a, b in zip(refs, res[0], res[1]):
+            N = ref.shape[1]
+            assert relerr(a[:, :N].cpu().numpy(), ref) < 2e-5
+            assert np.array_equal(a[:, N:].cpu().numpy(), C0[:, N:].astype(np.float32))   # padding untouched
+            assert torch.equal(a, b)
+
+
 def test_gemm_strided_views_and_asymmetric():
     '''sub-matrix operands with ld > width; asymmetric operands catch a
     transposed fragment/epilogue mapping'''
