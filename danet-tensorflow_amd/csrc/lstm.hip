@@ -747,6 +747,48 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// prefill: every "not yet published" pattern / zero block of one call in ONE launch
+// (hipMemsetAsync with a byte value lowers to a fill kernel PLUS copy kernels on this
+// runtime, and each memset is its own node on the critical path of the layer)
+// ---------------------------------------------------------------------------
+struct FillArgs {
+  void* ptr[4];
+  unsigned long long n16[4];   // 16-byte words per segment
+  unsigned value[4];
+  int nseg;
+};
+
+__global__ __launch_bounds__(256) void multi_fill_kernel(FillArgs a) {
+  const unsigned long long tid = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+#pragma unroll
+  for (int sgi = 0; sgi < 4; ++sgi) {
+    if (sgi >= a.nseg) break;
+    const unsigned v = a.value[sgi];
+    const v4u w = {v, v, v, v};
+    v4u* p = reinterpret_cast<v4u*>(a.ptr[sgi]);
+    for (unsigned long long i = tid; i < a.n16[sgi]; i += stride) p[i] = w;
+  }
+}
+
+struct FillList {
+  FillArgs a;
+  FillList() { a.nseg = 0; }
+  void add(void* p, size_t bytes, unsigned value) {
+    a.ptr[a.nseg] = p; a.n16[a.nseg] = bytes / 16; a.value[a.nseg] = value; ++a.nseg;
+  }
+  hipError_t launch(hipStream_t stream) {
+    unsigned long long tot = 0;
+    for (int i = 0; i < a.nseg; ++i) tot += a.n16[i];
+    unsigned long long blocks = (tot + 256 * 4 - 1) / (256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    multi_fill_kernel<<<(unsigned)blocks, 256, 0, stream>>>(a);
+    return hipGetLastError();
+  }
+};
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 struct LstmPlan { int MT, G, P, KP, NW; size_t lds; };
@@ -840,8 +882,8 @@ static int lstm_check_common(int T, int B, int H, int ndir, void* ws, size_t ws_
     danet_set_error("lstm: H=%d must be a multiple of 4", H);
     return DANET_ERR_UNSUPPORTED;
   }
-  if (!ws || ws_bytes < danet_lstm_workspace_bytes(T, B, H, ndir)) {
-    danet_set_error("lstm: workspace too small");
+  if (!ws || ((uintptr_t)ws & 15) != 0 || ws_bytes < danet_lstm_workspace_bytes(T, B, H, ndir)) {
+    danet_set_error("lstm: workspace too small or not 16-B aligned");
     return DANET_ERR_WORKSPACE;
   }
   return DANET_OK;
@@ -879,13 +921,17 @@ extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int n
   a.xmap = getenv("DANET_LSTM_XMAP") ? atoi(getenv("DANET_LSTM_XMAP")) : 1;
   a.plain = getenv("DANET_LSTM_PLAIN") ? atoi(getenv("DANET_LSTM_PLAIN")) : 0;
   if (!(a.xmap && a.ndir * a.G == 8)) a.plain = 0;   // one cluster per XCD only
-  DANET_CHECK_HIP(hipMemsetAsync(ws, 0, 64 + TRACE_BYTES(T), stream));
-  // "not yet published" sentinel everywhere, then the zero initial state in pad
-  // blocks 0 and T+1 (main.py:108-123)
+  // status word; "not yet published" sentinel in the T interior blocks of ypad; the
+  // zero initial state in pad blocks 0 and T+1 (main.py:108-123) -- one launch
   const size_t blk = (size_t)B * ldy * sizeof(float);
-  DANET_CHECK_HIP(hipMemsetAsync((char*)ypad + blk, 0xFF, (size_t)T * blk, stream));
-  DANET_CHECK_HIP(hipMemsetAsync(ypad, 0, blk, stream));
-  DANET_CHECK_HIP(hipMemsetAsync((char*)ypad + (size_t)(T + 1) * blk, 0, blk, stream));
+  {
+    FillList fl;
+    fl.add(ws, 64 + TRACE_BYTES(T), 0u);
+    fl.add((char*)ypad + blk, (size_t)T * blk, SENTINEL);
+    fl.add(ypad, blk, 0u);
+    fl.add((char*)ypad + (size_t)(T + 1) * blk, blk, 0u);
+    DANET_CHECK_HIP(fl.launch(stream));
+  }
 #define LAUNCH_FWD(MTV, NWV)                                                         \
   do {                                                                               \
     DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_kernel<MTV, NWV>,       \
@@ -925,8 +971,12 @@ extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int n
     a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.P = rs.P; a.G = rs.G; a.S = rs.S;
     a.NT = rs.NT; a.NI = rs.NI; a.D = rs.D;
     a.xmap = getenv("DANET_LSTM_XMAP") ? atoi(getenv("DANET_LSTM_XMAP")) : 1;
-    DANET_CHECK_HIP(hipMemsetAsync(ws, 0, 64 + TRACE_BYTES(T), stream));
-    DANET_CHECK_HIP(hipMemsetAsync(a.ring, 0x01, rs.ring_bytes, stream));   // phase 1
+    {
+      FillList fl;
+      fl.add(ws, 64 + TRACE_BYTES(T), 0u);
+      fl.add(a.ring, rs.ring_bytes, 1u);   // phase 1 in bit 0 of every word
+      DANET_CHECK_HIP(fl.launch(stream));
+    }
     const int nblk = ndir * rs.G * rs.P * rs.S;
 #define LAUNCH_RS(UV, NTWV) lstm_bwd_rs_kernel<UV, NTWV><<<nblk, 512, 0, stream>>>(a)
 #define LAUNCH_RS_U(UV)                                          \
@@ -962,10 +1012,14 @@ extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int n
   a.xmap = getenv("DANET_LSTM_XMAP") ? atoi(getenv("DANET_LSTM_XMAP")) : 0;
   a.plain = getenv("DANET_LSTM_PLAIN") ? atoi(getenv("DANET_LSTM_PLAIN")) : 0;
   if (!(a.xmap && a.ndir * a.G == 8)) a.plain = 0;   // one cluster per XCD only
-  DANET_CHECK_HIP(hipMemsetAsync(ws, 0, 64 + TRACE_BYTES(T), stream));
   const size_t dbytes = (size_t)T * B * 4 * H * sizeof(float);
-  DANET_CHECK_HIP(hipMemsetAsync(da_f, 0xFF, dbytes, stream));
-  if (ndir == 2) DANET_CHECK_HIP(hipMemsetAsync(da_b, 0xFF, dbytes, stream));
+  {
+    FillList fl;
+    fl.add(ws, 64 + TRACE_BYTES(T), 0u);
+    fl.add(da_f, dbytes, SENTINEL);
+    if (ndir == 2) fl.add(da_b, dbytes, SENTINEL);
+    DANET_CHECK_HIP(fl.launch(stream));
+  }
 #define LAUNCH_BWD(MTV, NWV)                                                         \
   do {                                                                               \
     DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_bwd_kernel<MTV, NWV>,       \
