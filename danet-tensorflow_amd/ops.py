@@ -594,6 +594,27 @@ def relu(s_x, alpha=0.):
 TRUTH_MODES = {'truth': 0, 'truth-threshold': 1, 'truth-weighted': 2}
 
 
+# The embedding feeds both the estimator and the separator; autograd would materialise
+# the two gradient contributions (42 MB each at cfg 2) and add them.  The separator's
+# backward runs first (it consumes the attractors): it leaves its dembed here and the
+# estimator's backward -- whose kernels accumulate (`dembed += ...`) -- adds into that
+# buffer in place and returns no gradient of its own.  DANET_FUSE_DEMBED=0 disables.
+FUSE_DEMBED = int(__import__('os').environ.get('DANET_FUSE_DEMBED', '1'))
+_dembed_slot = {}
+
+
+def _publish_dembed(embed_ptr, t):
+    if FUSE_DEMBED:
+        _dembed_slot['v'] = (embed_ptr, t)
+
+
+def _take_dembed(embed_ptr, numel):
+    v = _dembed_slot.pop('v', None)
+    if v is not None and v[0] == embed_ptr and v[1].numel() == numel:
+        return v[1]
+    return None
+
+
 class TruthAttractorFn(torch.autograd.Function):
     '''app/modules.py:382-487'''
 
@@ -615,17 +636,20 @@ class TruthAttractorFn(torch.autograd.Function):
                                           ptr(denom), ptr(w), wn))
         ctx.save_for_backward(src_pwr, mix_pwr, denom)
         ctx.args = (mode, eps, B, C, N, E, T, F)
+        ctx.embed_ptr = embed.data_ptr()
+        _dembed_slot.clear()
         return attr
 
     @staticmethod
     def backward(ctx, dattr):
         src_pwr, mix_pwr, denom = ctx.saved_tensors
         mode, eps, B, C, N, E, T, F = ctx.args
-        dembed = torch.zeros(B, T, F, E, device=dattr.device)
+        shared = _take_dembed(ctx.embed_ptr, B * T * F * E)
+        dembed = shared if shared is not None else torch.zeros(B, T, F, E, device=dattr.device)
         check(_L().danet_attractor_truth_bwd(
             _lib.stream(), mode, B, C, N, E, ptr(_f32(dattr.contiguous())), ptr(src_pwr),
             ptr(mix_pwr), ptr(denom), eps, ptr(dembed)))
-        return dembed, None, None, None, None
+        return (None if shared is not None else dembed), None, None, None, None
 
 
 class AnchorAttractorFn(torch.autograd.Function):
@@ -652,6 +676,7 @@ class AnchorAttractorFn(torch.autograd.Function):
         ctx.save_for_backward(embed, anchors, attr, asum, choice)
         ctx.args = (B, C, N, E, A, T, F)
         ctx.mark_non_differentiable(asets, choice)
+        _dembed_slot.clear()
         return attr, asets, choice
 
     @staticmethod
@@ -659,7 +684,8 @@ class AnchorAttractorFn(torch.autograd.Function):
         embed, anchors, attr, asum, choice = ctx.saved_tensors
         B, C, N, E, A, T, F = ctx.args
         dev = dattr.device
-        dembed = torch.zeros(B, T, F, E, device=dev)
+        shared = _take_dembed(embed.data_ptr(), B * T * F * E)
+        dembed = shared if shared is not None else torch.zeros(B, T, F, E, device=dev)
         danchors = torch.empty(A, E, device=dev)
         L = _L()
         w, wn = _ws(L.danet_attractor_anchor_workspace_bytes(B, C, N, E, A), dev)
@@ -667,7 +693,7 @@ class AnchorAttractorFn(torch.autograd.Function):
             _lib.stream(), B, C, N, E, A, ptr(_f32(dattr.contiguous())), ptr(embed),
             ptr(anchors), ptr(attr), ptr(asum), ptr(choice), ptr(dembed), ptr(danchors),
             ptr(w), wn))
-        return dembed, danchors, None
+        return (None if shared is not None else dembed), danchors, None
 
 
 class SeparateFn(torch.autograd.Function):
@@ -706,6 +732,8 @@ class SeparateFn(torch.autograd.Function):
         check(L.danet_separate_bwd(_lib.stream(), act, B, C, N, E, ptr(mix_pwr), ptr(attr),
                                    ptr(embed_flat), ptr(_f32(dout.contiguous())), ptr(dembed),
                                    ptr(dattr), ptr(w), wn))
+        if ctx.needs_input_grad[1]:      # an estimator backward follows (it made attr)
+            _publish_dembed(embed_flat.data_ptr(), dembed)
         return None, dattr, dembed, None, None
 
 
