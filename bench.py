@@ -229,6 +229,8 @@ def main():
         gemm_flops += 3 * 2.0 * B * T * 2 * H * F * E            # projection, dWout, dYc
         if 'gemm_f32' in prof:
             gn, gms = prof['gemm_f32']
+            if 'gemm_f32_group' in prof:       # grouped weight-gradient launches
+                gn, gms = gn + prof['gemm_f32_group'][0], gms + prof['gemm_f32_group'][1]
             gach = gemm_flops * args.steps / (gms * 1e-3) / 1e12
             roofline['gemm_f32'] = dict(kernel='gemm_f32_kernel', bound='mfma',
                                         achieved=round(gach, 2), peak=PEAK_F32_MFMA_TFLOPS,
