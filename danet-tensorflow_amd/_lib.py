@@ -40,6 +40,10 @@ PROTOTYPES = {
                                c_p, c_int, c_p, c_f32, c_p, c_sz]),
     'danet_gemm_f32_ex': (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_int,
                                   c_p, c_int, c_p, c_f32, c_p, c_sz, c_int]),
+    'danet_gemm_f32_kcat_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int]),
+    'danet_gemm_f32_kcat': (c_int, [c_p, c_int, c_int, c_int, c_int,
+                                    c_int, c_p, c_int, c_p, c_int, c_int, c_p, c_int, c_p, c_int,
+                                    c_p, c_int, c_p, c_f32, c_p, c_sz]),
     'danet_gemm_f32_streamk_workspace_bytes': (c_sz, [c_int, c_int, c_int]),
     'danet_gemm_f32_streamk': (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_int,
                                        c_p, c_int, c_p, c_f32, c_p, c_sz]),

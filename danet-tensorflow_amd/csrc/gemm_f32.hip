@@ -30,6 +30,10 @@ struct GemmArgs {
   int splitk;
   int vecA, vecB;
   float beta;
+  // optional second operand pair (K-concatenated product C = A B + A2 B2): K slices
+  // z >= split1 take pair 2, K2 elements in chunks of kchunk2
+  const float* A2; const float* B2;
+  int lda2, ldb2, K2, kchunk2, split1, vecA2, vecB2;
 };
 
 // Load this thread's share of one operand tile into registers.
@@ -116,8 +120,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int z = wi / nwg;
-  const int kbeg = z * g.kchunk;
-  const int kend = min(g.K, kbeg + g.kchunk);
+  const bool second = z >= g.split1;
+  const float* Ap = second ? g.A2 : g.A;
+  const float* Bp = second ? g.B2 : g.B;
+  const int lda = second ? g.lda2 : g.lda, ldb = second ? g.ldb2 : g.ldb;
+  const int vecA = second ? g.vecA2 : g.vecA, vecB = second ? g.vecB2 : g.vecB;
+  const int kbeg = second ? (z - g.split1) * g.kchunk2 : z * g.kchunk;
+  const int kend = second ? min(g.K2, kbeg + g.kchunk2) : min(g.K, kbeg + g.kchunk);
   const int nk = (kend - kbeg + BK - 1) / BK;
 
   f32x16 acc[2][2];
@@ -130,8 +139,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 
   f32x4 ra[2], rb[2];
   if (nk > 0) {
-    load_tile<A_KCONTIG>(g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, tid, ra);
-    load_tile<B_KCONTIG>(g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid, rb);
+    load_tile<A_KCONTIG>(Ap, lda, m0, g.M, kbeg, kend, vecA, tid, ra);
+    load_tile<B_KCONTIG>(Bp, ldb, n0, g.N, kbeg, kend, vecB, tid, rb);
     store_tile<A_KCONTIG>(smem, tid, ra);
     store_tile<B_KCONTIG>(smem + 2 * BK * LDT, tid, rb);
   }
@@ -145,8 +154,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
       const int k0 = kbeg + (kt + 1) * BK;
-      load_tile<A_KCONTIG>(g.A, g.lda, m0, g.M, k0, kend, g.vecA, tid, ra);
-      load_tile<B_KCONTIG>(g.B, g.ldb, n0, g.N, k0, kend, g.vecB, tid, rb);
+      load_tile<A_KCONTIG>(Ap, lda, m0, g.M, k0, kend, vecA, tid, ra);
+      load_tile<B_KCONTIG>(Bp, ldb, n0, g.N, k0, kend, vecB, tid, rb);
     }
     const float* as = smem + cur * (BK * LDT);
     const float* bs = smem + (2 + cur) * (BK * LDT);
@@ -245,27 +254,42 @@ extern "C" int danet_gemm_f32(danet_stream_t stream_, int transA, int transB,
                            ws, ws_bytes, 0);
 }
 
-extern "C" int danet_gemm_f32_ex(danet_stream_t stream_, int transA, int transB,
-                                 int M, int N, int K, const float* A, int lda,
-                                 const float* B, int ldb, float* C, int ldc,
-                                 const float* bias, float beta, void* ws,
-                                 size_t ws_bytes, int max_workgroups) {
-  hipStream_t stream = (hipStream_t)stream_;
-  DANET_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: non-positive shape %d %d %d", M, N, K);
-  DANET_CHECK_ARG(A && B && C, "gemm: null operand");
+static int gemm_launch(hipStream_t stream, int transA, int transB, int M, int N,
+                       int K, const float* A, int lda, const float* B, int ldb,
+                       int K2, const float* A2, int lda2, const float* B2, int ldb2,
+                       float* C, int ldc, const float* bias, float beta, void* ws,
+                       size_t ws_bytes, int max_workgroups) {
+  DANET_CHECK_ARG(M > 0 && N > 0 && K > 0 && K2 >= 0, "gemm: non-positive shape %d %d %d", M, N, K);
+  DANET_CHECK_ARG(A && B && C && (K2 == 0 || (A2 && B2)), "gemm: null operand");
   DANET_CHECK_ARG(beta == 0.f || beta == 1.f, "gemm: beta must be 0 or 1");
   DANET_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N,
                   "gemm: leading dimension too small");
+  DANET_CHECK_ARG(K2 == 0 || (lda2 >= (transA ? M : K2) && ldb2 >= (transB ? K2 : N)),
+                  "gemm: leading dimension of the second pair too small");
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.beta = beta;
   g.vecA = (((uintptr_t)A & 15) == 0) && (lda % 4 == 0);
   g.vecB = (((uintptr_t)B & 15) == 0) && (ldb % 4 == 0);
-  int splitk = choose_splitk(M, N, K);
-  int kchunk = cdiv(cdiv(K, splitk), BK) * BK;
-  splitk = cdiv(K, kchunk);
-  g.splitk = splitk; g.kchunk = kchunk; g.slab = nullptr;
+  g.A2 = A2; g.B2 = B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;
+  g.vecA2 = K2 && (((uintptr_t)A2 & 15) == 0) && (lda2 % 4 == 0);
+  g.vecB2 = K2 && (((uintptr_t)B2 & 15) == 0) && (ldb2 % 4 == 0);
+  int stot = choose_splitk(M, N, K + K2);
+  if (K2 > 0 && stot < 2) stot = 2;
+  int s1 = stot, s2 = 0;
+  if (K2 > 0) {
+    s1 = (int)((double)stot * K / (K + K2) + 0.5);
+    if (s1 < 1) s1 = 1;
+    if (s1 > stot - 1) s1 = stot - 1;
+    s2 = stot - s1;
+  }
+  const int kchunk = cdiv(cdiv(K, s1), BK) * BK;
+  s1 = cdiv(K, kchunk);
+  int kchunk2 = BK;
+  if (K2 > 0) { kchunk2 = cdiv(cdiv(K2, s2), BK) * BK; s2 = cdiv(K2, kchunk2); }
+  const int splitk = s1 + s2;
+  g.splitk = splitk; g.kchunk = kchunk; g.kchunk2 = kchunk2; g.split1 = s1; g.slab = nullptr;
   if (splitk > 1) {
     const size_t need = (size_t)splitk * M * N * sizeof(float);
     if (!ws || ws_bytes < need) {
@@ -290,6 +314,31 @@ extern "C" int danet_gemm_f32_ex(danet_stream_t stream_, int transA, int transB,
     DANET_CHECK_LAUNCH();
   }
   return DANET_OK;
+}
+
+extern "C" int danet_gemm_f32_ex(danet_stream_t stream_, int transA, int transB,
+                                 int M, int N, int K, const float* A, int lda,
+                                 const float* B, int ldb, float* C, int ldc,
+                                 const float* bias, float beta, void* ws,
+                                 size_t ws_bytes, int max_workgroups) {
+  return gemm_launch((hipStream_t)stream_, transA, transB, M, N, K, A, lda, B, ldb,
+                     0, nullptr, 0, nullptr, 0, C, ldc, bias, beta, ws, ws_bytes, max_workgroups);
+}
+
+extern "C" size_t danet_gemm_f32_kcat_workspace_bytes(int M, int N, int K1, int K2) {
+  int s = choose_splitk(M, N, K1 + K2);
+  if (s < 2) s = 2;
+  return (size_t)(s + 2) * M * N * sizeof(float);   // chunk rounding can add a slice per pair
+}
+
+extern "C" int danet_gemm_f32_kcat(danet_stream_t stream_, int transA, int transB, int M, int N,
+                                   int K1, const float* A1, int lda1, const float* B1, int ldb1,
+                                   int K2, const float* A2, int lda2, const float* B2, int ldb2,
+                                   float* C, int ldc, const float* bias, float beta,
+                                   void* ws, size_t ws_bytes) {
+  DANET_CHECK_ARG(K2 > 0, "gemm_kcat: K2 must be positive");
+  return gemm_launch((hipStream_t)stream_, transA, transB, M, N, K1, A1, lda1, B1, ldb1,
+                     K2, A2, lda2, B2, ldb2, C, ldc, bias, beta, ws, ws_bytes, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -416,6 +465,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(SkArgs sk) {
     g.M = pr.M; g.N = pr.N; g.K = sk.K; g.lda = pr.lda; g.ldb = pr.ldb; g.ldc = pr.ldc;
     g.vecA = pr.vecA; g.vecB = pr.vecB; g.beta = pr.beta;
     g.slab = nullptr; g.splitk = 1; g.kchunk = sk.K;
+    g.A2 = nullptr; g.B2 = nullptr; g.lda2 = g.ldb2 = g.K2 = 0; g.kchunk2 = BK; g.split1 = 1;
+    g.vecA2 = g.vecB2 = 0;
     const int ptile = tile - pr.tile0;
     const int tm = ptile / pr.tiles_n, tn = ptile % pr.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;

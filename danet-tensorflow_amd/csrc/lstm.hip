@@ -43,7 +43,6 @@
 #define SENTINEL 0xFFFFFFFFu
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-#define RLX_WG __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP
 
 // NB: the b128 buffer-load builtin must be assigned to a GCC-style
 // __vector_size__ vector; assigning it to an ext_vector_type silently lowers to
@@ -67,7 +66,7 @@ struct LstmFwdArgs {
   float* ypad;
   int* status;
   int T, B, H, ndir, ldy, ldw, P, G, KP;  // KP = H padded to 16
-  int xmap, plain;   // cluster = bid % nclusters placement; XCD-local plain publishes
+  int xmap;   // consecutive block ids cycle over the clusters (placement, see kernel)
 };
 
 struct LstmBwdArgs {
@@ -78,7 +77,7 @@ struct LstmBwdArgs {
   float* da[2];
   int* status;
   int T, B, H, ndir, lddy, ldw, P, G, R;   // R = batch rows per cluster (<= 16*MT)
-  int xmap, plain;
+  int xmap;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
@@ -297,7 +296,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
       const float h = og * tanh_hw(c_state);   // ops.py:147
       // publish h_t: one write-through 4-byte store, no drain, no flag
       float* hp = a.ypad + ((size_t)(t + 1) * B + bg) * a.ldy + dir * H + unit;
-      if (a.plain) __hip_atomic_store(hp, h, RLX_WG); else __hip_atomic_store(hp, h, RLX_AGENT);
+      __hip_atomic_store(hp, h, RLX_AGENT);
       // saved activations are only read by later kernels (plain stores)
       float* gs = a.gates[dir] + ((size_t)t * B + bg) * (4 * H) + unit;
       gs[0] = g; gs[H] = ig; gs[2 * H] = fg; gs[3 * H] = og;
@@ -483,17 +482,10 @@ __global__ __launch_bounds__(64 * NW) void lstm_bwd_kernel(LstmBwdArgs a) {
       dc_state[i] = dc * fg;
       // publish da_t (also the kernel's output): write-through 4-byte stores
       float* dp = a.da[dir] + ((size_t)t * B + bg) * H4 + unit;
-      if (a.plain) {
-        __hip_atomic_store(dp, da_g, RLX_WG);
-        __hip_atomic_store(dp + H, da_i, RLX_WG);
-        __hip_atomic_store(dp + 2 * H, da_f, RLX_WG);
-        __hip_atomic_store(dp + 3 * H, da_o, RLX_WG);
-      } else {
-        __hip_atomic_store(dp, da_g, RLX_AGENT);
-        __hip_atomic_store(dp + H, da_i, RLX_AGENT);
-        __hip_atomic_store(dp + 2 * H, da_f, RLX_AGENT);
-        __hip_atomic_store(dp + 3 * H, da_o, RLX_AGENT);
-      }
+      __hip_atomic_store(dp, da_g, RLX_AGENT);
+      __hip_atomic_store(dp + H, da_i, RLX_AGENT);
+      __hip_atomic_store(dp + 2 * H, da_f, RLX_AGENT);
+      __hip_atomic_store(dp + 3 * H, da_o, RLX_AGENT);
     }
     TRACE(4);
     __syncthreads();   // `red` reuse (see forward kernel)
@@ -919,8 +911,6 @@ extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int n
   a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.ldy = ldy; a.ldw = ldw;
   a.P = pl.P; a.G = pl.G; a.KP = pl.KP;
   a.xmap = getenv("DANET_LSTM_XMAP") ? atoi(getenv("DANET_LSTM_XMAP")) : 1;
-  a.plain = getenv("DANET_LSTM_PLAIN") ? atoi(getenv("DANET_LSTM_PLAIN")) : 0;
-  if (!(a.xmap && a.ndir * a.G == 8)) a.plain = 0;   // one cluster per XCD only
   // status word; "not yet published" sentinel in the T interior blocks of ypad; the
   // zero initial state in pad blocks 0 and T+1 (main.py:108-123) -- one launch
   const size_t blk = (size_t)B * ldy * sizeof(float);
@@ -1010,8 +1000,6 @@ extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int n
   a.da[0] = da_f; a.da[1] = da_b; a.status = (int*)ws;
   a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.P = pl.P; a.G = G; a.R = R;
   a.xmap = getenv("DANET_LSTM_XMAP") ? atoi(getenv("DANET_LSTM_XMAP")) : 0;
-  a.plain = getenv("DANET_LSTM_PLAIN") ? atoi(getenv("DANET_LSTM_PLAIN")) : 0;
-  if (!(a.xmap && a.ndir * a.G == 8)) a.plain = 0;   // one cluster per XCD only
   const size_t dbytes = (size_t)T * B * 4 * H * sizeof(float);
   {
     FillList fl;

@@ -67,6 +67,19 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None,
     return C
 
 
+def gemm_kcat(A1, lda1, B1, ldb1, K1, A2, lda2, B2, ldb2, K2, C, M, N, ldc,
+              transA=False, transB=False, bias=None, beta=0.0, tag=None):
+    '''C[M,N] = op(A1) op(B1) + op(A2) op(B2) (+bias) (+beta*C) in one launch'''
+    L = _L()
+    w, wn = _ws(L.danet_gemm_f32_kcat_workspace_bytes(M, N, K1, K2), C.device)
+    with _lib.timed('gemm_f32', tag):
+        check(L.danet_gemm_f32_kcat(_lib.stream(), int(transA), int(transB), M, N,
+                                    K1, ptr(_f32(A1)), lda1, ptr(_f32(B1)), ldb1,
+                                    K2, ptr(_f32(A2)), lda2, ptr(_f32(B2)), ldb2,
+                                    ptr(_f32(C)), ldc, ptr(bias), float(beta), ptr(w), wn))
+    return C
+
+
 def gemm_group(problems, K, transA=False, transB=False, max_workgroups=0):
     '''up to 6 products sharing K and the transpose flags as ONE stream-K launch.
     problems: list of (A, lda, B, ldb, C, ldc, M, N, beta) with tensors whose data_ptr()
@@ -418,6 +431,11 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
             colsum(das[d], T * B, 4 * H, 4 * H, dbs[d], beta=1.0 if direct[d][1] else 0.0)
 
     def input_grad():
+        if ndir == 2 and not STREAMK:
+            # dX = da_f Wx_f^T + da_b Wx_b^T: one K-concatenated launch
+            gemm_kcat(das[0], 4 * H, c.Ws[0], 4 * H, 4 * H, das[1], 4 * H, c.Ws[1], 4 * H, 4 * H,
+                      dx, T * B, D, D, transB=True, tag='dX')
+            return
         for d in range(ndir):
             # dX += da Wx^T
             gemm(das[d], c.Ws[d], dx, T * B, D, 4 * H, 4 * H, 4 * H, D, transB=True,

@@ -124,6 +124,17 @@ int danet_gemm_f32_ex(danet_stream_t stream, int transA, int transB,
                       float* C, int ldc, const float* bias, float beta,
                       void* ws, size_t ws_bytes, int max_workgroups);
 
+/* K-concatenated product  C = op(A1) op(B1) + op(A2) op(B2) (+bias) (+beta*C)  as one
+ * launch (the K slices of the two pairs share the deterministic split-K reduction):
+ * dX = da_fwd Wx_fwd^T + da_bwd Wx_bwd^T of a BiLSTM layer without a second GEMM and a
+ * second read-modify-write of dX.                                              */
+size_t danet_gemm_f32_kcat_workspace_bytes(int M, int N, int K1, int K2);
+int danet_gemm_f32_kcat(danet_stream_t stream, int transA, int transB, int M, int N,
+                        int K1, const float* A1, int lda1, const float* B1, int ldb1,
+                        int K2, const float* A2, int lda2, const float* B2, int ldb2,
+                        float* C, int ldc, const float* bias, float beta,
+                        void* ws, size_t ws_bytes);
+
 /* Same product, stream-K schedule: G persistent workgroups each take an equal
  * share of the (tile, k-iteration) space of their XCD band; cut tiles are finished
  * in-kernel in a fixed order (bit-reproducible, no second kernel).  Faster than

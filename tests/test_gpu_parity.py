@@ -146,6 +146,28 @@ def test_gemm_streamk_grouped(K, shapes, ta, tb):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('M,N,K1,K2,ta,tb', [(4096, 600, 1200, 1200, 0, 1), (130, 70, 33, 500, 0, 0),
+                                             (64, 300, 16, 17, 1, 0), (257, 129, 700, 90, 1, 1)])
+def test_gemm_kcat(M, N, K1, K2, ta, tb):
+    '''danet_gemm_f32_kcat: C = A1 B1 + A2 B2 (+bias)(+beta C) in one launch'''
+    from danet_amd import ops
+    rng = np.random.RandomState(M + N + K1 + K2)
+    mk = lambda K: (rng.randn(K, M) if ta else rng.randn(M, K), rng.randn(N, K) if tb else rng.randn(K, N))
+    (A1, B1), (A2, B2) = mk(K1), mk(K2)
+    op = lambda A, Bm: (A.T if ta else A) @ (Bm.T if tb else Bm)
+    ref = op(A1, B1) + op(A2, B2)
+    bias, C0 = rng.randn(N), rng.randn(M, N)
+    d = [cu(x) for x in (A1, B1, A2, B2)]
+    C = torch.empty(M, N, device='cuda')
+    ops.gemm_kcat(d[0], d[0].shape[1], d[1], d[1].shape[1], K1, d[2], d[2].shape[1], d[3], d[3].shape[1],
+                  K2, C, M, N, N, transA=ta, transB=tb)
+    assert relerr(C.cpu().numpy(), ref) < 2e-5
+    C2 = cu(C0)
+    ops.gemm_kcat(d[0], d[0].shape[1], d[1], d[1].shape[1], K1, d[2], d[2].shape[1], d[3], d[3].shape[1],
+                  K2, C2, M, N, N, transA=ta, transB=tb, bias=cu(bias), beta=1.0)
+    assert relerr(C2.cpu().numpy(), ref + bias + C0) < 2e-5
+
+
 def test_gemm_strided_views_and_asymmetric():
     '''sub-matrix operands with ld > width; asymmetric operands catch a
     transposed fragment/epilogue mapping'''
