@@ -83,16 +83,18 @@ def gemm_kcat(A1, lda1, B1, ldb1, K1, A2, lda2, B2, ldb2, K2, C, M, N, ldc,
 def gemm_group(problems, K, transA=False, transB=False, max_workgroups=0):
     '''up to 6 products sharing K and the transpose flags as ONE stream-K launch.
     problems: list of (A, lda, B, ldb, C, ldc, M, N, beta) with tensors whose data_ptr()
-    is element (0,0).'''
+    is element (0,0); an optional 10th entry is the bias vector.'''
     L = _L()
     arr = (_lib.GemmProblem * len(problems))()
     keep = []
-    for i, (A, lda, B, ldb, C, ldc, M, N, beta) in enumerate(problems):
+    for i, pr in enumerate(problems):
+        A, lda, B, ldb, C, ldc, M, N, beta = pr[:9]
+        bias = pr[9] if len(pr) > 9 else None
         A, B, C = _f32(A), _f32(B), _f32(C)
-        keep += [A, B, C]
+        keep += [A, B, C, bias]
         arr[i].A, arr[i].lda, arr[i].B, arr[i].ldb = ptr(A), lda, ptr(B), ldb
         arr[i].C, arr[i].ldc, arr[i].M, arr[i].N = ptr(C), ldc, M, N
-        arr[i].bias, arr[i].beta = None, float(beta)
+        arr[i].bias, arr[i].beta = ptr(bias), float(beta)
     dev = problems[0][4].device
     w = _lib.workspace(L.danet_gemm_f32_streamk_workspace_bytes(0, 0, K), dev, tag='gemm_sk')
     with _lib.timed('gemm_f32_group'):
@@ -105,6 +107,7 @@ def gemm_group(problems, K, transA=False, transB=False, max_workgroups=0):
 # four split-K launches + reduce kernels)
 GROUPED_DW = int(__import__('os').environ.get('DANET_GROUPED_DW', '1'))
 GROUPED_DW_WGS = int(__import__('os').environ.get('DANET_GROUPED_DW_WGS', '256'))
+GROUPED_GX = int(__import__('os').environ.get('DANET_GROUPED_GX', '512'))   # grid of the grouped gx launch (0: two launches on two streams)
 
 
 def colsum(A, M, N, lda, out, beta=0.0):
@@ -351,7 +354,15 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs):
     dev = x.device
     gates = [torch.empty(T * B, 4 * H, device=dev) for _ in range(ndir)]
     cells = [torch.empty(T * B, H, device=dev) for _ in range(ndir)]
-    with _Fork(dev, ndir) as f:
+    if GROUPED_GX and ndir == 2:
+        # hoisted input half of ops.lyr_lstm_flat's [x,h]W+b (app/ops.py:139-142) of both
+        # directions as one grouped stream-K launch (nothing else runs at this point of the
+        # forward pass: 2 x 320 tiles fill 512 workgroups evenly; -1.5% per step vs two
+        # launches on two streams); `gates[d]` is later overwritten in place by g,i,f,o
+        gemm_group([(x, ldx, Ws[d], 4 * H, gates[d], 4 * H, T * B, 4 * H, 0.0, bs[d])
+                    for d in range(ndir)], D, max_workgroups=GROUPED_GX)
+    else:
+      with _Fork(dev, ndir) as f:
         for d in range(ndir):
             # hoisted input half of ops.lyr_lstm_flat's [x,h]W+b (app/ops.py:139-142);
             # `gates[d]` is later overwritten in place by g,i,f,o
