@@ -34,10 +34,10 @@ def _ws(nbytes, dev):
 # ---------------------------------------------------------------------------
 # raw wrappers (no autograd)
 # ---------------------------------------------------------------------------
-# stream-K schedule for the products on the backward critical path (dYc, dX): opt-in.
-# Alone on the GPU they gain 1.5-1.75x (tools/bench_gemm.py), in the train step the
-# weight-gradient chains on the side streams take most of that back (4.53 -> 4.50 ms),
-# which does not pay for an inter-workgroup hand-off on the critical path.
+# stream-K schedule for single products on the critical path: opt-in bit mask
+# (1: dYc / unidirectional dX, 2: output projection).  Alone on the GPU they gain up to
+# 1.75x (tools/bench_gemm.py); in the train step dYc drops 164 -> 148 us but the step time
+# does not move (3.95 ms either way), so the default stays the split-K launch.
 STREAMK = int(__import__('os').environ.get('DANET_STREAMK', '0'))
 
 
@@ -48,7 +48,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None,
     max_workgroups > 0 caps the launch (persistent workgroups); streamk selects the
     stream-K schedule (for a product that has the GPU to itself).'''
     L = _L()
-    if streamk and STREAMK:
+    if streamk:
         need = L.danet_gemm_f32_streamk_workspace_bytes(M, N, K)
         # dedicated (zero-initialised, never shared) scratch: it holds the stream-K
         # hand-off flags, which must only ever contain earlier launch sequence numbers
@@ -442,7 +442,7 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
             colsum(das[d], T * B, 4 * H, 4 * H, dbs[d], beta=1.0 if direct[d][1] else 0.0)
 
     def input_grad():
-        if ndir == 2 and not STREAMK:
+        if ndir == 2:
             # dX = da_f Wx_f^T + da_b Wx_b^T: one K-concatenated launch
             gemm_kcat(das[0], 4 * H, c.Ws[0], 4 * H, 4 * H, das[1], 4 * H, c.Ws[1], 4 * H, 4 * H,
                       dx, T * B, D, D, transB=True, tag='dX')
@@ -450,7 +450,7 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
         for d in range(ndir):
             # dX += da Wx^T
             gemm(das[d], c.Ws[d], dx, T * B, D, 4 * H, 4 * H, 4 * H, D, transB=True,
-                 beta=0.0 if d == 0 else 1.0, streamk=True, tag='dX')
+                 beta=0.0 if d == 0 else 1.0, streamk=(STREAMK & 1) != 0, tag='dX')
 
     # dX is what the next layer's BPTT waits for: it is issued first, alone, on
     # the main stream.  The weight-gradient chains fork AFTER it (the fork event
@@ -532,7 +532,7 @@ class RnnEncoderFn(torch.autograd.Function):
         center(cur, B, T, D, 1, D, yc, 0, D)
         O = Wout.shape[1]
         embed = torch.empty(B, T, O, device=dev)
-        gemm(yc, Wout, embed, B * T, O, D, D, O, O, tag='proj')           # modules.py:249-255
+        gemm(yc, Wout, embed, B * T, O, D, D, O, O, tag='proj', streamk=(STREAMK & 2) != 0)           # modules.py:249-255
         ctx.ctxs, ctx.yc, ctx.Wout = ctxs, yc, Wout
         ctx.dims = (B, T, F, H, L, ndir, D, O)
         return embed
@@ -544,7 +544,7 @@ class RnnEncoderFn(torch.autograd.Function):
         dev = dembed.device
         dWout, direct_out = _grad_target(ctx.Wout, (D, O), dev)
         dyc = torch.empty(B, T, D, device=dev)
-        gemm(dembed, ctx.Wout, dyc, B * T, D, O, O, O, D, transB=True, streamk=True, tag='dYc')   # critical path first
+        gemm(dembed, ctx.Wout, dyc, B * T, D, O, O, O, D, transB=True, streamk=(STREAMK & 1) != 0, tag='dYc')   # critical path first
         with _Fork(dev, 2, defer=True, keep=(dembed, ctx.yc)) as f:
             if GROUPED_DW:    # alone on its stream under the top layer's BPTT kernel
                 f.run(1, lambda: gemm_group(
