@@ -128,13 +128,15 @@ template <int CP>
 __global__ __launch_bounds__(256) void pit_bwd_kernel(
     int mode, int B, int64_t N, const float2* __restrict__ src,
     const float* __restrict__ sep_pwr, const float2* __restrict__ phasor,
-    const int32_t* __restrict__ perm_idx, float dloss, float* __restrict__ dsep) {
+    const int32_t* __restrict__ perm_idx, float dloss, const float* __restrict__ dloss_dev,
+    float* __restrict__ dsep) {
   constexpr int C = CP;
   const int b = blockIdx.y;
   int perm[MAXC], inv[MAXC];
   nth_perm(C, perm_idx[b], perm);
   for (int i = 0; i < C; ++i) inv[perm[i]] = i;   // estimate j is paired with truth inv[j]
-  const float scale = dloss * 2.f / ((float)B * (float)N);
+  // the upstream gradient may live on the device (autograd): no host sync, no extra pass
+  const float scale = dloss * (dloss_dev ? *dloss_dev : 1.f) * 2.f / ((float)B * (float)N);
   for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N;
        n += (int64_t)gridDim.x * 256) {
     const float2 ph = phasor[(int64_t)b * N + n];
@@ -196,14 +198,14 @@ extern "C" int danet_pit_mse_fwd(danet_stream_t stream_, int mode, int B, int C,
 extern "C" int danet_pit_mse_bwd(danet_stream_t stream_, int mode, int B, int C, int64_t N,
                                  const float* src_c64, const float* sep_pwr,
                                  const float* phasor, const int32_t* perm_idx, float dloss,
-                                 float* dsep_pwr) {
+                                 const float* dloss_dev, float* dsep_pwr) {
   hipStream_t stream = (hipStream_t)stream_;
   DANET_CHECK_ARG(B > 0 && B <= 65535 && C > 0 && C <= MAXC && N > 0, "pit_mse_bwd: bad shape");
   DANET_CHECK_ARG(src_c64 && sep_pwr && phasor && perm_idx && dsep_pwr, "pit_mse_bwd: null pointer");
   dim3 grid((unsigned)min((int64_t)64, cdiv64(N, 256)), B);
   DISPATCH_C(C, (pit_bwd_kernel<CP><<<grid, 256, 0, stream>>>(
                     mode, B, N, (const float2*)src_c64, sep_pwr, (const float2*)phasor,
-                    perm_idx, dloss, dsep_pwr)));
+                    perm_idx, dloss, dloss_dev, dsep_pwr)));
   DANET_CHECK_LAUNCH();
   return DANET_OK;
 }

@@ -428,16 +428,20 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
         # Hprev(t) = ypad block t (fwd) / block t+2 (bwd)
         return c.ypad.view(-1)[(0 if d == 0 else 2 * B * ldy + H):]
 
-    def weight_grads_grouped():
+    def weight_grads_grouped(wgs=GROUPED_DW_WGS, with_bias=True):
         # dWx = X^T da and dWh = Hprev^T da of every direction: one stream-K launch
         probs = []
         for d in range(ndir):
             bW = 1.0 if direct[d][0] else 0.0
             probs.append((c.x, c.ldx, das[d], 4 * H, dWs[d], 4 * H, D, 4 * H, bW))
             probs.append((hprev_of(d), ldy, das[d], 4 * H, dWs[d][D:], 4 * H, H, 4 * H, bW))
-        gemm_group(probs, T * B, transA=True, max_workgroups=GROUPED_DW_WGS)
+        gemm_group(probs, T * B, transA=True, max_workgroups=wgs)
         # (the bias gradients as M = 1 members of the group were measured slower than
         # the two column-sum kernels: +25 us on the group for 128-row tiles with one row)
+        if with_bias:
+            bias_grads()
+
+    def bias_grads():
         for d in range(ndir):
             colsum(das[d], T * B, 4 * H, 4 * H, dbs[d], beta=1.0 if direct[d][1] else 0.0)
 
@@ -460,8 +464,11 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
     if need_dx:
         input_grad()
     with _Fork(dev, ndir + 1, defer=True, keep=(das, c.x, c.ypad, dy)) as f:
-        if GROUPED_DW == 2:       # experiment: not overlapped at all
-            weight_grads_grouped()
+        if GROUPED_DW and not need_dx:
+            # bottom layer: no BPTT kernel follows, so the group takes the whole GPU on
+            # the main stream while the column sums run beside it
+            f.run(1, bias_grads)
+            weight_grads_grouped(wgs=512, with_bias=False)
         elif GROUPED_DW:
             f.run(1, weight_grads_grouped)
         else:
@@ -705,11 +712,14 @@ class AnchorAttractorFn(torch.autograd.Function):
         ctx.save_for_backward(embed, anchors, attr, asum, choice)
         ctx.args = (B, C, N, E, A, T, F)
         ctx.mark_non_differentiable(asets, choice)
+        ctx.set_materialize_grads(False)
         _dembed_slot.clear()
         return attr, asets, choice
 
     @staticmethod
     def backward(ctx, dattr, _dasets, _dchoice):
+        if dattr is None:
+            return None, None, None
         embed, anchors, attr, asum, choice = ctx.saved_tensors
         B, C, N, E, A, T, F = ctx.args
         dev = dattr.device
@@ -747,10 +757,13 @@ class SeparateFn(torch.autograd.Function):
         if masks is None:
             masks = torch.empty(0, device=dev)
         ctx.mark_non_differentiable(masks)
+        ctx.set_materialize_grads(False)
         return out, masks
 
     @staticmethod
     def backward(ctx, dout, _dmasks):
+        if dout is None:
+            return None, None, None, None, None
         mix_pwr, attr, embed_flat = ctx.saved_tensors
         act, B, C, N, E = ctx.args
         dev = dout.device
@@ -781,29 +794,31 @@ class PitMseFn(torch.autograd.Function):
         src = src.contiguous()
         sep_pwr = _f32(sep_pwr.contiguous())
         phasor = _f32(phasor.contiguous())
-        out = torch.empty(2, device=dev)
+        loss, snr = torch.empty((), device=dev), torch.empty((), device=dev)
         perm_idx = torch.empty(B, dtype=torch.int32, device=dev)
         L = _L()
         w, wn = _ws(L.danet_pit_mse_workspace_bytes(B, C, N), dev)
         check(L.danet_pit_mse_fwd(_lib.stream(), mode, B, C, N, ptr(torch.view_as_real(src)),
-                                  ptr(sep_pwr), ptr(phasor), eps, ptr(out[0:]), ptr(out[1:]),
+                                  ptr(sep_pwr), ptr(phasor), eps, ptr(loss), ptr(snr),
                                   ptr(perm_idx), ptr(w), wn))
         ctx.save_for_backward(src, sep_pwr, phasor, perm_idx)
         ctx.args = (mode, B, C, N)
-        loss, snr = out[0].clone(), out[1].clone()
         ctx.mark_non_differentiable(snr, perm_idx)
+        ctx.set_materialize_grads(False)
         return loss, snr, perm_idx
 
     @staticmethod
     def backward(ctx, dloss, _dsnr, _dperm):
         src, sep_pwr, phasor, perm_idx = ctx.saved_tensors
         mode, B, C, N = ctx.args
+        if dloss is None:
+            return None, None, None, None, None
         dsep = torch.empty_like(sep_pwr)
-        # dloss is a device scalar; fold it in afterwards to avoid a host sync
+        # dloss is a device scalar: the kernel reads it (no host sync, no extra pass)
         check(_L().danet_pit_mse_bwd(_lib.stream(), mode, B, C, N,
                                      ptr(torch.view_as_real(src)), ptr(sep_pwr), ptr(phasor),
-                                     ptr(perm_idx), 1.0, ptr(dsep)))
-        return None, dsep * dloss, None, None, None
+                                     ptr(perm_idx), 1.0, ptr(_f32(dloss.contiguous())), ptr(dsep)))
+        return None, dsep, None, None, None
 
 
 def pit_mse_loss(s_x, s_y_pwr, phasor, mode=0, eps=1e-7):

@@ -281,11 +281,13 @@ int danet_pit_mse_fwd(danet_stream_t stream, int mode, int B, int C,
                       const float* phasor, float eps, float* loss,
                       float* snr, int32_t* perm_idx, void* ws,
                       size_t ws_bytes);
-/* dsep_pwr [B][C][N] = dloss * dL/dsep_pwr                                  */
+/* dsep_pwr [B][C][N] = dloss * (dloss_dev ? *dloss_dev : 1) * dL/dsep_pwr
+ * (dloss_dev: optional DEVICE scalar, e.g. the upstream gradient of an autograd
+ * engine, folded in without a host sync)                                    */
 int danet_pit_mse_bwd(danet_stream_t stream, int mode, int B, int C,
                       int64_t N, const float* src_c64, const float* sep_pwr,
                       const float* phasor, const int32_t* perm_idx,
-                      float dloss, float* dsep_pwr);
+                      float dloss, const float* dloss_dev, float* dsep_pwr);
 
 /* ---------------------------------------------------------------- a16
  * clip_by_value + tf.train.AdamOptimizer update (main.py:359-363,
