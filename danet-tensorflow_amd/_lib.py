@@ -149,11 +149,22 @@ def workspace(nbytes, device, tag=None):
 
 # ---- optional per-kernel timing (HIP events on the launch stream) ------------
 _prof = None
+_prof_only = None
+_prof_on = True
 
 
-def profile_start():
-    global _prof
+def profile_start(only=None):
+    '''only: optional set of labels to time (every event pair costs ~1 us of stream
+    time, so a timed benchmark region instruments just the kernel it reports)'''
+    global _prof, _prof_only
     _prof = {}
+    _prof_only = set(only) if only else None
+
+
+def profile_enable(flag):
+    '''pause / resume event recording inside a profile_start()..profile_stop() window'''
+    global _prof_on
+    _prof_on = bool(flag)
 
 
 def profile_stop():
@@ -177,13 +188,14 @@ class timed(object):
         self.label, self.tag = label, tag
 
     def __enter__(self):
-        if _prof is not None:
+        self.a = None
+        if _prof is not None and _prof_on and (_prof_only is None or self.label in _prof_only):
             self.a = torch.cuda.Event(enable_timing=True)
             self.a.record()
         return self
 
     def __exit__(self, *exc):
-        if _prof is not None:
+        if self.a is not None and _prof is not None:
             b = torch.cuda.Event(enable_timing=True)
             b.record()
             _prof.setdefault(self.label, []).append((self.a, b))
