@@ -3,9 +3,10 @@
 
     cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o tl -- \
         python $REPO/bench.py --steps 6 --warmup 3 --no-cpu-baseline
-    python tools/step_timeline.py /tmp/tl/.../tl_kernel_trace.csv
+    python tools/step_timeline.py /tmp/tl/.../tl_kernel_trace.csv [step_index [v]]
 
-Prints, for the last complete step (adam_clip_kernel to adam_clip_kernel), every kernel
+(bench.py records HIP events only on timed steps 0, 4, 8, ...: pick an un-instrumented one,
+e.g. step_index = warmup + 5.)  Prints, for the chosen step (adam_clip_kernel to adam_clip_kernel), every kernel
 with start offset / duration / queue, the busy time of the union of all kernels and the
 idle gaps (no kernel running at all).'''
 import csv
@@ -20,7 +21,8 @@ def main():
                    r.get('Queue_Id', '?')))
     ev.sort()
     adam = [i for i, e in enumerate(ev) if e[2].startswith('adam_clip')]
-    i0, i1 = adam[-2] + 1, adam[-1] + 1
+    k = int(sys.argv[2]) if len(sys.argv) > 2 else len(adam) - 1     # which step (its adam)
+    i0, i1 = adam[k - 1] + 1, adam[k] + 1
     step = ev[i0:i1]
     t0 = step[0][0]
     print('step: %d kernels, %.1f us wall' % (len(step), (step[-1][1] - t0) / 1e3))
@@ -35,7 +37,7 @@ def main():
             cur_end = e
     print('GPU busy (union) %.1f us; idle %.1f us in %d gaps' % (
         busy / 1e3, sum(g[1] for g in gaps) / 1e3, len(gaps)))
-    verbose = len(sys.argv) > 2
+    verbose = len(sys.argv) > 3
     for s, e, n, q in step:
         if verbose or (e - s) > 20000:
             print('%9.1f %8.1f  q%-3s %s' % ((s - t0) / 1e3, (e - s) / 1e3, q, n))
