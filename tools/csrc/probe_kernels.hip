@@ -1,0 +1,40 @@
+// Contention probes for tools/contention_probe.py (diagnostic, not part of the library):
+// a pure-MFMA burner and a pure memory streamer, each as 256-thread persistent workgroups.
+#include <hip/hip_runtime.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+extern "C" __global__ __launch_bounds__(256) void mfma_burn_kernel(float* out, int iters) {
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  const float a = threadIdx.x * 1e-6f, b = 1.0f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i) s += acc[i][0];
+  if (s == 123.456f) out[0] = s;
+}
+
+extern "C" __global__ __launch_bounds__(256) void mem_stream_kernel(const float4* in, float* out,
+                                                                   long n4, int iters) {
+  float s = 0.f;
+  const long stride = (long)gridDim.x * 256;
+  for (int it = 0; it < iters; ++it)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+      const float4 v = in[i];
+      s += v.x + v.y + v.z + v.w;
+    }
+  if (s == 123.456f) out[0] = s;
+}
+
+extern "C" int probe_mfma(void* stream, int wgs, float* out, int iters) {
+  mfma_burn_kernel<<<wgs, 256, 0, (hipStream_t)stream>>>(out, iters);
+  return (int)hipGetLastError();
+}
+extern "C" int probe_mem(void* stream, int wgs, const void* in, float* out, long n4, int iters) {
+  mem_stream_kernel<<<wgs, 256, 0, (hipStream_t)stream>>>((const float4*)in, out, n4, iters);
+  return (int)hipGetLastError();
+}
