@@ -268,9 +268,18 @@ def main():
             res['mask_max_abs_err_vs_oracle'] = mx
             if not args.no_cpu_baseline:
                 res['cpu_baseline'] = cpu_baseline(hp, model.param_dict(), args.cpu_sample)
-        print(json.dumps(res))
     if use_dist:
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner to the C stdout of the process; flush it first so
+        # that the JSON line is the LAST line of stdout
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == '__main__':
