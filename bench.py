@@ -153,14 +153,15 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     use_dist = world > 1 or os.environ.get('DANET_FORCE_DIST') == '1'   # 1-rank RCCL smoke
+    graft.load_package()
+    from danet_amd import _lib, ops
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
+        # the side streams must exist before the RCCL communicator (ops.prepare_streams)
+        ops.prepare_streams(device)
         torch.distributed.init_process_group('nccl', device_id=device)
-
-    graft.load_package()
-    from danet_amd import _lib, ops
     from danet_amd.model import Model
     hp = setup_hparams(args)
     batches = make_batches(hp, rank, 4, device)

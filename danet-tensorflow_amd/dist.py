@@ -39,6 +39,8 @@ def init_from_env(backend='nccl', device=None):
     kw = {}
     if backend == 'nccl' and device is not None:
         kw['device_id'] = device
+        from . import ops
+        ops.prepare_streams(device)       # side streams BEFORE the RCCL communicator
     dist.init_process_group(backend, **kw)
 
 

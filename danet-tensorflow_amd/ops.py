@@ -257,6 +257,16 @@ def _side_streams(dev, n):
     return pool[:n]
 
 
+def prepare_streams(dev):
+    '''Create the process's HIP context and the side streams NOW.  Must run before an
+    RCCL communicator is created: a group initialised first takes the hardware queues the
+    side streams would get, the chains then share a queue with the main stream and the
+    train step is 0.6 ms (16 %) slower (tools/dist_order_probe.py: 4.32 vs 3.72 ms).'''
+    torch.zeros(1, device=dev)
+    _side_streams(dev, max(SIDE_STREAMS, 1))
+    torch.cuda.synchronize(dev)
+
+
 class _Fork(object):
     '''with _Fork(dev, n) as f:  f.run(i, fn)  -> fn runs on chain i
     (chain 0 = the current stream, chain i>0 = side stream i-1); join on exit.'''
