@@ -16,6 +16,7 @@ from danet_amd import ops
 
 dev = torch.device('cuda', 0)
 torch.cuda.set_device(0)
+ops.prepare_streams(dev)          # side streams before the RCCL communicator
 torch.distributed.init_process_group('nccl', device_id=dev)
 class A: batch = 32; layers = 3; hdim = 300; frames = 128
 hp = bench.setup_hparams(A)
