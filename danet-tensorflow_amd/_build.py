@@ -22,6 +22,8 @@ ARCH = 'gfx950'
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE,
          '-I' + CSRC, '-Wno-unused-result']
+# extra -D switches for A/B builds, e.g. DANET_BUILD_DEFS='-DBK=32' (use --force)
+FLAGS += os.environ.get('DANET_BUILD_DEFS', '').split()
 
 
 def _sources():

@@ -15,7 +15,12 @@
 
 #define BM 128
 #define BN 128
+#ifndef BK
 #define BK 16
+#endif
+#define NLD (BK / 8)   // 16-byte loads per thread and operand tile (128 x BK floats / 256 threads)
+#define KQ (BK / 4)    // 4-float groups along k
+#define GEMM_SMEM_BYTES (2 * 2 * BK * (128 + 4) * sizeof(float))
 #define LDT 132  // BM + 4
 
 struct GemmArgs {
@@ -41,12 +46,12 @@ struct GemmArgs {
 template <bool KCONTIG>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld,
                                           int mn0, int mn_lim, int k0, int k_lim,
-                                          int vec, int tid, f32x4 (&r)[2]) {
+                                          int vec, int tid, f32x4 (&r)[NLD]) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NLD; ++i) {
     const int idx = tid + i * 256;
     int mn, k;
-    if (KCONTIG) { mn = mn0 + (idx >> 2); k = k0 + (idx & 3) * 4; }
+    if (KCONTIG) { mn = mn0 + idx / KQ; k = k0 + (idx % KQ) * 4; }
     else         { k = k0 + (idx >> 5);  mn = mn0 + (idx & 31) * 4; }
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (KCONTIG) {
@@ -80,12 +85,12 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld,
 
 template <bool KCONTIG>
 __device__ __forceinline__ void store_tile(float* __restrict__ S, int tid,
-                                           const f32x4 (&r)[2]) {
+                                           const f32x4 (&r)[NLD]) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NLD; ++i) {
     const int idx = tid + i * 256;
     if (KCONTIG) {
-      const int mn = idx >> 2, k = (idx & 3) * 4;
+      const int mn = idx / KQ, k = (idx % KQ) * 4;
       S[(k + 0) * LDT + mn] = r[i].x;
       S[(k + 1) * LDT + mn] = r[i].y;
       S[(k + 2) * LDT + mn] = r[i].z;
@@ -99,7 +104,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ S, int tid,
 
 template <bool A_KCONTIG, bool B_KCONTIG>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * LDT];
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // GEMM_SMEM_BYTES
   // layout: [A buf0 | A buf1 | B buf0 | B buf1], each BK*LDT floats
 
   const int tid = threadIdx.x;
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 ra[2], rb[2];
+  f32x4 ra[NLD], rb[NLD];
   if (nk > 0) {
     load_tile<A_KCONTIG>(Ap, lda, m0, g.M, kbeg, kend, vecA, tid, ra);
     load_tile<B_KCONTIG>(Bp, ldb, n0, g.N, kbeg, kend, vecB, tid, rb);
@@ -159,15 +164,27 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     }
     const float* as = smem + cur * (BK * LDT);
     const float* bs = smem + (2 + cur) * (BK * LDT);
+    // software-pipelined fragment reads: the LDS reads of k-pair kk+1 are issued before
+    // the four MFMAs of kk, so their latency hides under 256 cycles of MFMA work instead of
+    // stalling the (single wave per SIMD) issue stream after every group
+    float a0 = as[fk * LDT + fa], a1 = as[fk * LDT + fa + 32];
+    float b0 = bs[fk * LDT + fb], b1 = bs[fk * LDT + fb + 32];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      const int k = kk * 2 + fk;
-      const float a0 = as[k * LDT + fa], a1 = as[k * LDT + fa + 32];
-      const float b0 = bs[k * LDT + fb], b1 = bs[k * LDT + fb + 32];
+      float a0n = 0.f, a1n = 0.f, b0n = 0.f, b1n = 0.f;
+      if (kk + 1 < BK / 2) {
+        const int k = (kk + 1) * 2 + fk;
+        a0n = as[k * LDT + fa]; a1n = as[k * LDT + fa + 32];
+        b0n = bs[k * LDT + fb]; b1n = bs[k * LDT + fb + 32];
+      }
+      // keep the machine scheduler from sinking the prefetch back below the MFMAs
+      __builtin_amdgcn_sched_barrier(0);
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
     }
     if (kt + 1 < nk) {
       store_tile<A_KCONTIG>(smem + (cur ^ 1) * (BK * LDT), tid, ra);
@@ -219,6 +236,21 @@ __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slab,
   *c = s;
 }
 
+// dynamic LDS above 64 KB needs the attribute (BK = 32: 67.6 KB); set once per kernel
+template <typename KernelT>
+static void gemm_allow_lds(KernelT k) {
+  if (GEMM_SMEM_BYTES > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)GEMM_SMEM_BYTES);
+}
+static void gemm_init_once() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  gemm_allow_lds(gemm_f32_kernel<true, false>); gemm_allow_lds(gemm_f32_kernel<true, true>);
+  gemm_allow_lds(gemm_f32_kernel<false, false>); gemm_allow_lds(gemm_f32_kernel<false, true>);
+}
+
 static int choose_splitk(int M, int N, int K) {
   const int tiles = cdiv(M, BM) * cdiv(N, BN);
   if (tiles >= 192 || K < 512) return 1;
@@ -259,6 +291,7 @@ static int gemm_launch(hipStream_t stream, int transA, int transB, int M, int N,
                        int K2, const float* A2, int lda2, const float* B2, int ldb2,
                        float* C, int ldc, const float* bias, float beta, void* ws,
                        size_t ws_bytes, int max_workgroups) {
+  gemm_init_once();
   DANET_CHECK_ARG(M > 0 && N > 0 && K > 0 && K2 >= 0, "gemm: non-positive shape %d %d %d", M, N, K);
   DANET_CHECK_ARG(A && B && C && (K2 == 0 || (A2 && B2)), "gemm: null operand");
   DANET_CHECK_ARG(beta == 0.f || beta == 1.f, "gemm: beta must be 0 or 1");
@@ -302,10 +335,10 @@ static int gemm_launch(hipStream_t stream, int transA, int transB, int M, int N,
   if (max_workgroups > 0 && nblocks > max_workgroups) nblocks = max_workgroups;
   dim3 grid(nblocks, 1, 1), block(256);
   const bool ak = !transA, bk = (transB != 0);
-  if (ak && !bk) gemm_f32_kernel<true, false><<<grid, block, 0, stream>>>(g);
-  else if (ak && bk) gemm_f32_kernel<true, true><<<grid, block, 0, stream>>>(g);
-  else if (!ak && !bk) gemm_f32_kernel<false, false><<<grid, block, 0, stream>>>(g);
-  else gemm_f32_kernel<false, true><<<grid, block, 0, stream>>>(g);
+  if (ak && !bk) gemm_f32_kernel<true, false><<<grid, block, GEMM_SMEM_BYTES, stream>>>(g);
+  else if (ak && bk) gemm_f32_kernel<true, true><<<grid, block, GEMM_SMEM_BYTES, stream>>>(g);
+  else if (!ak && !bk) gemm_f32_kernel<false, false><<<grid, block, GEMM_SMEM_BYTES, stream>>>(g);
+  else gemm_f32_kernel<false, true><<<grid, block, GEMM_SMEM_BYTES, stream>>>(g);
   DANET_CHECK_LAUNCH();
   if (splitk > 1) {
     const int64_t total = (int64_t)M * N;
@@ -392,7 +425,7 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* smem, int
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int nk = (kend - kbeg + BK - 1) / BK;
-  f32x4 ra[2], rb[2];
+  f32x4 ra[NLD], rb[NLD];
   load_tile<A_KCONTIG>(g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, tid, ra);
   load_tile<B_KCONTIG>(g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid, rb);
   store_tile<A_KCONTIG>(smem, tid, ra);
@@ -412,15 +445,27 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* smem, int
     }
     const float* as = smem + cur * (BK * LDT);
     const float* bs = smem + (2 + cur) * (BK * LDT);
+    // software-pipelined fragment reads: the LDS reads of k-pair kk+1 are issued before
+    // the four MFMAs of kk, so their latency hides under 256 cycles of MFMA work instead of
+    // stalling the (single wave per SIMD) issue stream after every group
+    float a0 = as[fk * LDT + fa], a1 = as[fk * LDT + fa + 32];
+    float b0 = bs[fk * LDT + fb], b1 = bs[fk * LDT + fb + 32];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      const int k = kk * 2 + fk;
-      const float a0 = as[k * LDT + fa], a1 = as[k * LDT + fa + 32];
-      const float b0 = bs[k * LDT + fb], b1 = bs[k * LDT + fb + 32];
+      float a0n = 0.f, a1n = 0.f, b0n = 0.f, b1n = 0.f;
+      if (kk + 1 < BK / 2) {
+        const int k = (kk + 1) * 2 + fk;
+        a0n = as[k * LDT + fa]; a1n = as[k * LDT + fa + 32];
+        b0n = bs[k * LDT + fb]; b1n = bs[k * LDT + fb + 32];
+      }
+      // keep the machine scheduler from sinking the prefetch back below the MFMAs
+      __builtin_amdgcn_sched_barrier(0);
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
     }
     if (kt + 1 < nk) {
       store_tile<A_KCONTIG>(smem + (cur ^ 1) * (BK * LDT), tid, ra);
@@ -434,7 +479,7 @@ typedef unsigned v4u __attribute__((__vector_size__(16)));   // see lstm.hip (b1
 
 template <bool A_KCONTIG, bool B_KCONTIG>
 __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(SkArgs sk) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * LDT];
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // GEMM_SMEM_BYTES
   // layout: [A buf0 | A buf1 | B buf0 | B buf1], each BK*LDT floats
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -596,6 +641,12 @@ extern "C" int danet_gemm_f32_streamk_grouped(danet_stream_t stream_, int transA
                                               int K, int nprob, const danet_gemm_problem_t* probs,
                                               int max_workgroups, void* ws, size_t ws_bytes) {
   static unsigned launch_seq = 0x5eed0000u;   // flag value of the next launch
+  static bool lds_ok = false;
+  if (!lds_ok) {
+    lds_ok = true;
+    gemm_allow_lds(gemm_f32_sk_kernel<true, false>); gemm_allow_lds(gemm_f32_sk_kernel<true, true>);
+    gemm_allow_lds(gemm_f32_sk_kernel<false, false>); gemm_allow_lds(gemm_f32_sk_kernel<false, true>);
+  }
   hipStream_t stream = (hipStream_t)stream_;
   DANET_CHECK_ARG(probs && nprob >= 1 && nprob <= SK_MAX_PROBLEMS, "gemm group: 1..%d problems",
                   SK_MAX_PROBLEMS);
@@ -631,10 +682,10 @@ extern "C" int danet_gemm_f32_streamk_grouped(danet_stream_t stream_, int transA
   sk.seq = __atomic_add_fetch(&launch_seq, 1u, __ATOMIC_RELAXED);
   dim3 grid(gsz, 1, 1), block(256);
   const bool ak = !transA, bk = (transB != 0);
-  if (ak && !bk) gemm_f32_sk_kernel<true, false><<<grid, block, 0, stream>>>(sk);
-  else if (ak && bk) gemm_f32_sk_kernel<true, true><<<grid, block, 0, stream>>>(sk);
-  else if (!ak && !bk) gemm_f32_sk_kernel<false, false><<<grid, block, 0, stream>>>(sk);
-  else gemm_f32_sk_kernel<false, true><<<grid, block, 0, stream>>>(sk);
+  if (ak && !bk) gemm_f32_sk_kernel<true, false><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);
+  else if (ak && bk) gemm_f32_sk_kernel<true, true><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);
+  else if (!ak && !bk) gemm_f32_sk_kernel<false, false><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);
+  else gemm_f32_sk_kernel<false, true><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);
   DANET_CHECK_LAUNCH();
   return DANET_OK;
 }
