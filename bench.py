@@ -93,7 +93,18 @@ def cpu_baseline(hp, params_np, sample_b, n_steps=3):
     n_steps = len(times) - 1
     dt = float(np.mean(times[1:]))
     mix_s = sample_b * T * hp.FFT_STRIDE / hp.SMPRATE
+    # one more step on a single thread (SURVEY 8d asks for a 1-thread row beside it)
+    torch.set_num_threads(1)
+    t0 = time.time()
+    for k in tp:
+        tp[k].grad = None
+    R.model_forward(src, tp, cfg)['loss'].backward()
+    R.tf_adam_step_(tp, {k: tp[k].grad for k in tp}, m, v, n_steps + 2, hp.LR, clip=hp.GRAD_CLIP_THRES)
+    dt1 = time.time() - t0
+    torch.set_num_threads(cores)
+    print('[bench] cpu_baseline single-thread step: %.2f s' % dt1, file=sys.stderr, flush=True)
     return dict(value=mix_s / dt, unit='mixture-seconds/s', cores=cores, kind='port',
+                single_thread_value=mix_s / dt1,
                 sample='%d of %d mixtures/step, same T/F/L/H, %d timed train steps (%.2f s each), '
                        'torch-CPU fp32 restatement of the reference (TF1 unavailable)'
                        % (sample_b, hp.BATCH_SIZE, n_steps, dt))
