@@ -154,7 +154,7 @@ def main():
     ap.add_argument('--layers', type=int, default=3)
     ap.add_argument('--hdim', type=int, default=300)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=4)
+    ap.add_argument('--cpu-sample', type=int, default=32)
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
