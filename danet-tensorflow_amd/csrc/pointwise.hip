@@ -108,19 +108,22 @@ __device__ __forceinline__ int64_t center_index(int layout, int B, int T, int ld
   return layout == 0 ? ((int64_t)b * T + t) * ld : ((int64_t)t * B + b) * ld;
 }
 
+// Both kernels walk whole rows (t) with the threads striding over d: no per-element
+// 64-bit division, coalesced row segments.
 __global__ void center_sum_kernel(int B, int T, int D, const float* __restrict__ in,
                                   int layout, int ld, float* __restrict__ partial) {
   __shared__ float red[16];
   const int b = blockIdx.y, ch = blockIdx.x;
-  const int64_t total = (int64_t)T * D;
-  const int64_t per = cdiv64(total, CENTER_CHUNKS);
-  const int64_t beg = ch * per, end = min(total, beg + per);
-  float s = 0.f;
-  for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
-    const int t = (int)(i / D), d = (int)(i % D);
-    s += in[center_index(layout, B, T, ld, b, t) + d];
+  const int tper = cdiv(T, CENTER_CHUNKS);
+  const int t0 = ch * tper, t1 = min(T, t0 + tper);
+  float s0 = 0.f, s1 = 0.f;
+  for (int t = t0; t < t1; ++t) {
+    const float* row = in + center_index(layout, B, T, ld, b, t);
+    int d = threadIdx.x;
+    for (; d + (int)blockDim.x < D; d += 2 * blockDim.x) { s0 += row[d]; s1 += row[d + blockDim.x]; }
+    if (d < D) s0 += row[d];
   }
-  s = block_sum(s, red);
+  const float s = block_sum(s0 + s1, red);
   if (threadIdx.x == 0) partial[b * CENTER_CHUNKS + ch] = s;
 }
 
@@ -134,13 +137,11 @@ __global__ void center_apply_kernel(int B, int T, int D, const float* __restrict
   for (int i = 0; i < CENTER_CHUNKS; ++i) s += partial[b * CENTER_CHUNKS + i];
   const float mean = s / (float)((int64_t)T * D);
   if (mean_out && blockIdx.x == 0 && threadIdx.x == 0) mean_out[b] = mean;
-  const int64_t total = (int64_t)T * ld_out;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int t = (int)(i / ld_out), d = (int)(i % ld_out);
-    float v = 0.f;
-    if (d < D) v = in[center_index(in_layout, B, T, ld_in, b, t) + d] - mean;
-    out[center_index(out_layout, B, T, ld_out, b, t) + d] = v;
+  for (int t = blockIdx.x; t < T; t += gridDim.x) {
+    const float* src = in + center_index(in_layout, B, T, ld_in, b, t);
+    float* dst = out + center_index(out_layout, B, T, ld_out, b, t);
+    for (int d = threadIdx.x; d < ld_out; d += blockDim.x)
+      dst[d] = (d < D) ? src[d] - mean : 0.f;
   }
 }
 
@@ -158,7 +159,7 @@ extern "C" int danet_center(danet_stream_t stream, int B, int T, int D, const fl
   dim3 g1(CENTER_CHUNKS, B);
   center_sum_kernel<<<g1, 256, 0, (hipStream_t)stream>>>(B, T, D, in, in_layout, ld_in, partial);
   DANET_CHECK_LAUNCH();
-  const int gx = (int)min((int64_t)64, cdiv64((int64_t)T * ld_out, 256));
+  const int gx = T < 64 ? T : 64;   // row-strided
   dim3 g2(gx, B);
   center_apply_kernel<<<g2, 256, 0, (hipStream_t)stream>>>(
       B, T, D, in, in_layout, ld_in, out, out_layout, ld_out, partial, mean);
