@@ -243,6 +243,58 @@ def test_data_parallel_gloo_world2(tmp_path):
         assert int(tok[7]) == 1337 + int(tok[1])
 
 
+_BUCKET_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch
+import __graft_entry__ as g; g.load_package()
+from danet_amd import dist
+dist.init_from_env('gloo')
+rank, world = dist.rank(), dist.world_size()
+assert world == 2
+# a flat gradient bucket with five "parameters" (views), as Model._flatten lays them out
+sizes = [7, 40, 24, 13, 5]
+flat_p = torch.zeros(sum(sizes))
+flat_g = torch.arange(sum(sizes), dtype=torch.float32) * (rank + 1) + 0.25 * rank
+expect = torch.arange(sum(sizes), dtype=torch.float32) * 3 + 0.25          # rank 0 + rank 1
+views, offs, off = [], {}, 0
+for n in sizes:
+    v = flat_p[off:off + n]
+    views.append(v); offs[v.data_ptr()] = (off, off + n); off += n
+ok = True
+for trial in range(3):                       # the bucket object is reused step after step
+    gbuf = flat_g.clone()
+    b = dist.GradBuckets(gbuf, offs)
+    b.hook(('out',), [views[4]])                         # last variable first (backward order)
+    b.hook(('layer', 1), [views[2], views[3]])           # contiguous pair -> one collective
+    b.hook(('layer', 0), [views[0], views[2]])           # NOT contiguous -> left to finish()
+    b.hook(('x',), [torch.zeros(3)])                     # a tensor that is not ours -> ignored
+    assert len(b.works) == 2 and sorted(b.covered) == [(47, 84), (84, 89)]
+    scale = b.finish()                                   # reduces [0, 47) and waits for all
+    ok = ok and scale == 0.5 and bool(torch.equal(gbuf, expect)) and not b.works and not b.covered
+open(os.path.join(os.environ['DP_OUT'], 'bucket' + str(rank) + '.txt'), 'w').write('OK' if ok else 'BAD')
+'''
+
+
+def test_gradient_buckets_gloo_world2(tmp_path):
+    '''dist.GradBuckets (the opt-in overlapped all-reduce): pieces reduced as their hooks
+    fire + the uncovered remainder in finish() == one all-reduce of the whole bucket'''
+    script = tmp_path / 'bucket_worker.py'
+    script.write_text(_BUCKET_WORKER % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', DP_OUT=str(tmp_path))
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    out = subprocess.run(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+         '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
+        capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    for r in range(2):
+        assert (tmp_path / ('bucket%d.txt' % r)).read_text() == 'OK'
+
+
 def test_cli_flags_match_reference(hp):
     '''main.py:553-582 flag surface'''
     from danet_amd import cli
