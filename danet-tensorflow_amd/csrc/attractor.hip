@@ -945,7 +945,7 @@ extern "C" int danet_attractor_anchor_fwd(danet_stream_t stream_, int B, int C, 
   else { LAUNCH_ANCHOR(0, 0); }
   DANET_CHECK_LAUNCH();
   const size_t lds2 = ((size_t)PC * EPA + cb.P) * sizeof(float);
-  anchor_final_kernel<<<B, 128, lds2, stream>>>(C, E, EPA, cb.P, nch, (const float*)ws, attr,
+  anchor_final_kernel<<<B, 512, lds2, stream>>>(C, E, EPA, cb.P, nch, (const float*)ws, attr,
                                                 asets, asum, choice);
   DANET_CHECK_LAUNCH();
   return DANET_OK;
