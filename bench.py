@@ -2,23 +2,37 @@
 '''
 Benchmark of the DANet hot path on MI355X -- contract in the task brief.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ...`)
+    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg4|cfg4h600|cfg5|cfg5-kmeans]
 
-A "step" = one full train step (front-end -> BiLSTM encoder -> attractor
-estimator -> separator -> PIT loss -> backward -> gradient all-reduce ->
-value clip + Adam) on one synthetic batch per GPU.  Workload = BASELINE.json
-configs[1]: TIMIT-shaped synthetic 8 kHz 2-speaker mixtures, FFT 256 / stride
-64 (129 bins), 128 frames, 3 x 300 BiLSTM, E=20, BATCH_SIZE=32 per GPU, anchor
-estimator (A=6), dot-softmax separator.  Inputs (complex spectra) are resident
-in HBM before the timed region.  Metric: mixture-seconds/s, with
-mixture-seconds per step per GPU = B*T*FFT_STRIDE/SMPRATE = 32.768.
+`--gpus N` with N > 1 needs no prepared environment: when WORLD_SIZE is unset the script
+re-executes itself under `python -m torch.distributed.run --nproc-per-node N` (one rank per
+GPU, RCCL over xGMI, rendezvous on 127.0.0.1); launched by torch.distributed.run directly it
+reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.  DANET_FORCE_DIST=1
+takes the same spawn path with N = 1 (a 1-rank RCCL group).
 
-Prints ONE JSON line on rank 0.
+Default workload (the driver's line) = BASELINE.json configs[1] ("cfg2"): a "step" is one full
+train step (front-end -> BiLSTM encoder -> attractor estimator -> separator -> PIT loss ->
+backward -> gradient all-reduce -> value clip + Adam) on one synthetic batch per GPU:
+TIMIT-shaped synthetic 8 kHz 2-speaker mixtures, FFT 256 / stride 64 (129 bins), 128 frames,
+3 x 300 BiLSTM, E=20, BATCH_SIZE=32 per GPU, anchor estimator (A=6), dot-softmax separator.
+Inputs (complex spectra) are resident in HBM before the timed region.  Metric:
+mixture-seconds/s, with mixture-seconds per step per GPU = B*T*FFT_STRIDE/SMPRATE = 32.768.
+
+Other configs (BASELINE.json configs[3], [4]; not the driver's line):
+  cfg4      3-speaker, E=40, 4 x 300 BiLSTM, truth-weighted training estimator, train step
+  cfg4h600  the same at 600 units per direction ("4x600")
+  cfg5      16 kHz, FFT 512 / stride 128 (257 bins), one 10 s utterance (T=1251), B=1
+            INFERENCE: danet_stft -> front-end -> 4 x 300 BiLSTM -> anchor estimator ->
+            separator -> phase re-attach -> danet_istft; a step = one utterance
+  cfg5-kmeans  the same with the k-means attractor estimator (extension)
+
+Prints ONE JSON line on rank 0 (the last line of stdout).
 '''
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,18 +46,51 @@ import __graft_entry__ as graft  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PEAK_HBM_GBS = 8000.0
 
+CONFIGS = {
+    'cfg2': dict(kind='train', batch=32, frames=128, layers=3, hdim=300,
+                 hp=dict(MAX_N_SIGNAL=2, FFT_SIZE=256, FFT_STRIDE=64, SMPRATE=8000, EMBED_SIZE=20,
+                         NUM_ANCHOR=6, TRAIN_ESTIMATOR_METHOD='anchor',
+                         INFER_ESTIMATOR_METHOD='anchor', SEPARATOR_TYPE='dot-softmax-orig')),
+    'cfg4': dict(kind='train', batch=32, frames=128, layers=4, hdim=300,
+                 hp=dict(MAX_N_SIGNAL=3, FFT_SIZE=256, FFT_STRIDE=64, SMPRATE=8000, EMBED_SIZE=40,
+                         NUM_ANCHOR=6, TRAIN_ESTIMATOR_METHOD='truth-weighted',
+                         INFER_ESTIMATOR_METHOD='anchor', SEPARATOR_TYPE='dot-softmax-orig')),
+    'cfg4h600': dict(kind='train', batch=32, frames=128, layers=4, hdim=600,
+                     hp=dict(MAX_N_SIGNAL=3, FFT_SIZE=256, FFT_STRIDE=64, SMPRATE=8000,
+                             EMBED_SIZE=40, NUM_ANCHOR=6, TRAIN_ESTIMATOR_METHOD='truth-weighted',
+                             INFER_ESTIMATOR_METHOD='anchor', SEPARATOR_TYPE='dot-softmax-orig')),
+    'cfg5': dict(kind='infer', batch=1, frames=1251, layers=4, hdim=300,
+                 hp=dict(MAX_N_SIGNAL=2, FFT_SIZE=512, FFT_STRIDE=128, SMPRATE=16000,
+                         EMBED_SIZE=20, NUM_ANCHOR=6, TRAIN_ESTIMATOR_METHOD='truth-weighted',
+                         INFER_ESTIMATOR_METHOD='anchor', SEPARATOR_TYPE='dot-softmax-orig')),
+    'cfg5-kmeans': dict(kind='infer', batch=1, frames=1251, layers=4, hdim=300,
+                        hp=dict(MAX_N_SIGNAL=2, FFT_SIZE=512, FFT_STRIDE=128, SMPRATE=16000,
+                                EMBED_SIZE=20, NUM_ANCHOR=6,
+                                TRAIN_ESTIMATOR_METHOD='truth-weighted',
+                                INFER_ESTIMATOR_METHOD='kmeans',
+                                SEPARATOR_TYPE='dot-softmax-orig')),
+}
 
-def setup_hparams(args):
+
+def log(*a):
+    print('[bench r%s]' % os.environ.get('RANK', '0'), *a, file=sys.stderr, flush=True)
+
+
+def setup_hparams(args, cfg):
     from danet_amd.hparams import hparams
     hparams.reset()
-    hparams.load(dict(
-        BATCH_SIZE=args.batch, MAX_N_SIGNAL=2, FFT_SIZE=256, FFT_STRIDE=64, SMPRATE=8000,
-        EMBED_SIZE=20, NUM_LSTM_LAYERS=args.layers, LSTM_HDIM=args.hdim, NUM_ANCHOR=6,
-        MAX_TRAIN_LEN=args.frames, ENCODER_TYPE='bilstm-orig',
-        TRAIN_ESTIMATOR_METHOD='anchor', INFER_ESTIMATOR_METHOD='anchor',
-        SEPARATOR_TYPE='dot-softmax-orig', OPTIMIZER_TYPE='adam'))
+    kw = dict(cfg['hp'])
+    kw.update(BATCH_SIZE=args.batch, NUM_LSTM_LAYERS=args.layers, LSTM_HDIM=args.hdim,
+              MAX_TRAIN_LEN=args.frames, ENCODER_TYPE='bilstm-orig', OPTIMIZER_TYPE='adam')
+    hparams.load(kw)
     hparams.digest()
     return hparams
+
+
+def oracle_cfg(hp):
+    return dict(H=hp.LSTM_HDIM, L=hp.NUM_LSTM_LAYERS, E=hp.EMBED_SIZE, C=hp.MAX_N_SIGNAL,
+                A=hp.NUM_ANCHOR, train_est=hp.TRAIN_ESTIMATOR_METHOD,
+                infer_est='anchor', separator=hp.SEPARATOR_TYPE)
 
 
 def make_batches(hp, rank, n_batches, device):
@@ -59,72 +106,90 @@ def make_batches(hp, rank, n_batches, device):
     return out
 
 
+def host_info():
+    return dict(os_cpu_count=os.cpu_count(),
+                sched_affinity=len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None)
+
+
 def cpu_baseline(hp, params_np, sample_b, n_steps=3):
-    '''the oracle's torch-CPU float32 restatement of the same train step
-    (per-timestep loop like tf.scan), timed on the host cores.'''
+    '''the oracle's torch-CPU float32 restatement of the same train step (per-timestep loop
+    like tf.scan), timed on the host cores: a row at <= 16 threads (the tiny per-timestep
+    matmuls stop scaling beyond that), a row on ALL cores, and a single-thread row.'''
     from oracle import torch_ref as R
     from danet_amd import datasets
     from oracle import danet_oracle as O
-    # tiny per-timestep matmuls stop scaling (and thrash) beyond a few threads
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     C, T = hp.MAX_N_SIGNAL, hp.MAX_TRAIN_LEN
     waves = datasets.synth_waves(4242, sample_b * C, T)
     w = O.fft_window(hp.FFT_SIZE)
     spec = np.stack([O.stft(x, w, hp.FFT_SIZE, hp.FFT_STRIDE) for x in waves])
     src = torch.tensor(spec.reshape(sample_b, C, T, hp.FEATURE_SIZE))
-    cfg = dict(H=hp.LSTM_HDIM, L=hp.NUM_LSTM_LAYERS, E=hp.EMBED_SIZE, C=C, A=hp.NUM_ANCHOR,
-               train_est='anchor', infer_est='anchor', separator='dot-softmax-orig')
+    cfg = oracle_cfg(hp)
     tp = {k: torch.tensor(v, dtype=torch.float32, requires_grad=True) for k, v in params_np.items()}
     m = {k: torch.zeros_like(v) for k, v in tp.items()}
     v = {k: torch.zeros_like(x) for k, x in tp.items()}
-    times = []
-    budget_s, t_start = 20.0, time.time()
-    for t in range(1, n_steps + 2):
+    mix_s = sample_b * T * hp.FFT_STRIDE / hp.SMPRATE
+    tstep = [0]
+
+    def one_step():
+        tstep[0] += 1
         t0 = time.time()
         for k in tp:
             tp[k].grad = None
         R.model_forward(src, tp, cfg)['loss'].backward()
-        R.tf_adam_step_(tp, {k: tp[k].grad for k in tp}, m, v, t, hp.LR, clip=hp.GRAD_CLIP_THRES)
-        times.append(time.time() - t0)
-        print('[bench] cpu_baseline step %d: %.2f s' % (t, times[-1]), file=sys.stderr, flush=True)
-        if len(times) >= 2 and time.time() - t_start > budget_s:
-            break
-    n_steps = len(times) - 1
-    dt = float(np.mean(times[1:]))
-    mix_s = sample_b * T * hp.FFT_STRIDE / hp.SMPRATE
-    # one more step on a single thread (SURVEY 8d asks for a 1-thread row beside it)
-    torch.set_num_threads(1)
-    t0 = time.time()
-    for k in tp:
-        tp[k].grad = None
-    R.model_forward(src, tp, cfg)['loss'].backward()
-    R.tf_adam_step_(tp, {k: tp[k].grad for k in tp}, m, v, n_steps + 2, hp.LR, clip=hp.GRAD_CLIP_THRES)
-    dt1 = time.time() - t0
+        R.tf_adam_step_(tp, {k: tp[k].grad for k in tp}, m, v, tstep[0], hp.LR,
+                        clip=hp.GRAD_CLIP_THRES)
+        return time.time() - t0
+
+    def timed(threads, n, budget_s):
+        torch.set_num_threads(threads)
+        one_step()                               # untimed first step at this thread count
+        times, t_start = [], time.time()
+        for _ in range(n):
+            times.append(one_step())
+            if time.time() - t_start > budget_s:
+                break
+        log('cpu_baseline %d threads: %s s/step' % (threads, ['%.2f' % t for t in times]))
+        return float(np.mean(times)), len(times)
+
+    cores = min(ncpu, 16)
+    dt, n = timed(cores, n_steps, 12.0)
+    out = dict(value=mix_s / dt, unit='mixture-seconds/s', cores=cores, kind='port',
+               host_cpu_count=ncpu,
+               sample='%d of %d mixtures/step, same T/F/L/H, %d timed train steps (%.2f s each) at '
+                      '%d threads, torch-CPU fp32 restatement of the reference (TF1 unavailable)'
+                      % (sample_b, hp.BATCH_SIZE, n, dt, cores))
+    if ncpu > cores:
+        dta, na = timed(ncpu, 2, 6.0)
+        out['all_cores_value'] = mix_s / dta
+        out['all_cores'] = ncpu
+    dt1, _ = timed(1, 1, 1.0)
+    out['single_thread_value'] = mix_s / dt1
     torch.set_num_threads(cores)
-    print('[bench] cpu_baseline single-thread step: %.2f s' % dt1, file=sys.stderr, flush=True)
-    return dict(value=mix_s / dt, unit='mixture-seconds/s', cores=cores, kind='port',
-                single_thread_value=mix_s / dt1,
-                sample='%d of %d mixtures/step, same T/F/L/H, %d timed train steps (%.2f s each), '
-                       'torch-CPU fp32 restatement of the reference (TF1 unavailable)'
-                       % (sample_b, hp.BATCH_SIZE, n_steps, dt))
+    return out
 
 
-def pmc_traffic_bytes(kernel):
-    '''HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/run_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate runs, KB units).
-    Correction per MI355X_MICROARCH.md "HBM": on gfx950 FETCH_SIZE reports half of
-    a 16-B/lane coalesced read stream, so reads = 2*FETCH_SIZE (calibrated here on
-    adam_clip_kernel: 2*52.7 MB vs 110.5 MB algorithmic); WRITE_SIZE as is.
-    None if no PMC summary was collected for this kernel (cfg 2 only).'''
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')
-    if not os.path.exists(path):
-        return None
-    d = json.load(open(path))
-    for k, v in d.items():
-        if k.replace('void ', '').startswith(kernel) and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
-            return int((2.0 * v['FETCH_SIZE']['per_launch'] + v['WRITE_SIZE']['per_launch']) * 1024)
-    return None
+def pmc_traffic(kernel):
+    '''HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
+    (profiles/run_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate runs, KB units).  Correction
+    per MI355X_MICROARCH.md "HBM": on gfx950 FETCH_SIZE reports half of a 16-B/lane coalesced
+    read stream, so reads = 2*FETCH_SIZE (calibrated on adam_clip_kernel); WRITE_SIZE as is.
+    The record carries the summary's tag and git revision; a summary without this kernel
+    symbol yields None (the number is not carried over to a different kernel).'''
+    pdir = os.path.join(ROOT, 'profiles')
+    cands = sorted(f for f in os.listdir(pdir) if f.endswith('pmc_summary.json')) if os.path.isdir(pdir) else []
+    for name in reversed(cands):
+        d = json.load(open(os.path.join(pdir, name)))
+        meta = d.get('_meta', {})
+        for k, v in d.items():
+            if k.startswith('_') or not isinstance(v, dict):
+                continue
+            if k.replace('void ', '').startswith(kernel + '<') or k.replace('void ', '') == kernel:
+                if 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
+                    b = int((2.0 * v['FETCH_SIZE']['per_launch'] + v['WRITE_SIZE']['per_launch']) * 1024)
+                    return b, dict(file='profiles/' + name, git=meta.get('git'), symbol=k,
+                                   workload=meta.get('workload', 'cfg2'))
+    return None, None
 
 
 def mask_mse_vs_oracle(hp, model, src, n_check=2):
@@ -134,14 +199,39 @@ def mask_mse_vs_oracle(hp, model, src, n_check=2):
     with torch.no_grad():
         out = model.forward(src)
     masks = (out['sep_pwr'] / out['mix_pwr'][:, None].clamp_min(1e-30))[:n_check].double().cpu()
-    cfg = dict(H=hp.LSTM_HDIM, L=hp.NUM_LSTM_LAYERS, E=hp.EMBED_SIZE, C=hp.MAX_N_SIGNAL,
-               A=hp.NUM_ANCHOR, train_est='anchor', infer_est='anchor',
-               separator='dot-softmax-orig')
     tp = {k: torch.tensor(v, dtype=torch.float64) for k, v in model.param_dict().items()}
     with torch.no_grad():
-        r = R.model_forward(src[:n_check].cpu().to(torch.complex128), tp, cfg)
+        r = R.model_forward(src[:n_check].cpu().to(torch.complex128), tp, oracle_cfg(hp))
     ref = r['masks'].permute(0, 3, 1, 2)
     return float(((masks - ref) ** 2).mean()), float((masks - ref).abs().max())
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def maybe_spawn(args):
+    '''plain `python bench.py --gpus N` (no torchrun environment): become the launcher'''
+    if 'WORLD_SIZE' in os.environ:
+        return
+    if args.gpus == 1 and os.environ.get('DANET_FORCE_DIST') != '1':
+        return
+    n_vis = torch.cuda.device_count()
+    if n_vis < args.gpus:
+        raise SystemExit('bench.py --gpus %d: only %d GPU(s) visible' % (args.gpus, n_vis))
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log('spawning: %s' % ' '.join(cmd))
+    sys.stdout.flush()
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -149,42 +239,86 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32)
-    ap.add_argument('--frames', type=int, default=128)
-    ap.add_argument('--layers', type=int, default=3)
-    ap.add_argument('--hdim', type=int, default=300)
+    ap.add_argument('--config', default='cfg2', choices=sorted(CONFIGS))
+    ap.add_argument('--batch', type=int)
+    ap.add_argument('--frames', type=int)
+    ap.add_argument('--layers', type=int)
+    ap.add_argument('--hdim', type=int)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=32)
+    ap.add_argument('--cpu-sample', type=int)
     args = ap.parse_args()
+    maybe_spawn(args)
+    cfg = CONFIGS[args.config]
+    for k in ('batch', 'frames', 'layers', 'hdim'):
+        if getattr(args, k) is None:
+            setattr(args, k, cfg[k])
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    assert world == args.gpus, 'WORLD_SIZE=%d but --gpus %d' % (world, args.gpus)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    use_dist = world > 1 or os.environ.get('DANET_FORCE_DIST') == '1'   # 1-rank RCCL smoke
+    use_dist = 'WORLD_SIZE' in os.environ
     graft.load_package()
     from danet_amd import _lib, ops
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         # the side streams must exist before the RCCL communicator (ops.prepare_streams)
         ops.prepare_streams(device)
         torch.distributed.init_process_group('nccl', device_id=device)
-    from danet_amd.model import Model
-    hp = setup_hparams(args)
-    batches = make_batches(hp, rank, 4, device)
-    model = Model('bench', device=device, seed=1337).build()
-    log = lambda *a: print('[bench r%d]' % rank, *a, file=sys.stderr, flush=True)
-    log('built: %d params' % model.parameter_count())
+    hp = setup_hparams(args, cfg)
+    if cfg['kind'] == 'infer':
+        res = run_infer(args, cfg, hp, device, rank, world, use_dist)
+    else:
+        res = run_train(args, cfg, hp, device, rank, world, use_dist)
+    if use_dist:
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner to the C stdout of the process; flush it first so
+        # that the JSON line is the LAST line of stdout
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(res), flush=True)
 
+
+def make_barrier(use_dist):
     def barrier():
         torch.cuda.synchronize()
         if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+    return barrier
+
+
+def max_over_ranks(dt, device, use_dist):
+    if not use_dist:
+        return dt
+    tt = torch.tensor([dt], device=device, dtype=torch.float64)
+    torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+    return float(tt.item())
+
+
+def kernels_table(prof_all, nb):
+    kern = {}
+    for label, (n, ms) in prof_all.items():
+        kern[label] = dict(launches=n, total_ms=round(ms, 3), avg_us=round(1e3 * ms / n, 2))
+    kern['_note'] = 'separate instrumented pass of %d steps after the timed region' % nb
+    return kern
+
+
+def run_train(args, cfg, hp, device, rank, world, use_dist):
+    from danet_amd import _lib, ops
+    from danet_amd.model import Model
+    batches = make_batches(hp, rank, 4, device)
+    model = Model('bench', device=device, seed=1337).build()
+    log('built: %d params' % model.parameter_count())
+    barrier = make_barrier(use_dist)
 
     # one initialisation step outside the W warmup steps: HIP code objects are loaded and the
     # allocator pools are grown on first use (a 0.15 s one-off that must not land in the
@@ -215,87 +349,190 @@ def main():
     prof_all = _lib.profile_stop()
     ok = ops.lstm_status_ok()
     log('timed region: %.3f s for %d steps; lstm status ok=%s' % (dt, args.steps, ok))
-    if use_dist:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(dt, device, use_dist)
     assert ok, 'persistent LSTM kernel reported a hand-off timeout'
+
+    # the gradient all-reduce on its own (HIP events on the current stream, which the RCCL
+    # stream is joined to): what an un-overlapped reduction adds to a step
+    allreduce_ms = None
+    if use_dist:
+        g = model._flat_grad
+        for _ in range(3):
+            torch.distributed.all_reduce(g)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            torch.distributed.all_reduce(g)
+        e1.record()
+        torch.cuda.synchronize()
+        allreduce_ms = e0.elapsed_time(e1) / 10
+        g.zero_()
 
     mix_s_per_step = hp.BATCH_SIZE * hp.MAX_TRAIN_LEN * hp.FFT_STRIDE / hp.SMPRATE
     value = world * mix_s_per_step * args.steps / dt
+    if rank != 0:
+        return None
 
-    if rank == 0:
-        B, T, H, L = hp.BATCH_SIZE, hp.MAX_TRAIN_LEN, hp.LSTM_HDIM, hp.NUM_LSTM_LAYERS
-        # algorithmic flops per launch: recurrent half of one BiLSTM layer
-        lstm_flops = 2.0 * 2 * B * T * H * 4 * H
-        kern = {}
-        for label, (n, ms) in prof_all.items():
-            kern[label] = dict(launches=n, total_ms=round(ms, 3), avg_us=round(1e3 * ms / n, 2))
-        kern['_note'] = 'separate instrumented pass of %d steps after the timed region' % nb
-        dom = max(('lstm_fwd', 'lstm_bwd'), key=lambda k: prof.get(k, (1, 0.0))[1])
-        n, ms = prof[dom]
-        achieved = lstm_flops / (ms / n * 1e-3) / 1e12
-        # kernel symbol behind the label (csrc/lstm.hip): BPTT runs the reduce-scatter
-        # kernel unless DANET_LSTM_BWD_RS=0 selects the all-gather one
-        ksym = {'lstm_fwd': 'lstm_fwd_kernel',
-                'lstm_bwd': 'lstm_bwd_kernel' if os.environ.get('DANET_LSTM_BWD_RS') == '0'
-                else 'lstm_bwd_rs_kernel'}[dom]
-        roofline = dict(kernel=ksym, bound='mfma', achieved=round(achieved, 3),
-                        peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                        frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                        traffic=pmc_traffic_bytes(ksym),
-                        us_per_timestep=round(1e3 * ms / n / T, 3),
-                        note='latency-bound recurrence: T dependent steps per launch; '
-                             'see DESIGN.md for the step-latency model')
-        # second-largest consumer: the fp32 MFMA GEMMs (all launches of one step together)
-        F, E = hp.FFT_SIZE // 2 + 1, hp.EMBED_SIZE
-        gemm_flops = 0.0
-        for l in range(L):
-            D = F if l == 0 else 2 * H
-            gemm_flops += 2 * (2.0 * B * T * D * 4 * H) * 3      # gx, dWx, dX per direction
-            gemm_flops += 2 * (2.0 * B * T * H * 4 * H)          # dWh per direction
-        gemm_flops -= 2 * (2.0 * B * T * F * 4 * H)              # layer 0 needs no dX
-        gemm_flops += 3 * 2.0 * B * T * 2 * H * F * E            # projection, dWout, dYc
-        if 'gemm_f32' in prof_all:
-            gn, gms = prof_all['gemm_f32']
-            if 'gemm_f32_group' in prof_all:       # grouped launches
-                gn, gms = gn + prof_all['gemm_f32_group'][0], gms + prof_all['gemm_f32_group'][1]
-            gach = gemm_flops * nb / (gms * 1e-3) / 1e12
-            roofline['gemm_f32'] = dict(kernel='gemm_f32_kernel', bound='mfma',
-                                        achieved=round(gach, 2), peak=PEAK_F32_MFMA_TFLOPS,
-                                        unit='TFLOP/s', frac=round(gach / PEAK_F32_MFMA_TFLOPS, 4),
-                                        note='sum over the %d launches of a step, timed in-step '
-                                             '(instrumented pass; some run concurrently)' % (gn // nb))
-        res = dict(metric='mixture-seconds/s (train step)', value=round(value, 2),
-                   unit='mixture-seconds/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=round(1e3 * dt / args.steps, 3), higher_is_better=True,
-                   scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
-                   config=dict(workload='cfg2: synthetic 8 kHz 2-spk, FFT 256/64 (129 bins), '
-                                        'T=%d, %dx%d BiLSTM, E=20, anchor estimator (A=6), '
-                                        'dot-softmax, B=%d/GPU' % (T, L, H, B),
-                               global_batch=B * world, parallelism='dp%d' % world,
-                               grad_allreduce_bytes=int(model._flat_grad.numel() * 4)),
-                   roofline=roofline, kernels=kern)
-        if world == 1:
-            torch.set_num_threads(min(os.cpu_count() or 1, 16))
-            mse, mx = mask_mse_vs_oracle(hp, model, batches[0])
-            log('mask mse vs oracle %.3e (max abs %.3e)' % (mse, mx))
-            res['mask_mse_vs_oracle'] = mse
-            res['mask_max_abs_err_vs_oracle'] = mx
-            if not args.no_cpu_baseline:
-                res['cpu_baseline'] = cpu_baseline(hp, model.param_dict(), args.cpu_sample)
-    if use_dist:
-        torch.distributed.destroy_process_group()
-    if rank == 0:
-        # RCCL writes a version banner to the C stdout of the process; flush it first so
-        # that the JSON line is the LAST line of stdout
-        sys.stdout.flush()
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
-        print(json.dumps(res), flush=True)
+    B, T, H, L = hp.BATCH_SIZE, hp.MAX_TRAIN_LEN, hp.LSTM_HDIM, hp.NUM_LSTM_LAYERS
+    C, E, F = hp.MAX_N_SIGNAL, hp.EMBED_SIZE, hp.FFT_SIZE // 2 + 1
+    # algorithmic flops per launch: recurrent half of one BiLSTM layer
+    lstm_flops = 2.0 * 2 * B * T * H * 4 * H
+    dom = max(('lstm_fwd', 'lstm_bwd'), key=lambda k: prof.get(k, (1, 0.0))[1])
+    n, ms = prof[dom]
+    achieved = lstm_flops / (ms / n * 1e-3) / 1e12
+    # kernel symbol behind the label (csrc/lstm.hip): BPTT runs the reduce-scatter
+    # kernel unless DANET_LSTM_BWD_RS=0 selects the all-gather one
+    ksym = {'lstm_fwd': 'lstm_fwd_kernel',
+            'lstm_bwd': 'lstm_bwd_kernel' if os.environ.get('DANET_LSTM_BWD_RS') == '0'
+            else 'lstm_bwd_rs_kernel'}[dom]
+    traffic, tsrc = pmc_traffic(ksym)
+    if tsrc is not None and tsrc.get('workload', 'cfg2') != args.config:
+        traffic, tsrc = None, None
+    roofline = dict(kernel=ksym, bound='mfma', achieved=round(achieved, 3),
+                    peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
+                    frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                    traffic=traffic, traffic_source=tsrc,
+                    us_per_timestep=round(1e3 * ms / n / T, 3),
+                    events_in_timed_region=True,
+                    note='latency-bound recurrence: T dependent steps per launch; see DESIGN.md '
+                         'for the step-latency model.  HIP events bracket the two recurrent '
+                         'entry points on every 4th step INSIDE the timed region')
+    for other in ('lstm_fwd', 'lstm_bwd'):
+        if other in prof:
+            on, oms = prof[other]
+            roofline[other + '_us'] = round(1e3 * oms / on, 1)
+    # second-largest consumer: the fp32 MFMA GEMMs (all launches of one step together)
+    gemm_flops = 0.0
+    for l in range(L):
+        D = F if l == 0 else 2 * H
+        gemm_flops += 2 * (2.0 * B * T * D * 4 * H) * 3      # gx, dWx, dX per direction
+        gemm_flops += 2 * (2.0 * B * T * H * 4 * H)          # dWh per direction
+    gemm_flops -= 2 * (2.0 * B * T * F * 4 * H)              # layer 0 needs no dX
+    gemm_flops += 3 * 2.0 * B * T * 2 * H * F * E            # projection, dWout, dYc
+    if 'gemm_f32' in prof_all:
+        gn, gms = prof_all['gemm_f32']
+        if 'gemm_f32_group' in prof_all:       # grouped launches
+            gn, gms = gn + prof_all['gemm_f32_group'][0], gms + prof_all['gemm_f32_group'][1]
+        gach = gemm_flops * nb / (gms * 1e-3) / 1e12
+        roofline['gemm_f32'] = dict(kernel='gemm_f32_kernel', bound='mfma',
+                                    achieved=round(gach, 2), peak=PEAK_F32_MFMA_TFLOPS,
+                                    unit='TFLOP/s', frac=round(gach / PEAK_F32_MFMA_TFLOPS, 4),
+                                    note='sum over the %d launches of a step, timed in-step '
+                                         '(instrumented pass; some run concurrently)' % (gn // nb))
+    est = hp.TRAIN_ESTIMATOR_METHOD
+    res = dict(metric='mixture-seconds/s (train step)', value=round(value, 2),
+               unit='mixture-seconds/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=round(1e3 * dt / args.steps, 3), higher_is_better=True,
+               scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+               config=dict(workload='%s: synthetic 8 kHz %d-spk, FFT %d/%d (%d bins), T=%d, '
+                                    '%dx%d BiLSTM, E=%d, %s estimator%s, %s, B=%d/GPU'
+                                    % (args.config, C, hp.FFT_SIZE, hp.FFT_STRIDE, F, T, L, H, E, est,
+                                       ' (A=%d)' % hp.NUM_ANCHOR if est == 'anchor' else '',
+                                       hp.SEPARATOR_TYPE.replace('-orig', ''), B),
+                           global_batch=B * world, parallelism='dp%d' % world,
+                           grad_allreduce_bytes=int(model._flat_grad.numel() * 4),
+                           grad_allreduce_schedule=os.environ.get('DANET_OVERLAP_ALLREDUCE', 'tail')),
+               rccl_ranks=(torch.distributed.get_world_size() if use_dist else 0),
+               allreduce_ms_standalone=(round(allreduce_ms, 4) if allreduce_ms is not None else None),
+               roofline=roofline, kernels=kernels_table(prof_all, nb), host=host_info())
+    if world == 1:
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+        nchk = 2 if H <= 300 else 1
+        mse, mx = mask_mse_vs_oracle(hp, model, batches[0], nchk)
+        log('mask mse vs oracle %.3e (max abs %.3e)' % (mse, mx))
+        res['mask_mse_vs_oracle'] = mse
+        res['mask_max_abs_err_vs_oracle'] = mx
+        if not args.no_cpu_baseline:
+            sample = args.cpu_sample or (B if (H <= 300 and L <= 3) else max(2, B // 8))
+            res['cpu_baseline'] = cpu_baseline(hp, model.param_dict(), sample)
+    return res
+
+
+def run_infer(args, cfg, hp, device, rank, world, use_dist):
+    '''cfg 5: the demo path (main.py:623-627, 655-696) on one long utterance per step:
+    waveform in HBM -> danet_stft -> Model.infer -> danet_istft of every separated source.
+    N > 1 = independent replicas (B = 1 does not shard).'''
+    from danet_amd import _lib, ops, utils, datasets
+    from danet_amd.model import Model
+    assert hp.BATCH_SIZE == 1, 'the inference configs are B = 1 (main.py:623-624)'
+    T, S, N = hp.MAX_TRAIN_LEN, hp.FFT_STRIDE, hp.FFT_SIZE
+    Ls = (T - 1) * S
+    rng = np.random.RandomState(1337 + rank)
+    waves = []
+    for i in range(4):
+        w = sum(datasets.speech_shaped_wave(rng, Ls, hp.SMPRATE, phase=0.3 + 1.8 * c)
+                for c in range(hp.MAX_N_SIGNAL))
+        waves.append(torch.as_tensor(w.astype(np.float32)).to(device))
+    model = Model('bench', device=device, seed=1337).build()
+    wnd = torch.as_tensor(np.asarray(hp.FFT_WND)).to(device)
+    log('built: %d params' % model.parameter_count())
+    barrier = make_barrier(use_dist)
+
+    def step(w):
+        X = utils.stft(w)                                   # [T, F] complex64
+        sep = model.infer(X[None])                          # [1, C, T, F]
+        return ops.istft(sep[0].contiguous(), S, wnd)       # [C, T*S] float64
+
+    y = step(waves[0])
+    assert tuple(y.shape) == (hp.MAX_N_SIGNAL, T * S), y.shape
+    for i in range(args.warmup):
+        step(waves[i % len(waves)])
+    barrier()
+    _lib.profile_start(only=('lstm_fwd',))
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        _lib.profile_enable(i % 4 == 0)
+        step(waves[i % len(waves)])
+    _lib.profile_enable(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_stop()
+    nb = min(10, args.steps)
+    _lib.profile_start()
+    for i in range(nb):
+        step(waves[i % len(waves)])
+    barrier()
+    prof_all = _lib.profile_stop()
+    ok = ops.lstm_status_ok()
+    dt = max_over_ranks(dt, device, use_dist)
+    assert ok, 'persistent LSTM kernel reported a hand-off timeout'
+    if rank != 0:
+        return None
+    H, L, F, E = hp.LSTM_HDIM, hp.NUM_LSTM_LAYERS, hp.FFT_SIZE // 2 + 1, hp.EMBED_SIZE
+    mix_s = T * S / hp.SMPRATE
+    n, ms = prof['lstm_fwd']
+    per_launch_s = ms / n * 1e-3
+    # B = 1 recurrence: the per-step product is a GEMV.  Algorithmic HBM bytes of one launch
+    # (both directions): gx read + gates, cell, y written; Wh is read ONCE (it stays in LDS /
+    # registers for all T steps).  A formulation that re-streams Wh every step would move
+    # T * 2 * H*4H*4 bytes instead -- `wh_restream_equiv` prices our launch against that.
+    alg_bytes = 2 * (T * (4 * H + 4 * H + H + H) * 4 + H * 4 * H * 4)
+    restream = T * 2 * H * 4 * H * 4
+    roofline = dict(kernel='lstm_fwd_kernel', bound='hbm',
+                    achieved=round(alg_bytes / per_launch_s / 1e9, 2), peak=PEAK_HBM_GBS,
+                    unit='GB/s', frac=round(alg_bytes / per_launch_s / 1e9 / PEAK_HBM_GBS, 5),
+                    traffic=None, us_per_timestep=round(1e6 * per_launch_s / T, 3),
+                    algorithmic_bytes_per_launch=alg_bytes,
+                    wh_restream_equiv=dict(bytes=restream,
+                                           GBps=round(restream / per_launch_s / 1e9, 1),
+                                           frac_of_hbm_peak=round(restream / per_launch_s / 1e9 / PEAK_HBM_GBS, 4)),
+                    mfma_frac=round(2.0 * 2 * T * H * 4 * H / per_launch_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 5),
+                    events_in_timed_region=True,
+                    note='B=1: T dependent GEMV steps per launch, latency-bound; weights stationary, '
+                         'so the HBM fraction of the algorithmic bytes is tiny by design '
+                         '(DESIGN.md 3.1); us_per_timestep is the meaningful figure')
+    return dict(metric='mixture-seconds/s (inference, demo path)', value=round(world * mix_s * args.steps / dt, 2),
+                unit='mixture-seconds/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+                ms_per_step=round(1e3 * dt / args.steps, 3), higher_is_better=True,
+                scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                config=dict(workload='%s: synthetic %d Hz %d-spk utterance of %.1f s, FFT %d/%d (%d bins), '
+                                     'T=%d, %dx%d BiLSTM, E=%d, %s estimator, B=1: stft -> infer -> istft'
+                                     % (args.config, hp.SMPRATE, hp.MAX_N_SIGNAL, mix_s, N, S, F, T, L, H,
+                                        E, hp.INFER_ESTIMATOR_METHOD),
+                            global_batch=world, parallelism='replicas%d' % world),
+                rccl_ranks=(torch.distributed.get_world_size() if use_dist else 0),
+                roofline=roofline, kernels=kernels_table(prof_all, nb), host=host_info())
 
 
 if __name__ == '__main__':

@@ -53,9 +53,9 @@ PROTOTYPES = {
     'danet_colsum_f32': (c_int, [c_p, c_int, c_int, c_p, c_int, c_p, c_f32, c_p, c_sz]),
     'danet_lstm_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int]),
     'danet_lstm_fwd': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_int,
-                               c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_sz]),
+                               c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     'danet_lstm_bwd': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_int,
-                               c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz]),
+                               c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     'danet_attractor_truth_workspace_bytes': (c_sz, [c_int, c_int, c_i64, c_int]),
     'danet_attractor_truth_fwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p,
                                           c_f32, c_p, c_p, c_p, c_sz]),
@@ -75,7 +75,7 @@ PROTOTYPES = {
                                   c_p, c_p, c_p, c_sz]),
     'danet_pit_mse_bwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_p, c_p, c_p, c_p, c_f32, c_p, c_p]),
     'danet_adam_clip_step': (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_f32, c_f32, c_f32, c_f32,
-                                     c_f32, c_f32]),
+                                     c_f32, c_f32, c_int]),
 }
 
 _lib = None
@@ -106,7 +106,7 @@ def load():
             fn = getattr(lib, name)      # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.danet_abi_version() != 1:
+        if lib.danet_abi_version() != 2:
             raise DanetHipError('libdanet_hip.so ABI version mismatch')
         _lib = lib
     return _lib

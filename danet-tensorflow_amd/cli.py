@@ -72,32 +72,27 @@ def train(model, n_epoch, dataset, args, out=sys.stdout):
             out.flush()
             _dict_add(cli_report, step_fetch)
         _dict_mul(cli_report, 1. / (i_batch + 1))
-        if hparams.LR_DECAY_TYPE == 'adaptive':                                  # main.py:439-451
-            if cli_report['loss'] < best_loss:
-                best_loss, best_loss_time = cli_report['loss'], 0
-            else:
-                best_loss_time += 1
-        elif hparams.LR_DECAY_TYPE == 'fixed':
-            best_loss_time += 1
-        elif hparams.LR_DECAY_TYPE is not None:
-            raise ValueError('Unknown LR_DECAY_TYPE "%s"' % hparams.LR_DECAY_TYPE)
-        if best_loss_time == hparams.NUM_EPOCH_PER_LR_DECAY:                     # main.py:453-459
-            best_loss_time = 0
-            old_lr = model.get_learn_rate()
-            new_lr = old_lr * hparams.LR_DECAY
-            model.set_learn_rate(new_lr)
-            out.write('[LR %f -> %f]' % (old_lr, new_lr))
-        if not args.no_save_on_epoch and dist.rank() == 0:
+        model.check_status()       # hand-off timeouts of the persistent kernels surface here at the latest
+        # data parallel: every rank must take the SAME learning-rate and NaN decisions, so
+        # they are taken on the rank-mean of the epoch metrics (NaN anywhere -> NaN everywhere)
+        keys = list(cli_report.keys())
+        for k, v in zip(keys, dist.allreduce_mean_scalars([cli_report[k] for k in keys],
+                                                          model.device)):
+            cli_report[k] = v
+        best_loss, best_loss_time = lr_decay_update(model, cli_report['loss'], best_loss,
+                                                    best_loss_time, out)
+        if not args.no_save_on_epoch:
             if any(map(isnan, cli_report.values())):                             # main.py:462-476
                 if i_epoch:
                     out.write('\nEpoch %d/%d got NAN values, restoring last checkpoint ... '
                               % (i_epoch + 1, n_epoch))
-                    model.load_params('saves/' + model.name + ('_e%d' % i_epoch))
+                    restore_checkpoint(model, 'saves/' + model.name + ('_e%d' % i_epoch))
                     out.write('done')
                     continue                  # redo this epoch from the restored parameters
                 out.write('\nRun into NAN during 1st epoch, exiting ...')
                 sys.exit(-1)
-            model.save_params('saves/' + model.name + ('_e%d' % (i_epoch + 1)))
+            if dist.rank() == 0:              # only the file write is rank 0's
+                model.save_params('saves/' + model.name + ('_e%d' % (i_epoch + 1)))
             out.write('S')
         out.write('\nEpoch %d/%d %s\n' % (i_epoch + 1, n_epoch, _dict_format(cli_report)))
         out.flush()
@@ -107,6 +102,37 @@ def train(model, n_epoch, dataset, args, out=sys.stdout):
         rep = evaluate(model, dataset, 'valid', out)
         out.write('\nValid  %d/%d %s\n' % (i_epoch, n_epoch, _dict_format(rep)))
         out.flush()
+
+
+def lr_decay_update(model, epoch_loss, best_loss, best_loss_time, out=sys.stdout):
+    '''learning-rate schedule of Model.train (main.py:439-459): 'adaptive' counts epochs
+    without a new best loss, 'fixed' counts every epoch, None never decays; after
+    NUM_EPOCH_PER_LR_DECAY counted epochs LR *= LR_DECAY.  Returns the updated
+    (best_loss, best_loss_time).'''
+    if hparams.LR_DECAY_TYPE == 'adaptive':                                      # main.py:439-451
+        if epoch_loss < best_loss:
+            best_loss, best_loss_time = epoch_loss, 0
+        else:
+            best_loss_time += 1
+    elif hparams.LR_DECAY_TYPE == 'fixed':
+        best_loss_time += 1
+    elif hparams.LR_DECAY_TYPE is not None:
+        raise ValueError('Unknown LR_DECAY_TYPE "%s"' % hparams.LR_DECAY_TYPE)
+    if best_loss_time == hparams.NUM_EPOCH_PER_LR_DECAY:                         # main.py:453-459
+        best_loss_time = 0
+        old_lr = model.get_learn_rate()
+        new_lr = old_lr * hparams.LR_DECAY
+        model.set_learn_rate(new_lr)
+        out.write('[LR %f -> %f]' % (old_lr, new_lr))
+    return best_loss, best_loss_time
+
+
+def restore_checkpoint(model, filename):
+    '''NaN-restore (main.py:462-476) under data parallelism: rank 0 reads the file, every
+    rank receives the parameters by broadcast, so the replicas stay identical.'''
+    if dist.rank() == 0:
+        model.load_params(filename)
+    dist.broadcast_params_(model._flat)
 
 
 def evaluate(model, dataset, subset, out=sys.stdout):

@@ -67,6 +67,8 @@ struct LstmFwdArgs {
   int* status;
   int T, B, H, ndir, ldy, ldw, P, G, KP;  // KP = H padded to 16
   int xmap;   // consecutive block ids cycle over the clusters (placement, see kernel)
+  unsigned spin_limit;   // bound of every inter-workgroup wait (validation passes)
+  int fault;             // test hook: workgroup 0 exits without publishing (forces a timeout)
 };
 
 struct LstmBwdArgs {
@@ -78,6 +80,8 @@ struct LstmBwdArgs {
   int* status;
   int T, B, H, ndir, lddy, ldw, P, G, R;   // R = batch rows per cluster (<= 16*MT)
   int xmap;
+  unsigned spin_limit;
+  int fault;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
@@ -86,7 +90,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 
 // one failed validation pass: back off, and give up (once, for everybody) when
 // the bound is hit.  Returns true when the caller must stop waiting.
-__device__ __forceinline__ bool spin_fail(unsigned& spins, int* status, int lane) {
+__device__ __forceinline__ bool spin_fail(unsigned& spins, int* status, int lane, unsigned limit) {
   // the fragment loads are ordinary (non-volatile) reads to the compiler: this
   // clobber is what forces them to be re-issued on the next pass
   asm volatile("" ::: "memory");
@@ -94,7 +98,7 @@ __device__ __forceinline__ bool spin_fail(unsigned& spins, int* status, int lane
   ++spins;
   if ((spins & 255u) == 0) {
     if (__hip_atomic_load(status, RLX_AGENT) != 0) return true;   // someone gave up
-    if (spins >= SPIN_LIMIT) {
+    if (spins >= limit) {
       if (lane == 0) __hip_atomic_store(status, 1, RLX_AGENT);
       return true;
     }
@@ -133,6 +137,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bid = blockIdx.x;
+  if (a.fault && bid == 0) return;   // test hook (DANET_LSTM_FAULT_INJECT): never publishes
   const int ncl = a.ndir * a.G;
   const int cl = a.xmap ? bid % ncl : bid / a.P;   // xmap: members of a cluster share bid % 8
   const int dir = cl / a.G, grp = cl % a.G;
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) ok &= !has_sentinel(av[g][mt]);
           if (__all(ok)) break;
-          if (spin_fail(spins, a.status, lane)) break;
+          if (spin_fail(spins, a.status, lane, a.spin_limit)) break;
         }
         TRACE(1); TRACE_VAL(6, spins);
         // NO per-group branch here: a branch splits the accumulator chain into
@@ -329,6 +334,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_bwd_kernel(LstmBwdArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bid = blockIdx.x;
+  if (a.fault && bid == 0) return;   // test hook
   const int ncl = a.ndir * a.G;
   const int cl = a.xmap ? bid % ncl : bid / a.P;
   const int dir = cl / a.G, grp = cl % a.G;
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_bwd_kernel(LstmBwdArgs a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) ok &= !has_sentinel(av[g][mt]);
           if (__all(ok)) break;
-          if (spin_fail(spins, a.status, lane)) break;
+          if (spin_fail(spins, a.status, lane, a.spin_limit)) break;
         }
         TRACE(1); TRACE_VAL(6, spins);
         f32x4 wq[CH];     // straight-line MFMA chain (see forward kernel)
@@ -536,6 +542,8 @@ struct LstmBwdRsArgs {
   float* ring;
   int* status;
   int T, B, H, ndir, lddy, ldw, P, G, S, NT, NI, D, xmap;
+  unsigned spin_limit;
+  int fault;
 };
 
 __device__ __forceinline__ void store_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned off, v4u v) {
@@ -558,6 +566,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
   const int H = a.H, B = a.B, T = a.T, P = a.P, S = a.S;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bid = blockIdx.x;
+  if (a.fault && bid == 0) return;   // test hook
   const int ncl = a.ndir * a.G;
   // xmap: consecutive block ids cycle over the clusters (so a cluster's workgroups
   // share their id modulo 8 = their XCD whenever ncl divides 8 or vice versa)
@@ -646,7 +655,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
             ok &= (off[i] == rbytes) || !(mm & 1u);
           }
         if (__all(ok)) break;
-        if (spin_fail(spins, a.status, lane)) break;
+        if (spin_fail(spins, a.status, lane, a.spin_limit)) break;
       }
       TRACE(1); TRACE_VAL(6, spins);
       f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -785,6 +794,22 @@ struct FillList {
 // ---------------------------------------------------------------------------
 struct LstmPlan { int MT, G, P, KP, NW; size_t lds; };
 
+// compute units of the current device (one persistent workgroup per CU must be co-resident);
+// gfx950 = 256, also the fallback when no device is visible (size queries on a CPU-only host)
+static int num_cus() {
+  static int n = 0;
+  if (n) return n;
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) == hipSuccess &&
+      hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+    n = v;
+  else {
+    (void)hipGetLastError();
+    return 256;
+  }
+  return n;
+}
+
 // MT=1 (16-row clusters) halves the per-step MFMA time and the payload per
 // workgroup at the price of twice the workgroups; it is used whenever one
 // workgroup per CU still fits.  DANET_LSTM_FWD_MT / DANET_LSTM_BWD_MT = 1|2
@@ -793,7 +818,7 @@ static LstmPlan make_plan(int B, int H, int ndir, bool bwd) {
   LstmPlan pl;
   pl.P = cdiv(H, bwd ? LSTM_UNITS_BWD : LSTM_UNITS_FWD);
   pl.KP = cdiv(H, 16) * 16;
-  pl.MT = (ndir * cdiv(B, 16) * pl.P > 256) ? 2 : 1;
+  pl.MT = (ndir * cdiv(B, 16) * pl.P > num_cus()) ? 2 : 1;
   const char* force = getenv(bwd ? "DANET_LSTM_BWD_MT" : "DANET_LSTM_FWD_MT");
   if (force && (force[0] == '1' || force[0] == '2')) pl.MT = force[0] - '0';
   pl.G = cdiv(B, 16 * pl.MT);
@@ -820,7 +845,7 @@ static RsPlan make_rs_plan(int B, int H, int ndir, int U) {
   r.NT = cdiv(r.P * U, 16); r.D = 3;
   r.NI = cdiv(r.P, 512 / (4 * U));
   const int ncl = ndir * r.G;
-  int smax = 256 / (ncl * r.P);
+  int smax = num_cus() / (ncl * r.P);
   if (smax > r.NT) smax = r.NT;
   // twins: the fewest that leave at most two tiles per SIMD, else as many as fit
   r.S = smax;
@@ -856,6 +881,14 @@ static RsPlan choose_rs_plan(int B, int H, int ndir) {
   return best;
 }
 static size_t ring_offset(int T) { return (64 + TRACE_BYTES(T) + 255) / 256 * 256; }
+// DANET_LSTM_SPIN_LIMIT overrides the wait bound, DANET_LSTM_FAULT_INJECT=1 makes workgroup 0
+// of every launch exit without publishing (tests of the timeout path only)
+static unsigned spin_limit_env() {
+  const char* e = getenv("DANET_LSTM_SPIN_LIMIT");
+  const long v = e ? atol(e) : 0;
+  return v >= 256 ? (unsigned)v : SPIN_LIMIT;
+}
+static int fault_env() { const char* e = getenv("DANET_LSTM_FAULT_INJECT"); return e && atoi(e) == 1; }
 
 extern "C" size_t danet_lstm_workspace_bytes(int T, int B, int H, int ndir) {
   // status word (+ padding) (+ trace records) + partial-dh ring of the BPTT kernel
@@ -885,7 +918,8 @@ extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int n
                               const float* gx_f, const float* gx_b,
                               const float* Wh_f, const float* Wh_b, int ldw,
                               float* ypad, int ldy, float* gates_f, float* gates_b,
-                              float* cell_f, float* cell_b, void* ws, size_t ws_bytes) {
+                              float* cell_f, float* cell_b, void* ws, size_t ws_bytes,
+                              int32_t* status) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = lstm_check_common(T, B, H, ndir, ws, ws_bytes);
   if (rc) return rc;
@@ -900,14 +934,15 @@ extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int n
     return DANET_ERR_UNSUPPORTED;
   }
   const int nblk = ndir * pl.G * pl.P;
-  if (nblk > 256) {  // 1 workgroup per CU must be co-resident
-    danet_set_error("lstm_fwd: %d workgroups exceed the 256 CUs", nblk);
+  if (nblk > num_cus()) {  // 1 workgroup per CU must be co-resident
+    danet_set_error("lstm_fwd: %d workgroups exceed the %d CUs", nblk, num_cus());
     return DANET_ERR_UNSUPPORTED;
   }
   LstmFwdArgs a;
   a.gx[0] = gx_f; a.gx[1] = gx_b; a.Wh[0] = Wh_f; a.Wh[1] = Wh_b;
   a.gates[0] = gates_f; a.gates[1] = gates_b; a.cell[0] = cell_f; a.cell[1] = cell_b;
-  a.ypad = ypad; a.status = (int*)ws;
+  a.ypad = ypad; a.status = status ? (int*)status : (int*)ws;
+  a.spin_limit = spin_limit_env(); a.fault = fault_env();
   a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.ldy = ldy; a.ldw = ldw;
   a.P = pl.P; a.G = pl.G; a.KP = pl.KP;
   a.xmap = getenv("DANET_LSTM_XMAP") ? atoi(getenv("DANET_LSTM_XMAP")) : 1;
@@ -941,7 +976,8 @@ extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int n
                               const float* Wh_f, const float* Wh_b, int ldw,
                               const float* gates_f, const float* gates_b,
                               const float* cell_f, const float* cell_b,
-                              float* da_f, float* da_b, void* ws, size_t ws_bytes) {
+                              float* da_f, float* da_b, void* ws, size_t ws_bytes,
+                              int32_t* status) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = lstm_check_common(T, B, H, ndir, ws, ws_bytes);
   if (rc) return rc;
@@ -956,7 +992,8 @@ extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int n
     LstmBwdRsArgs a;
     a.dy = dy; a.lddy = lddy; a.Wh[0] = Wh_f; a.Wh[1] = Wh_b; a.ldw = ldw;
     a.gates[0] = gates_f; a.gates[1] = gates_b; a.cell[0] = cell_f; a.cell[1] = cell_b;
-    a.da[0] = da_f; a.da[1] = da_b; a.status = (int*)ws;
+    a.da[0] = da_f; a.da[1] = da_b; a.status = status ? (int*)status : (int*)ws;
+    a.spin_limit = spin_limit_env(); a.fault = fault_env();
     a.ring = (float*)((char*)ws + ring_offset(T));
     a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.P = rs.P; a.G = rs.G; a.S = rs.S;
     a.NT = rs.NT; a.NI = rs.NI; a.D = rs.D;
@@ -986,18 +1023,19 @@ extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int n
   // (measured -7% on the BPTT launch at cfg 2) while the MFMA tile stays 16 rows;
   // used whenever one workgroup per CU still fits.  DANET_LSTM_BWD_ROWS=16 overrides.
   int R = 16 * pl.MT;
-  if (pl.MT == 1 && ndir * cdiv(B, 8) * pl.P <= 256) R = 8;
+  if (pl.MT == 1 && ndir * cdiv(B, 8) * pl.P <= num_cus()) R = 8;
   { const char* er = getenv("DANET_LSTM_BWD_ROWS"); if (er && pl.MT == 1 && atoi(er) == 16) R = 16; }
   const int G = cdiv(B, R);
   const int nblk = ndir * G * pl.P;
-  if (nblk > 256) {
-    danet_set_error("lstm_bwd: %d workgroups exceed the 256 CUs", nblk);
+  if (nblk > num_cus()) {
+    danet_set_error("lstm_bwd: %d workgroups exceed the %d CUs", nblk, num_cus());
     return DANET_ERR_UNSUPPORTED;
   }
   LstmBwdArgs a;
   a.dy = dy; a.lddy = lddy; a.Wh[0] = Wh_f; a.Wh[1] = Wh_b; a.ldw = ldw;
   a.gates[0] = gates_f; a.gates[1] = gates_b; a.cell[0] = cell_f; a.cell[1] = cell_b;
-  a.da[0] = da_f; a.da[1] = da_b; a.status = (int*)ws;
+  a.da[0] = da_f; a.da[1] = da_b; a.status = status ? (int*)status : (int*)ws;
+  a.spin_limit = spin_limit_env(); a.fault = fault_env();
   a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.P = pl.P; a.G = G; a.R = R;
   a.xmap = getenv("DANET_LSTM_XMAP") ? atoi(getenv("DANET_LSTM_XMAP")) : 0;
   const size_t dbytes = (size_t)T * B * 4 * H * sizeof(float);

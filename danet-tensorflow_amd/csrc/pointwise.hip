@@ -226,29 +226,58 @@ extern "C" int danet_colsum_f32(danet_stream_t stream, int M, int N, const float
 }
 
 // ---------------------------------------------------------- clip + TF1 Adam
-__global__ void adam_clip_kernel(int64_t n, float* __restrict__ theta,
-                                 const float* __restrict__ grad, float* __restrict__ m,
-                                 float* __restrict__ v, float lr_t, float b1, float b2,
-                                 float eps, float clip, float gscale) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    float g = grad[i] * gscale;
-    if (clip > 0.f) g = fminf(fmaxf(g, -clip), clip);          // main.py:359-362
-    const float mi = b1 * m[i] + (1.f - b1) * g;
-    const float vi = b2 * v[i] + (1.f - b2) * g * g;
-    m[i] = mi; v[i] = vi;
-    theta[i] -= lr_t * mi / (sqrtf(vi) + eps);                 // eps outside the root (TF1)
+// One pass over the four flat buffers (16-B accesses).  A NaN gradient stays NaN through the
+// clip like tf.clip_by_value (fminf/fmaxf alone would turn it into -clip).  zero_grad: the
+// gradient is overwritten with 0 after use, so the next step's backward can accumulate into
+// it without a separate fill kernel.
+__device__ __forceinline__ void adam_one(float& th, float& gi, float& mi, float& vi, float lr_t,
+                                         float b1, float b2, float eps, float clip, float gscale) {
+  float g = gi * gscale;
+  if (clip > 0.f) g = (g != g) ? g : fminf(fmaxf(g, -clip), clip);   // main.py:359-362
+  mi = b1 * mi + (1.f - b1) * g;
+  vi = b2 * vi + (1.f - b2) * g * g;
+  th -= lr_t * mi / (sqrtf(vi) + eps);                              // eps outside the root (TF1)
+}
+
+__global__ __launch_bounds__(256) void adam_clip_kernel(
+    int64_t n, float* __restrict__ theta, float* __restrict__ grad, float* __restrict__ m,
+    float* __restrict__ v, float lr_t, float b1, float b2, float eps, float clip, float gscale,
+    int zero_grad, int vec) {
+  const int64_t n4 = vec ? n / 4 : 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = t0; i < n4; i += stride) {
+    f32x4 th = reinterpret_cast<f32x4*>(theta)[i], g = reinterpret_cast<f32x4*>(grad)[i];
+    f32x4 mi = reinterpret_cast<f32x4*>(m)[i], vi = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float t_ = th[c], g_ = g[c], m_ = mi[c], v_ = vi[c];
+      adam_one(t_, g_, m_, v_, lr_t, b1, b2, eps, clip, gscale);
+      th[c] = t_; mi[c] = m_; vi[c] = v_;
+    }
+    reinterpret_cast<f32x4*>(theta)[i] = th;
+    reinterpret_cast<f32x4*>(m)[i] = mi;
+    reinterpret_cast<f32x4*>(v)[i] = vi;
+    if (zero_grad) reinterpret_cast<f32x4*>(grad)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int64_t i = n4 * 4 + t0; i < n; i += stride) {
+    float th = theta[i], g = grad[i], mi = m[i], vi = v[i];
+    adam_one(th, g, mi, vi, lr_t, b1, b2, eps, clip, gscale);
+    theta[i] = th; m[i] = mi; v[i] = vi;
+    if (zero_grad) grad[i] = 0.f;
   }
 }
 
 extern "C" int danet_adam_clip_step(danet_stream_t stream, int64_t n, float* theta,
-                                    const float* grad, float* m, float* v, float lr_t,
+                                    float* grad, float* m, float* v, float lr_t,
                                     float beta1, float beta2, float eps, float clip,
-                                    float grad_scale) {
+                                    float grad_scale, int zero_grad) {
   DANET_CHECK_ARG(n > 0 && theta && grad && m && v, "adam: bad args");
-  const int grid = (int)min((int64_t)2048, cdiv64(n, 256));
+  const int vec = (((uintptr_t)theta | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+  const int grid = (int)min((int64_t)2048, cdiv64(vec ? cdiv64(n, 4) : n, 256));
   adam_clip_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(n, theta, grad, m, v, lr_t, beta1,
-                                                          beta2, eps, clip, grad_scale);
+                                                          beta2, eps, clip, grad_scale,
+                                                          zero_grad, vec);
   DANET_CHECK_LAUNCH();
   return DANET_OK;
 }

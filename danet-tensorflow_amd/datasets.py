@@ -86,3 +86,33 @@ class SynthSpeechData(Dataset):
 
     def install_and_load(self):
         self.is_loaded = True
+
+
+@hparams.register_dataset('synth-varlen')
+class SynthVarLenSpeechData(SynthSpeechData):
+    '''the same generator with utterances of DIFFERENT lengths, batched the way the
+    reference's WSJ0 / TIMIT iterators batch variable-length utterances
+    (app/datasets/wsj0.py:51-55, timit.py): every spectrogram is zero-padded on both sides
+    of the time axis to the longest of the batch by `utils.random_zeropad` (python
+    `random`, app/utils.py:78-92).  Padded frames are exact zeros, so a mixture whose
+    sources are all padded at a frame has |mix| = 0 there: the argmax / threshold /
+    weighted-mean tie cases of the estimators reach the full model.'''
+    MIN_FRAMES = 96
+
+    def epoch(self, subset, batch_size, shuffle=False):
+        if not self.is_loaded:
+            raise RuntimeError('Dataset is not loaded.')
+        import torch
+        from . import utils
+        base = {'train': 0, 'valid': 10 ** 6, 'test': 2 * 10 ** 6}[subset]
+        for i in range(self.N_BATCH[subset]):
+            seed = base + i if not shuffle else base + int(np.random.randint(0, 10 ** 5))
+            rng = np.random.RandomState(seed + 7)
+            lens = rng.randint(self.MIN_FRAMES, self.N_FRAMES + 1, size=batch_size)
+            waves = synth_waves(seed, batch_size, self.N_FRAMES)
+            S = hparams.FFT_STRIDE
+            data = [utils.stft(torch.as_tensor(w[:(n - 1) * S])).cpu().numpy()
+                    for w, n in zip(waves, lens)]
+            max_len = max(map(len, data))
+            spectra_li = [utils.random_zeropad(x, max_len - len(x), axis=-2) for x in data]
+            yield (np.stack(spectra_li),)

@@ -40,6 +40,9 @@ class Model(object):
         self.learn_rate = float(hparams.LR)
         self.step_count = 0
         self.built = False
+        # True: gradients stay readable after train_step (grad_dict); costs one fill
+        # kernel per step.  False: the optimiser kernel zeroes them after use.
+        self.keep_grads = False
 
     # ------------------------------------------------------------ variables
     def get_variable(self, name, shape, init):
@@ -118,15 +121,33 @@ class Model(object):
             self.vars[k] = nv
             off += m
         self._flat, self._flat_grad = flat, grad
+        # a backward pass outside train_step (tests, user code) leaves gradients behind:
+        # autograd's accumulation marks the bucket dirty so the next train_step clears it
+        self._grads_clean = True
+        import weakref
+        me = weakref.ref(self)
+
+        def _mark_dirty(_p):
+            m = me()
+            if m is not None:
+                m._grads_clean = False
+        for k in self._order:
+            self.vars[k].register_post_accumulate_grad_hook(_mark_dirty)
+        # gradient reduction schedule (dist.py): 'tail' (default) = everything but the
+        # bottom encoder layer is all-reduced under that layer's weight-gradient GEMMs, the
+        # rest after backward; '1' = per-layer buckets under the remaining BPTT kernels
+        # (opt-in); '0' = one all-reduce after backward
         self._buckets = None
-        if os.environ.get('DANET_OVERLAP_ALLREDUCE', '0') == '1':
+        mode = os.environ.get('DANET_OVERLAP_ALLREDUCE', 'tail')
+        if mode in ('1', 'tail'):
             offs, off = {}, 0
             for k in self._order:
                 v = self.vars[k]
                 offs[v.data_ptr()] = (off, off + v.numel())
                 off += v.numel()
-            self._buckets = dist.GradBuckets(grad, offs)
-            ops.GRAD_READY_HOOKS.append(self._buckets.hook)
+            cls = dist.GradBuckets if mode == '1' else dist.TailOverlap
+            self._buckets = cls(grad, offs)
+            ops.add_grad_ready_hook(self._buckets.hook)
 
     # -------------------------------------------------------------- forward
     def forward(self, s_src_signals, with_valid=False, with_train=True):
@@ -183,20 +204,25 @@ class Model(object):
         '''one `g_sess.run(train_fetches)` (main.py:430-431): forward, backward,
         gradient all-reduce, value clip, Adam.  Returns dict(loss, SNR, LR) of
         device scalars (no host sync unless the caller reads them).'''
-        self._flat_grad.zero_()
+        ops.poll_status(self.device)       # raises if an earlier launch reported a timeout
+        if not self._grads_clean:
+            self._flat_grad.zero_()
         out = self.forward(s_src_signals)
-        out['loss'].backward()
-        if self._buckets is not None:
-            grad_scale = self._buckets.finish()                # pieces launched during backward
-        else:
-            grad_scale = dist.allreduce_grads_(self._flat_grad)    # ONE RCCL all-reduce / step
+        with ops.fast_backward():          # kernels add straight into the flat bucket
+            out['loss'].backward()
+            if self._buckets is not None:
+                grad_scale = self._buckets.finish()            # pieces launched during backward
+            else:
+                grad_scale = dist.allreduce_grads_(self._flat_grad)    # ONE RCCL all-reduce / step
         self.step_count += 1
-        self.ozer.step(self.step_count, self.learn_rate,
-                       clip=hparams.GRAD_CLIP_THRES, grad_scale=grad_scale)
+        self.ozer.step(self.step_count, self.learn_rate, clip=hparams.GRAD_CLIP_THRES,
+                       grad_scale=grad_scale, zero_grad=not self.keep_grads)
+        self._grads_clean = not self.keep_grads
         return dict(loss=out['loss'].detach(), SNR=out['SNR'], LR=self.learn_rate)
 
     def valid_step(self, s_src_signals):
         '''`g_sess.run(valid_fetches)` (main.py:499-500)'''
+        ops.poll_status(self.device)
         with torch.no_grad():
             out = self.forward(s_src_signals, with_valid=True, with_train=False)
         return dict(loss=out['valid_loss'], SNR=out['valid_SNR'])
@@ -206,6 +232,7 @@ class Model(object):
         685-690): complex mixture [B,T,F] -> separated complex [B,C,T,F] using
         the inference estimator and the mixture phase (main.py:333-335).'''
         B, E = hparams.BATCH_SIZE, hparams.EMBED_SIZE
+        ops.poll_status(self.device)
         with torch.no_grad():
             fe = ops.frontend(s_mixed_signals[:, None].contiguous())
             s_embed = self.encoder(fe['mix_log'])
@@ -219,6 +246,15 @@ class Model(object):
 
     def get_learn_rate(self):
         return self.learn_rate
+
+    def check_status(self):
+        '''blocking check of the persistent kernels' hand-off status (end of an epoch /
+        before parameters are saved); raises DanetHipError after a timeout'''
+        ops.check_status(self.device)
+
+    def zero_grad(self):
+        self._flat_grad.zero_()
+        self._grads_clean = True
 
     def reset_state(self):
         '''RNN states are never carried (main.py:538-540 re-zeros zeros)'''

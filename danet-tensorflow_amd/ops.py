@@ -214,19 +214,86 @@ def istft(X, stride, window):
 # ---------------------------------------------------------------------------
 class _LayerCtx(object):
     __slots__ = ('x', 'ldx', 'D', 'T', 'B', 'H', 'ndir', 'ypad', 'gates', 'cells',
-                 'Ws', 'bs', 'status')
+                 'Ws', 'bs')
 
 
-_pending_status = []
+# ---- hand-off status of the persistent kernels ------------------------------
+# ONE sticky int32 per device (include/danet_hip.h: `status` of danet_lstm_fwd/bwd): the
+# kernels set it when a bounded inter-workgroup wait times out.  The product path reads it
+# back without a per-step synchronisation: every STATUS_POLL_EVERY calls of `poll_status`
+# an asynchronous 4-byte copy into pinned host memory is enqueued, and the previous copy is
+# inspected once its event has completed; `check_status` is the blocking form (end of an
+# epoch, tests, bench).  No launch workspace is ever retained.
+STATUS_POLL_EVERY = int(__import__('os').environ.get('DANET_STATUS_POLL_EVERY', '16'))
+TIMEOUT_MSG = ('persistent LSTM kernel: an inter-workgroup hand-off timed out -- the outputs of '
+               'that launch (and everything computed from them) are invalid')
+
+
+class _DeviceStatus(object):
+    __slots__ = ('word', 'host', 'event', 'pending', 'calls')
+
+    def __init__(self, dev):
+        self.word = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.host = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self.event = torch.cuda.Event()
+        self.pending = False
+        self.calls = 0
+
+
+_status = {}
+
+
+def _dev_status(dev):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _status.get(key)
+    if st is None:
+        st = _status[key] = _DeviceStatus(torch.device('cuda', key))
+    return st
+
+
+def status_word(dev):
+    '''the device's sticky int32 status tensor (element 0 = LSTM hand-off)'''
+    return _dev_status(dev).word
+
+
+def _raise_timeout(st):
+    st.word.zero_()              # so the caller may restore parameters and go on
+    st.pending = False
+    raise _lib.DanetHipError(TIMEOUT_MSG)
+
+
+def poll_status(dev):
+    '''non-blocking check (see above); raises DanetHipError one poll period after a
+    timeout at the latest.  Called by Model.train_step / valid_step / infer.'''
+    st = _dev_status(dev)
+    if st.pending and st.event.query():
+        st.pending = False
+        if int(st.host[0]) != 0:
+            _raise_timeout(st)
+    st.calls += 1
+    if not st.pending and st.calls % max(STATUS_POLL_EVERY, 1) == 0:
+        st.host.copy_(st.word, non_blocking=True)
+        st.event.record()
+        st.pending = True
+
+
+def check_status(dev=None):
+    '''blocking check of the status word; raises DanetHipError on a recorded timeout'''
+    for st in ([_dev_status(dev)] if dev is not None else list(_status.values())):
+        st.pending = False
+        if int(st.word[0].item()) != 0:
+            _raise_timeout(st)
 
 
 def lstm_status_ok():
     '''True when no persistent-LSTM launch since the last call reported an
-    inter-workgroup timeout.  Synchronises.'''
+    inter-workgroup timeout (clears the word).  Synchronises.'''
     ok = True
-    for s in _pending_status:
-        ok = ok and int(s.item()) == 0
-    del _pending_status[:]
+    for st in _status.values():
+        st.pending = False
+        if int(st.word[0].item()) != 0:
+            ok = False
+            st.word.zero_()
     return ok
 
 
@@ -298,17 +365,21 @@ class _Fork(object):
         with torch.cuda.stream(s):
             return fn()
 
-    def after_all(self, fn):
+    def after_all(self, fn, wait_main=False):
         '''run fn() on one of the used side streams once ALL side chains of this
         fork have been issued (that stream first waits for the others) -- the
         place to launch work that consumes everything the chains produce, e.g. a
-        gradient-bucket all-reduce.  With no side stream in use, fn runs in place.'''
+        gradient-bucket all-reduce.  wait_main: part of that work was issued on the
+        main stream (chain 0), so the side stream waits for the main stream's
+        current position too.  With no side stream in use, fn runs in place.'''
         used = list(self.used)
         if not used:
             return fn()
         first = used[0]
         for s in used[1:]:
             first.wait_stream(s)
+        if wait_main:
+            first.wait_stream(self.main)
         with torch.cuda.stream(first):
             return fn()
 
@@ -327,22 +398,61 @@ _deferred = []
 # issued (on the stream that is current during the call); tag = ('layer', l) /
 # ('out',).  Model uses it to launch per-bucket gradient all-reduces that overlap
 # the rest of backward (dist.GradBuckets).
+# ('rest', ) additionally fires on a side stream that has waited for the main stream right
+# after the BOTTOM layer's BPTT kernel of an encoder was issued: from then on every gradient
+# except the bottom layer's own is final (dist.TailOverlap reduces them under the bottom
+# layer's weight-gradient GEMMs).  Entries are weak references to bound methods (a
+# disposed Model drops out by itself).
 GRAD_READY_HOOKS = []
 
 
+def add_grad_ready_hook(bound_method):
+    import weakref
+    GRAD_READY_HOOKS.append(weakref.WeakMethod(bound_method))
+
+
+def _live_hooks():
+    live = [(r, r()) for r in GRAD_READY_HOOKS]
+    if any(h is None for _, h in live):
+        GRAD_READY_HOOKS[:] = [r for r, h in live if h is not None]
+    return [h for _, h in live if h is not None]
+
+
 def _fire_grad_ready(tag, params):
-    for h in GRAD_READY_HOOKS:
+    for h in _live_hooks():
         h(tag, params)
 
+
+# Fast backward (scoped: only inside `with ops.fast_backward():`, which Model.train_step
+# enters).  (1) kernels ADD the parameter gradients straight into an existing dense
+# `param.grad` (a view of Model's flat all-reduce bucket) and hand autograd None -- one
+# elementwise accumulate kernel less per parameter; outside the scope every backward returns
+# ordinary gradient tensors, so torch.autograd.grad / double backward / foreign optimisers see
+# standard autograd behaviour.  (2) the gradient-ready hooks above fire.
 DIRECT_GRADS = __import__('os').environ.get('DANET_DIRECT_GRADS', '1') == '1'
+_fast_depth = [0]
+
+
+class fast_backward(object):
+    def __enter__(self):
+        _fast_depth[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _fast_depth[0] -= 1
+        return False
+
+
+def _fast():
+    return _fast_depth[0] > 0
 
 
 def _grad_target(param, shape, dev):
     """(tensor to accumulate the gradient of `param` into, is_direct).  Direct =
-    the parameter already owns a dense .grad (e.g. a view of Model's flat
-    gradient bucket): kernels add into it (beta=1) and autograd is handed None,
-    which saves one elementwise accumulate kernel per parameter per step."""
-    g = param.grad if (DIRECT_GRADS and torch.is_tensor(param)) else None
+    inside `fast_backward()` and the parameter already owns a dense .grad (e.g. a
+    view of Model's flat gradient bucket): kernels add into it (beta=1) and
+    autograd is handed None."""
+    g = param.grad if (DIRECT_GRADS and _fast() and torch.is_tensor(param)) else None
     if g is not None and g.is_contiguous() and tuple(g.shape) == tuple(shape):
         return g, True
     return torch.empty(*shape, device=dev), False
@@ -386,12 +496,11 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs):
         check(L.danet_lstm_fwd(
             _lib.stream(), T, B, H, ndir, ptr(gates[0]), ptr(gates[-1]),
             ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(ypad), ndir * H,
-            ptr(gates[0]), ptr(gates[-1]), ptr(cells[0]), ptr(cells[-1]), ptr(ws), wn))
+            ptr(gates[0]), ptr(gates[-1]), ptr(cells[0]), ptr(cells[-1]), ptr(ws), wn,
+            ptr(status_word(dev))))
     c = _LayerCtx()
     c.x, c.ldx, c.D, c.T, c.B, c.H, c.ndir = x, ldx, D, T, B, H, ndir
     c.ypad, c.gates, c.cells, c.Ws, c.bs = ypad, gates, cells, Ws, bs
-    c.status = ws[:4].view(torch.int32)
-    _pending_status.append(c.status)
     return c
 
 
@@ -407,8 +516,8 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
         check(L.danet_lstm_bwd(
             _lib.stream(), T, B, H, ndir, ptr(_f32(dy)), ndir * H,
             ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(c.gates[0]), ptr(c.gates[-1]),
-            ptr(c.cells[0]), ptr(c.cells[-1]), ptr(das[0]), ptr(das[-1]), ptr(ws), wn))
-    _pending_status.append(ws[:4].view(torch.int32))
+            ptr(c.cells[0]), ptr(c.cells[-1]), ptr(das[0]), ptr(das[-1]), ptr(ws), wn,
+            ptr(status_word(dev))))
     ldy = ndir * H
     # gradients accumulate straight into the parameters' .grad (the model's flat
     # all-reduce bucket) when there is one; autograd then gets None for them
@@ -473,19 +582,36 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
     # (`join_deferred`).
     if need_dx:
         input_grad()
+    hooks = bool(GRAD_READY_HOOKS) and _fast() and layer_tag is not None and \
+        all(a and b for a, b in direct)
+    if hooks and not need_dx:
+        # bottom layer of an encoder: its BPTT kernel is on the main stream, the weight-
+        # gradient chains of every layer above are on the side streams -- a stream that has
+        # waited for all of them sees every gradient except this layer's in its final state
+        sides = _side_streams(dev, max(SIDE_STREAMS, 1))
+        main = torch.cuda.current_stream(dev)
+        for sd in sides[1:]:
+            sides[0].wait_stream(sd)
+        sides[0].wait_stream(main)
+        with torch.cuda.stream(sides[0]):
+            _fire_grad_ready(('rest',), list(c.Ws) + list(c.bs))
     with _Fork(dev, ndir + 1, defer=True, keep=(das, c.x, c.ypad, dy)) as f:
+        on_main = False
         if GROUPED_DW and not need_dx:
             # bottom layer: no BPTT kernel follows, so the group takes the whole GPU on
             # the main stream while the column sums run beside it
             f.run(1, bias_grads)
             weight_grads_grouped(wgs=512, with_bias=False)
+            on_main = True
         elif GROUPED_DW:
             f.run(1, weight_grads_grouped)
         else:
             for d in range(ndir):
                 f.run(d + 1, lambda d=d: weight_grads(d))
-        if GRAD_READY_HOOKS and all(a and b for a, b in direct):
-            f.after_all(lambda: _fire_grad_ready(('layer', layer_tag), list(c.Ws) + list(c.bs)))
+        if hooks:
+            # (wait_main: the bottom layer's group GEMM ran on the main stream)
+            f.after_all(lambda: _fire_grad_ready(('layer', layer_tag), list(c.Ws) + list(c.bs)),
+                        wait_main=on_main)
     dWs = [None if direct[d][0] else dWs[d] for d in range(ndir)]
     dbs = [None if direct[d][1] else dbs[d] for d in range(ndir)]
     return dx, dWs, dbs
@@ -571,7 +697,7 @@ class RnnEncoderFn(torch.autograd.Function):
                 f.run(1, lambda: gemm(ctx.yc, dembed, dWout, D, O, B * T, D, O, O, transA=True,
                                       beta=1.0 if direct_out else 0.0,
                                       max_workgroups=2 * OVERLAP_GEMM_WGS, tag='dWout'))
-            if GRAD_READY_HOOKS and direct_out:
+            if GRAD_READY_HOOKS and _fast() and direct_out:
                 f.after_all(lambda: _fire_grad_ready(('out',), [ctx.Wout]))
         dy = torch.empty(T, B, D, device=dev)
         center(dyc, B, T, D, 0, D, dy, 1, D)                 # centre is self-adjoint
@@ -646,18 +772,34 @@ TRUTH_MODES = {'truth': 0, 'truth-threshold': 1, 'truth-weighted': 2}
 # estimator's backward -- whose kernels accumulate (`dembed += ...`) -- adds into that
 # buffer in place and returns no gradient of its own.  DANET_FUSE_DEMBED=0 disables.
 FUSE_DEMBED = int(__import__('os').environ.get('DANET_FUSE_DEMBED', '1'))
-_dembed_slot = {}
 
 
-def _publish_dembed(embed_ptr, t):
-    if FUSE_DEMBED:
-        _dembed_slot['v'] = (embed_ptr, t)
+class _DembedToken(object):
+    '''links an estimator's autograd node to the separator node that consumes its
+    attractors: created in the estimator's forward, carried on the attractor tensor
+    (`attr._danet_dembed_token`; lost -- and the fusion with it -- if the caller
+    transforms the attractors in between), picked up by SeparateFn.forward.  No global
+    state, so several models / re-entrant backward passes cannot alias each other.'''
+    __slots__ = ('dembed',)
+
+    def __init__(self):
+        self.dembed = None
 
 
-def _take_dembed(embed_ptr, numel):
-    v = _dembed_slot.pop('v', None)
-    if v is not None and v[0] == embed_ptr and v[1].numel() == numel:
-        return v[1]
+def _new_token(attr):
+    if not FUSE_DEMBED:
+        return None
+    tok = _DembedToken()
+    attr._danet_dembed_token = tok
+    return tok
+
+
+def _take_dembed(tok, numel):
+    if tok is None:
+        return None
+    t, tok.dembed = tok.dembed, None
+    if t is not None and t.numel() == numel:
+        return t
     return None
 
 
@@ -682,15 +824,14 @@ class TruthAttractorFn(torch.autograd.Function):
                                           ptr(denom), ptr(w), wn))
         ctx.save_for_backward(src_pwr, mix_pwr, denom)
         ctx.args = (mode, eps, B, C, N, E, T, F)
-        ctx.embed_ptr = embed.data_ptr()
-        _dembed_slot.clear()
+        ctx.token = _new_token(attr)
         return attr
 
     @staticmethod
     def backward(ctx, dattr):
         src_pwr, mix_pwr, denom = ctx.saved_tensors
         mode, eps, B, C, N, E, T, F = ctx.args
-        shared = _take_dembed(ctx.embed_ptr, B * T * F * E)
+        shared = _take_dembed(ctx.token, B * T * F * E)
         dembed = shared if shared is not None else torch.zeros(B, T, F, E, device=dattr.device)
         check(_L().danet_attractor_truth_bwd(
             _lib.stream(), mode, B, C, N, E, ptr(_f32(dattr.contiguous())), ptr(src_pwr),
@@ -723,7 +864,7 @@ class AnchorAttractorFn(torch.autograd.Function):
         ctx.args = (B, C, N, E, A, T, F)
         ctx.mark_non_differentiable(asets, choice)
         ctx.set_materialize_grads(False)
-        _dembed_slot.clear()
+        ctx.token = _new_token(attr)
         return attr, asets, choice
 
     @staticmethod
@@ -733,7 +874,7 @@ class AnchorAttractorFn(torch.autograd.Function):
         embed, anchors, attr, asum, choice = ctx.saved_tensors
         B, C, N, E, A, T, F = ctx.args
         dev = dattr.device
-        shared = _take_dembed(embed.data_ptr(), B * T * F * E)
+        shared = _take_dembed(ctx.token, B * T * F * E)
         dembed = shared if shared is not None else torch.zeros(B, T, F, E, device=dev)
         danchors = torch.empty(A, E, device=dev)
         L = _L()
@@ -764,6 +905,7 @@ class SeparateFn(torch.autograd.Function):
                                       ptr(embed_flat), ptr(out), ptr(masks)))
         ctx.save_for_backward(mix_pwr, attr, embed_flat)
         ctx.args = (act, B, C, N, E)
+        ctx.token = getattr(attr, '_danet_dembed_token', None)
         if masks is None:
             masks = torch.empty(0, device=dev)
         ctx.mark_non_differentiable(masks)
@@ -784,8 +926,9 @@ class SeparateFn(torch.autograd.Function):
         check(L.danet_separate_bwd(_lib.stream(), act, B, C, N, E, ptr(mix_pwr), ptr(attr),
                                    ptr(embed_flat), ptr(_f32(dout.contiguous())), ptr(dembed),
                                    ptr(dattr), ptr(w), wn))
-        if ctx.needs_input_grad[1]:      # an estimator backward follows (it made attr)
-            _publish_dembed(embed_flat.data_ptr(), dembed)
+        if ctx.token is not None and ctx.needs_input_grad[1]:
+            # the estimator that made `attr` runs its backward next and adds into `dembed`
+            ctx.token.dembed = dembed
         return None, dattr, dembed, None, None
 
 
@@ -840,9 +983,10 @@ def pit_mse_loss(s_x, s_y_pwr, phasor, mode=0, eps=1e-7):
 
 
 def adam_clip_step(theta, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, clip=100.0,
-                   grad_scale=1.0):
+                   grad_scale=1.0, zero_grad=False):
     '''flat fp32 buffers; tf.train.AdamOptimizer + clip_by_value
     (main.py:359-363, app/ozers.py:15-18)'''
     check(_L().danet_adam_clip_step(_lib.stream(), theta.numel(), ptr(_f32(theta)),
                                     ptr(_f32(grad)), ptr(_f32(m)), ptr(_f32(v)), lr_t, beta1,
-                                    beta2, eps, clip if clip else 0.0, grad_scale))
+                                    beta2, eps, clip if clip else 0.0, grad_scale,
+                                    int(bool(zero_grad))))

@@ -37,19 +37,21 @@ class TfAdam(_FlatOptimizer):
         self.m = torch.zeros_like(theta)
         self.v = torch.zeros_like(theta)
 
-    def step(self, t, lr, clip=None, grad_scale=1.0):
+    def step(self, t, lr, clip=None, grad_scale=1.0, zero_grad=False):
         lr_t = lr * math.sqrt(1. - self.beta2 ** t) / (1. - self.beta1 ** t)
         ops.adam_clip_step(self.theta, self.grad, self.m, self.v, lr_t, self.beta1,
-                           self.beta2, self.epsilon, clip or 0.0, grad_scale)
+                           self.beta2, self.epsilon, clip or 0.0, grad_scale, zero_grad)
 
 
 class TfSgd(_FlatOptimizer):
     '''tf.train.GradientDescentOptimizer'''
-    def step(self, t, lr, clip=None, grad_scale=1.0):
+    def step(self, t, lr, clip=None, grad_scale=1.0, zero_grad=False):
         g = self.grad * grad_scale
         if clip:
             g = g.clamp_(-clip, clip)
         self.theta.add_(g, alpha=-lr)
+        if zero_grad:
+            self.grad.zero_()
 
 
 @hparams.register_optimizer('sgd')

@@ -40,7 +40,7 @@ extern "C" {
 #define DANET_ERR_UNSUPPORTED (-3)  /* shape outside the compiled envelope     */
 #define DANET_ERR_WORKSPACE (-4)    /* ws too small                            */
 
-#define DANET_ABI_VERSION 1
+#define DANET_ABI_VERSION 2
 
 typedef void* danet_stream_t;
 
@@ -186,11 +186,17 @@ size_t danet_colsum_f32_workspace_bytes(int M, int N);
  *   cell_d [T][B][H]   saved c_t
  * ndir = 1 (lstm-orig) or 2 (bilstm-orig); *_b pointers ignored if ndir=1.
  * Requirements: H % 4 == 0, H <= 608, ypad 16-byte aligned, ldy % 4 == 0,
- * all workgroups of the launch co-resident (checked: <= 256).  The call first
- * fills ypad blocks 1..T with the bit pattern 0xFFFFFFFF ("not yet published":
- * the exchanged state is its own flag), so ypad must not be read concurrently.
- * After the launch, ws word 0 (int32) is 0 on success and non-zero if a bounded
- * inter-workgroup wait timed out (the outputs are then invalid).            */
+ * all workgroups of the launch co-resident (checked: <= the device's CU count).
+ * The call first fills ypad blocks 1..T with the bit pattern 0xFFFFFFFF ("not
+ * yet published": the exchanged state is its own flag), so ypad must not be
+ * read concurrently.
+ * Hand-off status: `status` is an optional caller-owned DEVICE int32 that the
+ * kernels set non-zero when a bounded inter-workgroup wait timed out (the
+ * outputs of that launch are then invalid).  It is STICKY: the library never
+ * clears it, so one word can serve every launch of a training run and be read
+ * back once in a while (later launches that find it non-zero give up their
+ * waits early instead of spinning to the bound).  status == NULL: ws word 0 is
+ * used instead and is zeroed by the call.                                  */
 size_t danet_lstm_workspace_bytes(int T, int B, int H, int ndir);
 int danet_lstm_fwd(danet_stream_t stream, int T, int B, int H, int ndir,
                    const float* gx_f, const float* gx_b,
@@ -198,20 +204,20 @@ int danet_lstm_fwd(danet_stream_t stream, int T, int B, int H, int ndir,
                    float* ypad, int ldy,
                    float* gates_f, float* gates_b,
                    float* cell_f, float* cell_b,
-                   void* ws, size_t ws_bytes);
+                   void* ws, size_t ws_bytes, int32_t* status);
 
 /* BPTT of the above.  dy [T][B][lddy] (dir d uses columns [d*H,(d+1)*H)).
  * Outputs da_d [T][B][4H] = dL/d(pre-activation) (16-byte aligned; pre-filled
  * with the 0xFFFFFFFF sentinel by the call); the caller finishes with GEMMs:
  * dWx = X^T da, dWh = Hprev^T da, db = colsum(da), dX = da Wx^T.  Same status
- * word convention as danet_lstm_fwd.                                        */
+ * convention as danet_lstm_fwd.                                             */
 int danet_lstm_bwd(danet_stream_t stream, int T, int B, int H, int ndir,
                    const float* dy, int lddy,
                    const float* Wh_f, const float* Wh_b, int ldw,
                    const float* gates_f, const float* gates_b,
                    const float* cell_f, const float* cell_b,
                    float* da_f, float* da_b,
-                   void* ws, size_t ws_bytes);
+                   void* ws, size_t ws_bytes, int32_t* status);
 
 /* ---------------------------------------------------------------- a8-a10
  * Truth-family attractor estimators (app/modules.py:382-487).
@@ -293,11 +299,15 @@ int danet_pit_mse_bwd(danet_stream_t stream, int mode, int B, int C,
  * clip_by_value + tf.train.AdamOptimizer update (main.py:359-363,
  * app/ozers.py:15-18): g = clamp(grad*grad_scale, +-clip);
  * m,v EMA; theta -= lr_t * m / (sqrt(v) + eps), lr_t precomputed by host
- * as lr*sqrt(1-b2^t)/(1-b1^t).  clip <= 0 disables clipping.              */
+ * as lr*sqrt(1-b2^t)/(1-b1^t).  clip <= 0 disables clipping.  A NaN gradient
+ * stays NaN through the clip (tf.clip_by_value propagates NaN), so a diverged
+ * step poisons the parameters and the caller's NaN-restore (main.py:462-476)
+ * sees it.  zero_grad != 0: grad is overwritten with zeros after use (the
+ * next backward accumulates into it; no separate fill kernel).             */
 int danet_adam_clip_step(danet_stream_t stream, int64_t n, float* theta,
-                         const float* grad, float* m, float* v, float lr_t,
+                         float* grad, float* m, float* v, float lr_t,
                          float beta1, float beta2, float eps, float clip,
-                         float grad_scale);
+                         float grad_scale, int zero_grad);
 
 #ifdef __cplusplus
 }

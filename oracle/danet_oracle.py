@@ -473,6 +473,9 @@ def model_forward(src, params, cfg, dtype=np.float64):
         embed = bilstm_encoder(fe['mix_log'], p, H, L, E)   # main.py:243
     elif enc == 'lstm-orig':
         embed = lstm_encoder(fe['mix_log'], p, H, L, E)
+    elif enc == 'toy':                                      # app/modules.py:96-116
+        F_ = fe['mix_log'].shape[-1]
+        embed = toy_encoder(fe['mix_log'], p, F_, E, cfg['fft_size'], cfg.get('relu_leak', 0.))
     else:
         raise KeyError(enc)
     B, T, F, _ = embed.shape

@@ -81,6 +81,16 @@ def lstm_encoder(x, params, H, L, E):
     return out.reshape(B, T, F, E)
 
 
+def toy_encoder(x, params, E, relu_leak=0.):
+    '''ToyEncoder (app/modules.py:96-116): linear -> (leaky) relu (app/ops.py:93-107) ->
+    linear, both with bias (ops.lyr_linear, app/ops.py:72-89)'''
+    B, T, F = x.shape
+    m = x @ params['global/encoder/linear0/W'] + params['global/encoder/linear0/B']
+    m = torch.relu(m) if relu_leak == 0. else torch.maximum(m * relu_leak, m)
+    o = m @ params['global/encoder/linear1/W'] + params['global/encoder/linear1/B']
+    return o.reshape(B, T, F, E)
+
+
 def _truth_family(embed, src_pwr, wgt, denom_add):
     '''app/modules.py:390-487: segment sums by argmax_c |src|'''
     B, T, F, E = embed.shape
@@ -172,6 +182,8 @@ def model_forward(src, params, cfg):
     eps = cfg.get('eps', 1e-7)
     if cfg.get('encoder', 'bilstm-orig') == 'bilstm-orig':
         embed = bilstm_encoder(fe['mix_log'], params, H, L, E)
+    elif cfg['encoder'] == 'toy':
+        embed = toy_encoder(fe['mix_log'], params, E, cfg.get('relu_leak', 0.))
     else:
         embed = lstm_encoder(fe['mix_log'], params, H, L, E)
     B, T, F, _ = embed.shape

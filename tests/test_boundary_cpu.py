@@ -33,7 +33,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), 'missing export: ' + s
     assert set(_lib.PROTOTYPES) == set(syms), set(_lib.PROTOTYPES) ^ set(syms)
-    assert lib.danet_abi_version() == 1
+    assert lib.danet_abi_version() == 2
     # pure host-side helpers are callable without a GPU
     assert lib.danet_stft_num_frames(8000, 256, 64) == 126
     assert lib.danet_stft_num_frames(160000, 512, 128) == 1251
@@ -57,7 +57,7 @@ def test_bad_arguments_return_error_codes_not_crashes():
     rc = lib.danet_gemm_f32(None, 0, 0, 0, 4, 4, None, 4, None, 4, None, 4, None, 0.0, None, 0)
     assert rc == -1 and b'gemm' in lib.danet_last_error()
     rc = lib.danet_lstm_fwd(None, 4, 2, 6, 2, None, None, None, None, 24, None, 12,
-                            None, None, None, None, ctypes.c_void_p(8), 64)
+                            None, None, None, None, ctypes.c_void_p(8), 64, None)
     assert rc == -3 and b'multiple of 4' in lib.danet_last_error()
     with pytest.raises(_lib.DanetHipError):
         _lib.check(rc)

@@ -726,7 +726,7 @@ def test_lstm_bwd_handoff_under_uneven_load(B, T, H):
     ws = torch.zeros(n, dtype=torch.uint8, device=dev)
     _lib.check(L.danet_lstm_fwd(st, T, B, H, 2, ptr(gates[0]), ptr(gates[1]), ptr(Wh[0]), ptr(Wh[1]),
                                 4 * H, ptr(ypad), 2 * H, ptr(gates[0]), ptr(gates[1]),
-                                ptr(cells[0]), ptr(cells[1]), ptr(ws), n))
+                                ptr(cells[0]), ptr(cells[1]), ptr(ws), n, None))
     torch.cuda.synchronize()
     assert int(ws[:4].view(torch.int32)[0]) == 0
 
@@ -735,7 +735,7 @@ def test_lstm_bwd_handoff_under_uneven_load(B, T, H):
         w = torch.zeros(n, dtype=torch.uint8, device=dev)
         _lib.check(L.danet_lstm_bwd(st, T, B, H, 2, ptr(dy), 2 * H, ptr(Wh[0]), ptr(Wh[1]), 4 * H,
                                     ptr(gates[0]), ptr(gates[1]), ptr(cells[0]), ptr(cells[1]),
-                                    ptr(das[0]), ptr(das[1]), ptr(w), n))
+                                    ptr(das[0]), ptr(das[1]), ptr(w), n, None))
         return das, w
 
     old = os.environ.get('DANET_LSTM_BWD_RS')

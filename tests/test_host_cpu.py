@@ -1,0 +1,262 @@
+'''
+CPU tests (no GPU) of the host logic around the hot path -- SURVEY 8(f-2):
+the product's `utils.random_zeropad` against the reference golden G4, the
+learning-rate schedule and NaN-restore of the train loop (main.py:439-476), and
+the data-parallel pieces of that loop and of the default gradient-reduction
+schedule (dist.TailOverlap) under gloo, world_size 2.
+'''
+import io
+import os
+import random
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden', 'frontend_ref.npz')
+
+
+def test_product_random_zeropad_matches_reference_golden():
+    '''G4: danet_amd.utils.random_zeropad (the function the datasets call) under
+    random.seed(k) == outputs of the reference's app/utils.py:78-92'''
+    from danet_amd import utils
+    gold = np.load(GOLD)
+    base = gold['zeropad_base']
+    for k in range(4):
+        random.seed(k)
+        assert np.array_equal(utils.random_zeropad(base, 5, axis=0), gold['zeropad_seed%d_axis0' % k])
+        random.seed(k)
+        assert np.array_equal(utils.random_zeropad(base, 7, axis=-1), gold['zeropad_seed%d_axis-1' % k])
+    assert utils.random_zeropad(base, 0, axis=0) is base         # app/utils.py:83-84
+
+
+class _StubModel(object):
+    '''the surface cli.train touches, on CPU'''
+    def __init__(self, losses):
+        self.name = 'stub'
+        self.device = torch.device('cpu')
+        self.lr = None
+        self.losses = list(losses)          # one per train_step
+        self.i = 0
+        self._flat = torch.zeros(3)
+        self.saved, self.loaded, self.lr_log = [], [], []
+
+    def set_learn_rate(self, lr):
+        self.lr = float(lr)
+        self.lr_log.append(self.lr)
+
+    def get_learn_rate(self):
+        return self.lr
+
+    def train_step(self, spectra):
+        v = self.losses[min(self.i, len(self.losses) - 1)]
+        self.i += 1
+        self._flat += 1
+        return dict(loss=v, SNR=1.0, LR=self.lr)
+
+    def valid_step(self, spectra):
+        return dict(loss=0.5, SNR=1.0)
+
+    def reset_state(self):
+        pass
+
+    def check_status(self):
+        pass
+
+    def save_params(self, fn, step=None):
+        self.saved.append((fn, self._flat.clone()))
+
+    def load_params(self, fn):
+        self.loaded.append(fn)
+        for f, t in self.saved:
+            if f == fn:
+                self._flat.copy_(t)
+        return True
+
+
+def _args(**kw):
+    a = types.SimpleNamespace(no_save_on_epoch=False, no_valid_on_epoch=True)
+    a.__dict__.update(kw)
+    return a
+
+
+def _toy_dataset(hp):
+    hp.load(dict(DATASET_TYPE='toy', BATCH_SIZE=2, MAX_N_SIGNAL=2, FFT_SIZE=8, FFT_STRIDE=2,
+                 MAX_TRAIN_LEN=16))
+    hp.digest()
+    ds = hp.get_dataset()()
+    ds.install_and_load()
+    return ds
+
+
+@pytest.mark.parametrize('mode', ['fixed', 'adaptive', None])
+def test_lr_decay_modes(hp, mode):
+    '''main.py:439-459: 'fixed' decays every NUM_EPOCH_PER_LR_DECAY epochs, 'adaptive' only
+    after that many epochs WITHOUT a new best loss, None never'''
+    from danet_amd import cli
+    hp.load(dict(LR=1.0, LR_DECAY=0.5, LR_DECAY_TYPE=mode, NUM_EPOCH_PER_LR_DECAY=2))
+    m = _StubModel([])
+    m.set_learn_rate(1.0)
+    best, btime = float('inf'), 0
+    lrs = []
+    #           new best, new best, worse, worse -> decay, better, worse, worse -> decay
+    for loss in [5.0, 4.0, 4.5, 4.2, 3.0, 3.5, 3.1]:
+        best, btime = cli.lr_decay_update(m, loss, best, btime, io.StringIO())
+        lrs.append(m.get_learn_rate())
+    if mode == 'fixed':
+        assert lrs == [1.0, 0.5, 0.5, 0.25, 0.25, 0.125, 0.125]
+    elif mode == 'adaptive':
+        assert lrs == [1.0, 1.0, 1.0, 0.5, 0.5, 0.5, 0.25]
+        assert best == 3.0
+    else:
+        assert lrs == [1.0] * 7
+    hp.LR_DECAY_TYPE = 'bogus'
+    with pytest.raises(ValueError):
+        cli.lr_decay_update(m, 1.0, best, btime, io.StringIO())
+
+
+def test_nan_restore_redoes_the_epoch(hp, tmp_path, monkeypatch):
+    '''main.py:462-476: an epoch whose mean metrics contain NaN restores the last
+    checkpoint and is run again (the epoch counter does not advance); NaN in the very first
+    epoch exits'''
+    from danet_amd import cli
+    monkeypatch.chdir(tmp_path)
+    ds = _toy_dataset(hp)
+    hp.load(dict(LR=1e-3, LR_DECAY_TYPE=None))
+    nb = 10                                    # toy: 10 batches per epoch
+    losses = [1.0] * nb + [1.0] * (nb - 1) + [float('nan')] + [0.5] * (2 * nb)
+    m = _StubModel(losses)
+    out = io.StringIO()
+    cli.train(m, 3, ds, _args(), out)
+    # epoch 1 ok (saved _e1), epoch 2 NaN -> restore _e1, redo epoch 2, epoch 3
+    assert m.loaded == ['saves/stub_e1']
+    assert [f for f, _ in m.saved] == ['saves/stub_e1', 'saves/stub_e2', 'saves/stub_e3']
+    assert m.i == 4 * nb and 'restoring last checkpoint' in out.getvalue()
+    # parameters after the restore were those saved at the end of epoch 1 (+ the redone epochs)
+    assert float(m.saved[1][1][0]) == float(m.saved[0][1][0]) + nb
+    m2 = _StubModel([float('nan')])
+    with pytest.raises(SystemExit):
+        cli.train(m2, 2, ds, _args(), io.StringIO())
+
+
+_DP_LOOP_WORKER = r'''
+import io, os, sys, types
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+import numpy as np, torch
+import __graft_entry__ as g; g.load_package()
+from danet_amd import dist, cli
+from danet_amd.hparams import hparams
+import test_host_cpu as T
+dist.init_from_env('gloo')
+rank, world = dist.rank(), dist.world_size()
+assert world == 2
+os.chdir(os.environ['DP_OUT'])
+ok = True
+# --- epoch metrics are averaged over ranks; NaN on ONE rank is seen by both
+vals = dist.allreduce_mean_scalars([1.0 + rank, float('nan') if rank == 1 else 2.0], 'cpu')
+ok = ok and vals[0] == 1.5 and vals[1] != vals[1]
+# --- the whole loop: rank 1 alone hits NaN in epoch 2; BOTH ranks must restore and redo it,
+#     and end with identical parameters (rank 0 reads the file, the others get a broadcast)
+hparams.reset()
+ds = T._toy_dataset(hparams)
+hparams.load(dict(LR=1.0, LR_DECAY=0.5, LR_DECAY_TYPE='adaptive', NUM_EPOCH_PER_LR_DECAY=1))
+nb = 10
+if rank == 1:
+    losses = [1.0] * nb + [1.0] * (nb - 1) + [float('nan')] + [0.5] * (2 * nb)
+else:
+    losses = [1.0] * (2 * nb) + [0.5] * (2 * nb)
+m = T._StubModel(losses)
+m._flat += 100.0 * rank                     # replicas that would drift apart without the broadcast
+out = io.StringIO()
+cli.train(m, 3, ds, T._args(), out)
+ok = ok and m.i == 4 * nb and 'restoring last checkpoint' in out.getvalue()
+ok = ok and (rank != 0 or m.loaded == ['saves/stub_e1']) and (rank != 1 or m.loaded == [])
+ok = ok and (rank != 1 or m.saved == [])     # only rank 0 writes files
+# after the restore both ranks hold rank 0's checkpointed parameters + the same number of steps
+t = m._flat.clone()
+torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+ok = ok and bool(torch.equal(t, m._flat)) and float(m._flat[0]) == 4 * nb - nb
+# identical learning-rate history on both ranks (decisions taken on the rank-mean loss)
+lr = torch.tensor(m.lr_log + [0.0] * (8 - len(m.lr_log)))
+lr2 = lr.clone(); torch.distributed.all_reduce(lr2, op=torch.distributed.ReduceOp.MAX)
+ok = ok and bool(torch.equal(lr, lr2))
+# --- default gradient-reduction schedule: 'rest' piece from the hook + bottom layer in finish()
+sizes = [7, 40, 24, 13, 5]
+flat_p = torch.zeros(sum(sizes))
+flat_g = torch.arange(sum(sizes), dtype=torch.float32) * (rank + 1) + 0.25 * rank
+expect = torch.arange(sum(sizes), dtype=torch.float32) * 3 + 0.25
+views, offs, off = [], {}, 0
+for n in sizes:
+    v = flat_p[off:off + n]
+    views.append(v); offs[v.data_ptr()] = (off, off + n); off += n
+for bottom in ([views[0], views[1]], [views[2]], [views[4]]):
+    for trial in range(2):
+        gbuf = flat_g.clone()
+        b = dist.TailOverlap(gbuf, offs)
+        b.hook(('layer', 1), [views[3]])          # per-layer events are not this schedule's
+        assert not b.works
+        b.hook(('rest',), bottom)
+        n_pieces = len(b.works)
+        b.hook(('rest',), bottom)                 # fires once per step
+        assert len(b.works) == n_pieces and n_pieces in (1, 2)
+        scale = b.finish()
+        ok = ok and scale == 0.5 and bool(torch.equal(gbuf, expect)) and not b.works and not b.fired
+# no 'rest' event at all (e.g. the toy encoder): finish() reduces the whole bucket
+gbuf = flat_g.clone()
+b = dist.TailOverlap(gbuf, offs)
+ok = ok and b.finish() == 0.5 and bool(torch.equal(gbuf, expect))
+open(os.path.join(os.environ['DP_OUT'], 'loop' + str(rank) + '.txt'), 'w').write('OK' if ok else 'BAD')
+'''
+
+
+def test_data_parallel_train_loop_and_tail_overlap_gloo_world2(tmp_path):
+    '''rank-collective LR / NaN-restore decisions (cli.train) and dist.TailOverlap == one
+    all-reduce of the whole bucket, under gloo with 2 processes'''
+    script = tmp_path / 'loop_worker.py'
+    script.write_text(_DP_LOOP_WORKER % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', DP_OUT=str(tmp_path))
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    out = subprocess.run(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+         '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
+        capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    for r in range(2):
+        assert (tmp_path / ('loop%d.txt' % r)).read_text() == 'OK'
+
+
+def test_bench_cli_surface():
+    '''bench.py: configs named by BASELINE.json exist, the spawn path is taken exactly when no
+    torchrun environment is present and N > 1 (or DANET_FORCE_DIST=1)'''
+    sys.path.insert(0, ROOT)
+    import bench
+    assert {'cfg2', 'cfg4', 'cfg4h600', 'cfg5', 'cfg5-kmeans'} <= set(bench.CONFIGS)
+    c = bench.CONFIGS
+    assert (c['cfg2']['batch'], c['cfg2']['layers'], c['cfg2']['hdim']) == (32, 3, 300)
+    assert c['cfg4h600']['hdim'] == 600 and c['cfg4']['hp']['MAX_N_SIGNAL'] == 3 \
+        and c['cfg4']['hp']['EMBED_SIZE'] == 40
+    assert c['cfg5']['kind'] == 'infer' and c['cfg5']['hp']['FFT_SIZE'] == 512 \
+        and c['cfg5']['frames'] == 1251
+    a = types.SimpleNamespace(gpus=1)
+    env = dict(os.environ)
+    try:
+        os.environ.pop('WORLD_SIZE', None)
+        os.environ.pop('DANET_FORCE_DIST', None)
+        assert bench.maybe_spawn(a) is None                  # N = 1: runs in place
+        os.environ['WORLD_SIZE'] = '4'
+        assert bench.maybe_spawn(types.SimpleNamespace(gpus=4)) is None   # already under torchrun
+        os.environ.pop('WORLD_SIZE')
+        with pytest.raises(SystemExit) as e:                 # N > visible GPUs: clear error
+            bench.maybe_spawn(types.SimpleNamespace(gpus=64))
+        assert 'GPU(s) visible' in str(e.value)
+    finally:
+        os.environ.clear()
+        os.environ.update(env)

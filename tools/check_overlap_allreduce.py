@@ -1,7 +1,11 @@
 #!/usr/bin/env python
-'''1-rank RCCL check of the opt-in overlapped gradient all-reduce: after 3 train
-steps the parameters must be bit-identical to the single-all-reduce path.
-Run with DANET_FORCE_DIST=1 (see bench.py) on a GPU box.'''
+'''1-rank RCCL check of the gradient-reduction schedules (dist.py): after 3 train steps the
+parameters of 'tail' (default: everything but the bottom layer reduced under the bottom
+layer's weight-gradient GEMMs) and '1' (per-layer buckets) must be bit-identical to '0' (one
+all-reduce after backward), and the expected number of asynchronous pieces must have been
+launched from the gradient-ready hooks.  (A 1-rank all-reduce is an identity, so the STREAM
+ORDER of the pieces is checked separately with a doubling stand-in collective:
+tests/test_gpu_extensions.py::test_reduction_schedules_respect_stream_order.)'''
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29577')
@@ -19,23 +23,25 @@ torch.cuda.set_device(0)
 ops.prepare_streams(dev)          # side streams before the RCCL communicator
 torch.distributed.init_process_group('nccl', device_id=dev)
 class A: batch = 32; layers = 3; hdim = 300; frames = 128
-hp = bench.setup_hparams(A)
+hp = bench.setup_hparams(A, bench.CONFIGS['cfg2'])
 batches = bench.make_batches(hp, 0, 2, dev)
 res = {}
-for mode in ('0', '1'):
+for mode in ('0', 'tail', '1'):
     os.environ['DANET_OVERLAP_ALLREDUCE'] = mode
-    del ops.GRAD_READY_HOOKS[:]
     m = Model('o' + mode, device=dev, seed=5).build()
-    assert (m._buckets is not None) == (mode == '1')
+    assert (m._buckets is not None) == (mode != '0')
     for k in range(3):
         m.train_step(batches[k % 2])
     torch.cuda.synchronize()
-    if mode == '1':
-        print('buckets reduced per step:', 'hooks registered =', len(ops.GRAD_READY_HOOKS))
+    if m._buckets is not None:
+        print('mode', mode, 'asynchronous pieces launched from hooks in 3 steps:', m._buckets.launched)
+        assert m._buckets.launched == (3 if mode == 'tail' else 3 * 4), m._buckets.launched
     res[mode] = m.param_dict()
+    del m
 assert ops.lstm_status_ok()
-worst = max(np.abs(res['0'][k] - res['1'][k]).max() for k in res['0'])
-print('max |param diff| overlap vs single all-reduce after 3 steps:', worst)
-assert worst == 0.0
+for mode in ('tail', '1'):
+    worst = max(np.abs(res['0'][k] - res[mode][k]).max() for k in res['0'])
+    print('max |param diff| %s vs single all-reduce after 3 steps:' % mode, worst)
+    assert worst == 0.0
 torch.distributed.destroy_process_group()
 print('OK')

@@ -55,7 +55,7 @@ def main():
         gates = [x.clone() for x in gx]
         _lib.check(L.danet_lstm_fwd(st, T, B, H, ndir, ptr(gates[0]), ptr(gates[1]), ptr(Wh[0]),
                                     ptr(Wh[1]), 4 * H, ptr(ypad), 2 * H, ptr(gates[0]),
-                                    ptr(gates[1]), ptr(cells[0]), ptr(cells[1]), ptr(ws), n))
+                                    ptr(gates[1]), ptr(cells[0]), ptr(cells[1]), ptr(ws), n, None))
         torch.cuda.synchronize()
     assert int(ws[:4].view(torch.int32)[0]) == 0
     report('lstm_fwd', ws, T)
@@ -65,7 +65,7 @@ def main():
         ws = torch.zeros(n, dtype=torch.uint8, device=dev)
         _lib.check(L.danet_lstm_bwd(st, T, B, H, ndir, ptr(dy), 2 * H, ptr(Wh[0]), ptr(Wh[1]), 4 * H,
                                     ptr(gates[0]), ptr(gates[1]), ptr(cells[0]), ptr(cells[1]),
-                                    ptr(das[0]), ptr(das[1]), ptr(ws), n))
+                                    ptr(das[0]), ptr(das[1]), ptr(ws), n, None))
         torch.cuda.synchronize()
     assert int(ws[:4].view(torch.int32)[0]) == 0
     report('lstm_bwd', ws, T)
