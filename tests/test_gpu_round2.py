@@ -365,7 +365,7 @@ def test_varlen_zero_padded_batch_through_full_model(hp):
     from danet_amd import cli
     hp.load(dict(DATASET_TYPE='synth-varlen', BATCH_SIZE=4, MAX_N_SIGNAL=2, FFT_SIZE=64,
                  FFT_STRIDE=16, EMBED_SIZE=4, NUM_LSTM_LAYERS=1, LSTM_HDIM=8, NUM_ANCHOR=4,
-                 MAX_TRAIN_LEN=None))
+                 MAX_TRAIN_LEN=None, ENCODER_TYPE='bilstm-orig', INFER_ESTIMATOR_METHOD='anchor'))
     hp.digest()
     ds = hp.get_dataset()()
     ds.N_FRAMES, ds.MIN_FRAMES = 24, 10
