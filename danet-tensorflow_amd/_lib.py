@@ -54,6 +54,9 @@ PROTOTYPES = {
     'danet_lstm_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int]),
     'danet_lstm_fwd': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_int,
                                c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    'danet_lstm_fwd_fused_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    'danet_lstm_fwd_fused': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_int, c_p, c_p,
+                                     c_int, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     'danet_lstm_bwd': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_int,
                                c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     'danet_attractor_truth_workspace_bytes': (c_sz, [c_int, c_int, c_i64, c_int]),

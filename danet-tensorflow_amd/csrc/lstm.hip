@@ -115,8 +115,14 @@ __device__ __forceinline__ bool spin_fail(unsigned& spins, int* status, int lane
     ((unsigned long long*)((char*)a.status + 64))[(size_t)s * 8 + (slot)] = wall_clock64(); } while (0)
 #define TRACE_VAL(slot, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) \
     ((unsigned long long*)((char*)a.status + 64))[(size_t)s * 8 + (slot)] = (v); } while (0)
+#define TRACE_AT(thr, slot) do { if (blockIdx.x == 0 && threadIdx.x == (thr)) \
+    ((unsigned long long*)((char*)a.status_ws + 64))[(size_t)s * 8 + (slot)] = wall_clock64(); } while (0)
+#define TRACE_AT_VAL(thr, slot, v) do { if (blockIdx.x == 0 && threadIdx.x == (thr)) \
+    ((unsigned long long*)((char*)a.status_ws + 64))[(size_t)s * 8 + (slot)] = (v); } while (0)
 #define TRACE_BYTES(T) ((size_t)(T) * 64)
 #else
+#define TRACE_AT(thr, slot) do {} while (0)
+#define TRACE_AT_VAL(thr, slot, v) do {} while (0)
 #define TRACE(slot) do {} while (0)
 #define TRACE_VAL(slot, v) do {} while (0)
 #define TRACE_BYTES(T) ((size_t)0)
@@ -314,6 +320,319 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
     TRACE(4);
     __syncthreads();
     TRACE(5);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// forward, input projection fused (the whole cell of app/ops.py:139-147 in one kernel)
+// ---------------------------------------------------------------------------
+// The exchange of h_{t-1} costs ~1 us per step during which the matrix cores of the
+// recurrent workgroups idle (152 of 256 CUs at cfg 2, one MFMA chain of 0.66 us per
+// 2.3 us step).  The input half x_t*Wx of a = [x_t, h_{t-1}] W + b does not depend on the
+// recurrence, so this kernel computes it IN that window instead of in a hoisted GEMM.
+//
+// Wave specialisation (512 threads): a first version let the same four waves issue the
+// exchange loads, run the x_t*Wx MFMAs and validate afterwards -- correct, but 4.5 us per
+// step: whenever a first-attempt load had raced a slower producer it was re-issued only
+// after the whole MFMA block, a second full store->load round trip (measured 575 vs
+// 302 + 115 us per layer launch).  The latency-critical polling therefore gets waves of its
+// own:
+//   waves 4-7 ("exchange"): issue the sc1 loads of h_{t-1}, re-issue until every word is
+//     published (immediately, like lstm_fwd_kernel), drop the validated rows into LDS
+//     [16][KP+4]; also prefetch x_{t+1} (plain loads) and stage it in LDS [16][DP+4]; do the
+//     gate math, publish h_t, save gates / cell.
+//   waves 0-3 ("matrix"): hold the workgroup's 32 columns of Wx AND Wh stationary in
+//     registers (K split over the 4 waves, one per SIMD), run x_t*Wx from the LDS copy of
+//     x_t while the exchange waves wait, then h_{t-1}*Wh from the LDS copy of h_{t-1} into
+//     the SAME accumulators, and leave their partial tiles in LDS for the gate phase.
+// Two workgroup barriers per step:  B1 = h_{t-1} staged (exchange -> matrix),
+// B2 = partial tiles written (matrix -> exchange); x_{t+1} is staged between B1 and B2,
+// when no matrix wave reads the x buffer.  Critical path per step: publish -> visible
+// (~1.0 us) -> LDS -> 40 MFMAs -> LDS -> gate math, unchanged; the 80 MFMAs of the input
+// half sit in the shadow of gate math + exchange.  No gx tensor exists (the hoisted GEMM
+// wrote and this kernel re-read 2 x 19.7 MB per layer at cfg 2) and a layer's forward is
+// one launch.  Envelope: 16-row clusters, H <= 320 (every Wh fragment in registers),
+// D <= 640; other shapes take the hoisted-GEMM path (danet_lstm_fwd).
+struct LstmFwdFxArgs {
+  const float* x;        // [T][B][ldx] time-major layer input, columns >= D finite (zero pad)
+  const float* W[2];     // [D+H][ldw]: rows 0..D-1 input half, D..D+H-1 recurrent half
+  const float* bias[2];  // [4H]
+  float* gates[2];
+  float* cell[2];
+  float* ypad;
+  int* status;
+  void* status_ws;       // workspace base (trace records of the diagnostic build)
+  int T, B, H, D, ndir, ldx, ldy, ldw, P, G, KP, DP;   // KP / DP = H / D padded to 16
+  int xmap;
+  unsigned spin_limit;
+  int fault;
+  int mode;   // experiment switches: bit 0 = s_setprio 3 in the exchange waves,
+              // bit 1 = third barrier: the input-half MFMAs start only after the publish
+};
+
+template <int CHX>
+__global__ __launch_bounds__(512) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
+  constexpr int NW = 4, CH = FWD_CH;
+  constexpr int NHL = (16 * 16 * CH * NW / 4 + 255) / 256;    // h chunk loads per exchange thread (5)
+  constexpr int NXL = (16 * 16 * CHX * NW / 4 + 255) / 256;   // x chunk loads per exchange thread
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // smem: xbuf [16][DP+4] (first holds the recurrent weights [KP/4][32][4] for the one-time
+  //       register fill) | hbuf [16][KP+4] | red [NW][16][33]
+  const int HP = a.KP + 4, XP = a.DP + 4;
+  const int xbuf_floats = max(16 * XP, a.KP * 32);
+  float* xbuf = smem;
+  float* hbuf = smem + xbuf_floats;
+  float* red = hbuf + 16 * HP;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bid = blockIdx.x;
+  if (a.fault && bid == 0) return;   // test hook (DANET_LSTM_FAULT_INJECT): never publishes
+  const int ncl = a.ndir * a.G;
+  const int cl = a.xmap ? bid % ncl : bid / a.P;
+  const int dir = cl / a.G, grp = cl % a.G;
+  const int p = a.xmap ? bid / ncl : bid % a.P;
+  const int H = a.H, B = a.B, T = a.T, D = a.D;
+  const int u0 = p * LSTM_UNITS_FWD;
+  const int b0 = grp * 16;
+  const float* Wd = a.W[dir];
+  const bool matrix = wave < NW;
+
+  {
+    const float* W = Wd + (size_t)D * a.ldw;     // recurrent rows
+    for (int idx = tid; idx < a.KP * 32; idx += 512) {
+      const int k = idx >> 5, n = idx & 31;
+      const int gate = n >> 3, u = u0 + (n & 7);
+      float v = 0.f;
+      if (k < H && u < H) v = W[(size_t)k * a.ldw + gate * H + u];
+      xbuf[((k >> 2) * 32 + n) * 4 + (k & 3)] = v;
+    }
+  }
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+
+  if (matrix) {
+    // =========================== matrix waves ===========================
+    const int NG = a.KP / 16;
+    f32x4 wreg[CH][2];
+#pragma unroll
+    for (int g = 0; g < CH; ++g) {
+      const int kg = g * NW + wave;
+      const int k4 = (kg < NG ? kg : 0) * 4 + fq;
+      wreg[g][0] = *reinterpret_cast<const f32x4*>(&xbuf[(k4 * 32 + fr) * 4]);
+      wreg[g][1] = *reinterpret_cast<const f32x4*>(&xbuf[(k4 * 32 + 16 + fr) * 4]);
+      if (kg >= NG) { wreg[g][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; wreg[g][1] = wreg[g][0]; }
+    }
+    f32x4 wx[CHX][2];
+#pragma unroll
+    for (int g = 0; g < CHX; ++g) {
+      const int k0 = (g * NW + wave) * 16 + fq * 4;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int n = nt * 16 + fr;
+        const int gate = n >> 3, u = u0 + (n & 7);
+        f32x4 w = {0.f, 0.f, 0.f, 0.f};
+        if (u < H) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (k0 + j < D) w[j] = Wd[(size_t)(k0 + j) * a.ldw + gate * H + u];
+        }
+        wx[g][nt] = w;
+      }
+    }
+    __syncthreads();   // P1: weights are in registers, the x buffer may be overwritten
+    __syncthreads();   // P2: x of the first step staged
+    for (int s = 0; s < T; ++s) {
+      if ((a.mode & 2) && s > 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();   // B3: h_{t-1} published by this workgroup
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // input half from the staged x_t: four independent accumulator chains
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        acc[nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      f32x4 xf[CHX];
+#pragma unroll
+      for (int g = 0; g < CHX; ++g) {
+        const int k0 = (g * NW + wave) * 16 + fq * 4;
+        xf[g] = (k0 < a.DP) ? *reinterpret_cast<const f32x4*>(&xbuf[fr * XP + k0])
+                            : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int g = 0; g < CHX; ++g) {
+        const f32x4 w0 = wx[g][0], w1 = wx[g][1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[0][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[g][j], w0[j], acc[0][j & 1], 0, 0, 0);
+          acc[1][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[g][j], w1[j], acc[1][j & 1], 0, 0, 0);
+        }
+      }
+      TRACE_AT(0, 5);
+      // the MFMAs above have no memory effect, so nothing but this keeps the compiler from
+      // sinking them below the barrier (it did: barrier first, then all 120 MFMAs in series)
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();   // B1: h_{t-1} staged (zeros at step 0)
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 hf[CH];
+#pragma unroll
+      for (int g = 0; g < CH; ++g) {
+        const int k0 = (g * NW + wave) * 16 + fq * 4;
+        hf[g] = (k0 < a.KP) ? *reinterpret_cast<const f32x4*>(&hbuf[fr * HP + k0])
+                            : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int g = 0; g < CH; ++g) {
+        const f32x4 w0 = wreg[g][0], w1 = wreg[g][1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[0][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(hf[g][j], w0[j], acc[0][j & 1], 0, 0, 0);
+          acc[1][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(hf[g][j], w1[j], acc[1][j & 1], 0, 0, 0);
+        }
+      }
+      // partial tiles for the gate phase.  D layout 16x16: col = lane&15, row = 4*(lane>>4)+r
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          red[(wave * 16 + 4 * fq + r) * 33 + nt * 16 + fr] = acc[nt][0][r] + acc[nt][1][r];
+      TRACE_AT(0, 7);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();   // B2
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    // ========================== exchange waves ==========================
+    const int etid = tid - 64 * NW;
+    const int ewave = wave - NW;
+    const unsigned ybytes = (unsigned)((size_t)(T + 2) * B * a.ldy * sizeof(float));
+    const __amdgpu_buffer_rsrc_t yres = make_rsrc(a.ypad, ybytes);
+    const unsigned xbytes = (unsigned)((size_t)T * B * a.ldx * sizeof(float));
+    const __amdgpu_buffer_rsrc_t xres = make_rsrc(a.x, xbytes);
+    const unsigned xblk = (unsigned)((size_t)B * a.ldx * 4);
+
+    const int bl = etid >> 3, ul = etid & 7;
+    const bool owner = (bl < 16) && (b0 + bl < B) && (u0 + ul < H);
+    const int bg = b0 + bl, unit = u0 + ul;
+    float c_state = 0.f;
+    float bq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (owner) {
+#pragma unroll
+      for (int gte = 0; gte < 4; ++gte) bq[gte] = a.bias[dir][gte * H + unit];
+    }
+
+    // chunk maps: chunk = 4 consecutive floats of one batch row of the cluster
+    const int KQ = a.KP / 4, DQ = a.DP / 4;
+    int hlds[NHL];        // LDS float offset in hbuf (or -1)
+    unsigned hcol[NHL];   // byte offset of the chunk within a time block of ypad (or ~0)
+#pragma unroll
+    for (int i = 0; i < NHL; ++i) {
+      const int idx = etid + 256 * i;
+      const int row = idx / KQ, kq = idx % KQ;
+      hlds[i] = (row < 16) ? row * HP + kq * 4 : -1;
+      hcol[i] = (row < 16 && b0 + row < B && kq * 4 < H)
+                    ? (unsigned)((((size_t)(b0 + row)) * a.ldy + dir * H + kq * 4) * 4) : 0xFFFFFFFFu;
+    }
+    int xlds[NXL];
+    unsigned xcol[NXL];
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+      const int idx = etid + 256 * i;
+      const int row = idx / DQ, kq = idx % DQ;
+      xlds[i] = (row < 16) ? row * XP + kq * 4 : -1;
+      xcol[i] = (row < 16 && b0 + row < B && kq * 4 < D)
+                    ? (unsigned)((((size_t)(b0 + row)) * a.ldx + kq * 4) * 4) : 0xFFFFFFFFu;
+    }
+    const unsigned yblk = (unsigned)((size_t)B * a.ldy * 4);
+
+    __syncthreads();   // P1
+    {  // stage x of the first step
+      const int t0 = dir ? (T - 1) : 0;
+#pragma unroll
+      for (int i = 0; i < NXL; ++i) {
+        const v4u v = __builtin_amdgcn_raw_buffer_load_b128(
+            xres, xcol[i] == 0xFFFFFFFFu ? xbytes : xcol[i] + (unsigned)t0 * xblk, 0, 0);
+        if (xlds[i] >= 0) *reinterpret_cast<v4u*>(&xbuf[xlds[i]]) = v;
+      }
+    }
+    __syncthreads();   // P2
+    if (a.mode & 1) __builtin_amdgcn_s_setprio(3);
+
+    for (int s = 0; s < T; ++s) {
+      const int t = dir ? (T - 1 - s) : s;
+      const int blk_prev = dir ? (t + 2) : t;
+      if ((a.mode & 2) && s > 0) __syncthreads();   // B3
+      TRACE_AT(256, 0);
+      // exchange loads of h_{t-1} first, then the prefetch of the next step's x
+      v4u av[NHL];
+      unsigned hoff[NHL];
+#pragma unroll
+      for (int i = 0; i < NHL; ++i) {
+        hoff[i] = (s > 0 && hcol[i] != 0xFFFFFFFFu) ? hcol[i] + (unsigned)blk_prev * yblk : ybytes;
+        av[i] = load_sc1_b128(yres, hoff[i]);   // out of range -> 0 (valid)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      v4u xr[NXL];
+      {
+        const int tn = dir ? (t - 1) : (t + 1);
+        const bool have = (s + 1 < T);
+#pragma unroll
+        for (int i = 0; i < NXL; ++i)
+          xr[i] = __builtin_amdgcn_raw_buffer_load_b128(
+              xres, (!have || xcol[i] == 0xFFFFFFFFu) ? xbytes : xcol[i] + (unsigned)tn * xblk, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (s > 0) {
+        unsigned spins = 0;
+        for (;;) {
+          bool ok = true;
+#pragma unroll
+          for (int i = 0; i < NHL; ++i) ok &= !has_sentinel(av[i]);
+          if (__all(ok)) break;
+          if (spin_fail(spins, a.status, lane, a.spin_limit)) break;
+#pragma unroll
+          for (int i = 0; i < NHL; ++i) av[i] = load_sc1_b128(yres, hoff[i]);
+        }
+        TRACE_AT_VAL(256, 6, spins);
+      }
+      TRACE_AT(256, 1);
+#pragma unroll
+      for (int i = 0; i < NHL; ++i)
+        if (hlds[i] >= 0) *reinterpret_cast<v4u*>(&hbuf[hlds[i]]) = av[i];
+      __syncthreads();   // B1
+      TRACE_AT(256, 2);
+      // the matrix waves are done with x_t: stage x_{t+1}
+#pragma unroll
+      for (int i = 0; i < NXL; ++i)
+        if (xlds[i] >= 0) *reinterpret_cast<v4u*>(&xbuf[xlds[i]]) = xr[i];
+      __syncthreads();   // B2
+      TRACE_AT(256, 3);
+      if (owner) {
+        float pre[4];
+#pragma unroll
+        for (int gte = 0; gte < 4; ++gte) {
+          float v = bq[gte];
+#pragma unroll
+          for (int w = 0; w < NW; ++w) v += red[(w * 16 + bl) * 33 + gte * 8 + ul];
+          pre[gte] = v;
+        }
+        const float g = pre[0];                 // linear candidate (ops.py:143)
+        const float ig = sigmoid_hw(pre[1]);
+        const float fg = sigmoid_hw(pre[2]);
+        const float og = sigmoid_hw(pre[3]);
+        c_state = ig * g + fg * c_state;        // ops.py:146
+        const float h = og * tanh_hw(c_state);   // ops.py:147
+        float* hp = a.ypad + ((size_t)(t + 1) * B + bg) * a.ldy + dir * H + unit;
+        __hip_atomic_store(hp, h, RLX_AGENT);
+        float* gs = a.gates[dir] + ((size_t)t * B + bg) * (4 * H) + unit;
+        gs[0] = g; gs[H] = ig; gs[2 * H] = fg; gs[3 * H] = og;
+        a.cell[dir][((size_t)t * B + bg) * H + unit] = c_state;
+      }
+      TRACE_AT(256, 4);
+    }
   }
 }
 
@@ -967,6 +1286,86 @@ extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int n
   else if (pl.NW == 16) LAUNCH_FWD(1, 16);
   else if (pl.NW == 8) LAUNCH_FWD(1, 8);
   else LAUNCH_FWD(1, 4);
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
+
+// Fused forward: envelope check shared by the query and the launch
+static bool fwd_fused_ok(int T, int B, int H, int ndir, int D, int* CHX) {
+  if (T <= 0 || B <= 0 || H <= 0 || D <= 0 || (ndir != 1 && ndir != 2)) return false;
+  if (H % 4 != 0 || H > 16 * FWD_CH * 4 || D > 640) return false;
+  const int P = cdiv(H, LSTM_UNITS_FWD), G = cdiv(B, 16);
+  if (ndir * G * P > num_cus()) return false;
+  // Measured (profiles/r02_b_fused_fwd_trace.txt): correct, but SLOWER than the hoisted GEMM
+  // (4.2 vs 2.2 + 1.15 us per step at cfg 2): MFMA issue from one wave starves the co-resident
+  // waves of its SIMD, so the input-half MFMAs delay the gate math / the polling instead of
+  // hiding behind them.  Opt-in (DANET_LSTM_FWD_FUSED=1) until that is solved.
+  { const char* e = getenv("DANET_LSTM_FWD_FUSED"); if (!e || atoi(e) != 1) return false; }
+  const int per_wave = cdiv(cdiv(D, 16), 4);
+  if (CHX) *CHX = per_wave <= 3 ? 3 : 10;
+  return true;
+}
+
+extern "C" int danet_lstm_fwd_fused_supported(int T, int B, int H, int ndir, int D) {
+  return fwd_fused_ok(T, B, H, ndir, D, nullptr) ? 1 : 0;
+}
+
+extern "C" int danet_lstm_fwd_fused(danet_stream_t stream_, int T, int B, int H, int ndir,
+                                    const float* x, int ldx, int D,
+                                    const float* W_f, const float* W_b, int ldw,
+                                    const float* bias_f, const float* bias_b,
+                                    float* ypad, int ldy, float* gates_f, float* gates_b,
+                                    float* cell_f, float* cell_b, void* ws, size_t ws_bytes,
+                                    int32_t* status) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = lstm_check_common(T, B, H, ndir, ws, ws_bytes);
+  if (rc) return rc;
+  DANET_CHECK_ARG(x && W_f && bias_f && ypad && gates_f && cell_f, "lstm_fwd_fused: null pointer");
+  DANET_CHECK_ARG(ndir == 1 || (W_b && bias_b && gates_b && cell_b), "lstm_fwd_fused: null bwd pointer");
+  DANET_CHECK_ARG(D > 0 && ldx >= D && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0,
+                  "lstm_fwd_fused: x must be 16-B aligned with ldx %% 4 == 0, ldx >= D");
+  DANET_CHECK_ARG(ldy >= ndir * H && ldy % 4 == 0 && ldw >= 4 * H, "lstm_fwd_fused: bad ld");
+  DANET_CHECK_ARG(((uintptr_t)ypad & 15) == 0, "lstm_fwd_fused: ypad must be 16-B aligned");
+  DANET_CHECK_ARG((size_t)(T + 2) * B * ldy * 4 < 0xFFFFFFF0ull &&
+                  (size_t)T * B * ldx * 4 < 0xFFFFFFF0ull, "lstm_fwd_fused: tensor > 4 GiB");
+  int CHX = 0;
+  if (!fwd_fused_ok(T, B, H, ndir, D, &CHX)) {
+    danet_set_error("lstm_fwd_fused: T=%d B=%d H=%d D=%d outside the fused envelope "
+                    "(H <= 320, D <= 640, one workgroup per CU)", T, B, H, D);
+    return DANET_ERR_UNSUPPORTED;
+  }
+  LstmFwdFxArgs a;
+  a.x = x; a.W[0] = W_f; a.W[1] = W_b; a.bias[0] = bias_f; a.bias[1] = bias_b;
+  a.gates[0] = gates_f; a.gates[1] = gates_b; a.cell[0] = cell_f; a.cell[1] = cell_b;
+  a.ypad = ypad; a.status = status ? (int*)status : (int*)ws; a.status_ws = ws;
+  a.spin_limit = spin_limit_env(); a.fault = fault_env();
+  a.mode = getenv("DANET_LSTM_FX_MODE") ? atoi(getenv("DANET_LSTM_FX_MODE")) : 0;
+  a.T = T; a.B = B; a.H = H; a.D = D; a.ndir = ndir; a.ldx = ldx; a.ldy = ldy; a.ldw = ldw;
+  a.P = cdiv(H, LSTM_UNITS_FWD); a.G = cdiv(B, 16); a.KP = cdiv(H, 16) * 16;
+  a.DP = cdiv(D, 16) * 16;
+  a.xmap = getenv("DANET_LSTM_XMAP") ? atoi(getenv("DANET_LSTM_XMAP")) : 1;
+  const size_t xbuf_floats = (size_t)16 * (a.DP + 4) > (size_t)a.KP * 32 ? (size_t)16 * (a.DP + 4)
+                                                                       : (size_t)a.KP * 32;
+  const size_t lds = (xbuf_floats + (size_t)16 * (a.KP + 4) + (size_t)4 * 16 * 33) * sizeof(float);
+  const size_t blk = (size_t)B * ldy * sizeof(float);
+  {
+    FillList fl;
+    fl.add(ws, 64 + TRACE_BYTES(T), 0u);
+    fl.add((char*)ypad + blk, (size_t)T * blk, SENTINEL);
+    fl.add(ypad, blk, 0u);
+    fl.add((char*)ypad + (size_t)(T + 1) * blk, blk, 0u);
+    DANET_CHECK_HIP(fl.launch(stream));
+  }
+  const int nblk = ndir * a.G * a.P;
+  if (CHX == 3) {
+    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_fx_kernel<3>,
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lstm_fwd_fx_kernel<3><<<nblk, 512, lds, stream>>>(a);
+  } else {
+    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_fx_kernel<10>,
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lstm_fwd_fx_kernel<10><<<nblk, 512, lds, stream>>>(a);
+  }
   DANET_CHECK_LAUNCH();
   return DANET_OK;
 }

@@ -472,32 +472,43 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs):
     bs[d]: [4H].  Returns ctx with ypad [T+2, B, ndir*H].'''
     ndir = len(Ws)
     dev = x.device
+    L = _L()
     gates = [torch.empty(T * B, 4 * H, device=dev) for _ in range(ndir)]
     cells = [torch.empty(T * B, H, device=dev) for _ in range(ndir)]
-    if GROUPED_GX and ndir == 2:
-        # hoisted input half of ops.lyr_lstm_flat's [x,h]W+b (app/ops.py:139-142) of both
-        # directions as one grouped stream-K launch (nothing else runs at this point of the
-        # forward pass: 2 x 320 tiles fill 512 workgroups evenly; -1.5% per step vs two
-        # launches on two streams); `gates[d]` is later overwritten in place by g,i,f,o
-        gemm_group([(x, ldx, Ws[d], 4 * H, gates[d], 4 * H, T * B, 4 * H, 0.0, bs[d])
-                    for d in range(ndir)], D, max_workgroups=GROUPED_GX)
-    else:
-      with _Fork(dev, ndir) as f:
-        for d in range(ndir):
-            # hoisted input half of ops.lyr_lstm_flat's [x,h]W+b (app/ops.py:139-142);
-            # `gates[d]` is later overwritten in place by g,i,f,o
-            f.run(d, lambda d=d: gemm(x, Ws[d], gates[d], T * B, 4 * H, D, ldx, 4 * H, 4 * H,
-                                      bias=bs[d], tag='gx'))
     ypad = torch.empty(T + 2, B, ndir * H, device=dev)
     ws, wn = _lstm_ws(T, B, H, ndir, dev)
-    Whs = [W[D:] for W in Ws]
-    L = _L()
-    with _lib.timed('lstm_fwd'):
-        check(L.danet_lstm_fwd(
-            _lib.stream(), T, B, H, ndir, ptr(gates[0]), ptr(gates[-1]),
-            ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(ypad), ndir * H,
-            ptr(gates[0]), ptr(gates[-1]), ptr(cells[0]), ptr(cells[-1]), ptr(ws), wn,
-            ptr(status_word(dev))))
+    fused = (ldx % 4 == 0 and x.data_ptr() % 16 == 0 and
+             all(W.stride(0) == 4 * H and W.stride(1) == 1 for W in Ws) and
+             L.danet_lstm_fwd_fused_supported(T, B, H, ndir, D) == 1)
+    if fused:
+        # the whole cell [x_t, h_{t-1}] W + b (app/ops.py:139-147) in ONE launch: the input
+        # half runs on the matrix cores inside the per-step exchange wait (csrc/lstm.hip)
+        with _lib.timed('lstm_fwd'):
+            check(L.danet_lstm_fwd_fused(
+                _lib.stream(), T, B, H, ndir, ptr(_f32(x)), ldx, D,
+                ptr(Ws[0]), ptr(Ws[-1]), 4 * H, ptr(bs[0]), ptr(bs[-1]), ptr(ypad), ndir * H,
+                ptr(gates[0]), ptr(gates[-1]), ptr(cells[0]), ptr(cells[-1]), ptr(ws), wn,
+                ptr(status_word(dev))))
+    else:
+        if GROUPED_GX and ndir == 2:
+            # hoisted input half of ops.lyr_lstm_flat's [x,h]W+b (app/ops.py:139-142) of both
+            # directions as one grouped stream-K launch (nothing else runs at this point of the
+            # forward pass: 2 x 320 tiles fill 512 workgroups evenly; -1.5% per step vs two
+            # launches on two streams); `gates[d]` is later overwritten in place by g,i,f,o
+            gemm_group([(x, ldx, Ws[d], 4 * H, gates[d], 4 * H, T * B, 4 * H, 0.0, bs[d])
+                        for d in range(ndir)], D, max_workgroups=GROUPED_GX)
+        else:
+            with _Fork(dev, ndir) as f:
+                for d in range(ndir):
+                    f.run(d, lambda d=d: gemm(x, Ws[d], gates[d], T * B, 4 * H, D, ldx, 4 * H,
+                                              4 * H, bias=bs[d], tag='gx'))
+        Whs = [W[D:] for W in Ws]
+        with _lib.timed('lstm_fwd'):
+            check(L.danet_lstm_fwd(
+                _lib.stream(), T, B, H, ndir, ptr(gates[0]), ptr(gates[-1]),
+                ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(ypad), ndir * H,
+                ptr(gates[0]), ptr(gates[-1]), ptr(cells[0]), ptr(cells[-1]), ptr(ws), wn,
+                ptr(status_word(dev))))
     c = _LayerCtx()
     c.x, c.ldx, c.D, c.T, c.B, c.H, c.ndir = x, ldx, D, T, B, H, ndir
     c.ypad, c.gates, c.cells, c.Ws, c.bs = ypad, gates, cells, Ws, bs

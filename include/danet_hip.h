@@ -206,6 +206,29 @@ int danet_lstm_fwd(danet_stream_t stream, int T, int B, int H, int ndir,
                    float* cell_f, float* cell_b,
                    void* ws, size_t ws_bytes, int32_t* status);
 
+/* The same layer forward with the INPUT projection fused (no hoisted GEMM, no gx
+ * tensor): the kernel computes a_t = [x_t, h_{t-1}] W + b itself -- x_t*Wx of step t
+ * runs on the matrix cores while the workgroup waits for h_{t-1} to arrive from the
+ * other workgroups (that window is ~1 us per step and otherwise idle), with its 32
+ * columns of Wx stationary in registers.  x [T][B][ldx] time-major (16-byte aligned,
+ * ldx % 4 == 0, columns D..ldx-1 that fall into the last 4-float group must be finite,
+ * e.g. zero padding); W_d [D+H][ldw] in the reference layout (rows 0..D-1 input half,
+ * rows D.. recurrent half, app/ops.py:138-142); bias_d [4H].  Outputs as danet_lstm_fwd.
+ * Envelope: H % 4 == 0, H <= 320, D <= 640, ndir*ceil(B/16)*ceil(H/8) <= CUs;
+ * danet_lstm_fwd_fused_supported() returns 1 inside it AND when the path is switched on
+ * (DANET_LSTM_FWD_FUSED=1 in the environment: it is correct but currently slower than the
+ * hoisted GEMM, see csrc/lstm.hip), otherwise callers hoist the projection
+ * (danet_gemm_f32*) and call danet_lstm_fwd.                                  */
+int danet_lstm_fwd_fused_supported(int T, int B, int H, int ndir, int D);
+int danet_lstm_fwd_fused(danet_stream_t stream, int T, int B, int H, int ndir,
+                         const float* x, int ldx, int D,
+                         const float* W_f, const float* W_b, int ldw,
+                         const float* bias_f, const float* bias_b,
+                         float* ypad, int ldy,
+                         float* gates_f, float* gates_b,
+                         float* cell_f, float* cell_b,
+                         void* ws, size_t ws_bytes, int32_t* status);
+
 /* BPTT of the above.  dy [T][B][lddy] (dir d uses columns [d*H,(d+1)*H)).
  * Outputs da_d [T][B][4H] = dL/d(pre-activation) (16-byte aligned; pre-filled
  * with the 0xFFFFFFFF sentinel by the call); the caller finishes with GEMMs:

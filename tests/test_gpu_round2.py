@@ -573,3 +573,64 @@ def test_adam_nan_gradient_propagates():
     assert np.isnan(t[7]) and np.isfinite(np.delete(t, 7)).all()
     assert abs(m[8].item() - 10.0) < 1e-5 and abs(m[9].item() + 10.0) < 1e-5     # clipped to +-100
     assert float(g.abs().nan_to_num().max()) == 0.0                                # zeroed after use
+
+
+# ------------------------------- forward with the input projection fused into the scan
+def _lstm_ref(x, Ws, bs, H, dy):
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    Wt = [torch.tensor(W, dtype=torch.float64, requires_grad=True) for W in Ws]
+    bt = [torch.tensor(b, dtype=torch.float64, requires_grad=True) for b in bs]
+    outs = [R.lstm_scan(xt, Wt[0], bt[0], H)]
+    if len(Ws) == 2:
+        outs.append(R.lstm_scan(xt, Wt[1], bt[1], H, reverse=True))
+    y = torch.cat(outs, dim=-1)
+    (y * torch.tensor(dy)).sum().backward()
+    return y.detach().numpy(), xt.grad.numpy(), [w.grad.numpy() for w in Wt], [b.grad.numpy() for b in bt]
+
+
+@pytest.mark.parametrize('B,T,D,H,ndir', [
+    (32, 20, 600, 300, 2),     # cfg 2 layers 1..L-1
+    (32, 16, 132, 300, 2),     # layer-0-like width (3 k-groups per wave)
+    (48, 7, 600, 300, 2),      # 3 clusters per direction: 228 workgroups
+    (5, 9, 20, 36, 2), (16, 12, 64, 128, 1), (3, 1, 8, 8, 2), (20, 6, 640, 320, 1)])
+@pytest.mark.parametrize('fused', ['1', '0'])
+def test_lstm_forward_fused_input_projection(B, T, D, H, ndir, fused, monkeypatch):
+    '''danet_lstm_fwd_fused (x_t*Wx computed inside the persistent scan, in the exchange
+    wait) and the hoisted-GEMM path give the oracle's outputs and gradients; the envelope
+    query decides which one runs'''
+    from danet_amd import ops, _lib
+    monkeypatch.setenv('DANET_LSTM_FWD_FUSED', fused)
+    assert _lib.load().danet_lstm_fwd_fused_supported(T, B, H, ndir, D) == int(fused)
+    rng = np.random.RandomState(B * 100 + T * 10 + H + D)
+    r = 0.75 / np.sqrt(H)
+    x = rng.randn(B, T, D) * 0.7
+    Ws = [rng.uniform(-r, r, size=(D + H, 4 * H)) * 2 for _ in range(ndir)]
+    bs = [O.lstm_bias_init(H) + rng.randn(4 * H) * 0.1 for _ in range(ndir)]
+    dy = rng.randn(B, T, ndir * H)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    ry, rdx, rdW, rdb = _lstm_ref(x, Ws, bs, H, dy)
+    xc = cu(x).requires_grad_(True)
+    params = []
+    for W, b in zip(Ws, bs):
+        params += [cu(W).requires_grad_(True), cu(b).requires_grad_(True)]
+    y = ops.LstmLayerFn.apply(xc, H, *params)
+    assert relerr(y.detach().cpu().numpy(), ry) < TOL
+    y.backward(cu(dy))
+    assert relerr(xc.grad.cpu().numpy(), rdx) < TOL
+    for d in range(ndir):
+        assert relerr(params[2 * d].grad.cpu().numpy(), rdW[d]) < TOL
+        assert relerr(params[2 * d + 1].grad.cpu().numpy(), rdb[d]) < TOL
+
+
+def test_lstm_fused_envelope_query(monkeypatch):
+    from danet_amd import _lib
+    L = _lib.load()
+    monkeypatch.delenv('DANET_LSTM_FWD_FUSED', raising=False)
+    assert L.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 600) == 0      # opt-in path
+    monkeypatch.setenv('DANET_LSTM_FWD_FUSED', '1')
+    assert L.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 600) == 1
+    assert L.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 129) == 1
+    assert L.danet_lstm_fwd_fused_supported(128, 32, 600, 2, 1200) == 0     # H > 320
+    assert L.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 644) == 0      # D > 640
+    assert L.danet_lstm_fwd_fused_supported(128, 64, 300, 2, 600) == 0      # 304 workgroups
+    assert L.danet_lstm_fwd_fused_supported(128, 32, 302, 2, 600) == 0      # H % 4

@@ -40,8 +40,52 @@ def report(name, ws, T):
         print('   %-24s mean %.2f  median %.2f  p90 %.2f' % (k, v.mean(), np.median(v), np.percentile(v, 90)))
 
 
+def report_fused(name, ws, T):
+    '''lstm_fwd_fx_kernel: exchange-wave thread stamps 0 top, 1 exchange valid, 2 after B1,
+    3 after B2, 4 gate math + publish done, 6 retries; matrix-wave thread stamps 5 input-half
+    MFMAs issued (before B1), 7 recurrent MFMAs + partial tiles written (before B2)'''
+    tr = ws[64:64 + T * 64].view(torch.int64).view(T, 8).cpu().numpy().astype(np.float64)
+    tr = tr[2:]
+    us = lambda a: a / 100.0
+    step = us(np.diff(tr[:, 0]))
+    ph = dict(X_top_to_valid=us(tr[:, 1] - tr[:, 0]), X_valid_to_B1=us(tr[:, 2] - tr[:, 1]),
+              X_B1_to_B2=us(tr[:, 3] - tr[:, 2]), X_B2_to_published=us(tr[:, 4] - tr[:, 3]),
+              M_B2prev_to_M1done=us(tr[1:, 5] - tr[:-1, 3]), M_M1done_to_B1=us(tr[:, 2] - tr[:, 5]),
+              M_B1_to_M2done=us(tr[:, 7] - tr[:, 2]), M_M2done_to_B2=us(tr[:, 3] - tr[:, 7]))
+    print('%s: step %.2f us (median %.2f)  retries/step %.2f' % (
+        name, step.mean(), np.median(step), tr[:, 6].mean()))
+    for k, v in ph.items():
+        print('   %-24s mean %.2f  median %.2f  p90 %.2f' % (k, v.mean(), np.median(v), np.percentile(v, 90)))
+
+
+def fused(B, T, H, D):
+    dev = torch.device('cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    ndir = 2
+    if L.danet_lstm_fwd_fused_supported(T, B, H, ndir, D) != 1:
+        print('fused forward: shape outside the envelope')
+        return
+    x = torch.randn(T, B, D, device=dev) * 0.5
+    W = [torch.randn(D + H, 4 * H, device=dev) * (0.75 / H ** 0.5) for _ in range(2)]
+    b = [torch.zeros(4 * H, device=dev) for _ in range(2)]
+    ypad = torch.empty(T + 2, B, 2 * H, device=dev)
+    gates = [torch.empty(T * B, 4 * H, device=dev) for _ in range(2)]
+    cells = [torch.empty(T * B, H, device=dev) for _ in range(2)]
+    n = L.danet_lstm_workspace_bytes(T, B, H, ndir)
+    for it in range(3):
+        ws = torch.zeros(n, dtype=torch.uint8, device=dev)
+        _lib.check(L.danet_lstm_fwd_fused(st, T, B, H, ndir, ptr(x), D, D, ptr(W[0]), ptr(W[1]), 4 * H,
+                                          ptr(b[0]), ptr(b[1]), ptr(ypad), 2 * H, ptr(gates[0]),
+                                          ptr(gates[1]), ptr(cells[0]), ptr(cells[1]), ptr(ws), n, None))
+        torch.cuda.synchronize()
+    assert int(ws[:4].view(torch.int32)[0]) == 0
+    report_fused('lstm_fwd_fused D=%d' % D, ws, T)
+
+
 def main():
     B, T, H = (int(x) for x in sys.argv[1:4]) if len(sys.argv) >= 4 else (32, 128, 300)
+    fused(B, T, H, 2 * H)
+    fused(B, T, H, 132)
     dev = torch.device('cuda')
     st = torch.cuda.current_stream().cuda_stream
     ndir = 2
