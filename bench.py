@@ -407,16 +407,25 @@ def run_train(args, cfg, hp, device, rank, world, use_dist):
 
     B, T, H, L = hp.BATCH_SIZE, hp.MAX_TRAIN_LEN, hp.LSTM_HDIM, hp.NUM_LSTM_LAYERS
     C, E, F = hp.MAX_N_SIGNAL, hp.EMBED_SIZE, hp.FFT_SIZE // 2 + 1
-    # algorithmic flops per launch: recurrent half of one BiLSTM layer
-    lstm_flops = 2.0 * 2 * B * T * H * 4 * H
+    # algorithmic flops per launch: the recurrent half of one BiLSTM layer, plus --
+    # where the fused kernels run (csrc/lstm.hip) -- the input projection (forward) / the
+    # weight gradients (BPTT) that the same launch computes; averaged over the L layers
+    L_ = _lib.load()
+    Ds = [F if l == 0 else 2 * H for l in range(L)]
+    fwd_fused = [L_.danet_lstm_fwd_fused_supported(T, B, H, 2, D) == 1 for D in Ds]
+    bwd_fused = [L_.danet_lstm_bwd_fused_supported(T, B, H, 2, D) == 1 for D in Ds]
+    rec = 2.0 * 2 * B * T * H * 4 * H
+    flops = dict(
+        lstm_fwd=sum(rec + (2.0 * 2 * B * T * D * 4 * H if f else 0.0) for D, f in zip(Ds, fwd_fused)) / L,
+        lstm_bwd=sum(rec + (2.0 * 2 * B * T * (D + H) * 4 * H if f else 0.0) for D, f in zip(Ds, bwd_fused)) / L)
     dom = max(('lstm_fwd', 'lstm_bwd'), key=lambda k: prof.get(k, (1, 0.0))[1])
     n, ms = prof[dom]
-    achieved = lstm_flops / (ms / n * 1e-3) / 1e12
-    # kernel symbol behind the label (csrc/lstm.hip): BPTT runs the reduce-scatter
-    # kernel unless DANET_LSTM_BWD_RS=0 selects the all-gather one
-    ksym = {'lstm_fwd': 'lstm_fwd_kernel',
-            'lstm_bwd': 'lstm_bwd_kernel' if os.environ.get('DANET_LSTM_BWD_RS') == '0'
-            else 'lstm_bwd_rs_kernel'}[dom]
+    achieved = flops[dom] / (ms / n * 1e-3) / 1e12
+    # kernel symbol behind the label (csrc/lstm.hip)
+    ksym = {'lstm_fwd': 'lstm_fwd_fx_kernel' if any(fwd_fused) else 'lstm_fwd_kernel',
+            'lstm_bwd': 'lstm_bwd_rsw_kernel' if any(bwd_fused) else
+                        ('lstm_bwd_kernel' if os.environ.get('DANET_LSTM_BWD_RS') == '0'
+                         else 'lstm_bwd_rs_kernel')}[dom]
     traffic, tsrc = pmc_traffic(ksym)
     if tsrc is not None and tsrc.get('workload', 'cfg2') != args.config:
         traffic, tsrc = None, None
@@ -425,6 +434,8 @@ def run_train(args, cfg, hp, device, rank, world, use_dist):
                     frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                     traffic=traffic, traffic_source=tsrc,
                     us_per_timestep=round(1e3 * ms / n / T, 3),
+                    flops_per_launch=flops[dom],
+                    fused=dict(forward_input_projection=fwd_fused, bptt_weight_gradients=bwd_fused),
                     events_in_timed_region=True,
                     note='latency-bound recurrence: T dependent steps per launch; see DESIGN.md '
                          'for the step-latency model.  HIP events bracket the two recurrent '
@@ -433,13 +444,16 @@ def run_train(args, cfg, hp, device, rank, world, use_dist):
         if other in prof:
             on, oms = prof[other]
             roofline[other + '_us'] = round(1e3 * oms / on, 1)
+            roofline[other + '_tflops'] = round(flops[other] / (oms / on * 1e-3) / 1e12, 2)
     # second-largest consumer: the fp32 MFMA GEMMs (all launches of one step together)
     gemm_flops = 0.0
     for l in range(L):
-        D = F if l == 0 else 2 * H
-        gemm_flops += 2 * (2.0 * B * T * D * 4 * H) * 3      # gx, dWx, dX per direction
-        gemm_flops += 2 * (2.0 * B * T * H * 4 * H)          # dWh per direction
-    gemm_flops -= 2 * (2.0 * B * T * F * 4 * H)              # layer 0 needs no dX
+        D = Ds[l]
+        per = 2 * (2.0 * B * T * D * 4 * H)                  # one x-sized product, both directions
+        gemm_flops += (0 if fwd_fused[l] else per)           # gx
+        gemm_flops += (per if l > 0 else 0)                  # dX (layer 0 needs none)
+        if not bwd_fused[l]:
+            gemm_flops += per + 2 * (2.0 * B * T * H * 4 * H)    # dWx, dWh
     gemm_flops += 3 * 2.0 * B * T * 2 * H * F * E            # projection, dWout, dYc
     if 'gemm_f32' in prof_all:
         gn, gms = prof_all['gemm_f32']

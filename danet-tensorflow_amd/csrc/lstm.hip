@@ -329,30 +329,25 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
 // The exchange of h_{t-1} costs ~1 us per step during which the matrix cores of the
 // recurrent workgroups idle (152 of 256 CUs at cfg 2, one MFMA chain of 0.66 us per
 // 2.3 us step).  The input half x_t*Wx of a = [x_t, h_{t-1}] W + b does not depend on the
-// recurrence, so this kernel computes it IN that window instead of in a hoisted GEMM.
-//
-// Wave specialisation (512 threads): a first version let the same four waves issue the
-// exchange loads, run the x_t*Wx MFMAs and validate afterwards -- correct, but 4.5 us per
-// step: whenever a first-attempt load had raced a slower producer it was re-issued only
-// after the whole MFMA block, a second full store->load round trip (measured 575 vs
-// 302 + 115 us per layer launch).  The latency-critical polling therefore gets waves of its
-// own:
-//   waves 4-7 ("exchange"): issue the sc1 loads of h_{t-1}, re-issue until every word is
-//     published (immediately, like lstm_fwd_kernel), drop the validated rows into LDS
-//     [16][KP+4]; also prefetch x_{t+1} (plain loads) and stage it in LDS [16][DP+4]; do the
-//     gate math, publish h_t, save gates / cell.
-//   waves 0-3 ("matrix"): hold the workgroup's 32 columns of Wx AND Wh stationary in
-//     registers (K split over the 4 waves, one per SIMD), run x_t*Wx from the LDS copy of
-//     x_t while the exchange waves wait, then h_{t-1}*Wh from the LDS copy of h_{t-1} into
-//     the SAME accumulators, and leave their partial tiles in LDS for the gate phase.
-// Two workgroup barriers per step:  B1 = h_{t-1} staged (exchange -> matrix),
-// B2 = partial tiles written (matrix -> exchange); x_{t+1} is staged between B1 and B2,
-// when no matrix wave reads the x buffer.  Critical path per step: publish -> visible
-// (~1.0 us) -> LDS -> 40 MFMAs -> LDS -> gate math, unchanged; the 80 MFMAs of the input
-// half sit in the shadow of gate math + exchange.  No gx tensor exists (the hoisted GEMM
-// wrote and this kernel re-read 2 x 19.7 MB per layer at cfg 2) and a layer's forward is
-// one launch.  Envelope: 16-row clusters, H <= 320 (every Wh fragment in registers),
-// D <= 640; other shapes take the hoisted-GEMM path (danet_lstm_fwd).
+// recurrence, so this kernel computes it IN that window instead of in a hoisted GEMM:
+//   - the workgroup's 32 columns of Wx (all D rows) are stationary in REGISTERS, K split
+//     over the 4 waves like Wh (D <= 640: <= 10 k-groups of 16 per wave, 80 VGPRs);
+//   - per step a wave runs a quarter of the x_t*Wx MFMAs, issues the sc1 exchange loads of
+//     h_{t-1} (not earlier: a first-attempt load that races a slower producer is only
+//     re-issued after the MFMA block), issues the prefetch of x_{t+1}, runs the rest of the
+//     MFMAs while the loads fly, validates, and continues the SAME accumulators with
+//     h_{t-1}*Wh; reduction, gate math and publish are those of lstm_fwd_kernel (bias added
+//     in the gate phase).
+// Two things the compiler does with such a loop had to be defeated (each cost ~1 us per
+// step): (1) a loop-carried prefetch is waited for at the loop latch with s_waitcnt vmcnt(0),
+// which on gfx9 also waits for the write-through publish stores issued just before -- the
+// prefetched registers are therefore consumed BEFORE the publish; (2) MFMAs have no memory
+// effect and are moved across barriers / waits unless pinned with sched_barrier.
+// (A wave-specialised variant -- separate exchange and matrix waves -- was slower: MFMA
+// issue from one wave starves the other waves of its SIMD, so the gate math of the exchange
+// waves waited for the whole MFMA block; profiles/r02_b_fused_fwd_trace.txt.)
+// Envelope: 16-row clusters (MT = 1), H <= 320 (every Wh fragment in registers), D <= 640;
+// other shapes take the hoisted-GEMM path (danet_lstm_fwd).
 struct LstmFwdFxArgs {
   const float* x;        // [T][B][ldx] time-major layer input, columns >= D finite (zero pad)
   const float* W[2];     // [D+H][ldw]: rows 0..D-1 input half, D..D+H-1 recurrent half
@@ -366,23 +361,24 @@ struct LstmFwdFxArgs {
   int xmap;
   unsigned spin_limit;
   int fault;
-  int mode;   // experiment switches: bit 0 = s_setprio 3 in the exchange waves,
-              // bit 1 = third barrier: the input-half MFMAs start only after the publish
+  int mode;
 };
 
+#ifndef FX_CHA_NUM
+#define FX_CHA_NUM 1
+#endif
 template <int CHX>
-__global__ __launch_bounds__(512) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
+__global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
   constexpr int NW = 4, CH = FWD_CH;
-  constexpr int NHL = (16 * 16 * CH * NW / 4 + 255) / 256;    // h chunk loads per exchange thread (5)
-  constexpr int NXL = (16 * 16 * CHX * NW / 4 + 255) / 256;   // x chunk loads per exchange thread
+#ifdef FX_CHA_ABS
+  constexpr int CHA = FX_CHA_ABS < CHX ? FX_CHA_ABS : CHX;
+#else
+  constexpr int CHA = FX_CHA_NUM * (CHX + 3) / 4;   // k-groups of the input half done before the exchange loads
+#endif
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // smem: xbuf [16][DP+4] (first holds the recurrent weights [KP/4][32][4] for the one-time
-  //       register fill) | hbuf [16][KP+4] | red [NW][16][33]
-  const int HP = a.KP + 4, XP = a.DP + 4;
-  const int xbuf_floats = max(16 * XP, a.KP * 32);
-  float* xbuf = smem;
-  float* hbuf = smem + xbuf_floats;
-  float* red = hbuf + 16 * HP;
+  // smem: recurrent weights [KP/4][32][4] (read once into registers) | red [NW][16][33]
+  float* Wl = smem;
+  float* red = smem + (size_t)a.KP * 32;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bid = blockIdx.x;
@@ -395,245 +391,217 @@ __global__ __launch_bounds__(512) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
   const int u0 = p * LSTM_UNITS_FWD;
   const int b0 = grp * 16;
   const float* Wd = a.W[dir];
-  const bool matrix = wave < NW;
 
   {
     const float* W = Wd + (size_t)D * a.ldw;     // recurrent rows
-    for (int idx = tid; idx < a.KP * 32; idx += 512) {
+    for (int idx = tid; idx < a.KP * 32; idx += 64 * NW) {
       const int k = idx >> 5, n = idx & 31;
       const int gate = n >> 3, u = u0 + (n & 7);
       float v = 0.f;
       if (k < H && u < H) v = W[(size_t)k * a.ldw + gate * H + u];
-      xbuf[((k >> 2) * 32 + n) * 4 + (k & 3)] = v;
+      Wl[((k >> 2) * 32 + n) * 4 + (k & 3)] = v;
     }
   }
   __syncthreads();
 
-  const int fr = lane & 15, fq = lane >> 4;
+  const unsigned ybytes = (unsigned)((size_t)(T + 2) * B * a.ldy * sizeof(float));
+  const __amdgpu_buffer_rsrc_t yres = make_rsrc(a.ypad, ybytes);
+  const unsigned xbytes = (unsigned)((size_t)T * B * a.ldx * sizeof(float));
+  const __amdgpu_buffer_rsrc_t xres = make_rsrc(a.x, xbytes);
 
-  if (matrix) {
-    // =========================== matrix waves ===========================
-    const int NG = a.KP / 16;
-    f32x4 wreg[CH][2];
+  const int bl = tid >> 3, ul = tid & 7;
+  const bool owner = (bl < 16) && (b0 + bl < B) && (u0 + ul < H);
+  const int bg = b0 + bl, unit = u0 + ul;
+  float c_state = 0.f;
+  float bq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (owner) {
 #pragma unroll
-    for (int g = 0; g < CH; ++g) {
-      const int kg = g * NW + wave;
-      const int k4 = (kg < NG ? kg : 0) * 4 + fq;
-      wreg[g][0] = *reinterpret_cast<const f32x4*>(&xbuf[(k4 * 32 + fr) * 4]);
-      wreg[g][1] = *reinterpret_cast<const f32x4*>(&xbuf[(k4 * 32 + 16 + fr) * 4]);
-      if (kg >= NG) { wreg[g][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; wreg[g][1] = wreg[g][0]; }
+    for (int gte = 0; gte < 4; ++gte) bq[gte] = a.bias[dir][gte * H + unit];
+  }
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int NG = a.KP / 16;
+
+  // stationary fragments: recurrent half (from LDS) and input half (straight from global)
+  f32x4 wreg[CH][2];
+#pragma unroll
+  for (int g = 0; g < CH; ++g) {
+    const int kg = g * NW + wave;
+    const int k4 = (kg < NG ? kg : 0) * 4 + fq;
+    wreg[g][0] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + fr) * 4]);
+    wreg[g][1] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + 16 + fr) * 4]);
+    if (kg >= NG) { wreg[g][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; wreg[g][1] = wreg[g][0]; }
+  }
+  f32x4 wx[CHX][2];
+#pragma unroll
+  for (int g = 0; g < CHX; ++g) {
+    const int k0 = (g * NW + wave) * 16 + fq * 4;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int n = nt * 16 + fr;
+      const int gate = n >> 3, u = u0 + (n & 7);
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+      if (u < H) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (k0 + j < D) w[j] = Wd[(size_t)(k0 + j) * a.ldw + gate * H + u];
+      }
+      wx[g][nt] = w;
     }
-    f32x4 wx[CHX][2];
+  }
+
+  // byte offsets of this lane's x / h fragments within one time block (out of range -> 0)
+  unsigned xoff[CHX], hcol[CH];
+  {
+    const int row = b0 + fr;
 #pragma unroll
     for (int g = 0; g < CHX; ++g) {
       const int k0 = (g * NW + wave) * 16 + fq * 4;
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int n = nt * 16 + fr;
-        const int gate = n >> 3, u = u0 + (n & 7);
-        f32x4 w = {0.f, 0.f, 0.f, 0.f};
-        if (u < H) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (k0 + j < D) w[j] = Wd[(size_t)(k0 + j) * a.ldw + gate * H + u];
-        }
-        wx[g][nt] = w;
-      }
+      xoff[g] = (row < B && k0 < D) ? (unsigned)(((size_t)row * a.ldx + k0) * 4) : 0xFFFFFFFFu;
     }
-    __syncthreads();   // P1: weights are in registers, the x buffer may be overwritten
-    __syncthreads();   // P2: x of the first step staged
-    for (int s = 0; s < T; ++s) {
-      if ((a.mode & 2) && s > 0) {
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();   // B3: h_{t-1} published by this workgroup
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // input half from the staged x_t: four independent accumulator chains
-      f32x4 acc[2][2];
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        acc[nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        acc[nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-      f32x4 xf[CHX];
-#pragma unroll
-      for (int g = 0; g < CHX; ++g) {
-        const int k0 = (g * NW + wave) * 16 + fq * 4;
-        xf[g] = (k0 < a.DP) ? *reinterpret_cast<const f32x4*>(&xbuf[fr * XP + k0])
-                            : (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int g = 0; g < CHX; ++g) {
-        const f32x4 w0 = wx[g][0], w1 = wx[g][1];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[0][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[g][j], w0[j], acc[0][j & 1], 0, 0, 0);
-          acc[1][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[g][j], w1[j], acc[1][j & 1], 0, 0, 0);
-        }
-      }
-      TRACE_AT(0, 5);
-      // the MFMAs above have no memory effect, so nothing but this keeps the compiler from
-      // sinking them below the barrier (it did: barrier first, then all 120 MFMAs in series)
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();   // B1: h_{t-1} staged (zeros at step 0)
-      __builtin_amdgcn_sched_barrier(0);
-      f32x4 hf[CH];
-#pragma unroll
-      for (int g = 0; g < CH; ++g) {
-        const int k0 = (g * NW + wave) * 16 + fq * 4;
-        hf[g] = (k0 < a.KP) ? *reinterpret_cast<const f32x4*>(&hbuf[fr * HP + k0])
-                            : (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int g = 0; g < CH; ++g) {
-        const f32x4 w0 = wreg[g][0], w1 = wreg[g][1];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[0][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(hf[g][j], w0[j], acc[0][j & 1], 0, 0, 0);
-          acc[1][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(hf[g][j], w1[j], acc[1][j & 1], 0, 0, 0);
-        }
-      }
-      // partial tiles for the gate phase.  D layout 16x16: col = lane&15, row = 4*(lane>>4)+r
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          red[(wave * 16 + 4 * fq + r) * 33 + nt * 16 + fr] = acc[nt][0][r] + acc[nt][1][r];
-      TRACE_AT(0, 7);
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();   // B2
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  } else {
-    // ========================== exchange waves ==========================
-    const int etid = tid - 64 * NW;
-    const int ewave = wave - NW;
-    const unsigned ybytes = (unsigned)((size_t)(T + 2) * B * a.ldy * sizeof(float));
-    const __amdgpu_buffer_rsrc_t yres = make_rsrc(a.ypad, ybytes);
-    const unsigned xbytes = (unsigned)((size_t)T * B * a.ldx * sizeof(float));
-    const __amdgpu_buffer_rsrc_t xres = make_rsrc(a.x, xbytes);
-    const unsigned xblk = (unsigned)((size_t)B * a.ldx * 4);
-
-    const int bl = etid >> 3, ul = etid & 7;
-    const bool owner = (bl < 16) && (b0 + bl < B) && (u0 + ul < H);
-    const int bg = b0 + bl, unit = u0 + ul;
-    float c_state = 0.f;
-    float bq[4] = {0.f, 0.f, 0.f, 0.f};
-    if (owner) {
-#pragma unroll
-      for (int gte = 0; gte < 4; ++gte) bq[gte] = a.bias[dir][gte * H + unit];
-    }
-
-    // chunk maps: chunk = 4 consecutive floats of one batch row of the cluster
-    const int KQ = a.KP / 4, DQ = a.DP / 4;
-    int hlds[NHL];        // LDS float offset in hbuf (or -1)
-    unsigned hcol[NHL];   // byte offset of the chunk within a time block of ypad (or ~0)
-#pragma unroll
-    for (int i = 0; i < NHL; ++i) {
-      const int idx = etid + 256 * i;
-      const int row = idx / KQ, kq = idx % KQ;
-      hlds[i] = (row < 16) ? row * HP + kq * 4 : -1;
-      hcol[i] = (row < 16 && b0 + row < B && kq * 4 < H)
-                    ? (unsigned)((((size_t)(b0 + row)) * a.ldy + dir * H + kq * 4) * 4) : 0xFFFFFFFFu;
-    }
-    int xlds[NXL];
-    unsigned xcol[NXL];
-#pragma unroll
-    for (int i = 0; i < NXL; ++i) {
-      const int idx = etid + 256 * i;
-      const int row = idx / DQ, kq = idx % DQ;
-      xlds[i] = (row < 16) ? row * XP + kq * 4 : -1;
-      xcol[i] = (row < 16 && b0 + row < B && kq * 4 < D)
-                    ? (unsigned)((((size_t)(b0 + row)) * a.ldx + kq * 4) * 4) : 0xFFFFFFFFu;
-    }
-    const unsigned yblk = (unsigned)((size_t)B * a.ldy * 4);
-
-    __syncthreads();   // P1
-    {  // stage x of the first step
-      const int t0 = dir ? (T - 1) : 0;
-#pragma unroll
-      for (int i = 0; i < NXL; ++i) {
-        const v4u v = __builtin_amdgcn_raw_buffer_load_b128(
-            xres, xcol[i] == 0xFFFFFFFFu ? xbytes : xcol[i] + (unsigned)t0 * xblk, 0, 0);
-        if (xlds[i] >= 0) *reinterpret_cast<v4u*>(&xbuf[xlds[i]]) = v;
-      }
-    }
-    __syncthreads();   // P2
-    if (a.mode & 1) __builtin_amdgcn_s_setprio(3);
-
-    for (int s = 0; s < T; ++s) {
-      const int t = dir ? (T - 1 - s) : s;
-      const int blk_prev = dir ? (t + 2) : t;
-      if ((a.mode & 2) && s > 0) __syncthreads();   // B3
-      TRACE_AT(256, 0);
-      // exchange loads of h_{t-1} first, then the prefetch of the next step's x
-      v4u av[NHL];
-      unsigned hoff[NHL];
-#pragma unroll
-      for (int i = 0; i < NHL; ++i) {
-        hoff[i] = (s > 0 && hcol[i] != 0xFFFFFFFFu) ? hcol[i] + (unsigned)blk_prev * yblk : ybytes;
-        av[i] = load_sc1_b128(yres, hoff[i]);   // out of range -> 0 (valid)
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      v4u xr[NXL];
-      {
-        const int tn = dir ? (t - 1) : (t + 1);
-        const bool have = (s + 1 < T);
-#pragma unroll
-        for (int i = 0; i < NXL; ++i)
-          xr[i] = __builtin_amdgcn_raw_buffer_load_b128(
-              xres, (!have || xcol[i] == 0xFFFFFFFFu) ? xbytes : xcol[i] + (unsigned)tn * xblk, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (s > 0) {
-        unsigned spins = 0;
-        for (;;) {
-          bool ok = true;
-#pragma unroll
-          for (int i = 0; i < NHL; ++i) ok &= !has_sentinel(av[i]);
-          if (__all(ok)) break;
-          if (spin_fail(spins, a.status, lane, a.spin_limit)) break;
-#pragma unroll
-          for (int i = 0; i < NHL; ++i) av[i] = load_sc1_b128(yres, hoff[i]);
-        }
-        TRACE_AT_VAL(256, 6, spins);
-      }
-      TRACE_AT(256, 1);
-#pragma unroll
-      for (int i = 0; i < NHL; ++i)
-        if (hlds[i] >= 0) *reinterpret_cast<v4u*>(&hbuf[hlds[i]]) = av[i];
-      __syncthreads();   // B1
-      TRACE_AT(256, 2);
-      // the matrix waves are done with x_t: stage x_{t+1}
-#pragma unroll
-      for (int i = 0; i < NXL; ++i)
-        if (xlds[i] >= 0) *reinterpret_cast<v4u*>(&xbuf[xlds[i]]) = xr[i];
-      __syncthreads();   // B2
-      TRACE_AT(256, 3);
-      if (owner) {
-        float pre[4];
-#pragma unroll
-        for (int gte = 0; gte < 4; ++gte) {
-          float v = bq[gte];
-#pragma unroll
-          for (int w = 0; w < NW; ++w) v += red[(w * 16 + bl) * 33 + gte * 8 + ul];
-          pre[gte] = v;
-        }
-        const float g = pre[0];                 // linear candidate (ops.py:143)
-        const float ig = sigmoid_hw(pre[1]);
-        const float fg = sigmoid_hw(pre[2]);
-        const float og = sigmoid_hw(pre[3]);
-        c_state = ig * g + fg * c_state;        // ops.py:146
-        const float h = og * tanh_hw(c_state);   // ops.py:147
-        float* hp = a.ypad + ((size_t)(t + 1) * B + bg) * a.ldy + dir * H + unit;
-        __hip_atomic_store(hp, h, RLX_AGENT);
-        float* gs = a.gates[dir] + ((size_t)t * B + bg) * (4 * H) + unit;
-        gs[0] = g; gs[H] = ig; gs[2 * H] = fg; gs[3 * H] = og;
-        a.cell[dir][((size_t)t * B + bg) * H + unit] = c_state;
-      }
-      TRACE_AT(256, 4);
+    for (int g = 0; g < CH; ++g) {
+      const int k0 = (g * NW + wave) * 16 + fq * 4;
+      hcol[g] = (row < B && k0 < H) ? (unsigned)(((size_t)row * a.ldy + dir * H + k0) * 4) : 0xFFFFFFFFu;
     }
   }
+  const unsigned xblk = (unsigned)((size_t)B * a.ldx * 4);
+  const unsigned yblk = (unsigned)((size_t)B * a.ldy * 4);
+  v4u xc[CHX];
+  {
+    const int t0 = dir ? (T - 1) : 0;
+#pragma unroll
+    for (int g = 0; g < CHX; ++g)
+      xc[g] = __builtin_amdgcn_raw_buffer_load_b128(
+          xres, xoff[g] == 0xFFFFFFFFu ? xbytes : xoff[g] + (unsigned)t0 * xblk, 0, 0);
+    // wait for them HERE: loads still pending at loop entry make the compiler put one
+    // s_waitcnt vmcnt(0) into the loop header, where it then also waits for the previous
+    // step's publish stores on every iteration
+#pragma unroll
+    for (int g = 0; g < CHX; ++g) asm volatile("" : "+v"(xc[g]));
+  }
+
+#define FX_GX(g)                                                                               \
+  do {                                                                                         \
+    const f32x4 xf_ = __builtin_bit_cast(f32x4, xc[g]);                                        \
+    const f32x4 w0_ = wx[g][0], w1_ = wx[g][1];                                                \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
+      acc[0][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf_[j], w0_[j], acc[0][j & 1], 0, 0, 0); \
+      acc[1][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf_[j], w1_[j], acc[1][j & 1], 0, 0, 0); \
+    }                                                                                          \
+  } while (0)
+
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? (T - 1 - s) : s;
+    const int blk_prev = dir ? (t + 2) : t;
+
+    TRACE_AT(0, 0);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      acc[nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc[nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // (a) first quarter of the input half
+#pragma unroll
+    for (int g = 0; g < CHA; ++g) FX_GX(g);
+    __builtin_amdgcn_sched_barrier(0);
+    // (b) exchange loads of h_{t-1} (step 0: out of range -> zeros)
+    v4u av[CH];
+    unsigned hoff[CH];
+#pragma unroll
+    for (int g = 0; g < CH; ++g) {
+      hoff[g] = (s > 0 && hcol[g] != 0xFFFFFFFFu) ? hcol[g] + (unsigned)blk_prev * yblk : ybytes;
+      av[g] = load_sc1_b128(yres, hoff[g]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    TRACE_AT(0, 1);
+    // (c) rest of the input half while the loads fly
+#pragma unroll
+    for (int g = CHA; g < CHX; ++g) FX_GX(g);
+    __builtin_amdgcn_sched_barrier(0);
+    TRACE_AT(0, 2);
+
+    // (d) every exchanged word published?  re-issue until so (bounded)
+    {
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int g = 0; g < CH; ++g) ok &= !has_sentinel(av[g]);
+        if (__all(ok)) break;
+        if (spin_fail(spins, a.status, lane, a.spin_limit)) break;
+#pragma unroll
+        for (int g = 0; g < CH; ++g) av[g] = load_sc1_b128(yres, hoff[g]);
+      }
+      TRACE_AT_VAL(0, 6, spins);
+    }
+    TRACE_AT(0, 3);
+    // x of the next step: issued only now -- fifteen loads at the top of the step queued behind
+    // the previous step's stores in the memory pipeline and delayed the exchange loads
+    v4u xn[CHX];
+    {
+      const int tn = dir ? (t - 1) : (t + 1);
+      const bool have = (s + 1 < T);
+#pragma unroll
+      for (int g = 0; g < CHX; ++g)
+        xn[g] = __builtin_amdgcn_raw_buffer_load_b128(
+            xres, (!have || xoff[g] == 0xFFFFFFFFu) ? xbytes : xoff[g] + (unsigned)tn * xblk, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // (e) recurrent half continues the same accumulators
+#pragma unroll
+    for (int g = 0; g < CH; ++g) {
+      const f32x4 af = __builtin_bit_cast(f32x4, av[g]);
+      const f32x4 w0 = wreg[g][0], w1 = wreg[g][1];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[0][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], w0[j], acc[0][j & 1], 0, 0, 0);
+        acc[1][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], w1[j], acc[1][j & 1], 0, 0, 0);
+      }
+    }
+    // cross-wave reduction.  D layout 16x16: col = lane&15, row = 4*(lane>>4)+r
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        red[(wave * 16 + 4 * fq + r) * 33 + nt * 16 + fr] = acc[nt][0][r] + acc[nt][1][r];
+    __syncthreads();
+    TRACE_AT(0, 4);
+    // the prefetched x becomes the current x HERE, before anything is stored: the wait for
+    // it must not sit behind the write-through publish stores (see the header comment)
+#pragma unroll
+    for (int g = 0; g < CHX; ++g) {
+      xc[g] = xn[g];
+      asm volatile("" : "+v"(xc[g]));
+    }
+
+    if (owner) {
+      float pre[4];
+#pragma unroll
+      for (int gte = 0; gte < 4; ++gte) {
+        float v = bq[gte];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[(w * 16 + bl) * 33 + gte * 8 + ul];
+        pre[gte] = v;
+      }
+      const float g = pre[0];                 // linear candidate (ops.py:143)
+      const float ig = sigmoid_hw(pre[1]);
+      const float fg = sigmoid_hw(pre[2]);
+      const float og = sigmoid_hw(pre[3]);
+      c_state = ig * g + fg * c_state;        // ops.py:146
+      const float h = og * tanh_hw(c_state);   // ops.py:147
+      float* hp = a.ypad + ((size_t)(t + 1) * B + bg) * a.ldy + dir * H + unit;
+      __hip_atomic_store(hp, h, RLX_AGENT);
+      float* gs = a.gates[dir] + ((size_t)t * B + bg) * (4 * H) + unit;
+      gs[0] = g; gs[H] = ig; gs[2 * H] = fg; gs[3 * H] = og;
+      a.cell[dir][((size_t)t * B + bg) * H + unit] = c_state;
+    }
+    TRACE_AT(0, 5);
+    __syncthreads();   // `red` reuse
+    TRACE_AT(0, 7);
+  }
+#undef FX_GX
 }
 
 // ---------------------------------------------------------------------------
@@ -1067,6 +1035,399 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// backward (BPTT), reduce-scatter form, WEIGHT GRADIENTS FUSED
+// ---------------------------------------------------------------------------
+// dW = [X | Hprev]^T da and db = colsum(da) of a layer are 3x the flops of its recurrence
+// (17.7 vs 5.9 GFLOP at cfg 2).  As separate GEMMs they ran on a side stream UNDER the next
+// layer's BPTT kernel and cost it 1.0 us per step (fabric contention on the exchange hops),
+// and the bottom layer's group sat on the critical path.  But the BPTT workgroup that owns
+// 4U columns of da_t already has them in LDS every step, its matrix cores idle during the
+// ~1.2 us exchange wait, and dW[:, own columns] += A_t^T da_t is a rank-16 update that needs
+// no other workgroup's data.  So: the S twins of a group split the D+H feature rows, every
+// wave keeps NFT feature tiles x 4U/16 column tiles of fp32 accumulators in registers
+// (<= 48 VGPRs), and the update of step s-1 runs at the TOP of step s -- a quarter of it
+// before the exchange loads are issued (so the first-attempt loads are not issued ahead of
+// slower producers: a miss would only be noticed after the MFMA block), the rest while the
+// loads fly.  The A operand (16 batch rows x 16 features of x_t / h_prev) is prefetched one
+// step ahead with coalesced dword loads straight into MFMA operand layout; the B operand
+// is the da_t tile the gate phase left in LDS.  At the end each workgroup writes its
+// [features x 4U] block of its cluster's partial dW (and twin 0 the partial db) to a slab;
+// a small kernel adds the ceil(B/16) cluster partials into dW / db (fixed order:
+// deterministic).  No weight-gradient GEMM, no column-sum kernel, nothing on a side stream.
+struct LstmBwdRswArgs {
+  LstmBwdRsArgs r;
+  const float* x;      // [T][B][ldx] layer input (time-major)
+  const float* ypad;   // [T+2][B][ldy] layer output: h_prev(t) = block t (fwd) / t+2 (bwd)
+  float* dwslab;       // [ndir*G][NFP][4H]
+  float* dbslab;       // [ndir*G][4H]
+  // feature space of the slab: [0, Dp) = x columns (Dp = Din padded to 16), [Dp, Dp+Hp) =
+  // h_prev units, so that a 16-feature tile never mixes the two sources (its base pointer
+  // and strides stay scalar).  NFt = feature rows per twin (multiple of 16), NFP = S*NFt.
+  int ldx, ldy, Din, Dp, NFt, NFP;
+};
+
+#define RSW_NI_MAX 3
+
+template <int U, int NTW, int NFT>
+__global__ __launch_bounds__(512) void lstm_bwd_rsw_kernel(LstmBwdRswArgs aa) {
+  const LstmBwdRsArgs& a = aa.r;
+  constexpr int NW = 8;
+  constexpr int KG = U / 4;
+  constexpr int OWN = 16 * U;
+  constexpr int CPP = 4 * U;
+  constexpr int PPR = 512 / CPP;
+  constexpr int LDA = 4 * U + 4;
+  constexpr int NCT = U / 4;         // 16-wide column tiles of the own 4U columns
+  __shared__ __attribute__((aligned(16))) float psum[PPR * OWN];
+  __shared__ __attribute__((aligned(16))) float atile[16 * LDA];
+
+  const int H = a.H, B = a.B, T = a.T, P = a.P, S = a.S;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave-uniform by construction: keep what derives from it (tile base pointers, strides) scalar
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bid = blockIdx.x;
+  if (a.fault && bid == 0) return;   // test hook
+  const int ncl = a.ndir * a.G;
+  const int cl = a.xmap ? bid % ncl : bid / (P * S);
+  const int m = a.xmap ? bid / ncl : bid % (P * S);
+  const int p = m / S, tw = m % S;
+  const int dir = cl / a.G, grp = cl % a.G;
+  const int u0 = p * U, b0 = grp * 16;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  f32x4 wreg[NTW][KG];
+  {
+    const float* W = a.Wh[dir];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      const int tl = tw + S * (wave + NW * i);
+      const int unit_i = tl * 16 + fr;
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg) {
+        const int k0 = kg * 16 + fq * 4;
+        const int gate = k0 / U, j0 = k0 % U;
+        f32x4 w = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (tl < a.NT && unit_i < H && u0 + j0 < H)
+          w = *reinterpret_cast<const f32x4*>(&W[(size_t)unit_i * a.ldw + gate * H + u0 + j0]);
+        wreg[i][kg] = w;
+      }
+    }
+  }
+
+  const size_t slot_floats = (size_t)ncl * P * a.NT * 256;
+  const unsigned rbytes = (unsigned)(slot_floats * a.D * sizeof(float));
+  const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.ring, rbytes);
+
+  const int qq = tid / CPP, within = tid % CPP;
+  const int xr = within / (U / 4), xunit = u0 + (within % (U / 4)) * 4;
+  const unsigned xoff = (unsigned)((((xunit >> 4) * 16 + xr) * 16 + (xunit & 15)) * 4);
+
+  const bool othr = tid < OWN;
+  const int orow = tid / U, oj = tid % U;
+  const int bg = b0 + orow, unit = u0 + oj;
+  const bool owner = othr && bg < B && unit < H;
+  float dc_state = 0.f;
+  float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // Feature tiles go to waves by RANK, not by wave id: the last slot is partly filled (19
+  // tiles over 8 waves at cfg 2) and its tiles must land on different SIMDs whether the
+  // hardware deals waves to SIMDs round-robin (w % 4) or in pairs (w / 2): ranks 0,1,2,3 =
+  // waves 0,3,5,6.  (Waves 0,1,2 holding the three extra tiles put 6 tiles on one SIMD if
+  // waves 0,1 share it: 96 instead of 80 MFMAs per step on the busiest SIMD.)
+  const int wrank = (0x73261540u >> (4 * wave)) & 7;
+  // ---- weight-gradient accumulators and their A-operand addressing -------------------
+  // feature tile i of this wave: slab rows tw*NFt + (wave + 8 i)*16 + [0,16); MFMA kk pairs
+  // batch rows 4 kk + fq.  Tile-uniform source: x_t (slab rows < Dp) or h_prev(t).
+  f32x4 wacc[NFT][NCT];
+  const float* abase[NFT];   // (wave-uniform) element (row b0, first feature of the tile), t = 0
+  int ald[NFT], atstride[NFT], avalid[NFT];   // avalid: number of real features in the tile
+#pragma unroll
+  for (int i = 0; i < NFT; ++i) {
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) wacc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int ftile = wrank + NW * i;
+    const int fb = tw * aa.NFt + ftile * 16;          // first slab row of the tile
+    abase[i] = aa.x; ald[i] = 0; atstride[i] = 0; avalid[i] = 0;
+    if (ftile * 16 < aa.NFt) {
+      if (fb < aa.Dp) {
+        abase[i] = aa.x + (size_t)b0 * aa.ldx + fb;
+        ald[i] = aa.ldx; atstride[i] = B * aa.ldx; avalid[i] = aa.Din - fb;
+      } else {
+        const int hf = fb - aa.Dp;
+        abase[i] = aa.ypad + (size_t)((dir ? 2 : 0) * B + b0) * aa.ldy + dir * H + hf;
+        ald[i] = aa.ldy; atstride[i] = B * aa.ldy; avalid[i] = H - hf;
+      }
+    }
+  }
+  // does this wave's LAST tile slot hold a tile?  (wave-uniform)
+  const bool full_tiles = (NFT == 1) || ((wrank + NW * (NFT - 1)) * 16 < aa.NFt);
+  float af[NFT][4];
+#pragma unroll
+  for (int i = 0; i < NFT; ++i)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) af[i][kk] = 0.f;
+  // step 0 runs the update on zeros (no branch around the MFMA chains: a branch makes the
+  // compiler move the accumulators around it)
+  for (int i = tid; i < 16 * LDA; i += 512) atile[i] = 0.f;
+  __syncthreads();
+
+  for (int s = 0; s <= T; ++s) {
+    const int t = dir ? s : (T - 1 - s);
+    const int t_cprev = dir ? (t + 1) : (t - 1);
+
+    // ---- exchange loads of the partial dh of step s-1 (issued now, validated below).
+    // Branch-free: producers that do not exist (and everything at step 0) are out-of-range
+    // offsets, which return 0 without a memory access and count as valid.  (Conditional
+    // loads into a partly defined array made the compiler copy the first result right
+    // after issuing it -- an s_waitcnt vmcnt(0) that exposed the whole exchange latency.)
+    TRACE(0);
+    unsigned off[RSW_NI_MAX];
+    v4u av[RSW_NI_MAX];
+    const int sm1 = s > 0 ? s - 1 : 0;
+    const unsigned par = (unsigned)((sm1 / a.D) & 1);
+    {
+      const int slot = sm1 % a.D;
+#pragma unroll
+      for (int i = 0; i < RSW_NI_MAX; ++i) {
+        const int q = qq + PPR * i;
+        off[i] = (s > 0 && q < P)
+                     ? (unsigned)((((size_t)slot * ncl + cl) * P + q) * a.NT * 1024) + xoff : rbytes;
+      }
+#pragma unroll
+      for (int i = 0; i < RSW_NI_MAX; ++i) av[i] = load_sc1_b128(rres, off[i]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- weight-gradient update of step s-1: first quarter
+    // (two straight-line copies: waves whose last tile slot is empty -- 19 tiles over 8 waves
+    // at cfg 2 -- skip its MFMAs; a branch INSIDE a chain would make the compiler shuffle
+    // the accumulators)
+    // B operand (da of step s-1, all four row groups) in one batch of LDS reads: MFMA chains
+    // that wait on an LDS read per group ran at 22 ns per MFMA and SIMD instead of 15
+    float bfv[4][NCT];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) bfv[kk][ct] = atile[(4 * kk + fq) * LDA + ct * 16 + fr];
+#define DW_UPDATE_N(kk, NT_)                                                                  \
+    do {                                                                                      \
+      _Pragma("unroll") for (int i = 0; i < (NT_); ++i)                                       \
+        _Pragma("unroll") for (int ct = 0; ct < NCT; ++ct)                                    \
+          wacc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][kk], bfv[kk][ct],          \
+                                                             wacc[i][ct], 0, 0, 0);           \
+    } while (0)
+#define DW_UPDATE(kk)                                                                         \
+    do { if (full_tiles) DW_UPDATE_N(kk, NFT); else DW_UPDATE_N(kk, NFT - 1); } while (0)
+    DW_UPDATE(0);
+    TRACE(1);
+    if (s == T) {
+      // last update: no further step
+      DW_UPDATE(1); DW_UPDATE(2); DW_UPDATE(3);
+      break;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- everything of step s that does not depend on the exchange
+    float gv[4] = {0.f, 0.f, 0.f, 0.f}, cv = 0.f, cpv = 0.f, dyv = 0.f;
+    if (owner) {
+      const float* gp = a.gates[dir] + ((size_t)t * B + bg) * (4 * H) + unit;
+      gv[0] = gp[0]; gv[1] = gp[H]; gv[2] = gp[2 * H]; gv[3] = gp[3 * H];
+      cv = a.cell[dir][((size_t)t * B + bg) * H + unit];
+      if (t_cprev >= 0 && t_cprev < T) cpv = a.cell[dir][((size_t)t_cprev * B + bg) * H + unit];
+      dyv = a.dy[((size_t)t * B + bg) * a.lddy + dir * H + unit];
+    }
+
+    // ---- rest of the weight-gradient update of step s-1, under the exchange wait
+    if (full_tiles) { DW_UPDATE_N(1, NFT); DW_UPDATE_N(2, NFT); DW_UPDATE_N(3, NFT); }
+    else { DW_UPDATE_N(1, NFT - 1); DW_UPDATE_N(2, NFT - 1); DW_UPDATE_N(3, NFT - 1); }
+#undef DW_UPDATE
+#undef DW_UPDATE_N
+    __builtin_amdgcn_sched_barrier(0);
+    TRACE(2);
+    {
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < RSW_NI_MAX; ++i) {
+          const unsigned mm = par ? ~(av[i][0] & av[i][1] & av[i][2] & av[i][3])
+                                  : (av[i][0] | av[i][1] | av[i][2] | av[i][3]);
+          ok &= (off[i] == rbytes) || !(mm & 1u);
+        }
+        if (__all(ok)) break;
+        if (spin_fail(spins, a.status, lane, a.spin_limit)) break;
+#pragma unroll
+        for (int i = 0; i < RSW_NI_MAX; ++i) av[i] = load_sc1_b128(rres, off[i]);
+      }
+      TRACE(3); TRACE_VAL(6, spins);
+      f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < RSW_NI_MAX; ++i) {
+        v4u w = av[i];
+        if (off[i] == rbytes) w = (v4u){0u, 0u, 0u, 0u};
+        w[0] &= ~1u; w[1] &= ~1u; w[2] &= ~1u; w[3] &= ~1u;
+        sum += __builtin_bit_cast(f32x4, w);
+      }
+      *reinterpret_cast<f32x4*>(&psum[qq * OWN + within * 4]) = sum;
+    }
+    // A operand of THIS step's update (consumed at the top of the next step).  Issued only now:
+    // guarded loads in flight make the compiler wait for ALL outstanding loads (vmcnt(0)) at
+    // the validation above, i.e. the exchange would also wait for this prefetch.
+#pragma unroll
+    for (int i = 0; i < NFT; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        float v = 0.f;
+        if (fr < avalid[i] && b0 + 4 * kk + fq < B)
+          v = abase[i][(size_t)t * atstride[i] + (size_t)(4 * kk + fq) * ald[i] + fr];
+        af[i][kk] = v;
+      }
+
+    __syncthreads();   // also: every wave is done reading atile (da of step s-1)
+    TRACE(4);
+
+    float dav[4] = {0.f, 0.f, 0.f, 0.f};
+    if (othr) {
+      float dh = dyv;
+#pragma unroll
+      for (int k = 0; k < PPR; ++k) dh += psum[k * OWN + tid];   // zeros at step 0
+      if (owner) {
+        const float g = gv[0], ig = gv[1], fg = gv[2], og = gv[3];
+        const float tc = tanh_hw(cv);
+        const float dc = dc_state + dh * og * (1.f - tc * tc);
+        dav[0] = dc * ig;
+        dav[1] = dc * g * ig * (1.f - ig);
+        dav[2] = dc * cpv * fg * (1.f - fg);
+        dav[3] = dh * tc * og * (1.f - og);
+        dc_state = dc * fg;
+        dbacc[0] += dav[0]; dbacc[1] += dav[1]; dbacc[2] += dav[2]; dbacc[3] += dav[3];
+      }
+      float* ap = &atile[orow * LDA + oj];
+      ap[0] = dav[0]; ap[U] = dav[1]; ap[2 * U] = dav[2]; ap[3 * U] = dav[3];
+    }
+    __syncthreads();
+    TRACE(5);
+    // The prefetched A operand is loop-carried: without this, the compiler waits for it at the
+    // loop latch with s_waitcnt vmcnt(0) -- which on gfx9 also waits for the write-through
+    // publish stores issued just before (0.5 us per step).  Consuming the values HERE puts the
+    // wait where only loads are outstanding (they were issued two phases ago).
+#pragma unroll
+    for (int i = 0; i < NFT; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) asm volatile("" : "+v"(af[i][kk]));
+
+    if (s + 1 < T) {
+      f32x4 bq[KG];
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg)
+        bq[kg] = *reinterpret_cast<const f32x4*>(&atile[fr * LDA + kg * 16 + fq * 4]);
+      constexpr int NACC = 2;
+      f32x4 acc2[NTW][NACC];
+#pragma unroll
+      for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int c = 0; c < NACC; ++c) acc2[i][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < NTW; ++i)
+            acc2[i][j % NACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                wreg[i][kg][j], bq[kg][j], acc2[i][j % NACC], 0, 0, 0);
+      const int slot = s % a.D;
+      const unsigned ppub = (unsigned)((s / a.D) & 1);
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        const f32x4 accs = acc2[i][0] + acc2[i][1];
+        const int tl = tw + S * (wave + NW * i);
+        unsigned o = rbytes;
+        if (tl < a.NT)
+          o = (unsigned)(((((size_t)slot * ncl + cl) * P + p) * a.NT + tl) * 1024) +
+              (unsigned)((fr * 16 + fq * 4) * 4);
+        v4u w = __builtin_bit_cast(v4u, accs);
+        w[0] = (w[0] & ~1u) | ppub; w[1] = (w[1] & ~1u) | ppub;
+        w[2] = (w[2] & ~1u) | ppub; w[3] = (w[3] & ~1u) | ppub;
+        store_sc1_b128(rres, o, w);
+      }
+    }
+    if (owner && tw == 0) {
+      float* dp = a.da[dir] + ((size_t)t * B + bg) * (4 * H) + unit;
+      dp[0] = dav[0]; dp[H] = dav[1]; dp[2 * H] = dav[2]; dp[3 * H] = dav[3];
+    }
+    TRACE(7);
+  }
+
+  // ---- this workgroup's block of the cluster's partial dW: D layout row = 4 fq + r, col = fr
+  {
+    float* slab = aa.dwslab + (size_t)cl * aa.NFP * (4 * H);
+#pragma unroll
+    for (int i = 0; i < NFT; ++i) {
+      const int ftile = wrank + NW * i;
+      if (ftile * 16 >= aa.NFt) continue;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const int acol = ct * 16 + fr;
+        const int gate = acol / U, j = acol % U;
+        if (u0 + j >= H) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = tw * aa.NFt + ftile * 16 + 4 * fq + r;     // slab row (padded space)
+          slab[(size_t)f * (4 * H) + gate * H + u0 + j] = wacc[i][ct][r];
+        }
+      }
+    }
+  }
+  // ---- partial db of the cluster: sum of the own da columns over the 16 rows (twin 0)
+  __syncthreads();
+  if (tw == 0) {
+    if (othr) {
+      float* ap = &atile[orow * LDA + oj];
+      ap[0] = dbacc[0]; ap[U] = dbacc[1]; ap[2 * U] = dbacc[2]; ap[3 * U] = dbacc[3];
+    }
+    __syncthreads();
+    if (tid < 4 * U) {
+      float v = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) v += atile[rr * LDA + tid];
+      const int gate = tid / U, j = tid % U;
+      if (u0 + j < H) aa.dbslab[(size_t)cl * (4 * H) + gate * H + u0 + j] = v;
+    }
+  }
+}
+
+// dW_d[f][c] (+)= sum over the G clusters of direction d of their partial; same for db
+__global__ __launch_bounds__(256) void lstm_dw_reduce_kernel(
+    const float* __restrict__ dwslab, const float* __restrict__ dbslab, float* dW0, float* dW1,
+    float* db0, float* db1, int G, int Din, int Dp, int NF, int NFP, int H4, float beta) {
+  const int dir = blockIdx.y;
+  float* dW = dir ? dW1 : dW0;
+  float* db = dir ? db1 : db0;
+  const int q4 = H4 / 4;
+  const int64_t n4 = (int64_t)NF * q4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4 + q4;
+       i += (int64_t)gridDim.x * 256) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4) {
+      const int row = (int)(i / q4), c4 = (int)(i % q4);
+      const int srow = row < Din ? row : row - Din + Dp;      // slab row (padded feature space)
+      for (int g = 0; g < G; ++g)
+        v += reinterpret_cast<const f32x4*>(dwslab + ((size_t)(dir * G + g) * NFP + srow) * H4)[c4];
+      f32x4* o = reinterpret_cast<f32x4*>(dW) + i;
+      if (beta != 0.f) v += *o;
+      *o = v;
+    } else {
+      const int64_t j = i - n4;
+      for (int g = 0; g < G; ++g)
+        v += reinterpret_cast<const f32x4*>(dbslab + (size_t)(dir * G + g) * H4)[j];
+      f32x4* o = reinterpret_cast<f32x4*>(db) + j;
+      if (beta != 0.f) v += *o;
+      *o = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // prefill: every "not yet published" pattern / zero block of one call in ONE launch
 // (hipMemsetAsync with a byte value lowers to a fill kernel PLUS copy kernels on this
 // runtime, and each memset is its own node on the critical path of the layer)
@@ -1296,11 +1657,14 @@ static bool fwd_fused_ok(int T, int B, int H, int ndir, int D, int* CHX) {
   if (H % 4 != 0 || H > 16 * FWD_CH * 4 || D > 640) return false;
   const int P = cdiv(H, LSTM_UNITS_FWD), G = cdiv(B, 16);
   if (ndir * G * P > num_cus()) return false;
-  // Measured (profiles/r02_b_fused_fwd_trace.txt): correct, but SLOWER than the hoisted GEMM
-  // (4.2 vs 2.2 + 1.15 us per step at cfg 2): MFMA issue from one wave starves the co-resident
-  // waves of its SIMD, so the input-half MFMAs delay the gate math / the polling instead of
-  // hiding behind them.  Opt-in (DANET_LSTM_FWD_FUSED=1) until that is solved.
-  { const char* e = getenv("DANET_LSTM_FWD_FUSED"); if (!e || atoi(e) != 1) return false; }
+  // DANET_LSTM_FWD_FUSED=0 turns the path off, =1 forces it inside the envelope; otherwise it is
+  // used where it beats the hoisted GEMM: the input-half MFMAs add ~1.0 us * D/600 to a step
+  // (measured, profiles/r02_d_fused_fwd_trace.txt), the hoisted GEMM costs ~1.15 us * B/32 *
+  // D/600 per step (80 TFLOP/s) -- i.e. from about B >= 24 on; B = 1 inference (cfg 5) stays
+  // on the hoisted path (2.66 vs 1.84 us per step).
+  { const char* e = getenv("DANET_LSTM_FWD_FUSED");
+    if (e && atoi(e) == 0) return false;
+    if (!(e && atoi(e) == 1) && B < 24) return false; }
   const int per_wave = cdiv(cdiv(D, 16), 4);
   if (CHX) *CHX = per_wave <= 3 ? 3 : 10;
   return true;
@@ -1344,9 +1708,7 @@ extern "C" int danet_lstm_fwd_fused(danet_stream_t stream_, int T, int B, int H,
   a.P = cdiv(H, LSTM_UNITS_FWD); a.G = cdiv(B, 16); a.KP = cdiv(H, 16) * 16;
   a.DP = cdiv(D, 16) * 16;
   a.xmap = getenv("DANET_LSTM_XMAP") ? atoi(getenv("DANET_LSTM_XMAP")) : 1;
-  const size_t xbuf_floats = (size_t)16 * (a.DP + 4) > (size_t)a.KP * 32 ? (size_t)16 * (a.DP + 4)
-                                                                       : (size_t)a.KP * 32;
-  const size_t lds = (xbuf_floats + (size_t)16 * (a.KP + 4) + (size_t)4 * 16 * 33) * sizeof(float);
+  const size_t lds = ((size_t)a.KP * 32 + (size_t)4 * 16 * 33) * sizeof(float);
   const size_t blk = (size_t)B * ldy * sizeof(float);
   {
     FillList fl;
@@ -1360,12 +1722,126 @@ extern "C" int danet_lstm_fwd_fused(danet_stream_t stream_, int T, int B, int H,
   if (CHX == 3) {
     DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_fx_kernel<3>,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lstm_fwd_fx_kernel<3><<<nblk, 512, lds, stream>>>(a);
+    lstm_fwd_fx_kernel<3><<<nblk, 256, lds, stream>>>(a);
   } else {
     DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_fx_kernel<10>,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lstm_fwd_fx_kernel<10><<<nblk, 512, lds, stream>>>(a);
+    lstm_fwd_fx_kernel<10><<<nblk, 256, lds, stream>>>(a);
   }
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
+
+// ---- BPTT with fused weight gradients: geometry and entry points ---------------------
+struct RswPlan { bool ok; RsPlan rs; int NFt, NFP, NFT; size_t dw_bytes, db_bytes; };
+static RswPlan make_rsw_plan(int B, int H, int ndir, int D) {
+  RswPlan w; w.ok = false; w.NFt = w.NFP = w.NFT = 0; w.dw_bytes = w.db_bytes = 0;
+  w.rs = choose_rs_plan(B, H, ndir);
+  // Opt-in (DANET_LSTM_BWD_FUSED=1): measured at parity with the GEMM path, not ahead of it
+  // (cfg 2: 3.615 vs 3.602 ms per step, cfg 4: 5.21 vs 5.09; profiles/r02_d_fused_bwd_trace.txt):
+  // the 80 weight-gradient MFMAs per SIMD and step run at 22 ns instead of the 15 ns the pipe
+  // can do, which makes the step MFMA-bound at 3.6 us where the exchange would allow 2.5.
+  { const char* e = getenv("DANET_LSTM_BWD_FUSED"); if (!e || atoi(e) != 1) return w; }
+  if (!w.rs.ok || D <= 0) return w;
+  if (w.rs.U != 8 && w.rs.U != 16) return w;
+  if (w.rs.NTW > 2 || w.rs.NI > RSW_NI_MAX) return w;
+  const int Dp = cdiv(D, 16) * 16, Hp = cdiv(H, 16) * 16;
+  w.NFt = cdiv((Dp + Hp) / 16, w.rs.S) * 16;
+  w.NFP = w.rs.S * w.NFt;
+  w.NFT = cdiv(w.NFt / 16, 8);
+  if (w.NFT > 3 || (w.rs.U == 16 && w.rs.NTW == 2 && w.NFT == 3)) return w;   // register budget
+  const size_t ncl = (size_t)ndir * w.rs.G;
+  w.dw_bytes = align_up(ncl * w.NFP * 4 * H * sizeof(float), 256);
+  w.db_bytes = align_up(ncl * 4 * H * sizeof(float), 256);
+  w.ok = true;
+  return w;
+}
+
+extern "C" int danet_lstm_bwd_fused_supported(int T, int B, int H, int ndir, int D) {
+  if (T <= 0 || B <= 0 || H <= 0 || H % 4 != 0 || (ndir != 1 && ndir != 2)) return 0;
+  return make_rsw_plan(B, H, ndir, D).ok ? 1 : 0;
+}
+
+extern "C" size_t danet_lstm_bwd_fused_workspace_bytes(int T, int B, int H, int ndir, int D) {
+  const RswPlan w = make_rsw_plan(B, H, ndir, D);
+  if (!w.ok) return 0;
+  return align_up(ring_offset(T) + w.rs.ring_bytes, 256) + w.dw_bytes + w.db_bytes;
+}
+
+extern "C" int danet_lstm_bwd_fused(danet_stream_t stream_, int T, int B, int H, int ndir,
+                                    const float* dy, int lddy,
+                                    const float* W_f, const float* W_b, int ldw,
+                                    const float* gates_f, const float* gates_b,
+                                    const float* cell_f, const float* cell_b,
+                                    const float* x, int ldx, int D,
+                                    const float* ypad, int ldy,
+                                    float* da_f, float* da_b,
+                                    float* dW_f, float* dW_b, float* db_f, float* db_b,
+                                    float beta, void* ws, size_t ws_bytes, int32_t* status) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DANET_CHECK_ARG(T > 0 && B > 0 && H > 0 && D > 0, "lstm_bwd_fused: non-positive shape");
+  DANET_CHECK_ARG(ndir == 1 || ndir == 2, "lstm_bwd_fused: ndir must be 1 or 2");
+  if (H % 4 != 0) {
+    danet_set_error("lstm: H=%d must be a multiple of 4", H);
+    return DANET_ERR_UNSUPPORTED;
+  }
+  const RswPlan w = make_rsw_plan(B, H, ndir, D);
+  if (!w.ok) {
+    danet_set_error("lstm_bwd_fused: T=%d B=%d H=%d D=%d outside the fused envelope", T, B, H, D);
+    return DANET_ERR_UNSUPPORTED;
+  }
+  const size_t need = danet_lstm_bwd_fused_workspace_bytes(T, B, H, ndir, D);
+  if (!ws || ((uintptr_t)ws & 15) != 0 || ws_bytes < need) {
+    danet_set_error("lstm_bwd_fused: workspace too small or not 16-B aligned");
+    return DANET_ERR_WORKSPACE;
+  }
+  DANET_CHECK_ARG(dy && W_f && gates_f && cell_f && da_f && x && ypad && dW_f && db_f,
+                  "lstm_bwd_fused: null pointer");
+  DANET_CHECK_ARG(ndir == 1 || (W_b && gates_b && cell_b && da_b && dW_b && db_b),
+                  "lstm_bwd_fused: null bwd pointer");
+  DANET_CHECK_ARG(lddy >= ndir * H && ldw >= 4 * H && ldw % 4 == 0 && ldx >= D && ldy >= ndir * H,
+                  "lstm_bwd_fused: bad ld");
+  DANET_CHECK_ARG(beta == 0.f || beta == 1.f, "lstm_bwd_fused: beta must be 0 or 1");
+  DANET_CHECK_ARG((((uintptr_t)da_f | (uintptr_t)da_b | (uintptr_t)dW_f | (uintptr_t)dW_b |
+                    (uintptr_t)db_f | (uintptr_t)db_b | (uintptr_t)W_f | (uintptr_t)W_b) & 15) == 0,
+                  "lstm_bwd_fused: W, da, dW, db must be 16-B aligned");
+  DANET_CHECK_ARG((size_t)T * B * 4 * H * 4 < 0xFFFFFFF0ull, "lstm_bwd_fused: da > 4 GiB");
+  const RsPlan& rs = w.rs;
+  LstmBwdRswArgs aa;
+  LstmBwdRsArgs& a = aa.r;
+  a.dy = dy; a.lddy = lddy;
+  a.Wh[0] = W_f + (size_t)D * ldw; a.Wh[1] = W_b ? W_b + (size_t)D * ldw : nullptr; a.ldw = ldw;
+  a.gates[0] = gates_f; a.gates[1] = gates_b; a.cell[0] = cell_f; a.cell[1] = cell_b;
+  a.da[0] = da_f; a.da[1] = da_b; a.status = status ? (int*)status : (int*)ws;
+  a.spin_limit = spin_limit_env(); a.fault = fault_env();
+  a.ring = (float*)((char*)ws + ring_offset(T));
+  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.P = rs.P; a.G = rs.G; a.S = rs.S;
+  a.NT = rs.NT; a.NI = rs.NI; a.D = rs.D;
+  a.xmap = getenv("DANET_LSTM_XMAP") ? atoi(getenv("DANET_LSTM_XMAP")) : 1;
+  aa.x = x; aa.ypad = ypad; aa.ldx = ldx; aa.ldy = ldy; aa.Din = D; aa.Dp = cdiv(D, 16) * 16;
+  aa.NFt = w.NFt; aa.NFP = w.NFP;
+  aa.dwslab = (float*)((char*)ws + align_up(ring_offset(T) + rs.ring_bytes, 256));
+  aa.dbslab = (float*)((char*)aa.dwslab + w.dw_bytes);
+  {
+    FillList fl;
+    fl.add(ws, 64 + TRACE_BYTES(T), 0u);
+    fl.add(a.ring, rs.ring_bytes, 1u);   // phase 1 in bit 0 of every word
+    DANET_CHECK_HIP(fl.launch(stream));
+  }
+  const int nblk = ndir * rs.G * rs.P * rs.S;
+#define LAUNCH_RSW(UV, NTWV, NFTV) lstm_bwd_rsw_kernel<UV, NTWV, NFTV><<<nblk, 512, 0, stream>>>(aa)
+#define LAUNCH_RSW_F(UV, NTWV)                                            \
+    switch (w.NFT) {                                                      \
+      case 1: LAUNCH_RSW(UV, NTWV, 1); break; case 2: LAUNCH_RSW(UV, NTWV, 2); break; \
+      default: LAUNCH_RSW(UV, NTWV, 3); break; }
+  if (rs.U == 8) { if (rs.NTW == 1) { LAUNCH_RSW_F(8, 1) } else { LAUNCH_RSW_F(8, 2) } }
+  else { if (rs.NTW == 1) { LAUNCH_RSW_F(16, 1) } else { LAUNCH_RSW_F(16, 2) } }
+  DANET_CHECK_LAUNCH();
+  const int NF = D + H;
+  const int64_t items = (int64_t)NF * H + H;
+  dim3 grid((unsigned)(cdiv64(items, 256) < 1024 ? cdiv64(items, 256) : 1024), ndir);
+  lstm_dw_reduce_kernel<<<grid, 256, 0, stream>>>(aa.dwslab, aa.dbslab, dW_f, dW_b, db_f, db_b,
+                                                  rs.G, D, aa.Dp, NF, w.NFP, 4 * H, beta);
   DANET_CHECK_LAUNCH();
   return DANET_OK;
 }

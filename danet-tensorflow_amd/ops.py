@@ -520,15 +520,7 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
     T, B, H, D, ndir = c.T, c.B, c.H, c.D, c.ndir
     dev = dy.device
     das = [torch.empty(T * B, 4 * H, device=dev) for _ in range(ndir)]
-    ws, wn = _lstm_ws(T, B, H, ndir, dev)
-    Whs = [W[D:] for W in c.Ws]
     L = _L()
-    with _lib.timed('lstm_bwd'):
-        check(L.danet_lstm_bwd(
-            _lib.stream(), T, B, H, ndir, ptr(_f32(dy)), ndir * H,
-            ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(c.gates[0]), ptr(c.gates[-1]),
-            ptr(c.cells[0]), ptr(c.cells[-1]), ptr(das[0]), ptr(das[-1]), ptr(ws), wn,
-            ptr(status_word(dev))))
     ldy = ndir * H
     # gradients accumulate straight into the parameters' .grad (the model's flat
     # all-reduce bucket) when there is one; autograd then gets None for them
@@ -538,6 +530,33 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
         gb, okb = _grad_target(c.bs[d], (4 * H,), dev)
         dWs.append(gW); dbs.append(gb); direct.append((okW, okb))
     dx = torch.empty(T * B, D, device=dev) if need_dx else None
+    all_direct = all(a and b for a, b in direct)
+    none_direct = not any(a or b for a, b in direct)
+    fused = ((all_direct or none_direct) and
+             all(W.stride(0) == 4 * H and W.stride(1) == 1 and W.data_ptr() % 16 == 0 for W in c.Ws) and
+             all(t.data_ptr() % 16 == 0 for t in dWs + dbs) and
+             L.danet_lstm_bwd_fused_supported(T, B, H, ndir, D) == 1)
+    if fused:
+        # BPTT with dW / db accumulated inside the persistent kernel (csrc/lstm.hip): no
+        # weight-gradient GEMMs, no column sums, nothing on a side stream
+        wn = L.danet_lstm_bwd_fused_workspace_bytes(T, B, H, ndir, D)
+        ws = torch.empty(wn, dtype=torch.uint8, device=dev)
+        with _lib.timed('lstm_bwd'):
+            check(L.danet_lstm_bwd_fused(
+                _lib.stream(), T, B, H, ndir, ptr(_f32(dy)), ndir * H,
+                ptr(c.Ws[0]), ptr(c.Ws[-1]), 4 * H, ptr(c.gates[0]), ptr(c.gates[-1]),
+                ptr(c.cells[0]), ptr(c.cells[-1]), ptr(c.x), c.ldx, D, ptr(c.ypad), ldy,
+                ptr(das[0]), ptr(das[-1]), ptr(dWs[0]), ptr(dWs[-1]), ptr(dbs[0]), ptr(dbs[-1]),
+                1.0 if all_direct else 0.0, ptr(ws), wn, ptr(status_word(dev))))
+    else:
+        ws, wn = _lstm_ws(T, B, H, ndir, dev)
+        Whs = [W[D:] for W in c.Ws]
+        with _lib.timed('lstm_bwd'):
+            check(L.danet_lstm_bwd(
+                _lib.stream(), T, B, H, ndir, ptr(_f32(dy)), ndir * H,
+                ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(c.gates[0]), ptr(c.gates[-1]),
+                ptr(c.cells[0]), ptr(c.cells[-1]), ptr(das[0]), ptr(das[-1]), ptr(ws), wn,
+                ptr(status_word(dev))))
 
     # the weight-gradient products overlap the NEXT layer's BPTT kernel (152 of
     # 256 CUs at cfg 2): cap each chain so both together stay on the idle CUs
@@ -608,7 +627,9 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
             _fire_grad_ready(('rest',), list(c.Ws) + list(c.bs))
     with _Fork(dev, ndir + 1, defer=True, keep=(das, c.x, c.ypad, dy)) as f:
         on_main = False
-        if GROUPED_DW and not need_dx:
+        if fused:
+            on_main = True           # everything was issued on the main stream
+        elif GROUPED_DW and not need_dx:
             # bottom layer: no BPTT kernel follows, so the group takes the whole GPU on
             # the main stream while the column sums run beside it
             f.run(1, bias_grads)

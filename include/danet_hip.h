@@ -215,9 +215,9 @@ int danet_lstm_fwd(danet_stream_t stream, int T, int B, int H, int ndir,
  * e.g. zero padding); W_d [D+H][ldw] in the reference layout (rows 0..D-1 input half,
  * rows D.. recurrent half, app/ops.py:138-142); bias_d [4H].  Outputs as danet_lstm_fwd.
  * Envelope: H % 4 == 0, H <= 320, D <= 640, ndir*ceil(B/16)*ceil(H/8) <= CUs;
- * danet_lstm_fwd_fused_supported() returns 1 inside it AND when the path is switched on
- * (DANET_LSTM_FWD_FUSED=1 in the environment: it is correct but currently slower than the
- * hoisted GEMM, see csrc/lstm.hip), otherwise callers hoist the projection
+ * danet_lstm_fwd_fused_supported() returns 1 inside it when the path is expected to be the
+ * faster one (B >= 24: below that the hoisted GEMM is cheaper than the extra MFMAs per step;
+ * DANET_LSTM_FWD_FUSED=1 forces it, =0 turns it off), otherwise callers hoist the projection
  * (danet_gemm_f32*) and call danet_lstm_fwd.                                  */
 int danet_lstm_fwd_fused_supported(int T, int B, int H, int ndir, int D);
 int danet_lstm_fwd_fused(danet_stream_t stream, int T, int B, int H, int ndir,
@@ -241,6 +241,31 @@ int danet_lstm_bwd(danet_stream_t stream, int T, int B, int H, int ndir,
                    const float* cell_f, const float* cell_b,
                    float* da_f, float* da_b,
                    void* ws, size_t ws_bytes, int32_t* status);
+
+/* BPTT with the layer's weight and bias gradients FUSED: dW_d = [X | Hprev]^T da_d and
+ * db_d = colsum(da_d) are accumulated inside the persistent kernel -- every workgroup owns
+ * a block of da_t columns, has them in LDS each step, and runs the rank-16 update of its
+ * dW columns on the matrix cores while it waits for the other workgroups' partial dh --
+ * instead of in separate GEMM / column-sum launches.  x [T][B][ldx] and ypad [T+2][B][ldy]
+ * are the layer's forward input and output (h_prev(t) = ypad block t for the forward scan,
+ * block t+2 for the reversed one); W_d is the full [D+H][ldw] matrix (recurrent rows at D);
+ * dW_d [D+H][4H] and db_d [4H] (16-byte aligned, dense) are overwritten (beta = 0) or
+ * accumulated into (beta = 1).  da_d as in danet_lstm_bwd (the caller still computes
+ * dX = da Wx^T).  Envelope: the reduce-scatter BPTT geometry with U <= 16 units per group
+ * and H <= 384.  Opt-in: danet_lstm_bwd_fused_supported returns 1 only with
+ * DANET_LSTM_BWD_FUSED=1 in the environment (measured at parity with the GEMM path).      */
+int danet_lstm_bwd_fused_supported(int T, int B, int H, int ndir, int D);
+size_t danet_lstm_bwd_fused_workspace_bytes(int T, int B, int H, int ndir, int D);
+int danet_lstm_bwd_fused(danet_stream_t stream, int T, int B, int H, int ndir,
+                         const float* dy, int lddy,
+                         const float* W_f, const float* W_b, int ldw,
+                         const float* gates_f, const float* gates_b,
+                         const float* cell_f, const float* cell_b,
+                         const float* x, int ldx, int D,
+                         const float* ypad, int ldy,
+                         float* da_f, float* da_b,
+                         float* dW_f, float* dW_b, float* db_f, float* db_b,
+                         float beta, void* ws, size_t ws_bytes, int32_t* status);
 
 /* ---------------------------------------------------------------- a8-a10
  * Truth-family attractor estimators (app/modules.py:382-487).

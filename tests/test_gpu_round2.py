@@ -596,11 +596,17 @@ def _lstm_ref(x, Ws, bs, H, dy):
 @pytest.mark.parametrize('fused', ['1', '0'])
 def test_lstm_forward_fused_input_projection(B, T, D, H, ndir, fused, monkeypatch):
     '''danet_lstm_fwd_fused (x_t*Wx computed inside the persistent scan, in the exchange
-    wait) and the hoisted-GEMM path give the oracle's outputs and gradients; the envelope
-    query decides which one runs'''
+    wait) + danet_lstm_bwd_fused (dW / db accumulated inside the BPTT kernel) on one side, the
+    hoisted-GEMM / separate-GEMM paths on the other: both give the oracle's outputs and
+    gradients; the envelope queries decide which one runs'''
     from danet_amd import ops, _lib
     monkeypatch.setenv('DANET_LSTM_FWD_FUSED', fused)
+    monkeypatch.setenv('DANET_LSTM_BWD_FUSED', fused)      # BPTT with fused dW / db alongside
     assert _lib.load().danet_lstm_fwd_fused_supported(T, B, H, ndir, D) == int(fused)
+    bwd_fused = _lib.load().danet_lstm_bwd_fused_supported(T, B, H, ndir, D)
+    assert bwd_fused in (0, int(fused))        # (48, ...) and tiny shapes fall outside its envelope
+    if (B, H, D) in ((32, 300, 600), (32, 300, 132)):
+        assert bwd_fused == int(fused)
     rng = np.random.RandomState(B * 100 + T * 10 + H + D)
     r = 0.75 / np.sqrt(H)
     x = rng.randn(B, T, D) * 0.7
@@ -626,9 +632,15 @@ def test_lstm_fused_envelope_query(monkeypatch):
     from danet_amd import _lib
     L = _lib.load()
     monkeypatch.delenv('DANET_LSTM_FWD_FUSED', raising=False)
-    assert L.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 600) == 0      # opt-in path
+    monkeypatch.delenv('DANET_LSTM_BWD_FUSED', raising=False)
+    assert L.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 600) == 1      # default: B >= 24
+    assert L.danet_lstm_fwd_fused_supported(1251, 1, 300, 2, 600) == 0      # B = 1: hoisted GEMM
+    assert L.danet_lstm_bwd_fused_supported(128, 32, 300, 2, 600) == 0      # opt-in path
+    monkeypatch.setenv('DANET_LSTM_BWD_FUSED', '1')
+    assert L.danet_lstm_bwd_fused_supported(128, 32, 300, 2, 600) == 1
+    assert L.danet_lstm_bwd_fused_supported(128, 32, 600, 2, 1200) == 0     # U = 32 geometry
     monkeypatch.setenv('DANET_LSTM_FWD_FUSED', '1')
-    assert L.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 600) == 1
+    assert L.danet_lstm_fwd_fused_supported(1251, 1, 300, 2, 600) == 1
     assert L.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 129) == 1
     assert L.danet_lstm_fwd_fused_supported(128, 32, 600, 2, 1200) == 0     # H > 320
     assert L.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 644) == 0      # D > 640

@@ -41,17 +41,17 @@ def report(name, ws, T):
 
 
 def report_fused(name, ws, T):
-    '''lstm_fwd_fx_kernel: exchange-wave thread stamps 0 top, 1 exchange valid, 2 after B1,
-    3 after B2, 4 gate math + publish done, 6 retries; matrix-wave thread stamps 5 input-half
-    MFMAs issued (before B1), 7 recurrent MFMAs + partial tiles written (before B2)'''
+    '''lstm_fwd_fx_kernel: 0 top | 1 first quarter of the input half + loads issued | 2 rest
+    of the input half issued | 3 exchange valid (6 retries) | 4 recurrent MFMAs + reduce barrier
+    | 5 gate math, publish | 7 barrier'''
     tr = ws[64:64 + T * 64].view(torch.int64).view(T, 8).cpu().numpy().astype(np.float64)
     tr = tr[2:]
     us = lambda a: a / 100.0
     step = us(np.diff(tr[:, 0]))
-    ph = dict(X_top_to_valid=us(tr[:, 1] - tr[:, 0]), X_valid_to_B1=us(tr[:, 2] - tr[:, 1]),
-              X_B1_to_B2=us(tr[:, 3] - tr[:, 2]), X_B2_to_published=us(tr[:, 4] - tr[:, 3]),
-              M_B2prev_to_M1done=us(tr[1:, 5] - tr[:-1, 3]), M_M1done_to_B1=us(tr[:, 2] - tr[:, 5]),
-              M_B1_to_M2done=us(tr[:, 7] - tr[:, 2]), M_M2done_to_B2=us(tr[:, 3] - tr[:, 7]))
+    ph = dict(top_to_loads=us(tr[:, 1] - tr[:, 0]), input_half_rest=us(tr[:, 2] - tr[:, 1]),
+              rest_to_valid=us(tr[:, 3] - tr[:, 2]), recurrent_reduce=us(tr[:, 4] - tr[:, 3]),
+              gate_publish=us(tr[:, 5] - tr[:, 4]), barrier=us(tr[:, 7] - tr[:, 5]),
+              to_next_top=us(tr[1:, 0] - tr[:-1, 7]))
     print('%s: step %.2f us (median %.2f)  retries/step %.2f' % (
         name, step.mean(), np.median(step), tr[:, 6].mean()))
     for k, v in ph.items():
@@ -82,10 +82,60 @@ def fused(B, T, H, D):
     report_fused('lstm_fwd_fused D=%d' % D, ws, T)
 
 
+def report_bwd_fused(name, ws, T):
+    '''lstm_bwd_rsw_kernel: 0 top | 1 first quarter of the dW update issued | 2 rest issued,
+    A operand prefetched | 3 exchange valid (6 retries) | 4 barrier after partial sums |
+    5 gate math + barrier | 7 partial dh published'''
+    tr = ws[64:64 + T * 64].view(torch.int64).view(T, 8).cpu().numpy().astype(np.float64)
+    tr = tr[2:-1]
+    us = lambda a: a / 100.0
+    step = us(np.diff(tr[:, 0]))
+    ph = dict(top_to_quarter=us(tr[:, 1] - tr[:, 0]), quarter_to_rest_issued=us(tr[:, 2] - tr[:, 1]),
+              rest_to_valid=us(tr[:, 3] - tr[:, 2]), valid_to_barrier=us(tr[:, 4] - tr[:, 3]),
+              gate_barrier=us(tr[:, 5] - tr[:, 4]), mfma_publish=us(tr[:, 7] - tr[:, 5]),
+              publish_to_next_top=us(tr[1:, 0] - tr[:-1, 7]))
+    print('%s: step %.2f us (median %.2f)  retries/step %.2f' % (
+        name, step.mean(), np.median(step), tr[:, 6].mean()))
+    for k, v in ph.items():
+        print('   %-24s mean %.2f  median %.2f  p90 %.2f' % (k, v.mean(), np.median(v), np.percentile(v, 90)))
+
+
+def bwd_fused(B, T, H, D):
+    dev = torch.device('cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    ndir = 2
+    if L.danet_lstm_bwd_fused_supported(T, B, H, ndir, D) != 1:
+        print('fused BPTT: shape outside the envelope')
+        return
+    x = torch.randn(T, B, D, device=dev) * 0.5
+    W = [torch.randn(D + H, 4 * H, device=dev) * (0.75 / H ** 0.5) for _ in range(2)]
+    ypad = torch.randn(T + 2, B, 2 * H, device=dev) * 0.3
+    gates = [torch.rand(T * B, 4 * H, device=dev) for _ in range(2)]
+    cells = [torch.randn(T * B, H, device=dev) * 0.5 for _ in range(2)]
+    dy = torch.randn(T, B, 2 * H, device=dev)
+    das = [torch.empty(T * B, 4 * H, device=dev) for _ in range(2)]
+    dW = [torch.empty(D + H, 4 * H, device=dev) for _ in range(2)]
+    db = [torch.empty(4 * H, device=dev) for _ in range(2)]
+    n = L.danet_lstm_bwd_fused_workspace_bytes(T, B, H, ndir, D)
+    for it in range(3):
+        ws = torch.zeros(n, dtype=torch.uint8, device=dev)
+        _lib.check(L.danet_lstm_bwd_fused(st, T, B, H, ndir, ptr(dy), 2 * H, ptr(W[0]), ptr(W[1]), 4 * H,
+                                          ptr(gates[0]), ptr(gates[1]), ptr(cells[0]), ptr(cells[1]),
+                                          ptr(x), D, D, ptr(ypad), 2 * H, ptr(das[0]), ptr(das[1]),
+                                          ptr(dW[0]), ptr(dW[1]), ptr(db[0]), ptr(db[1]), 0.0,
+                                          ptr(ws), n, None))
+        torch.cuda.synchronize()
+    assert int(ws[:4].view(torch.int32)[0]) == 0
+    report_bwd_fused('lstm_bwd_fused D=%d' % D, ws, T)
+
+
 def main():
     B, T, H = (int(x) for x in sys.argv[1:4]) if len(sys.argv) >= 4 else (32, 128, 300)
-    fused(B, T, H, 2 * H)
-    fused(B, T, H, 132)
+    if os.environ.get('DANET_LSTM_FWD_FUSED') == '1':
+        fused(B, T, H, 2 * H)
+        fused(B, T, H, 132)
+    bwd_fused(B, T, H, 2 * H)
+    bwd_fused(B, T, H, 132)
     dev = torch.device('cuda')
     st = torch.cuda.current_stream().cuda_stream
     ndir = 2
