@@ -1737,11 +1737,14 @@ struct RswPlan { bool ok; RsPlan rs; int NFt, NFP, NFT; size_t dw_bytes, db_byte
 static RswPlan make_rsw_plan(int B, int H, int ndir, int D) {
   RswPlan w; w.ok = false; w.NFt = w.NFP = w.NFT = 0; w.dw_bytes = w.db_bytes = 0;
   w.rs = choose_rs_plan(B, H, ndir);
-  // Opt-in (DANET_LSTM_BWD_FUSED=1): measured at parity with the GEMM path, not ahead of it
-  // (cfg 2: 3.615 vs 3.602 ms per step, cfg 4: 5.21 vs 5.09; profiles/r02_d_fused_bwd_trace.txt):
-  // the 80 weight-gradient MFMAs per SIMD and step run at 22 ns instead of the 15 ns the pipe
-  // can do, which makes the step MFMA-bound at 3.6 us where the exchange would allow 2.5.
-  { const char* e = getenv("DANET_LSTM_BWD_FUSED"); if (!e || atoi(e) != 1) return w; }
+  // Envelope only; WHERE it is used is the caller's policy.  Measured (profiles/
+  // r02_d_fused_bwd_trace.txt): at parity with the separate GEMMs for a layer whose weight-
+  // gradient group can hide under the next layer's BPTT kernel (cfg 2: 3.615 vs 3.602 ms per
+  // step with all layers fused) -- the 80 weight-gradient MFMAs per SIMD and step run at 22 ns
+  // instead of the 15 ns the pipe can do and make the step MFMA-bound at 3.6 us.  Fusing only
+  // the bottom layer (whose group has nothing to hide under) LOSES: the layer-1 group then runs
+  // beside an MFMA-heavy kernel (3.82 ms).  DANET_LSTM_BWD_FUSED=0 turns the kernel off.
+  { const char* e = getenv("DANET_LSTM_BWD_FUSED"); if (e && e[0] == '0' && e[1] == 0) return w; }
   if (!w.rs.ok || D <= 0) return w;
   if (w.rs.U != 8 && w.rs.U != 16) return w;
   if (w.rs.NTW > 2 || w.rs.NI > RSW_NI_MAX) return w;

@@ -515,6 +515,22 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs):
     return c
 
 
+# Where BPTT accumulates dW / db inside the persistent kernel (danet_lstm_bwd_fused): '0'
+# (default) = nowhere; '1' = every layer inside the kernel's envelope; 'bottom' = only the
+# layer whose input needs no gradient.  Measured at cfg 2 / cfg 4 (ms per step): '0' 3.60 /
+# 5.09, '1' 3.62 / 5.21, 'bottom' 3.82 / 5.30 -- the fused kernel is MFMA-bound at 3.6 us per
+# step, the same the GEMM path reaches with its contention, and a fused bottom layer slows the
+# layer-1 weight-gradient group that runs beside it.  Kept as a tested opt-in.
+BWD_FUSED = __import__('os').environ.get('DANET_LSTM_BWD_FUSED', '0')
+
+
+def bptt_fused(T, B, H, ndir, D, need_dx):
+    '''policy + envelope: does lstm_layer_bwd take the fused kernel for this layer?'''
+    if BWD_FUSED == '0' or (BWD_FUSED != '1' and need_dx):
+        return False
+    return _L().danet_lstm_bwd_fused_supported(T, B, H, ndir, D) == 1
+
+
 def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
     '''dy: [T, B, ndir*H] contiguous.  Returns (dx [T*B, D] or None, dWs, dbs).'''
     T, B, H, D, ndir = c.T, c.B, c.H, c.D, c.ndir
@@ -535,7 +551,7 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
     fused = ((all_direct or none_direct) and
              all(W.stride(0) == 4 * H and W.stride(1) == 1 and W.data_ptr() % 16 == 0 for W in c.Ws) and
              all(t.data_ptr() % 16 == 0 for t in dWs + dbs) and
-             L.danet_lstm_bwd_fused_supported(T, B, H, ndir, D) == 1)
+             bptt_fused(T, B, H, ndir, D, need_dx))
     if fused:
         # BPTT with dW / db accumulated inside the persistent kernel (csrc/lstm.hip): no
         # weight-gradient GEMMs, no column sums, nothing on a side stream

@@ -252,8 +252,9 @@ int danet_lstm_bwd(danet_stream_t stream, int T, int B, int H, int ndir,
  * dW_d [D+H][4H] and db_d [4H] (16-byte aligned, dense) are overwritten (beta = 0) or
  * accumulated into (beta = 1).  da_d as in danet_lstm_bwd (the caller still computes
  * dX = da Wx^T).  Envelope: the reduce-scatter BPTT geometry with U <= 16 units per group
- * and H <= 384.  Opt-in: danet_lstm_bwd_fused_supported returns 1 only with
- * DANET_LSTM_BWD_FUSED=1 in the environment (measured at parity with the GEMM path).      */
+ * and H <= 384 (danet_lstm_bwd_fused_supported; DANET_LSTM_BWD_FUSED=0 turns it off).
+ * Measured at parity with separate GEMMs that hide under another layer's BPTT kernel, not
+ * ahead of them: callers choose per layer (the Python mirror keeps it opt-in).            */
 int danet_lstm_bwd_fused_supported(int T, int B, int H, int ndir, int D);
 size_t danet_lstm_bwd_fused_workspace_bytes(int T, int B, int H, int ndir, int D);
 int danet_lstm_bwd_fused(danet_stream_t stream, int T, int B, int H, int ndir,

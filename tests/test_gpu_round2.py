@@ -602,6 +602,7 @@ def test_lstm_forward_fused_input_projection(B, T, D, H, ndir, fused, monkeypatc
     from danet_amd import ops, _lib
     monkeypatch.setenv('DANET_LSTM_FWD_FUSED', fused)
     monkeypatch.setenv('DANET_LSTM_BWD_FUSED', fused)      # BPTT with fused dW / db alongside
+    monkeypatch.setattr(ops, 'BWD_FUSED', fused)
     assert _lib.load().danet_lstm_fwd_fused_supported(T, B, H, ndir, D) == int(fused)
     bwd_fused = _lib.load().danet_lstm_bwd_fused_supported(T, B, H, ndir, D)
     assert bwd_fused in (0, int(fused))        # (48, ...) and tiny shapes fall outside its envelope
@@ -635,9 +636,15 @@ def test_lstm_fused_envelope_query(monkeypatch):
     monkeypatch.delenv('DANET_LSTM_BWD_FUSED', raising=False)
     assert L.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 600) == 1      # default: B >= 24
     assert L.danet_lstm_fwd_fused_supported(1251, 1, 300, 2, 600) == 0      # B = 1: hoisted GEMM
-    assert L.danet_lstm_bwd_fused_supported(128, 32, 300, 2, 600) == 0      # opt-in path
+    assert L.danet_lstm_bwd_fused_supported(128, 32, 300, 2, 600) == 1      # envelope
+    from danet_amd import ops
+    assert ops.BWD_FUSED == '0' and ops.bptt_fused(128, 32, 300, 2, 129, need_dx=False) is False
+    monkeypatch.setattr(ops, 'BWD_FUSED', 'bottom')
+    assert ops.bptt_fused(128, 32, 300, 2, 129, need_dx=False) is True
+    assert ops.bptt_fused(128, 32, 300, 2, 600, need_dx=True) is False
+    monkeypatch.setenv('DANET_LSTM_BWD_FUSED', '0')
+    assert L.danet_lstm_bwd_fused_supported(128, 32, 300, 2, 600) == 0
     monkeypatch.setenv('DANET_LSTM_BWD_FUSED', '1')
-    assert L.danet_lstm_bwd_fused_supported(128, 32, 300, 2, 600) == 1
     assert L.danet_lstm_bwd_fused_supported(128, 32, 600, 2, 1200) == 0     # U = 32 geometry
     monkeypatch.setenv('DANET_LSTM_FWD_FUSED', '1')
     assert L.danet_lstm_fwd_fused_supported(1251, 1, 300, 2, 600) == 1
