@@ -324,6 +324,158 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// forward, tiny batch (B <= 4): the demo / inference path (main.py:623-627, B = 1)
+// ---------------------------------------------------------------------------
+// With one batch row a 16-row MFMA tile is 1/16 used and the 40 MFMAs per wave and step
+// (0.64 us) are the largest phase of the 1.83 us step.  Same decomposition, hand-off and
+// weight layout as lstm_fwd_kernel, but the product is a GEMV on the vector ALU: lane
+// (fr, fq) holds the weights of columns fr and 16+fr for k = 16 kg + 4 fq + j (the MFMA
+// fragment layout, reused), loads h[row][k..k+3] for each of the <= 4 rows, does 8 FMAs
+// per row and k-group, and the four fq lane groups are summed with two DPP-style shuffles
+// before the usual cross-wave reduction through LDS.
+template <int RMAX>
+__global__ __launch_bounds__(256) void lstm_fwd_small_kernel(LstmFwdArgs a) {
+  constexpr int NW = 4, CH = FWD_CH;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Wl = smem;
+  float* red = smem + (size_t)a.KP * 32;     // [NW][RMAX][33]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bid = blockIdx.x;
+  if (a.fault && bid == 0) return;
+  const int dir = a.xmap ? bid % a.ndir : bid / a.P;
+  const int p = a.xmap ? bid / a.ndir : bid % a.P;
+  const int H = a.H, B = a.B, T = a.T;
+  const int u0 = p * LSTM_UNITS_FWD;
+
+  {
+    const float* W = a.Wh[dir];
+    for (int idx = tid; idx < a.KP * 32; idx += 64 * NW) {
+      const int k = idx >> 5, n = idx & 31;
+      const int gate = n >> 3, u = u0 + (n & 7);
+      float v = 0.f;
+      if (k < H && u < H) v = W[(size_t)k * a.ldw + gate * H + u];
+      Wl[((k >> 2) * 32 + n) * 4 + (k & 3)] = v;
+    }
+  }
+  __syncthreads();
+
+  const unsigned ybytes = (unsigned)((size_t)(T + 2) * B * a.ldy * sizeof(float));
+  const __amdgpu_buffer_rsrc_t yres = make_rsrc(a.ypad, ybytes);
+
+  // gate-math ownership: thread -> (batch row bl, unit ul), bl < B <= RMAX
+  const int bl = tid >> 3, ul = tid & 7;
+  const bool owner = (bl < B) && (u0 + ul < H);
+  const int unit = u0 + ul;
+  float c_state = 0.f;
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int NG = a.KP / 16;
+  f32x4 wreg[CH][2];
+#pragma unroll
+  for (int g = 0; g < CH; ++g) {
+    const int kg = g * NW + wave;
+    const int k4 = (kg < NG ? kg : 0) * 4 + fq;
+    wreg[g][0] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + fr) * 4]);
+    wreg[g][1] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + 16 + fr) * 4]);
+    if (kg >= NG) { wreg[g][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; wreg[g][1] = wreg[g][0]; }
+  }
+
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? (T - 1 - s) : s;
+    const int blk_prev = dir ? (t + 2) : t;
+    float gxv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (owner) {
+      const float* gp = a.gx[dir] + ((size_t)t * B + bl) * (4 * H) + unit;
+#pragma unroll
+      for (int gte = 0; gte < 4; ++gte) gxv[gte] = gp[gte * H];
+    }
+    float acc[RMAX][2];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) acc[r][0] = acc[r][1] = 0.f;
+
+    if (s > 0) {
+      v4u av[CH][RMAX];
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int g = 0; g < CH; ++g) {
+          const int k = (g * NW + wave) * 16 + fq * 4;
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r) {
+            unsigned off = ybytes;     // out of range -> 0 (valid)
+            if (r < B && k < H)
+              off = (unsigned)((((size_t)blk_prev * B + r) * a.ldy + dir * H + k) * 4);
+            av[g][r] = load_sc1_b128(yres, off);
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < CH; ++g)
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r) ok &= !has_sentinel(av[g][r]);
+        if (__all(ok)) break;
+        if (spin_fail(spins, a.status, lane, a.spin_limit)) break;
+      }
+#pragma unroll
+      for (int g = 0; g < CH; ++g) {
+        const f32x4 w0 = wreg[g][0], w1 = wreg[g][1];
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+          const f32x4 hf = __builtin_bit_cast(f32x4, av[g][r]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc[r][0] = fmaf(hf[j], w0[j], acc[r][0]);
+            acc[r][1] = fmaf(hf[j], w1[j], acc[r][1]);
+          }
+        }
+      }
+    }
+    // sum the four fq lane groups (lanes fr, fr+16, fr+32, fr+48), then the waves via LDS
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        float v = acc[r][nt];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        acc[r][nt] = v;
+      }
+    if (fq == 0) {
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) {
+        red[(wave * RMAX + r) * 33 + fr] = acc[r][0];
+        red[(wave * RMAX + r) * 33 + 16 + fr] = acc[r][1];
+      }
+    }
+    __syncthreads();
+
+    if (owner) {
+      float pre[4];
+#pragma unroll
+      for (int gte = 0; gte < 4; ++gte) {
+        float v = gxv[gte];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[(w * RMAX + bl) * 33 + gte * 8 + ul];
+        pre[gte] = v;
+      }
+      const float g = pre[0];
+      const float ig = sigmoid_hw(pre[1]);
+      const float fg = sigmoid_hw(pre[2]);
+      const float og = sigmoid_hw(pre[3]);
+      c_state = ig * g + fg * c_state;
+      const float h = og * tanh_hw(c_state);
+      float* hp = a.ypad + ((size_t)(t + 1) * B + bl) * a.ldy + dir * H + unit;
+      __hip_atomic_store(hp, h, RLX_AGENT);
+      float* gs = a.gates[dir] + ((size_t)t * B + bl) * (4 * H) + unit;
+      gs[0] = g; gs[H] = ig; gs[2 * H] = fg; gs[3 * H] = og;
+      a.cell[dir][((size_t)t * B + bl) * H + unit] = c_state;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
 // forward, input projection fused (the whole cell of app/ops.py:139-147 in one kernel)
 // ---------------------------------------------------------------------------
 // The exchange of h_{t-1} costs ~1 us per step during which the matrix cores of the
@@ -1643,6 +1795,20 @@ extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int n
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));                   \
     lstm_fwd_kernel<MTV, NWV><<<nblk, 64 * NWV, pl.lds, stream>>>(a);                \
   } while (0)
+  // tiny batch (the B = 1 demo / inference path): GEMV on the vector ALU instead of 1/16-used
+  // MFMA tiles.  DANET_LSTM_FWD_SMALL=0 keeps the MFMA kernel.
+  const char* esm = getenv("DANET_LSTM_FWD_SMALL");
+  if (B <= 4 && H <= 16 * FWD_CH * 4 && !(esm && atoi(esm) == 0)) {
+    const size_t lds = ((size_t)pl.KP * 32 + (size_t)4 * 4 * 33) * sizeof(float);
+    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_small_kernel<4>,
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_small_kernel<1>,
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (B == 1) lstm_fwd_small_kernel<1><<<ndir * pl.P, 256, lds, stream>>>(a);
+    else lstm_fwd_small_kernel<4><<<ndir * pl.P, 256, lds, stream>>>(a);
+    DANET_CHECK_LAUNCH();
+    return DANET_OK;
+  }
   if (pl.MT == 2) LAUNCH_FWD(2, 4);
   else if (pl.NW == 16) LAUNCH_FWD(1, 16);
   else if (pl.NW == 8) LAUNCH_FWD(1, 8);
