@@ -59,6 +59,9 @@ PROTOTYPES = {
                                      c_int, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     'danet_lstm_bwd': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_int,
                                c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    'danet_lstm_bwd_db_supported': (c_int, [c_int, c_int, c_int, c_int]),
+    'danet_lstm_bwd_db': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_int,
+                                  c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_sz, c_p]),
     'danet_lstm_bwd_fused_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'danet_lstm_bwd_fused_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     'danet_lstm_bwd_fused': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_int,
@@ -73,7 +76,7 @@ PROTOTYPES = {
     'danet_attractor_anchor_fwd': (c_int, [c_p, c_int, c_int, c_i64, c_int, c_int, c_p, c_p, c_p,
                                            c_p, c_p, c_p, c_p, c_sz]),
     'danet_attractor_anchor_bwd': (c_int, [c_p, c_int, c_int, c_i64, c_int, c_int, c_p, c_p, c_p,
-                                           c_p, c_p, c_p, c_p, c_p, c_p, c_sz]),
+                                           c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_f32]),
     'danet_separate_fwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p, c_p, c_p]),
     'danet_separate_bwd_workspace_bytes': (c_sz, [c_int, c_int, c_i64, c_int]),
     'danet_separate_bwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p, c_p,

@@ -714,7 +714,7 @@ __global__ __launch_bounds__(256) void anchor_bwd_kernel(
 __global__ __launch_bounds__(256) void anchor_bwd_final_kernel(
     int B, int C, int E, int EP, int A, int nch, AnchorCombos cb,
     const float* __restrict__ partial, const int32_t* __restrict__ choice,
-    float* __restrict__ danchors) {
+    float* __restrict__ danchors, float beta) {
   // one block per anchor; thread = (e, 1 of 4 utterance lanes); fixed summation
   // order => deterministic scatter over utterances
   __shared__ float red[4][64];
@@ -739,8 +739,11 @@ __global__ __launch_bounds__(256) void anchor_bwd_final_kernel(
   }
   red[bl][e] = s;
   __syncthreads();
-  if (bl == 0 && e < E)
-    danchors[a * E + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+  if (bl == 0 && e < E) {
+    float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    if (beta != 0.f) v += danchors[a * E + e];
+    danchors[a * E + e] = v;
+  }
 }
 
 // =========================================================================
@@ -956,7 +959,7 @@ extern "C" int danet_attractor_anchor_bwd(danet_stream_t stream_, int B, int C, 
                                           const float* anchors, const float* attr,
                                           const float* asum, const int32_t* choice,
                                           float* dembed, float* danchors, void* ws,
-                                          size_t ws_bytes) {
+                                          size_t ws_bytes, float danchors_beta) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = anchor_check("attractor_anchor_bwd", B, C, N, E, A);
   if (rc) return rc;
@@ -974,8 +977,9 @@ extern "C" int danet_attractor_anchor_bwd(danet_stream_t stream_, int B, int C, 
                        C, N, E, A, cb, dattr, embed, anchors, attr, asum, choice, dembed,
                        (float*)ws))));
   DANET_CHECK_LAUNCH();
+  DANET_CHECK_ARG(danchors_beta == 0.f || danchors_beta == 1.f, "attractor_anchor_bwd: beta must be 0 or 1");
   anchor_bwd_final_kernel<<<A, 256, 0, stream>>>(B, C, E, EPV, A, nch, cb, (const float*)ws,
-                                                 choice, danchors);
+                                                 choice, danchors, danchors_beta);
   DANET_CHECK_LAUNCH();
   return DANET_OK;
 }

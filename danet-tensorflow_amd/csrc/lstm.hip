@@ -983,6 +983,7 @@ struct LstmBwdRsArgs {
   int T, B, H, ndir, lddy, ldw, P, G, S, NT, NI, D, xmap;
   unsigned spin_limit;
   int fault;
+  float* dbslab;   // optional [ndir*G][4H]: per-cluster bias-gradient partials (colsum of da)
 };
 
 __device__ __forceinline__ void store_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned off, v4u v) {
@@ -1053,6 +1054,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
   const int bg = b0 + orow, unit = u0 + oj;
   const bool owner = othr && bg < B && unit < H;
   float dc_state = 0.f;
+  float dbacc[4] = {0.f, 0.f, 0.f, 0.f};   // bias gradient: this (row, unit)'s da summed over time
 
   for (int s = 0; s < T; ++s) {
     const int t = dir ? s : (T - 1 - s);
@@ -1127,6 +1129,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
         dav[2] = dc * cpv * fg * (1.f - fg);
         dav[3] = dh * tc * og * (1.f - og);
         dc_state = dc * fg;
+        dbacc[0] += dav[0]; dbacc[1] += dav[1]; dbacc[2] += dav[2]; dbacc[3] += dav[3];
       }
       float* ap = &atile[orow * LDA + oj];
       ap[0] = dav[0]; ap[U] = dav[1]; ap[2 * U] = dav[2]; ap[3 * U] = dav[3];
@@ -1183,6 +1186,24 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
       dp[0] = dav[0]; dp[H] = dav[1]; dp[2 * H] = dav[2]; dp[3 * H] = dav[3];
     }
     TRACE(5);
+  }
+  // partial db of the cluster (twin 0): the own 4U da columns summed over the 16 rows, so the
+  // caller needs no column-sum kernels (6 launches per step at cfg 2, and a cross-stream join
+  // at the tail of backward)
+  if (a.dbslab != nullptr && tw == 0) {
+    __syncthreads();
+    if (othr) {
+      float* ap = &atile[orow * LDA + oj];
+      ap[0] = dbacc[0]; ap[U] = dbacc[1]; ap[2 * U] = dbacc[2]; ap[3 * U] = dbacc[3];
+    }
+    __syncthreads();
+    if (tid < 4 * U) {
+      float v = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) v += atile[rr * LDA + tid];
+      const int gate = tid / U, j = tid % U;
+      if (u0 + j < H) a.dbslab[(size_t)cl * (4 * H) + gate * H + u0 + j] = v;
+    }
   }
 }
 
@@ -1729,7 +1750,8 @@ extern "C" size_t danet_lstm_workspace_bytes(int T, int B, int H, int ndir) {
     RsPlan r = make_rs_plan(B, H, ndir, U);
     if (r.ok && r.ring_bytes > ring) ring = r.ring_bytes;
   }
-  return ring_offset(T) + ring;
+  // + per-cluster bias-gradient partials of danet_lstm_bwd_db
+  return align_up(ring_offset(T) + ring, 256) + align_up((size_t)ndir * cdiv(B, 16) * 4 * H * sizeof(float), 256);
 }
 
 static int lstm_check_common(int T, int B, int H, int ndir, void* ws, size_t ws_bytes) {
@@ -1987,6 +2009,7 @@ extern "C" int danet_lstm_bwd_fused(danet_stream_t stream_, int T, int B, int H,
   a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.P = rs.P; a.G = rs.G; a.S = rs.S;
   a.NT = rs.NT; a.NI = rs.NI; a.D = rs.D;
   a.xmap = getenv("DANET_LSTM_XMAP") ? atoi(getenv("DANET_LSTM_XMAP")) : 1;
+  a.dbslab = nullptr;
   aa.x = x; aa.ypad = ypad; aa.ldx = ldx; aa.ldy = ldy; aa.Din = D; aa.Dp = cdiv(D, 16) * 16;
   aa.NFt = w.NFt; aa.NFP = w.NFP;
   aa.dwslab = (float*)((char*)ws + align_up(ring_offset(T) + rs.ring_bytes, 256));
@@ -2015,6 +2038,14 @@ extern "C" int danet_lstm_bwd_fused(danet_stream_t stream_, int T, int B, int H,
   return DANET_OK;
 }
 
+static int lstm_bwd_impl(danet_stream_t stream_, int T, int B, int H, int ndir,
+                         const float* dy, int lddy,
+                         const float* Wh_f, const float* Wh_b, int ldw,
+                         const float* gates_f, const float* gates_b,
+                         const float* cell_f, const float* cell_b,
+                         float* da_f, float* da_b, void* ws, size_t ws_bytes,
+                         int32_t* status, float* db_f, float* db_b, float beta);
+
 extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int ndir,
                               const float* dy, int lddy,
                               const float* Wh_f, const float* Wh_b, int ldw,
@@ -2022,6 +2053,40 @@ extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int n
                               const float* cell_f, const float* cell_b,
                               float* da_f, float* da_b, void* ws, size_t ws_bytes,
                               int32_t* status) {
+  return lstm_bwd_impl(stream_, T, B, H, ndir, dy, lddy, Wh_f, Wh_b, ldw, gates_f, gates_b,
+                       cell_f, cell_b, da_f, da_b, ws, ws_bytes, status, nullptr, nullptr, 0.f);
+}
+
+extern "C" int danet_lstm_bwd_db_supported(int T, int B, int H, int ndir) {
+  if (T <= 0 || B <= 0 || H <= 0 || H % 4 != 0 || (ndir != 1 && ndir != 2)) return 0;
+  return choose_rs_plan(B, H, ndir).ok ? 1 : 0;
+}
+
+extern "C" int danet_lstm_bwd_db(danet_stream_t stream_, int T, int B, int H, int ndir,
+                                 const float* dy, int lddy,
+                                 const float* Wh_f, const float* Wh_b, int ldw,
+                                 const float* gates_f, const float* gates_b,
+                                 const float* cell_f, const float* cell_b,
+                                 float* da_f, float* da_b, float* db_f, float* db_b, float beta,
+                                 void* ws, size_t ws_bytes, int32_t* status) {
+  DANET_CHECK_ARG(db_f && (ndir == 1 || db_b), "lstm_bwd_db: null db pointer");
+  DANET_CHECK_ARG((((uintptr_t)db_f | (uintptr_t)db_b) & 15) == 0, "lstm_bwd_db: db must be 16-B aligned");
+  DANET_CHECK_ARG(beta == 0.f || beta == 1.f, "lstm_bwd_db: beta must be 0 or 1");
+  if (!danet_lstm_bwd_db_supported(T, B, H, ndir)) {
+    danet_set_error("lstm_bwd_db: B=%d H=%d outside the reduce-scatter geometry", B, H);
+    return DANET_ERR_UNSUPPORTED;
+  }
+  return lstm_bwd_impl(stream_, T, B, H, ndir, dy, lddy, Wh_f, Wh_b, ldw, gates_f, gates_b,
+                       cell_f, cell_b, da_f, da_b, ws, ws_bytes, status, db_f, db_b, beta);
+}
+
+static int lstm_bwd_impl(danet_stream_t stream_, int T, int B, int H, int ndir,
+                         const float* dy, int lddy,
+                         const float* Wh_f, const float* Wh_b, int ldw,
+                         const float* gates_f, const float* gates_b,
+                         const float* cell_f, const float* cell_b,
+                         float* da_f, float* da_b, void* ws, size_t ws_bytes,
+                         int32_t* status, float* db_f, float* db_b, float beta) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = lstm_check_common(T, B, H, ndir, ws, ws_bytes);
   if (rc) return rc;
@@ -2042,6 +2107,7 @@ extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int n
     a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.P = rs.P; a.G = rs.G; a.S = rs.S;
     a.NT = rs.NT; a.NI = rs.NI; a.D = rs.D;
     a.xmap = getenv("DANET_LSTM_XMAP") ? atoi(getenv("DANET_LSTM_XMAP")) : 1;
+    a.dbslab = db_f ? (float*)((char*)ws + align_up(ring_offset(T) + rs.ring_bytes, 256)) : nullptr;
     {
       FillList fl;
       fl.add(ws, 64 + TRACE_BYTES(T), 0u);
@@ -2056,6 +2122,12 @@ extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int n
       default: LAUNCH_RS(UV, 3); break; }
     if (rs.U == 8) { LAUNCH_RS_U(8) } else if (rs.U == 16) { LAUNCH_RS_U(16) } else { LAUNCH_RS_U(32) }
     DANET_CHECK_LAUNCH();
+    if (db_f) {
+      dim3 grid((unsigned)cdiv(H, 256), ndir);
+      lstm_dw_reduce_kernel<<<grid, 256, 0, stream>>>(nullptr, a.dbslab, nullptr, nullptr, db_f, db_b,
+                                                      rs.G, 0, 0, 0, 0, 4 * H, beta);
+      DANET_CHECK_LAUNCH();
+    }
     return DANET_OK;
   }
   LstmPlan pl = make_plan(B, H, ndir, true);

@@ -121,6 +121,7 @@ class Model(object):
             self.vars[k] = nv
             off += m
         self._flat, self._flat_grad = flat, grad
+        self._one = torch.ones((), device=self.device)
         # a backward pass outside train_step (tests, user code) leaves gradients behind:
         # autograd's accumulation marks the bucket dirty so the next train_step clears it
         self._grads_clean = True
@@ -209,7 +210,7 @@ class Model(object):
             self._flat_grad.zero_()
         out = self.forward(s_src_signals)
         with ops.fast_backward():          # kernels add straight into the flat bucket
-            out['loss'].backward()
+            out['loss'].backward(self._one)    # (a persistent 1: no ones_like fill per step)
             if self._buckets is not None:
                 grad_scale = self._buckets.finish()            # pieces launched during backward
             else:

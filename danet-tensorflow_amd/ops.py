@@ -522,6 +522,8 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs):
 # step, the same the GEMM path reaches with its contention, and a fused bottom layer slows the
 # layer-1 weight-gradient group that runs beside it.  Kept as a tested opt-in.
 BWD_FUSED = __import__('os').environ.get('DANET_LSTM_BWD_FUSED', '0')
+# bias gradients summed inside the (unfused) BPTT kernel instead of by column-sum launches
+BWD_DB = __import__('os').environ.get('DANET_LSTM_BWD_DB', '1') == '1'
 
 
 def bptt_fused(T, B, H, ndir, D, need_dx):
@@ -552,6 +554,7 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
              all(W.stride(0) == 4 * H and W.stride(1) == 1 and W.data_ptr() % 16 == 0 for W in c.Ws) and
              all(t.data_ptr() % 16 == 0 for t in dWs + dbs) and
              bptt_fused(T, B, H, ndir, D, need_dx))
+    db_in_kernel = False
     if fused:
         # BPTT with dW / db accumulated inside the persistent kernel (csrc/lstm.hip): no
         # weight-gradient GEMMs, no column sums, nothing on a side stream
@@ -567,12 +570,24 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
     else:
         ws, wn = _lstm_ws(T, B, H, ndir, dev)
         Whs = [W[D:] for W in c.Ws]
+        b_direct = [okb for _, okb in direct]
+        db_in_kernel = (BWD_DB and (all(b_direct) or not any(b_direct)) and
+                        all(t.data_ptr() % 16 == 0 for t in dbs) and
+                        L.danet_lstm_bwd_db_supported(T, B, H, ndir) == 1)
         with _lib.timed('lstm_bwd'):
-            check(L.danet_lstm_bwd(
-                _lib.stream(), T, B, H, ndir, ptr(_f32(dy)), ndir * H,
-                ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(c.gates[0]), ptr(c.gates[-1]),
-                ptr(c.cells[0]), ptr(c.cells[-1]), ptr(das[0]), ptr(das[-1]), ptr(ws), wn,
-                ptr(status_word(dev))))
+            if db_in_kernel:      # bias gradients summed inside the BPTT kernel: no colsum launches
+                check(L.danet_lstm_bwd_db(
+                    _lib.stream(), T, B, H, ndir, ptr(_f32(dy)), ndir * H,
+                    ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(c.gates[0]), ptr(c.gates[-1]),
+                    ptr(c.cells[0]), ptr(c.cells[-1]), ptr(das[0]), ptr(das[-1]),
+                    ptr(dbs[0]), ptr(dbs[-1]), 1.0 if all(b_direct) else 0.0, ptr(ws), wn,
+                    ptr(status_word(dev))))
+            else:
+                check(L.danet_lstm_bwd(
+                    _lib.stream(), T, B, H, ndir, ptr(_f32(dy)), ndir * H,
+                    ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(c.gates[0]), ptr(c.gates[-1]),
+                    ptr(c.cells[0]), ptr(c.cells[-1]), ptr(das[0]), ptr(das[-1]), ptr(ws), wn,
+                    ptr(status_word(dev))))
 
     # the weight-gradient products overlap the NEXT layer's BPTT kernel (152 of
     # 256 CUs at cfg 2): cap each chain so both together stay on the idle CUs
@@ -587,7 +602,8 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
         hprev = c.ypad.view(-1)[(0 if d == 0 else 2 * B * ldy + H):]
         gemm(hprev, das[d], dWs[d][D:], H, 4 * H, T * B, ldy, 4 * H, 4 * H, transA=True, beta=bW,
              max_workgroups=cap)
-        colsum(das[d], T * B, 4 * H, 4 * H, dbs[d], beta=bb)
+        if not db_in_kernel:
+            colsum(das[d], T * B, 4 * H, 4 * H, dbs[d], beta=bb)
 
     def hprev_of(d):
         # Hprev(t) = ypad block t (fwd) / block t+2 (bwd)
@@ -607,6 +623,8 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
             bias_grads()
 
     def bias_grads():
+        if db_in_kernel:
+            return
         for d in range(ndir):
             colsum(das[d], T * B, 4 * H, 4 * H, dbs[d], beta=1.0 if direct[d][1] else 0.0)
 
@@ -647,8 +665,9 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
             on_main = True           # everything was issued on the main stream
         elif GROUPED_DW and not need_dx:
             # bottom layer: no BPTT kernel follows, so the group takes the whole GPU on
-            # the main stream while the column sums run beside it
-            f.run(1, bias_grads)
+            # the main stream while the column sums (if any) run beside it
+            if not db_in_kernel:
+                f.run(1, bias_grads)
             weight_grads_grouped(wgs=512, with_bias=False)
             on_main = True
         elif GROUPED_DW:
@@ -897,6 +916,7 @@ class AnchorAttractorFn(torch.autograd.Function):
         N = T * F
         dev = embed.device
         embed = _f32(embed.contiguous())
+        anchors_in = anchors
         anchors = _f32(anchors.contiguous())
         P = math.comb(A, C)
         attr = torch.empty(B, C, E, device=dev)
@@ -909,6 +929,7 @@ class AnchorAttractorFn(torch.autograd.Function):
                                            ptr(anchors), ptr(attr), ptr(asets), ptr(asum),
                                            ptr(choice), ptr(w), wn))
         ctx.save_for_backward(embed, anchors, attr, asum, choice)
+        ctx.anchors_param = anchors_in      # the parameter object (owner of .grad), not a copy
         ctx.args = (B, C, N, E, A, T, F)
         ctx.mark_non_differentiable(asets, choice)
         ctx.set_materialize_grads(False)
@@ -924,14 +945,15 @@ class AnchorAttractorFn(torch.autograd.Function):
         dev = dattr.device
         shared = _take_dembed(ctx.token, B * T * F * E)
         dembed = shared if shared is not None else torch.zeros(B, T, F, E, device=dev)
-        danchors = torch.empty(A, E, device=dev)
+        # fast backward: add straight into the parameter's .grad (no autograd accumulate kernel)
+        danchors, direct = _grad_target(ctx.anchors_param, (A, E), dev)
         L = _L()
         w, wn = _ws(L.danet_attractor_anchor_workspace_bytes(B, C, N, E, A), dev)
         check(L.danet_attractor_anchor_bwd(
             _lib.stream(), B, C, N, E, A, ptr(_f32(dattr.contiguous())), ptr(embed),
             ptr(anchors), ptr(attr), ptr(asum), ptr(choice), ptr(dembed), ptr(danchors),
-            ptr(w), wn))
-        return (None if shared is not None else dembed), danchors, None
+            ptr(w), wn, 1.0 if direct else 0.0))
+        return (None if shared is not None else dembed), (None if direct else danchors), None
 
 
 class SeparateFn(torch.autograd.Function):

@@ -242,6 +242,20 @@ int danet_lstm_bwd(danet_stream_t stream, int T, int B, int H, int ndir,
                    float* da_f, float* da_b,
                    void* ws, size_t ws_bytes, int32_t* status);
 
+/* danet_lstm_bwd that also returns the bias gradients db_d[4H] = sum_{t,b} da_d (overwritten
+ * for beta = 0, accumulated into for beta = 1; 16-byte aligned): the owner threads of the
+ * reduce-scatter kernel add their da to a register per step, so no column-sum launches are
+ * needed.  Only for shapes the reduce-scatter kernel covers (danet_lstm_bwd_db_supported);
+ * workspace as danet_lstm_bwd.                                                 */
+int danet_lstm_bwd_db_supported(int T, int B, int H, int ndir);
+int danet_lstm_bwd_db(danet_stream_t stream, int T, int B, int H, int ndir,
+                      const float* dy, int lddy,
+                      const float* Wh_f, const float* Wh_b, int ldw,
+                      const float* gates_f, const float* gates_b,
+                      const float* cell_f, const float* cell_b,
+                      float* da_f, float* da_b, float* db_f, float* db_b, float beta,
+                      void* ws, size_t ws_bytes, int32_t* status);
+
 /* BPTT with the layer's weight and bias gradients FUSED: dW_d = [X | Hprev]^T da_d and
  * db_d = colsum(da_d) are accumulated inside the persistent kernel -- every workgroup owns
  * a block of da_t columns, has them in LDS each step, and runs the rank-16 update of its
@@ -298,13 +312,15 @@ int danet_attractor_anchor_fwd(danet_stream_t stream, int B, int C, int64_t N,
                                const float* anchors, float* attr,
                                float* asets, float* asum, int32_t* choice,
                                void* ws, size_t ws_bytes);
-/* dembed [B][N][E] += ..., danchors [A][E] = ... (through the chosen subset) */
+/* dembed [B][N][E] += ..., danchors [A][E] = ... (through the chosen subset);
+ * danchors_beta = 1 accumulates into danchors instead of overwriting it              */
 int danet_attractor_anchor_bwd(danet_stream_t stream, int B, int C, int64_t N,
                                int E, int A, const float* dattr,
                                const float* embed, const float* anchors,
                                const float* attr, const float* asum,
                                const int32_t* choice, float* dembed,
-                               float* danchors, void* ws, size_t ws_bytes);
+                               float* danchors, void* ws, size_t ws_bytes,
+                               float danchors_beta);
 
 /* ---------------------------------------------------------------- a12
  * Dot-product separators (app/modules.py:548-603). act 0 = softmax over C
