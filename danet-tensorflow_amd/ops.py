@@ -522,6 +522,9 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs):
 # step, the same the GEMM path reaches with its contention, and a fused bottom layer slows the
 # layer-1 weight-gradient group that runs beside it.  Kept as a tested opt-in.
 BWD_FUSED = __import__('os').environ.get('DANET_LSTM_BWD_FUSED', '0')
+# experiment: fork the weight-gradient group BEFORE dX (the two GEMMs share the GPU, the next
+# BPTT kernel then has the group beside it for a shorter time)
+DW_FORK_EARLY = __import__('os').environ.get('DANET_DW_FORK_EARLY', '0') == '1'
 # bias gradients summed inside the (unfused) BPTT kernel instead of by column-sum launches
 BWD_DB = __import__('os').environ.get('DANET_LSTM_BWD_DB', '1') == '1'
 
@@ -644,7 +647,8 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
     # is recorded behind dX), so they do not compete with dX for CUs but overlap
     # the next layer's latency-bound BPTT kernel instead; the caller joins them
     # (`join_deferred`).
-    if need_dx:
+    fork_early = DW_FORK_EARLY and need_dx and GROUPED_DW and not fused
+    if need_dx and not fork_early:
         input_grad()
     hooks = bool(GRAD_READY_HOOKS) and _fast() and layer_tag is not None and \
         all(a and b for a, b in direct)
@@ -672,6 +676,8 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
             on_main = True
         elif GROUPED_DW:
             f.run(1, weight_grads_grouped)
+            if fork_early:
+                input_grad()          # beside the group, both behind this layer's BPTT kernel
         else:
             for d in range(ndir):
                 f.run(d + 1, lambda d=d: weight_grads(d))
