@@ -414,13 +414,15 @@ struct SkArgs {
   float* slab;          // [G][16][256][4] partial accumulators
   unsigned* flags;      // [G] launch sequence number when slab[w] is valid
   unsigned seq;
+  int yield;            // > 0: s_sleep(yield) after every k-tile (32 MFMAs per wave): a group that
+                        // runs UNDER a latency-bound recurrent kernel leaves issue slots to it
 };
 
 #define SK_SPIN_LIMIT (1u << 22)
 
 template <bool A_KCONTIG, bool B_KCONTIG>
 __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* smem, int m0, int n0,
-                                             int kbeg, int kend, f32x16 (&acc)[2][2]) {
+                                             int kbeg, int kend, f32x16 (&acc)[2][2], int yield) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -471,6 +473,10 @@ __device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* smem, int
       store_tile<A_KCONTIG>(smem + (cur ^ 1) * (BK * LDT), tid, ra);
       store_tile<B_KCONTIG>(smem + (2 + (cur ^ 1)) * (BK * LDT), tid, rb);
     }
+    if (yield == 1) __builtin_amdgcn_s_sleep(1);
+    else if (yield == 2) __builtin_amdgcn_s_sleep(2);
+    else if (yield == 4) __builtin_amdgcn_s_sleep(4);
+    else if (yield >= 8) __builtin_amdgcn_s_sleep(8);
     __syncthreads();   // also makes the LDS reusable by the next segment
   }
 }
@@ -524,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(SkArgs sk) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
-    gemm_segment<A_KCONTIG, B_KCONTIG>(g, smem, m0, n0, kb * BK, min(g.K, ke * BK), acc);
+    gemm_segment<A_KCONTIG, B_KCONTIG>(g, smem, m0, n0, kb * BK, min(g.K, ke * BK), acc, sk.yield);
 
     if (ke < sk.nk) {
       // contributor: the tile's later k-segments belong to higher workgroups
@@ -680,6 +686,8 @@ extern "C" int danet_gemm_f32_streamk_grouped(danet_stream_t stream_, int transA
   sk.flags = (unsigned*)ws;
   sk.slab = (float*)((char*)ws + SK_HEADER);
   sk.seq = __atomic_add_fetch(&launch_seq, 1u, __ATOMIC_RELAXED);
+  // DANET_GEMM_YIELD=n: capped (overlapped) group launches sleep n*64 clocks after every k-tile
+  sk.yield = (max_workgroups > 0 && max_workgroups <= 256) ? sk_env("DANET_GEMM_YIELD", 0) : 0;
   dim3 grid(gsz, 1, 1), block(256);
   const bool ak = !transA, bk = (transB != 0);
   if (ak && !bk) gemm_f32_sk_kernel<true, false><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);
