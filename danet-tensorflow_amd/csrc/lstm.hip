@@ -1708,7 +1708,7 @@ static RsPlan make_rs_plan(int B, int H, int ndir, int U) {
     if (es && atoi(es) >= 1 && atoi(es) <= smax) r.S = atoi(es); }
   r.NTW = r.S > 0 ? cdiv(cdiv(r.NT, r.S), 8) : 99;
   r.ring_bytes = (size_t)r.D * ncl * r.P * r.NT * 1024;
-  r.ok = (H % 4 == 0) && smax >= 1 && r.NTW <= 3 && r.NI <= RS_NI_MAX &&
+  r.ok = (H % 4 == 0) && smax >= 1 && r.NTW <= 5 && r.NI <= RS_NI_MAX &&
          r.ring_bytes < 0xFFFFFFF0ull;
   return r;
 }
@@ -1728,7 +1728,12 @@ static RsPlan choose_rs_plan(int B, int H, int ndir) {
     if (pin && pin != U) continue;
     RsPlan r = make_rs_plan(B, H, ndir, U);
     if (!r.ok) continue;
-    const int cost = cdiv(cdiv(r.NT, r.S), 4) * U;
+    int cost = cdiv(cdiv(r.NT, r.S), 4) * U;
+    // wide layers (cfg 4 as written, H = 600): the kernel spends most of its life beside a 1 ms
+    // weight-gradient group, and 152 workgroups (U = 16, no twins, 5 tiles per wave) suffer
+    // less from it than 228 (U = 32, 3 twins): 14.4 vs 16.5 ms per cfg-4h600 step, although
+    // alone U = 32 is faster (4.8 vs 7.6 us per step)
+    if (H > 384 && U == 16 && !pin) cost = 0;
     if (cost < best_cost) { best = r; best_cost = cost; }
   }
   return best;
@@ -2119,7 +2124,8 @@ static int lstm_bwd_impl(danet_stream_t stream_, int T, int B, int H, int ndir,
 #define LAUNCH_RS_U(UV)                                          \
     switch (rs.NTW) {                                            \
       case 1: LAUNCH_RS(UV, 1); break; case 2: LAUNCH_RS(UV, 2); break; \
-      default: LAUNCH_RS(UV, 3); break; }
+      case 3: LAUNCH_RS(UV, 3); break; case 4: LAUNCH_RS(UV, 4); break; \
+      default: LAUNCH_RS(UV, 5); break; }
     if (rs.U == 8) { LAUNCH_RS_U(8) } else if (rs.U == 16) { LAUNCH_RS_U(16) } else { LAUNCH_RS_U(32) }
     DANET_CHECK_LAUNCH();
     if (db_f) {
