@@ -85,6 +85,7 @@ PROTOTYPES = {
     'danet_pit_mse_fwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_p, c_p, c_p, c_f32, c_p,
                                   c_p, c_p, c_p, c_sz]),
     'danet_pit_mse_bwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_p, c_p, c_p, c_p, c_f32, c_p, c_p]),
+    'danet_leaky_relu': (c_int, [c_p, c_i64, c_p, c_p, c_f32, c_p]),
     'danet_adam_clip_step': (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_f32, c_f32, c_f32, c_f32,
                                      c_f32, c_f32, c_int]),
 }

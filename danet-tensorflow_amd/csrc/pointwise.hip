@@ -225,6 +225,32 @@ extern "C" int danet_colsum_f32(danet_stream_t stream, int M, int N, const float
   return DANET_OK;
 }
 
+// ------------------------------------------------------------- leaky relu
+// ops.relu (app/ops.py:93-107): y = max(x, 0) for alpha = 0, max(alpha*x, x) otherwise;
+// backward dx = dy * (x > 0 ? 1 : alpha) for 0 <= alpha < 1 (tf.maximum routes the gradient
+// to the larger argument; at x = 0 both are equal and TF sends it to the FIRST operand,
+// alpha*x, i.e. the slope there is alpha -- for alpha = 0 tf.nn.relu gives 0 at x = 0 too).
+__global__ __launch_bounds__(256) void leaky_relu_kernel(int64_t n, const float* __restrict__ x,
+                                                         const float* __restrict__ dy, float alpha,
+                                                         float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    if (dy) out[i] = dy[i] * (v > 0.f ? 1.f : alpha);
+    else out[i] = v > 0.f ? v : alpha * v;
+  }
+}
+
+extern "C" int danet_leaky_relu(danet_stream_t stream, int64_t n, const float* x, const float* dy,
+                                float alpha, float* out) {
+  DANET_CHECK_ARG(n > 0 && x && out, "leaky_relu: bad args");
+  DANET_CHECK_ARG(alpha >= 0.f && alpha < 1.f, "leaky_relu: alpha must be in [0, 1)");
+  const int grid = (int)min((int64_t)4096, cdiv64(n, 256));
+  leaky_relu_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(n, x, dy, alpha, out);
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
+
 // ---------------------------------------------------------- clip + TF1 Adam
 // One pass over the four flat buffers (16-B accesses).  A NaN gradient stays NaN through the
 // clip like tf.clip_by_value (fminf/fmaxf alone would turn it into -clip).  zero_grad: the

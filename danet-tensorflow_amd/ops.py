@@ -826,11 +826,30 @@ def lyr_linear(x, W, b=None):
     return LinearFn.apply(x, W, b)
 
 
+class LeakyReluFn(torch.autograd.Function):
+    '''ops.relu (app/ops.py:93-107) as a HIP kernel pair'''
+
+    @staticmethod
+    def forward(ctx, x, alpha):
+        x = _f32(x.contiguous())
+        y = torch.empty_like(x)
+        check(_L().danet_leaky_relu(_lib.stream(), x.numel(), ptr(x), None, float(alpha), ptr(y)))
+        ctx.save_for_backward(x)
+        ctx.alpha = float(alpha)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        check(_L().danet_leaky_relu(_lib.stream(), x.numel(), ptr(x), ptr(_f32(dy.contiguous())),
+                                    ctx.alpha, ptr(dx)))
+        return dx, None
+
+
 def relu(s_x, alpha=0.):
-    '''app/ops.py:93-107 (toy encoder only; elementwise torch op)'''
-    if alpha == 0.:
-        return torch.relu(s_x)
-    return torch.maximum(s_x * alpha, s_x)
+    '''app/ops.py:93-107 (toy encoder)'''
+    return LeakyReluFn.apply(s_x, alpha)
 
 
 # ---------------------------------------------------------------------------

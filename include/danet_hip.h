@@ -360,6 +360,13 @@ int danet_pit_mse_bwd(danet_stream_t stream, int mode, int B, int C,
                       const float* phasor, const int32_t* perm_idx,
                       float dloss, const float* dloss_dev, float* dsep_pwr);
 
+/* ---------------------------------------------------------------- f-4 (toy encoder)
+ * ops.relu (app/ops.py:93-107), the activation of the reference's default `toy` encoder
+ * (app/modules.py:96-116).  dy == NULL: out = x > 0 ? x : alpha*x;  dy != NULL (backward):
+ * out = dy * (x > 0 ? 1 : alpha).  0 <= alpha < 1.                                   */
+int danet_leaky_relu(danet_stream_t stream, int64_t n, const float* x, const float* dy,
+                     float alpha, float* out);
+
 /* ---------------------------------------------------------------- a16
  * clip_by_value + tf.train.AdamOptimizer update (main.py:359-363,
  * app/ozers.py:15-18): g = clamp(grad*grad_scale, +-clip);

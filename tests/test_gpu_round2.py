@@ -653,3 +653,18 @@ def test_lstm_fused_envelope_query(monkeypatch):
     assert L.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 644) == 0      # D > 640
     assert L.danet_lstm_fwd_fused_supported(128, 64, 300, 2, 600) == 0      # 304 workgroups
     assert L.danet_lstm_fwd_fused_supported(128, 32, 302, 2, 600) == 0      # H % 4
+
+
+@pytest.mark.parametrize('alpha', [0.0, 0.3])
+def test_leaky_relu_kernel(alpha):
+    '''ops.relu (app/ops.py:93-107): values and gradient incl. exact zeros'''
+    from danet_amd import ops
+    rng = np.random.RandomState(2)
+    x = rng.randn(3, 37, 11).astype(np.float32)
+    x[0, 0, :4] = 0.0
+    dy = rng.randn(3, 37, 11).astype(np.float32)
+    xt = cu(x).requires_grad_(True)
+    y = ops.relu(xt, alpha)
+    assert np.array_equal(y.detach().cpu().numpy(), O.relu(x, alpha).astype(np.float32))
+    y.backward(cu(dy))
+    assert np.array_equal(xt.grad.cpu().numpy(), dy * np.where(x > 0, 1.0, alpha).astype(np.float32))
