@@ -1348,29 +1348,6 @@ __global__ __launch_bounds__(512) void lstm_bwd_rsw_kernel(LstmBwdRswArgs aa) {
     const int t = dir ? s : (T - 1 - s);
     const int t_cprev = dir ? (t + 1) : (t - 1);
 
-    // ---- exchange loads of the partial dh of step s-1 (issued now, validated below).
-    // Branch-free: producers that do not exist (and everything at step 0) are out-of-range
-    // offsets, which return 0 without a memory access and count as valid.  (Conditional
-    // loads into a partly defined array made the compiler copy the first result right
-    // after issuing it -- an s_waitcnt vmcnt(0) that exposed the whole exchange latency.)
-    TRACE(0);
-    unsigned off[RSW_NI_MAX];
-    v4u av[RSW_NI_MAX];
-    const int sm1 = s > 0 ? s - 1 : 0;
-    const unsigned par = (unsigned)((sm1 / a.D) & 1);
-    {
-      const int slot = sm1 % a.D;
-#pragma unroll
-      for (int i = 0; i < RSW_NI_MAX; ++i) {
-        const int q = qq + PPR * i;
-        off[i] = (s > 0 && q < P)
-                     ? (unsigned)((((size_t)slot * ncl + cl) * P + q) * a.NT * 1024) + xoff : rbytes;
-      }
-#pragma unroll
-      for (int i = 0; i < RSW_NI_MAX; ++i) av[i] = load_sc1_b128(rres, off[i]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
     // ---- weight-gradient update of step s-1: first quarter
     // (two straight-line copies: waves whose last tile slot is empty -- 19 tiles over 8 waves
     // at cfg 2 -- skip its MFMAs; a branch INSIDE a chain would make the compiler shuffle
@@ -1391,12 +1368,45 @@ __global__ __launch_bounds__(512) void lstm_bwd_rsw_kernel(LstmBwdRswArgs aa) {
     } while (0)
 #define DW_UPDATE(kk)                                                                         \
     do { if (full_tiles) DW_UPDATE_N(kk, NFT); else DW_UPDATE_N(kk, NFT - 1); } while (0)
+    TRACE(0);
     DW_UPDATE(0);
     TRACE(1);
     if (s == T) {
       // last update: no further step
       DW_UPDATE(1); DW_UPDATE(2); DW_UPDATE(3);
       break;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- rest of the weight-gradient update of step s-1, under the exchange wait
+    if (full_tiles) { DW_UPDATE_N(1, NFT); DW_UPDATE_N(2, NFT); DW_UPDATE_N(3, NFT); }
+    else { DW_UPDATE_N(1, NFT - 1); DW_UPDATE_N(2, NFT - 1); DW_UPDATE_N(3, NFT - 1); }
+#undef DW_UPDATE
+#undef DW_UPDATE_N
+    __builtin_amdgcn_sched_barrier(0);
+    TRACE(2);
+    // ---- exchange loads of the partial dh of step s-1, issued only NOW: the previous step's
+    // write-through stores block the wave's next vector-memory instruction until they are
+    // acknowledged (~0.8 us); behind the MFMA block that wait is free, in front of it the
+    // matrix cores idle for it.  (They are also late enough never to race a producer.)
+    // Branch-free: producers that do not exist (and everything at step 0) are out-of-range
+    // offsets, which return 0 without a memory access and count as valid.  (Conditional
+    // loads into a partly defined array made the compiler copy the first result right
+    // after issuing it -- an s_waitcnt vmcnt(0) that exposed the whole exchange latency.)
+    unsigned off[RSW_NI_MAX];
+    v4u av[RSW_NI_MAX];
+    const int sm1 = s > 0 ? s - 1 : 0;
+    const unsigned par = (unsigned)((sm1 / a.D) & 1);
+    {
+      const int slot = sm1 % a.D;
+#pragma unroll
+      for (int i = 0; i < RSW_NI_MAX; ++i) {
+        const int q = qq + PPR * i;
+        off[i] = (s > 0 && q < P)
+                     ? (unsigned)((((size_t)slot * ncl + cl) * P + q) * a.NT * 1024) + xoff : rbytes;
+      }
+#pragma unroll
+      for (int i = 0; i < RSW_NI_MAX; ++i) av[i] = load_sc1_b128(rres, off[i]);
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -1410,13 +1420,6 @@ __global__ __launch_bounds__(512) void lstm_bwd_rsw_kernel(LstmBwdRswArgs aa) {
       dyv = a.dy[((size_t)t * B + bg) * a.lddy + dir * H + unit];
     }
 
-    // ---- rest of the weight-gradient update of step s-1, under the exchange wait
-    if (full_tiles) { DW_UPDATE_N(1, NFT); DW_UPDATE_N(2, NFT); DW_UPDATE_N(3, NFT); }
-    else { DW_UPDATE_N(1, NFT - 1); DW_UPDATE_N(2, NFT - 1); DW_UPDATE_N(3, NFT - 1); }
-#undef DW_UPDATE
-#undef DW_UPDATE_N
-    __builtin_amdgcn_sched_barrier(0);
-    TRACE(2);
     {
       unsigned spins = 0;
       for (;;) {

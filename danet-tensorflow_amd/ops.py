@@ -518,9 +518,10 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs):
 # Where BPTT accumulates dW / db inside the persistent kernel (danet_lstm_bwd_fused): '0'
 # (default) = nowhere; '1' = every layer inside the kernel's envelope; 'bottom' = only the
 # layer whose input needs no gradient.  Measured at cfg 2 / cfg 4 (ms per step): '0' 3.60 /
-# 5.09, '1' 3.62 / 5.21, 'bottom' 3.82 / 5.30 -- the fused kernel is MFMA-bound at 3.6 us per
-# step, the same the GEMM path reaches with its contention, and a fused bottom layer slows the
-# layer-1 weight-gradient group that runs beside it.  Kept as a tested opt-in.
+# 5.12, '1' 3.61 / 5.27, 'bottom' 3.82 / 5.30 -- the fused kernel runs at 3.4 us per step alone
+# (MFMA block first, all loads behind it) but ~3.9 in the step, what the GEMM path reaches with
+# its contention; a fused bottom layer slows the layer-1 weight-gradient group that runs beside
+# it.  Kept as a tested opt-in.
 BWD_FUSED = __import__('os').environ.get('DANET_LSTM_BWD_FUSED', '0')
 # experiment: fork the weight-gradient group BEFORE dX (the two GEMMs share the GPU, the next
 # BPTT kernel then has the group beside it for a shorter time)

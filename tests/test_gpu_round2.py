@@ -638,7 +638,8 @@ def test_lstm_fused_envelope_query(monkeypatch):
     assert L.danet_lstm_fwd_fused_supported(1251, 1, 300, 2, 600) == 0      # B = 1: hoisted GEMM
     assert L.danet_lstm_bwd_fused_supported(128, 32, 300, 2, 600) == 1      # envelope
     from danet_amd import ops
-    assert ops.BWD_FUSED == '0' and ops.bptt_fused(128, 32, 300, 2, 129, need_dx=False) is False
+    monkeypatch.setattr(ops, 'BWD_FUSED', '0')                              # the default policy
+    assert ops.bptt_fused(128, 32, 300, 2, 129, need_dx=False) is False
     monkeypatch.setattr(ops, 'BWD_FUSED', 'bottom')
     assert ops.bptt_fused(128, 32, 300, 2, 129, need_dx=False) is True
     assert ops.bptt_fused(128, 32, 300, 2, 600, need_dx=True) is False
