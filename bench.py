@@ -413,7 +413,8 @@ def run_train(args, cfg, hp, device, rank, world, use_dist):
     L_ = _lib.load()
     Ds = [F if l == 0 else 2 * H for l in range(L)]
     fwd_fused = [L_.danet_lstm_fwd_fused_supported(T, B, H, 2, D) == 1 for D in Ds]
-    bwd_fused = [ops.bptt_fused(T, B, H, 2, D, need_dx=(l > 0)) for l, D in enumerate(Ds)]
+    bwd_fused = [ops.bptt_fused(T, B, H, 2, D, need_dx=(l > 0), is_top=(l == L - 1))
+                 for l, D in enumerate(Ds)]
     rec = 2.0 * 2 * B * T * H * 4 * H
     flops = dict(
         lstm_fwd=sum(rec + (2.0 * 2 * B * T * D * 4 * H if f else 0.0) for D, f in zip(Ds, fwd_fused)) / L,

@@ -530,14 +530,18 @@ DW_FORK_EARLY = __import__('os').environ.get('DANET_DW_FORK_EARLY', '0') == '1'
 BWD_DB = __import__('os').environ.get('DANET_LSTM_BWD_DB', '1') == '1'
 
 
-def bptt_fused(T, B, H, ndir, D, need_dx):
+def bptt_fused(T, B, H, ndir, D, need_dx, is_top=False):
     '''policy + envelope: does lstm_layer_bwd take the fused kernel for this layer?'''
-    if BWD_FUSED == '0' or (BWD_FUSED != '1' and need_dx):
-        return False
-    return _L().danet_lstm_bwd_fused_supported(T, B, H, ndir, D) == 1
+    if BWD_FUSED == '1':
+        use = True
+    elif BWD_FUSED == 'bottom':
+        use = not need_dx
+    else:
+        use = False
+    return use and _L().danet_lstm_bwd_fused_supported(T, B, H, ndir, D) == 1
 
 
-def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
+def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False):
     '''dy: [T, B, ndir*H] contiguous.  Returns (dx [T*B, D] or None, dWs, dbs).'''
     T, B, H, D, ndir = c.T, c.B, c.H, c.D, c.ndir
     dev = dy.device
@@ -557,7 +561,7 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None):
     fused = ((all_direct or none_direct) and
              all(W.stride(0) == 4 * H and W.stride(1) == 1 and W.data_ptr() % 16 == 0 for W in c.Ws) and
              all(t.data_ptr() % 16 == 0 for t in dWs + dbs) and
-             bptt_fused(T, B, H, ndir, D, need_dx))
+             bptt_fused(T, B, H, ndir, D, need_dx, is_top))
     db_in_kernel = False
     if fused:
         # BPTT with dW / db accumulated inside the persistent kernel (csrc/lstm.hip): no
@@ -777,7 +781,8 @@ class RnnEncoderFn(torch.autograd.Function):
         center(dyc, B, T, D, 0, D, dy, 1, D)                 # centre is self-adjoint
         grads = [None] * (2 * L * ndir)
         for l in reversed(range(L)):
-            dx, dWs, dbs = lstm_layer_bwd(ctx.ctxs[l], dy, need_dx=(l > 0), layer_tag=l)
+            dx, dWs, dbs = lstm_layer_bwd(ctx.ctxs[l], dy, need_dx=(l > 0), layer_tag=l,
+                                          is_top=(l == L - 1))
             for d in range(ndir):
                 grads[(l * ndir + d) * 2] = dWs[d]
                 grads[(l * ndir + d) * 2 + 1] = dbs[d]
