@@ -1731,12 +1731,11 @@ static RsPlan choose_rs_plan(int B, int H, int ndir) {
     if (pin && pin != U) continue;
     RsPlan r = make_rs_plan(B, H, ndir, U);
     if (!r.ok) continue;
-    int cost = cdiv(cdiv(r.NT, r.S), 4) * U;
-    // wide layers (cfg 4 as written, H = 600): the kernel spends most of its life beside a 1 ms
-    // weight-gradient group, and 152 workgroups (U = 16, no twins, 5 tiles per wave) suffer
-    // less from it than 228 (U = 32, 3 twins): 14.4 vs 16.5 ms per cfg-4h600 step, although
-    // alone U = 32 is faster (4.8 vs 7.6 us per step)
-    if (H > 384 && U == 16 && !pin) cost = 0;
+    const int cost = cdiv(cdiv(r.NT, r.S), 4) * U;
+    // (wide layers, H = 600: beside a 1 ms weight-gradient group the 152-workgroup geometry
+    // U = 16 / no twins suffers less than U = 32 / 3 twins (14.4 vs 16.5 ms per cfg-4h600 step),
+    // but the caller now runs those groups serially there (13.7 ms), where the faster-alone
+    // U = 32 geometry wins: 4.8 vs 7.6 us per step.  DANET_LSTM_BWD_U pins U.)
     if (cost < best_cost) { best = r; best_cost = cost; }
   }
   return best;

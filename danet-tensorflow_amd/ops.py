@@ -523,6 +523,20 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs):
 # its contention; a fused bottom layer slows the layer-1 weight-gradient group that runs beside
 # it.  Kept as a tested opt-in.
 BWD_FUSED = __import__('os').environ.get('DANET_LSTM_BWD_FUSED', '0')
+# Do the weight-gradient groups run UNDER the next BPTT kernel (side stream) or serially on the
+# main stream?  Under: the group is hidden but the BPTT kernel beside it slows down for as long as
+# the overlap lasts.  Measured: H = 300 (cfg 2 / cfg 4) 3.61 / 5.13 ms per step overlapped vs
+# 3.90 / 5.62 serial; H = 600 (cfg 4 as written) 14.3 overlapped vs 13.7 serial (the group lasts
+# 0.9-1.3 ms there and costs the BPTT kernel 0.7 ms).  'auto' = overlap up to H = 384.
+DW_OVERLAP = __import__('os').environ.get('DANET_DW_OVERLAP', 'auto')
+
+
+def _overlap_dw(H):
+    if DW_OVERLAP in ('0', '1'):
+        return DW_OVERLAP == '1'
+    return H <= 384
+
+
 # experiment: fork the weight-gradient group BEFORE dX (the two GEMMs share the GPU, the next
 # BPTT kernel then has the group beside it for a shorter time)
 DW_FORK_EARLY = __import__('os').environ.get('DANET_DW_FORK_EARLY', '0') == '1'
@@ -679,6 +693,9 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False):
                 f.run(1, bias_grads)
             weight_grads_grouped(wgs=512, with_bias=False)
             on_main = True
+        elif GROUPED_DW and not _overlap_dw(H):
+            weight_grads_grouped(wgs=512)      # serial: alone on the main stream, whole GPU
+            on_main = True
         elif GROUPED_DW:
             f.run(1, weight_grads_grouped)
             if fork_early:
@@ -767,10 +784,11 @@ class RnnEncoderFn(torch.autograd.Function):
         dyc = torch.empty(B, T, D, device=dev)
         gemm(dembed, ctx.Wout, dyc, B * T, D, O, O, O, D, transB=True, streamk=(STREAMK & 1) != 0, tag='dYc')   # critical path first
         with _Fork(dev, 2, defer=True, keep=(dembed, ctx.yc)) as f:
-            if GROUPED_DW:    # alone on its stream under the top layer's BPTT kernel
-                f.run(1, lambda: gemm_group(
+            if GROUPED_DW:    # alone on its stream under the top layer's BPTT kernel (or serial)
+                ov = _overlap_dw(H)
+                f.run(1 if ov else 0, lambda: gemm_group(
                     [(ctx.yc, D, dembed, O, dWout, O, D, O, 1.0 if direct_out else 0.0)], B * T,
-                    transA=True, max_workgroups=GROUPED_DW_WGS))
+                    transA=True, max_workgroups=GROUPED_DW_WGS if ov else 512))
             else:
                 f.run(1, lambda: gemm(ctx.yc, dembed, dWout, D, O, B * T, D, O, O, transA=True,
                                       beta=1.0 if direct_out else 0.0,
