@@ -6,9 +6,9 @@
 // Tiling: 128x128x16 block tile, 256 threads = 4 waves in 2x2, each wave owns a
 // 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 acc VGPRs).  Operands are
 // staged global -> registers -> LDS as [k][mn] (ld 132: conflict-free
-// ds_read_b32 fragment reads, 2-way-at-most transposing writes), double
-// buffered so the next tile's global loads fly under the current tile's 32
-// MFMAs.  Small-output / long-K products (weight gradients) use a
+// ds_read_b32 fragment reads, 2-way-at-most transposing writes) through a ring of
+// three LDS stages (see gemm_kloop: one barrier per k-tile, nothing but the barrier
+// itself between the MFMAs of consecutive k-tiles).  Small-output / long-K products (weight gradients) use a
 // deterministic split-K: per-slice slabs in `ws`, summed by a second kernel.
 #include "common.h"
 #include <stdlib.h>
@@ -18,10 +18,13 @@
 #ifndef BK
 #define BK 16
 #endif
+static_assert(BK == 16, "gemm_kloop places its side work for BK = 16 (2 pieces per operand)");
 #define NLD (BK / 8)   // 16-byte loads per thread and operand tile (128 x BK floats / 256 threads)
 #define KQ (BK / 4)    // 4-float groups along k
-#define GEMM_SMEM_BYTES (2 * 2 * BK * (128 + 4) * sizeof(float))
 #define LDT 132  // BM + 4
+#define NSTAGE 3
+#define STG (BK * LDT)      // floats per operand stage
+#define GEMM_SMEM_BYTES (NSTAGE * 2 * STG * sizeof(float))
 
 struct GemmArgs {
   const float* A;
@@ -33,79 +36,190 @@ struct GemmArgs {
   int lda, ldb, ldc;
   int kchunk;   // K range per z-slice (multiple of BK)
   int splitk;
-  int vecA, vecB;
   float beta;
   // optional second operand pair (K-concatenated product C = A B + A2 B2): K slices
   // z >= split1 take pair 2, K2 elements in chunks of kchunk2
   const float* A2; const float* B2;
-  int lda2, ldb2, K2, kchunk2, split1, vecA2, vecB2;
+  int lda2, ldb2, K2, kchunk2, split1;
 };
 
-// Load this thread's share of one operand tile into registers.
-// KCONTIG: element (mn, k) at P[mn*ld + k]; else at P[k*ld + mn].
+typedef unsigned v4u __attribute__((__vector_size__(16)));   // see lstm.hip (b128 builtins)
+#define GEMM_OOB 0xfffffff0u   // voffset beyond num_records: the buffer load returns 0, no access
+
+// Buffer view of an operand from a tile's origin (element (mn0, kbeg)) to the operand's last
+// element; the host checks that no operand spans 2 GiB or more.  Guards are turned into
+// out-of-range OFFSETS (no branches: a conditionally executed load makes the compiler wait
+// vmcnt(0) where the paths join, which would serialise the loads hidden behind the MFMAs).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float* p, const float* end) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)((end - p) * 4), 0x00020000);
+}
+
+// Load piece i (one 16-byte vector, 4-byte aligned) of this thread's share of an operand tile.
+// KCONTIG: element (mn, k) at P[mn*ld + k]; else at P[k*ld + mn].  adv: byte offset of the
+// k-tile from the view's origin; mn_rem / k_rem: valid extent from the k-tile's origin.  A vector that STARTS out of range is not fetched (zeros); one
+// that straddles the edge of a row is fetched whole (what lies beyond is the next row, or is
+// cut off by the buffer range at the operand's end) and masked by store_piece.
 template <bool KCONTIG>
-__device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld,
-                                          int mn0, int mn_lim, int k0, int k_lim,
-                                          int vec, int tid, f32x4 (&r)[NLD]) {
-#pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    const int idx = tid + i * 256;
-    int mn, k;
-    if (KCONTIG) { mn = mn0 + idx / KQ; k = k0 + (idx % KQ) * 4; }
-    else         { k = k0 + (idx >> 5);  mn = mn0 + (idx & 31) * 4; }
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (KCONTIG) {
-      if (mn < mn_lim) {
-        const float* p = P + (size_t)mn * ld + k;
-        if (vec && k + 3 < k_lim) {
-          v = *reinterpret_cast<const f32x4*>(p);
-        } else {
-          if (k + 0 < k_lim) v.x = p[0];
-          if (k + 1 < k_lim) v.y = p[1];
-          if (k + 2 < k_lim) v.z = p[2];
-          if (k + 3 < k_lim) v.w = p[3];
-        }
-      }
-    } else {
-      if (k < k_lim) {
-        const float* p = P + (size_t)k * ld + mn;
-        if (vec && mn + 3 < mn_lim) {
-          v = *reinterpret_cast<const f32x4*>(p);
-        } else {
-          if (mn + 0 < mn_lim) v.x = p[0];
-          if (mn + 1 < mn_lim) v.y = p[1];
-          if (mn + 2 < mn_lim) v.z = p[2];
-          if (mn + 3 < mn_lim) v.w = p[3];
-        }
-      }
-    }
-    r[i] = v;
-  }
+__device__ __forceinline__ f32x4 load_piece(__amdgpu_buffer_rsrc_t rs, int ld, int mn_rem,
+                                            int k_rem, int tid, int i, unsigned adv) {
+  const int idx = tid + i * 256;
+  int mn, k;
+  if (KCONTIG) { mn = idx / KQ; k = (idx % KQ) * 4; }
+  else         { k = idx >> 5;  mn = (idx & 31) * 4; }
+  const unsigned off = (unsigned)(KCONTIG ? mn * ld + k : k * ld + mn) * 4u + adv;
+  const bool ok = mn < mn_rem && k < k_rem;
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : GEMM_OOB, 0, 0));
 }
 
 template <bool KCONTIG>
-__device__ __forceinline__ void store_tile(float* __restrict__ S, int tid,
-                                           const f32x4 (&r)[NLD]) {
+__device__ __forceinline__ void store_piece(float* __restrict__ S, int tid, f32x4 r, int i,
+                                            int mn_rem, int k_rem) {
+  const int idx = tid + i * 256;
+  int mn, k;
+  if (KCONTIG) { mn = idx / KQ; k = (idx % KQ) * 4; }
+  else         { k = idx >> 5;  mn = (idx & 31) * 4; }
+  const int left = KCONTIG ? k_rem - k : mn_rem - mn;   // valid elements of this vector
+  r.y = left > 1 ? r.y : 0.f;
+  r.z = left > 2 ? r.z : 0.f;
+  r.w = left > 3 ? r.w : 0.f;
+  if (KCONTIG) {
+    S[(k + 0) * LDT + mn] = r.x;
+    S[(k + 1) * LDT + mn] = r.y;
+    S[(k + 2) * LDT + mn] = r.z;
+    S[(k + 3) * LDT + mn] = r.w;
+  } else {
+    *reinterpret_cast<f32x4*>(&S[k * LDT + mn]) = r;
+  }
+}
+
+// One operand pair's k-range [kbeg, kend) of the 128x128 tile at (m0, n0), accumulated into
+// the wave's 2x2 accumulators.  LDS: [A stage 0..2 | B stage 0..2].
+//
+// Pipeline (k-tile kt of BK): the global loads of tile kt+2 are issued during tile kt and
+// written to the third LDS stage at the end of it; tile kt+1 is already in LDS (written
+// during kt-1, published by the barrier that ended kt-1), so the first fragments of kt+1 are
+// read BEFORE the barrier that ends kt.  After that barrier the wave therefore starts the
+// next 32 MFMAs at once -- with the two-stage ring it had to store, wait for the barrier and
+// then wait for its first ds_reads (~300 of 2350 clocks per k-tile with one wave per SIMD,
+// which is what the last round of tiles and every few-tile product of the train step run at).
+// All side work sits in the shadow of an MFMA: one piece after each MFMA (every piece is
+// followed by a sched_barrier, or the machine scheduler gathers them again).
+template <bool A_KCONTIG, bool B_KCONTIG>
+__device__ __forceinline__ void gemm_kloop(const float* __restrict__ Ap, int lda,
+                                           const float* __restrict__ Bp, int ldb,
+                                           int M, int N, int m0, int n0, int kbeg, int kend,
+                                           float* smem, f32x16 (&acc)[2][2], int yield) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk <= 0) return;
+  float* const sA = smem;
+  float* const sB = smem + NSTAGE * STG;
+  // views from the tile origin, per-k-tile strides in bytes (uniform)
+  const float* pa = Ap + (A_KCONTIG ? (size_t)m0 * lda + kbeg : (size_t)kbeg * lda + m0);
+  const float* pb = Bp + (B_KCONTIG ? (size_t)n0 * ldb + kbeg : (size_t)kbeg * ldb + n0);
+  const unsigned sta = (A_KCONTIG ? BK : BK * lda) * 4u;
+  const unsigned stb = (B_KCONTIG ? BK : BK * ldb) * 4u;
+  const int mrem = M - m0, nrem = N - n0;
+  // one past the last element this segment may touch
+  const float* enda = Ap + (A_KCONTIG ? (size_t)(M - 1) * lda + kend : (size_t)(kend - 1) * lda + M);
+  const float* endb = Bp + (B_KCONTIG ? (size_t)(N - 1) * ldb + kend : (size_t)(kend - 1) * ldb + N);
+  const __amdgpu_buffer_rsrc_t rsa = tile_rsrc(pa, enda), rsb = tile_rsrc(pb, endb);
+  f32x4 ra[NLD], rb[NLD];
+  {
+    f32x4 ra1[NLD], rb1[NLD];
 #pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    const int idx = tid + i * 256;
-    if (KCONTIG) {
-      const int mn = idx / KQ, k = (idx % KQ) * 4;
-      S[(k + 0) * LDT + mn] = r[i].x;
-      S[(k + 1) * LDT + mn] = r[i].y;
-      S[(k + 2) * LDT + mn] = r[i].z;
-      S[(k + 3) * LDT + mn] = r[i].w;
-    } else {
-      const int k = idx >> 5, mn = (idx & 31) * 4;
-      *reinterpret_cast<f32x4*>(&S[k * LDT + mn]) = r[i];
+    for (int i = 0; i < NLD; ++i) {
+      ra[i] = load_piece<A_KCONTIG>(rsa, lda, mrem, kend - kbeg, tid, i, 0u);
+      rb[i] = load_piece<B_KCONTIG>(rsb, ldb, nrem, kend - kbeg, tid, i, 0u);
     }
+    if (nk > 1) {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        ra1[i] = load_piece<A_KCONTIG>(rsa, lda, mrem, kend - kbeg - BK, tid, i, sta);
+        rb1[i] = load_piece<B_KCONTIG>(rsb, ldb, nrem, kend - kbeg - BK, tid, i, stb);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      store_piece<A_KCONTIG>(sA, tid, ra[i], i, mrem, kend - kbeg);
+      store_piece<B_KCONTIG>(sB, tid, rb[i], i, nrem, kend - kbeg);
+    }
+    if (nk > 1) {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        store_piece<A_KCONTIG>(sA + STG, tid, ra1[i], i, mrem, kend - kbeg - BK);
+        store_piece<B_KCONTIG>(sB + STG, tid, rb1[i], i, nrem, kend - kbeg - BK);
+      }
+    }
+  }
+  unsigned adva = 2 * sta, advb = 2 * stb;     // k-tile kt + 2
+  __syncthreads();
+
+  const int fa = wm * 64 + (lane & 31);  // fragment column within the tile
+  const int fb = wn * 64 + (lane & 31);
+  const int fk = lane >> 5;
+  int s_cur = 0, s_nxt = STG, s_fill = 2 * STG;
+  float a0 = sA[fk * LDT + fa], a1 = sA[fk * LDT + fa + 32];
+  float b0 = sB[fk * LDT + fb], b1 = sB[fk * LDT + fb + 32];
+
+  for (int kt = 0; kt < nk; ++kt) {
+    // The first instruction after the barrier is an MFMA (its fragments were read before the
+    // barrier); everything else of the k-tile -- stage addresses, buffer descriptors, the
+    // fragment reads of the next k-pair, the fetch of tile kt + 2 (past the last tile
+    // k2rem <= 0 turns every load into an out-of-range one: zeros, stored to the stage nobody
+    // reads, so there is no branch in here) -- follows in the MFMAs' shadows.
+    float a0n, a1n, b0n, b1n;
+    int k2rem;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      // fragments of the next k-pair (of the next k-tile after the last pair: that stage was
+      // published by the previous barrier; past the last tile the values are never used)
+      if (kk + 1 < BK / 2) {
+        const int k = (kk + 1) * 2 + fk;
+        a0n = sA[s_cur + k * LDT + fa]; a1n = sA[s_cur + k * LDT + fa + 32];
+        b0n = sB[s_cur + k * LDT + fb]; b1n = sB[s_cur + k * LDT + fb + 32];
+      } else {
+        a0n = sA[s_nxt + fk * LDT + fa]; a1n = sA[s_nxt + fk * LDT + fa + 32];
+        b0n = sB[s_nxt + fk * LDT + fb]; b1n = sB[s_nxt + fk * LDT + fb + 32];
+      }
+      if (kk == 0) {
+        k2rem = kend - kbeg - (kt + 2) * BK;
+        ra[0] = load_piece<A_KCONTIG>(rsa, lda, mrem, k2rem, tid, 0, adva);
+      }
+      if (kk == BK / 2 - 2) store_piece<A_KCONTIG>(sA + s_fill, tid, ra[0], 0, mrem, k2rem);
+      if (kk == BK / 2 - 1) store_piece<B_KCONTIG>(sB + s_fill, tid, rb[0], 0, nrem, k2rem);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      if (kk == 0) ra[1] = load_piece<A_KCONTIG>(rsa, lda, mrem, k2rem, tid, 1, adva);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      if (kk == 0) rb[0] = load_piece<B_KCONTIG>(rsb, ldb, nrem, k2rem, tid, 0, advb);
+      if (kk == BK / 2 - 2) store_piece<A_KCONTIG>(sA + s_fill, tid, ra[1], 1, mrem, k2rem);
+      if (kk == BK / 2 - 1) store_piece<B_KCONTIG>(sB + s_fill, tid, rb[1], 1, nrem, k2rem);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      if (kk == 0) rb[1] = load_piece<B_KCONTIG>(rsb, ldb, nrem, k2rem, tid, 1, advb);
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
+    }
+    if (yield == 1) __builtin_amdgcn_s_sleep(1);
+    else if (yield == 2) __builtin_amdgcn_s_sleep(2);
+    else if (yield == 4) __builtin_amdgcn_s_sleep(4);
+    else if (yield >= 8) __builtin_amdgcn_s_sleep(8);
+    __syncthreads();   // publishes stage s_fill; also makes the ring reusable by the next segment
+    const int t = s_cur; s_cur = s_nxt; s_nxt = s_fill; s_fill = t;
+    adva += sta; advb += stb;
   }
 }
 
 template <bool A_KCONTIG, bool B_KCONTIG>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // GEMM_SMEM_BYTES
-  // layout: [A buf0 | A buf1 | B buf0 | B buf1], each BK*LDT floats
+  // layout: see gemm_kloop
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -129,11 +243,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   const float* Ap = second ? g.A2 : g.A;
   const float* Bp = second ? g.B2 : g.B;
   const int lda = second ? g.lda2 : g.lda, ldb = second ? g.ldb2 : g.ldb;
-  const int vecA = second ? g.vecA2 : g.vecA, vecB = second ? g.vecB2 : g.vecB;
   const int kbeg = second ? (z - g.split1) * g.kchunk2 : z * g.kchunk;
   const int kend = second ? min(g.K2, kbeg + g.kchunk2) : min(g.K, kbeg + g.kchunk);
-  const int nk = (kend - kbeg + BK - 1) / BK;
-
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -142,56 +253,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 ra[NLD], rb[NLD];
-  if (nk > 0) {
-    load_tile<A_KCONTIG>(Ap, lda, m0, g.M, kbeg, kend, vecA, tid, ra);
-    load_tile<B_KCONTIG>(Bp, ldb, n0, g.N, kbeg, kend, vecB, tid, rb);
-    store_tile<A_KCONTIG>(smem, tid, ra);
-    store_tile<B_KCONTIG>(smem + 2 * BK * LDT, tid, rb);
-  }
-  __syncthreads();
-
-  const int fa = wm * 64 + (lane & 31);  // fragment column within the tile
-  const int fb = wn * 64 + (lane & 31);
-  const int fk = lane >> 5;
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      const int k0 = kbeg + (kt + 1) * BK;
-      load_tile<A_KCONTIG>(Ap, lda, m0, g.M, k0, kend, vecA, tid, ra);
-      load_tile<B_KCONTIG>(Bp, ldb, n0, g.N, k0, kend, vecB, tid, rb);
-    }
-    const float* as = smem + cur * (BK * LDT);
-    const float* bs = smem + (2 + cur) * (BK * LDT);
-    // software-pipelined fragment reads: the LDS reads of k-pair kk+1 are issued before
-    // the four MFMAs of kk, so their latency hides under 256 cycles of MFMA work instead of
-    // stalling the (single wave per SIMD) issue stream after every group
-    float a0 = as[fk * LDT + fa], a1 = as[fk * LDT + fa + 32];
-    float b0 = bs[fk * LDT + fb], b1 = bs[fk * LDT + fb + 32];
-#pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      float a0n = 0.f, a1n = 0.f, b0n = 0.f, b1n = 0.f;
-      if (kk + 1 < BK / 2) {
-        const int k = (kk + 1) * 2 + fk;
-        a0n = as[k * LDT + fa]; a1n = as[k * LDT + fa + 32];
-        b0n = bs[k * LDT + fb]; b1n = bs[k * LDT + fb + 32];
-      }
-      // keep the machine scheduler from sinking the prefetch back below the MFMAs
-      __builtin_amdgcn_sched_barrier(0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
-    }
-    if (kt + 1 < nk) {
-      store_tile<A_KCONTIG>(smem + (cur ^ 1) * (BK * LDT), tid, ra);
-      store_tile<B_KCONTIG>(smem + (2 + (cur ^ 1)) * (BK * LDT), tid, rb);
-    }
-    __syncthreads();
-  }
+  gemm_kloop<A_KCONTIG, B_KCONTIG>(Ap, lda, Bp, ldb, g.M, g.N, m0, n0, kbeg, kend,
+                                   smem, acc, 0);
 
   // epilogue.  D layout (32x32): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int col_l = lane & 31, row_l = 4 * (lane >> 5);
@@ -286,6 +349,11 @@ extern "C" int danet_gemm_f32(danet_stream_t stream_, int transA, int transB,
                            ws, ws_bytes, 0);
 }
 
+// the kernels address an operand through one 32-bit buffer view per tile
+static bool operand_fits(int rows, int cols, int ld) {
+  return ((size_t)(rows - 1) * ld + cols) * sizeof(float) < ((size_t)1 << 31);
+}
+
 static int gemm_launch(hipStream_t stream, int transA, int transB, int M, int N,
                        int K, const float* A, int lda, const float* B, int ldb,
                        int K2, const float* A2, int lda2, const float* B2, int ldb2,
@@ -299,15 +367,16 @@ static int gemm_launch(hipStream_t stream, int transA, int transB, int M, int N,
                   "gemm: leading dimension too small");
   DANET_CHECK_ARG(K2 == 0 || (lda2 >= (transA ? M : K2) && ldb2 >= (transB ? K2 : N)),
                   "gemm: leading dimension of the second pair too small");
+  DANET_CHECK_ARG(operand_fits(transA ? K : M, transA ? M : K, lda) &&
+                  operand_fits(transB ? N : K, transB ? K : N, ldb) &&
+                  (K2 == 0 || (operand_fits(transA ? K2 : M, transA ? M : K2, lda2) &&
+                               operand_fits(transB ? N : K2, transB ? K2 : N, ldb2))),
+                  "gemm: an operand spans 2 GiB or more");
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.beta = beta;
-  g.vecA = (((uintptr_t)A & 15) == 0) && (lda % 4 == 0);
-  g.vecB = (((uintptr_t)B & 15) == 0) && (ldb % 4 == 0);
   g.A2 = A2; g.B2 = B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;
-  g.vecA2 = K2 && (((uintptr_t)A2 & 15) == 0) && (lda2 % 4 == 0);
-  g.vecB2 = K2 && (((uintptr_t)B2 & 15) == 0) && (ldb2 % 4 == 0);
   int stot = choose_splitk(M, N, K + K2);
   if (K2 > 0 && stot < 2) stot = 2;
   int s1 = stot, s2 = 0;
@@ -403,7 +472,6 @@ extern "C" int danet_gemm_f32_kcat(danet_stream_t stream_, int transA, int trans
 struct SkProblem {
   const float* A; const float* B; float* C; const float* bias;
   int M, N, lda, ldb, ldc;
-  int vecA, vecB;
   int tiles_n;     // N tiles of this problem
   int tile0;       // first global tile index of this problem
   float beta;
@@ -421,72 +489,9 @@ struct SkArgs {
 #define SK_SPIN_LIMIT (1u << 22)
 
 template <bool A_KCONTIG, bool B_KCONTIG>
-__device__ __forceinline__ void gemm_segment(const GemmArgs& g, float* smem, int m0, int n0,
-                                             int kbeg, int kend, f32x16 (&acc)[2][2], int yield) {
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nk = (kend - kbeg + BK - 1) / BK;
-  f32x4 ra[NLD], rb[NLD];
-  load_tile<A_KCONTIG>(g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, tid, ra);
-  load_tile<B_KCONTIG>(g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid, rb);
-  store_tile<A_KCONTIG>(smem, tid, ra);
-  store_tile<B_KCONTIG>(smem + 2 * BK * LDT, tid, rb);
-  __syncthreads();
-
-  const int fa = wm * 64 + (lane & 31);  // fragment column within the tile
-  const int fb = wn * 64 + (lane & 31);
-  const int fk = lane >> 5;
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      const int k0 = kbeg + (kt + 1) * BK;
-      load_tile<A_KCONTIG>(g.A, g.lda, m0, g.M, k0, kend, g.vecA, tid, ra);
-      load_tile<B_KCONTIG>(g.B, g.ldb, n0, g.N, k0, kend, g.vecB, tid, rb);
-    }
-    const float* as = smem + cur * (BK * LDT);
-    const float* bs = smem + (2 + cur) * (BK * LDT);
-    // software-pipelined fragment reads: the LDS reads of k-pair kk+1 are issued before
-    // the four MFMAs of kk, so their latency hides under 256 cycles of MFMA work instead of
-    // stalling the (single wave per SIMD) issue stream after every group
-    float a0 = as[fk * LDT + fa], a1 = as[fk * LDT + fa + 32];
-    float b0 = bs[fk * LDT + fb], b1 = bs[fk * LDT + fb + 32];
-#pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      float a0n = 0.f, a1n = 0.f, b0n = 0.f, b1n = 0.f;
-      if (kk + 1 < BK / 2) {
-        const int k = (kk + 1) * 2 + fk;
-        a0n = as[k * LDT + fa]; a1n = as[k * LDT + fa + 32];
-        b0n = bs[k * LDT + fb]; b1n = bs[k * LDT + fb + 32];
-      }
-      // keep the machine scheduler from sinking the prefetch back below the MFMAs
-      __builtin_amdgcn_sched_barrier(0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
-    }
-    if (kt + 1 < nk) {
-      store_tile<A_KCONTIG>(smem + (cur ^ 1) * (BK * LDT), tid, ra);
-      store_tile<B_KCONTIG>(smem + (2 + (cur ^ 1)) * (BK * LDT), tid, rb);
-    }
-    if (yield == 1) __builtin_amdgcn_s_sleep(1);
-    else if (yield == 2) __builtin_amdgcn_s_sleep(2);
-    else if (yield == 4) __builtin_amdgcn_s_sleep(4);
-    else if (yield >= 8) __builtin_amdgcn_s_sleep(8);
-    __syncthreads();   // also makes the LDS reusable by the next segment
-  }
-}
-
-typedef unsigned v4u __attribute__((__vector_size__(16)));   // see lstm.hip (b128 builtins)
-
-template <bool A_KCONTIG, bool B_KCONTIG>
 __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(SkArgs sk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // GEMM_SMEM_BYTES
-  // layout: [A buf0 | A buf1 | B buf0 | B buf1], each BK*LDT floats
+  // layout: see gemm_kloop
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -514,10 +519,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(SkArgs sk) {
     GemmArgs g;
     g.A = pr.A; g.B = pr.B; g.C = pr.C; g.bias = pr.bias;
     g.M = pr.M; g.N = pr.N; g.K = sk.K; g.lda = pr.lda; g.ldb = pr.ldb; g.ldc = pr.ldc;
-    g.vecA = pr.vecA; g.vecB = pr.vecB; g.beta = pr.beta;
+    g.beta = pr.beta;
     g.slab = nullptr; g.splitk = 1; g.kchunk = sk.K;
     g.A2 = nullptr; g.B2 = nullptr; g.lda2 = g.ldb2 = g.K2 = 0; g.kchunk2 = BK; g.split1 = 1;
-    g.vecA2 = g.vecB2 = 0;
     const int ptile = tile - pr.tile0;
     const int tm = ptile / pr.tiles_n, tn = ptile % pr.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -530,7 +534,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(SkArgs sk) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
-    gemm_segment<A_KCONTIG, B_KCONTIG>(g, smem, m0, n0, kb * BK, min(g.K, ke * BK), acc, sk.yield);
+    gemm_kloop<A_KCONTIG, B_KCONTIG>(g.A, g.lda, g.B, g.ldb, g.M, g.N, m0, n0,
+                                     kb * BK, min(g.K, ke * BK), smem, acc, sk.yield);
 
     if (ke < sk.nk) {
       // contributor: the tile's later k-segments belong to higher workgroups
@@ -666,11 +671,12 @@ extern "C" int danet_gemm_f32_streamk_grouped(danet_stream_t stream_, int transA
     DANET_CHECK_ARG(q.beta == 0.f || q.beta == 1.f, "gemm: beta must be 0 or 1");
     DANET_CHECK_ARG(q.lda >= (transA ? q.M : K) && q.ldb >= (transB ? K : q.N) && q.ldc >= q.N,
                     "gemm: leading dimension too small");
+    DANET_CHECK_ARG(operand_fits(transA ? K : q.M, transA ? q.M : K, q.lda) &&
+                    operand_fits(transB ? q.N : K, transB ? K : q.N, q.ldb),
+                    "gemm: an operand spans 2 GiB or more");
     SkProblem& p = sk.p[i];
     p.A = q.A; p.B = q.B; p.C = q.C; p.bias = q.bias;
     p.M = q.M; p.N = q.N; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.beta = q.beta;
-    p.vecA = (((uintptr_t)q.A & 15) == 0) && (q.lda % 4 == 0);
-    p.vecB = (((uintptr_t)q.B & 15) == 0) && (q.ldb % 4 == 0);
     p.tiles_n = cdiv(q.N, BN);
     p.tile0 = tiles;
     tiles += cdiv(q.M, BM) * p.tiles_n;
