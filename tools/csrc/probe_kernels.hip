@@ -38,3 +38,27 @@ extern "C" int probe_mem(void* stream, int wgs, const void* in, float* out, long
   mem_stream_kernel<<<wgs, 256, 0, (hipStream_t)stream>>>((const float4*)in, out, n4, iters);
   return (int)hipGetLastError();
 }
+
+// ---- CU-masked streams (tools/cumask_probe.py) ---------------------------------------------
+extern "C" int probe_stream_create_cumask(const unsigned* mask, int nwords, void** stream) {
+  hipStream_t s;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, mask);
+  *stream = (void*)s;
+  return (int)e;
+}
+extern "C" int probe_stream_destroy(void* stream) { return (int)hipStreamDestroy((hipStream_t)stream); }
+
+// where does each workgroup run: out[b] = XCC_ID << 16 | HW_ID[15:0] (after `spin` clocks, so that
+// a grid of <= #CUs workgroups is resident all at once)
+extern "C" __global__ __launch_bounds__(256) void whereami_kernel(unsigned* out, int spin) {
+  unsigned hw, xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  while (__builtin_readcyclecounter() - t0 < (unsigned long long)spin) __builtin_amdgcn_s_sleep(8);
+  if (threadIdx.x == 0) out[blockIdx.x] = (xcc << 16) | (hw & 0xffff);
+}
+extern "C" int probe_whereami(void* stream, int wgs, unsigned* out, int spin) {
+  whereami_kernel<<<wgs, 256, 0, (hipStream_t)stream>>>(out, spin);
+  return (int)hipGetLastError();
+}
