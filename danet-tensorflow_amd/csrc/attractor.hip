@@ -13,7 +13,8 @@
 #include "common.h"
 #include <stdlib.h>
 
-#define CHUNK_N 2048       // bins per workgroup (reduction granularity)
+#define CHUNK_N 2048       // bins per workgroup (reduction granularity; 512 / 1024 measured: the
+                           // backward kernels gain 4 us, the chunk sums lose as much)
 #define MAXC 4
 #define MAXA 8
 #define MAXP 70            // C(8,4)
@@ -23,6 +24,11 @@ __host__ __device__ static inline int n_chunks(int64_t N) { return (int)((N + CH
 // 4x the workgroups hide its latencies (73 -> 51 us at cfg 2; its finalize 16 -> 22 us)
 #define ANCH_CHUNK_N 512
 __host__ __device__ static inline int n_chunks_anchor_fwd(int64_t N) { return (int)((N + ANCH_CHUNK_N - 1) / ANCH_CHUNK_N); }
+
+// a wave-uniform value as a scalar register
+__device__ __forceinline__ float uniform(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
 
 // ---- per-thread embedding row -------------------------------------------------
 template <int EP>
@@ -245,6 +251,14 @@ __global__ __launch_bounds__(256) void separate_bwd_kernel(
   const int64_t n0 = (int64_t)ch * CHUNK_N, n1 = min(N, n0 + CHUNK_N);
   const float* eb = embed + (int64_t)b * N * E;
   float* db = dembed + (int64_t)b * N * E;
+  // the attractor table is uniform: in scalar registers it costs no VGPRs and no LDS reads
+  // (hoisted LDS broadcasts had pushed the kernel to 176 VGPRs = 2 waves per SIMD, and with 8
+  // dependent load -> compute -> store rounds per thread the kernel is latency-bound)
+  float st[CP][EP];
+#pragma unroll
+  for (int c = 0; c < CP; ++c)
+#pragma unroll
+    for (int e = 0; e < EP; ++e) st[c][e] = uniform(tab[c * EP + e]);
   float accs[CP][EP];
 #pragma unroll
   for (int c = 0; c < CP; ++c)
@@ -260,7 +274,7 @@ __global__ __launch_bounds__(256) void separate_bwd_kernel(
       float s = 0.f;
       if (c < C) {
 #pragma unroll
-        for (int e = 0; e < EP; ++e) s += x[e] * tab[c * EP + e];
+        for (int e = 0; e < EP; ++e) s += x[e] * st[c][e];
       }
       m[c] = s;
     }
@@ -298,7 +312,7 @@ __global__ __launch_bounds__(256) void separate_bwd_kernel(
       if (c < C) {
 #pragma unroll
         for (int e = 0; e < EP; ++e) {
-          dx[e] += dl[c] * tab[c * EP + e];
+          dx[e] += dl[c] * st[c][e];
           accs[c][e] += dl[c] * x[e];
         }
       }
@@ -666,43 +680,49 @@ __global__ __launch_bounds__(256) void anchor_bwd_kernel(
   const int64_t n0 = (int64_t)ch * CHUNK_N, n1 = min(N, n0 + CHUNK_N);
   const float* eb = embed + (int64_t)b * N * E;
   float* db = dembed + (int64_t)b * N * E;
+  // the per-utterance tables are uniform: as scalar registers they cost the vector ALU nothing
+  // (as LDS broadcasts the compiler hoisted 80 of them into VGPRs: 264 VGPRs, one wave per SIMD)
+  float sAn[CP][EP], sG[CP][EP], sg0[CP];
+#pragma unroll
+  for (int c = 0; c < CP; ++c) {
+    sg0[c] = uniform(g0[c]);
+#pragma unroll
+    for (int e = 0; e < EP; ++e) { sAn[c][e] = uniform(An[c * EP + e]); sG[c][e] = uniform(G[c * EP + e]); }
+  }
   float accs[CP][EP];
 #pragma unroll
   for (int c = 0; c < CP; ++c)
 #pragma unroll
     for (int e = 0; e < EP; ++e) accs[c][e] = 0.f;
   for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
-    float x[EP];
+    float x[EP], dx[EP];
     load_row<EP>(eb + n * E, E, x);
+    load_row<EP>(db + n * E, E, dx);
     float s[CP], ds[CP];
     float mx = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < CP; ++c)
-      if (c < C) {
-        float v = 0.f, w = 0.f;
+    for (int c = 0; c < CP; ++c) {
+      float v = 0.f, w = 0.f;
 #pragma unroll
-        for (int e = 0; e < EP; ++e) { v += x[e] * An[c * EP + e]; w += x[e] * G[c * EP + e]; }
-        s[c] = v; ds[c] = w + g0[c];
-        mx = fmaxf(mx, v);
-      }
+      for (int e = 0; e < EP; ++e) { v += x[e] * sAn[c][e]; w += x[e] * sG[c][e]; }
+      s[c] = v; ds[c] = w + sg0[c];
+      mx = fmaxf(mx, v);
+    }
     float den = 0.f;
 #pragma unroll
-    for (int c = 0; c < CP; ++c) if (c < C) { s[c] = expf(s[c] - mx); den += s[c]; }
+    for (int c = 0; c < CP; ++c) { s[c] = expf(s[c] - mx); den += s[c]; }
     float dot = 0.f;
 #pragma unroll
-    for (int c = 0; c < CP; ++c) if (c < C) { s[c] /= den; dot += s[c] * ds[c]; }
-    float dx[EP];
-    load_row<EP>(db + n * E, E, dx);
+    for (int c = 0; c < CP; ++c) { s[c] /= den; dot += s[c] * ds[c]; }
 #pragma unroll
-    for (int c = 0; c < CP; ++c)
-      if (c < C) {
-        const float dl = s[c] * (ds[c] - dot);
+    for (int c = 0; c < CP; ++c) {
+      const float dl = s[c] * (ds[c] - dot);
 #pragma unroll
-        for (int e = 0; e < EP; ++e) {
-          dx[e] += s[c] * G[c * EP + e] + dl * An[c * EP + e];
-          accs[c][e] += dl * x[e];
-        }
+      for (int e = 0; e < EP; ++e) {
+        dx[e] += s[c] * sG[c][e] + dl * sAn[c][e];
+        accs[c][e] += dl * x[e];
       }
+    }
     store_row<EP>(db + n * E, E, dx);
   }
   float* out = partial + ((int64_t)b * nch + ch) * C * EP;
