@@ -184,6 +184,51 @@ def test_gemm_strided_views_and_asymmetric():
     assert np.all(got[:, :4] == -7.0)
 
 
+@pytest.mark.parametrize('M,N,K,ta,tb', [(130, 70, 129, 0, 0), (130, 70, 129, 0, 1), (129, 70, 130, 1, 0),
+                                         (257, 131, 67, 1, 1), (64, 600, 2577, 0, 1)])
+def test_gemm_ragged_operands_next_to_poison(M, N, K, ta, tb):
+    '''The k-loop fetches 16-byte vectors at 4-byte alignment and relies on (a) the buffer range
+    for what lies past an operand's LAST element and (b) masks for what lies past the end of a
+    ROW: operands are packed into one buffer at odd (4-byte aligned only) offsets with NaN
+    between and after them -- any element read from outside an operand poisons the product.'''
+    from danet_amd import ops
+    rng = np.random.RandomState(M + 3 * N + 5 * K + ta + 2 * tb)
+    A = rng.randn(K, M) if ta else rng.randn(M, K)
+    Bm = rng.randn(N, K) if tb else rng.randn(K, N)
+    ref = (A.T if ta else A) @ (Bm.T if tb else Bm)
+    pool = torch.full((A.size + Bm.size + 64,), float('nan'), device='cuda')
+    oa = 5                                    # 20-byte offset: not 16-byte aligned
+    ob = oa + A.size + 3
+    pool[oa:oa + A.size] = cu(A).reshape(-1)
+    pool[ob:ob + Bm.size] = cu(Bm).reshape(-1)
+    dA = pool[oa:oa + A.size].view(*A.shape)
+    dB = pool[ob:ob + Bm.size].view(*Bm.shape)
+    C = torch.empty(M, N, device='cuda')
+    ops.gemm(dA, dB, C, M, N, K, A.shape[1], Bm.shape[1], N, transA=ta, transB=tb)
+    got = C.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert relerr(got, ref) < 2e-5
+    C2 = torch.empty(M, N, device='cuda')
+    ops.gemm(dA, dB, C2, M, N, K, A.shape[1], Bm.shape[1], N, transA=ta, transB=tb, streamk=True)
+    assert relerr(C2.cpu().numpy(), ref) < 2e-5
+    # an operand whose LAST row ends exactly where its allocation ends
+    tail_a = torch.empty(A.size, device='cuda'); tail_a.copy_(cu(A).reshape(-1))
+    C3 = torch.empty(M, N, device='cuda')
+    ops.gemm(tail_a.view(*A.shape), dB, C3, M, N, K, A.shape[1], Bm.shape[1], N, transA=ta, transB=tb)
+    assert relerr(C3.cpu().numpy(), ref) < 2e-5
+
+
+def test_gemm_rejects_operands_of_2gib():
+    '''operands are addressed through 32-bit buffer views: a span of 2 GiB or more is an
+    argument error, not a wrong product (nothing is launched, the pointers are never read)'''
+    from danet_amd import _lib
+    L = _lib.load()
+    t = torch.zeros(16, device='cuda')
+    rc = L.danet_gemm_f32(_lib.stream(), 0, 0, 128, 128, 128, _lib.ptr(t), 1 << 23,
+                          _lib.ptr(t), 128, _lib.ptr(t), 128, None, 0.0, None, 0)
+    assert rc == -1 and b'2 GiB' in L.danet_last_error()
+
+
 # ------------------------------------------------------------------ centre
 @pytest.mark.parametrize('B,T,D', [(2, 3, 5), (4, 16, 129), (32, 8, 600)])
 def test_center_layouts(B, T, D):
