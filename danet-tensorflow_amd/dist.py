@@ -131,6 +131,12 @@ class TailOverlap(object):
             self.covered.append((lo, hi))
             self.launched += 1
 
+    def wait_launched(self):
+        '''the current stream waits for the collectives launched so far (their ranges are then
+        final on it: Model steps the optimizer over them early)'''
+        for wk in self.works:
+            wk.wait()
+
     def finish(self):
         '''returns the 1/world factor like allreduce_grads_'''
         w = world_size()

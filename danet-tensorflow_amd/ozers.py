@@ -37,21 +37,26 @@ class TfAdam(_FlatOptimizer):
         self.m = torch.zeros_like(theta)
         self.v = torch.zeros_like(theta)
 
-    def step(self, t, lr, clip=None, grad_scale=1.0, zero_grad=False):
+    def step(self, t, lr, clip=None, grad_scale=1.0, zero_grad=False, ranges=None):
+        '''ranges: [lo, hi) element ranges of the flat buffers to update (default: all) --
+        the update is elementwise, so a step may be issued in pieces as gradients become final'''
         lr_t = lr * math.sqrt(1. - self.beta2 ** t) / (1. - self.beta1 ** t)
-        ops.adam_clip_step(self.theta, self.grad, self.m, self.v, lr_t, self.beta1,
-                           self.beta2, self.epsilon, clip or 0.0, grad_scale, zero_grad)
+        for lo, hi in (ranges if ranges is not None else [(0, self.theta.numel())]):
+            ops.adam_clip_step(self.theta[lo:hi], self.grad[lo:hi], self.m[lo:hi], self.v[lo:hi],
+                               lr_t, self.beta1, self.beta2, self.epsilon, clip or 0.0,
+                               grad_scale, zero_grad)
 
 
 class TfSgd(_FlatOptimizer):
     '''tf.train.GradientDescentOptimizer'''
-    def step(self, t, lr, clip=None, grad_scale=1.0, zero_grad=False):
-        g = self.grad * grad_scale
-        if clip:
-            g = g.clamp_(-clip, clip)
-        self.theta.add_(g, alpha=-lr)
-        if zero_grad:
-            self.grad.zero_()
+    def step(self, t, lr, clip=None, grad_scale=1.0, zero_grad=False, ranges=None):
+        for lo, hi in (ranges if ranges is not None else [(0, self.theta.numel())]):
+            g = self.grad[lo:hi] * grad_scale
+            if clip:
+                g = g.clamp_(-clip, clip)
+            self.theta[lo:hi].add_(g, alpha=-lr)
+            if zero_grad:
+                self.grad[lo:hi].zero_()
 
 
 @hparams.register_optimizer('sgd')

@@ -560,6 +560,32 @@ def test_adam_parameters_to_1e5(hp):
         assert np.abs(p3[k] - want).max() <= 2e-2 * moved + 2e-7, k
 
 
+def test_early_optimizer_step_is_the_same_update(hp):
+    '''clip + Adam over everything outside the bottom encoder layer is issued on the side stream
+    as soon as those gradients are final (Model._grad_ready); the parameters after three steps
+    are bit-identical to the single update after backward'''
+    src = None
+    res = []
+    for early in (True, False):
+        torch.manual_seed(5)
+        np.random.seed(5)
+        model = _small_model(hp, BATCH_SIZE=3, FFT_SIZE=16, FFT_STRIDE=4, EMBED_SIZE=4,
+                             NUM_LSTM_LAYERS=2, LSTM_HDIM=8)
+        if src is None:
+            src = _rand_src(hp, 6, 8, scale=6.0)
+            p0 = model.param_dict()
+        else:
+            model.load_param_dict(p0)
+        model._early_adam = early
+        for _ in range(3):
+            model.train_step(torch.as_tensor(src).cuda())
+        assert model.early_steps == (3 if early else 0)
+        res.append(model.param_dict())
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+        assert not np.array_equal(res[0][k], p0[k]) or k.endswith('/B') or np.abs(p0[k]).max() == 0, k
+
+
 def test_adam_nan_gradient_propagates():
     '''tf.clip_by_value passes NaN through; a NaN gradient must poison the parameter (so the
     train loop's NaN-restore sees it), not become a +-clip update'''
