@@ -519,7 +519,12 @@ struct LstmFwdFxArgs {
 #ifndef FX_CHA_NUM
 #define FX_CHA_NUM 1
 #endif
-template <int CHX>
+// Input-half k-groups (16 k each): CHX "window" groups per wave, computed in the exchange wait of
+// the step they belong to, plus CHE "early" groups owned by waves 2 and 3 only, computed one step
+// AHEAD while waves 0 and 1 do the gate math of the previous step (the 128 owner threads are all in
+// waves 0 and 1; waves 2 and 3 used to idle through that phase).  k-group of (wave, window g) =
+// g * 4 + wave; of (wave >= 2, early e) = 4 * CHX + 2 * e + wave - 2.
+template <int CHX, int CHE>
 __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
   constexpr int NW = 4, CH = FWD_CH;
 #ifdef FX_CHA_ABS
@@ -532,7 +537,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
   float* Wl = smem;
   float* red = smem + (size_t)a.KP * 32;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool early = wave >= 2;      // uniform
   const int bid = blockIdx.x;
   if (a.fault && bid == 0) return;   // test hook (DANET_LSTM_FAULT_INJECT): never publishes
   const int ncl = a.ndir * a.G;
@@ -602,14 +608,37 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
     }
   }
 
+  f32x4 wxe[CHE][2];
+#pragma unroll
+  for (int g = 0; g < CHE; ++g) {
+    const int k0 = (NW * CHX + 2 * g + (wave - 2)) * 16 + fq * 4;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int n = nt * 16 + fr;
+      const int gate = n >> 3, u = u0 + (n & 7);
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+      if (early && u < H) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (k0 + j < D) w[j] = Wd[(size_t)(k0 + j) * a.ldw + gate * H + u];
+      }
+      wxe[g][nt] = w;
+    }
+  }
+
   // byte offsets of this lane's x / h fragments within one time block (out of range -> 0)
-  unsigned xoff[CHX], hcol[CH];
+  unsigned xoff[CHX], xoffe[CHE], hcol[CH];
   {
     const int row = b0 + fr;
 #pragma unroll
     for (int g = 0; g < CHX; ++g) {
       const int k0 = (g * NW + wave) * 16 + fq * 4;
       xoff[g] = (row < B && k0 < D) ? (unsigned)(((size_t)row * a.ldx + k0) * 4) : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int g = 0; g < CHE; ++g) {
+      const int k0 = (NW * CHX + 2 * g + (wave - 2)) * 16 + fq * 4;
+      xoffe[g] = (early && row < B && k0 < D) ? (unsigned)(((size_t)row * a.ldx + k0) * 4) : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int g = 0; g < CH; ++g) {
@@ -619,18 +648,24 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
   }
   const unsigned xblk = (unsigned)((size_t)B * a.ldx * 4);
   const unsigned yblk = (unsigned)((size_t)B * a.ldy * 4);
-  v4u xc[CHX];
+  v4u xc[CHX], xce[CHE];
   {
     const int t0 = dir ? (T - 1) : 0;
 #pragma unroll
     for (int g = 0; g < CHX; ++g)
       xc[g] = __builtin_amdgcn_raw_buffer_load_b128(
           xres, xoff[g] == 0xFFFFFFFFu ? xbytes : xoff[g] + (unsigned)t0 * xblk, 0, 0);
+#pragma unroll
+    for (int g = 0; g < CHE; ++g)
+      xce[g] = __builtin_amdgcn_raw_buffer_load_b128(
+          xres, xoffe[g] == 0xFFFFFFFFu ? xbytes : xoffe[g] + (unsigned)t0 * xblk, 0, 0);
     // wait for them HERE: loads still pending at loop entry make the compiler put one
     // s_waitcnt vmcnt(0) into the loop header, where it then also waits for the previous
     // step's publish stores on every iteration
 #pragma unroll
     for (int g = 0; g < CHX; ++g) asm volatile("" : "+v"(xc[g]));
+#pragma unroll
+    for (int g = 0; g < CHE; ++g) asm volatile("" : "+v"(xce[g]));
   }
 
 #define FX_GX(g)                                                                               \
@@ -643,16 +678,38 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
     }                                                                                          \
   } while (0)
 
+#define FX_GXE(g)                                                                              \
+  do {                                                                                         \
+    const f32x4 xf_ = __builtin_bit_cast(f32x4, xce[g]);                                       \
+    const f32x4 w0_ = wxe[g][0], w1_ = wxe[g][1];                                              \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
+      accn[0][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf_[j], w0_[j], accn[0][j & 1], 0, 0, 0); \
+      accn[1][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf_[j], w1_[j], accn[1][j & 1], 0, 0, 0); \
+    }                                                                                          \
+  } while (0)
+
+  // early groups of step 0
+  f32x4 accn[2][2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    accn[nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    accn[nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  if (early) {
+#pragma unroll
+    for (int g = 0; g < CHE; ++g) FX_GXE(g);
+  }
+
   for (int s = 0; s < T; ++s) {
     const int t = dir ? (T - 1 - s) : s;
     const int blk_prev = dir ? (t + 2) : t;
 
     TRACE_AT(0, 0);
-    f32x4 acc[2][2];
+    f32x4 acc[2][2];       // starts from the early groups' sums (zeros in waves 0 and 1)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      acc[nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acc[nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc[nt][0] = accn[nt][0];
+      acc[nt][1] = accn[nt][1];
     }
     // (a) first quarter of the input half
 #pragma unroll
@@ -689,19 +746,17 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
       TRACE_AT_VAL(0, 6, spins);
     }
     TRACE_AT(0, 3);
-    // x of the next step: issued only now -- fifteen loads at the top of the step queued behind
-    // the previous step's stores in the memory pipeline and delayed the exchange loads
-    v4u xn[CHX];
-    {
-      const int tn = dir ? (t - 1) : (t + 1);
-      const bool have = (s + 1 < T);
+    // (e) recurrent half continues the same accumulators.  x of the next step is fetched HERE,
+    // a few loads behind each k-group's MFMAs (a load costs ~60 clocks of issue, which then
+    // overlap the matrix pipe's 256 clocks per group): at the top of the step the loads queued
+    // behind the previous step's stores in the memory pipeline and delayed the exchange loads,
+    // and as one block between validation and this phase they cost 0.2 us of the critical path.
+    v4u xn[CHX], xne[CHE];
+    const int tn = dir ? (t - 1) : (t + 1);
+    const bool have = (s + 1 < T);
 #pragma unroll
-      for (int g = 0; g < CHX; ++g)
-        xn[g] = __builtin_amdgcn_raw_buffer_load_b128(
-            xres, (!have || xoff[g] == 0xFFFFFFFFu) ? xbytes : xoff[g] + (unsigned)tn * xblk, 0, 0);
-    }
+    for (int g = 0; g < CHE; ++g) xne[g] = (v4u){0u, 0u, 0u, 0u};
     __builtin_amdgcn_sched_barrier(0);
-    // (e) recurrent half continues the same accumulators
 #pragma unroll
     for (int g = 0; g < CH; ++g) {
       const f32x4 af = __builtin_bit_cast(f32x4, av[g]);
@@ -711,6 +766,19 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
         acc[0][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], w0[j], acc[0][j & 1], 0, 0, 0);
         acc[1][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], w1[j], acc[1][j & 1], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = g; i < CHX; i += CH)
+        xn[i] = __builtin_amdgcn_raw_buffer_load_b128(
+            xres, (!have || xoff[i] == 0xFFFFFFFFu) ? xbytes : xoff[i] + (unsigned)tn * xblk, 0, 0);
+      // (waves 0 and 1 skip the early groups' loads: even an out-of-range load costs issue time)
+      if (early) {
+#pragma unroll
+        for (int i = g; i < CHE; i += CH)
+          xne[i] = __builtin_amdgcn_raw_buffer_load_b128(
+              xres, (!have || xoffe[i] == 0xFFFFFFFFu) ? xbytes : xoffe[i] + (unsigned)tn * xblk, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     // cross-wave reduction.  D layout 16x16: col = lane&15, row = 4*(lane>>4)+r
 #pragma unroll
@@ -726,6 +794,21 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
     for (int g = 0; g < CHX; ++g) {
       xc[g] = xn[g];
       asm volatile("" : "+v"(xc[g]));
+    }
+#pragma unroll
+    for (int g = 0; g < CHE; ++g) {
+      xce[g] = xne[g];
+      asm volatile("" : "+v"(xce[g]));
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      accn[nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      accn[nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // waves 2 and 3: early groups of the NEXT step, beside the gate math of waves 0 and 1
+    if (early && s + 1 < T) {
+#pragma unroll
+      for (int g = 0; g < CHE; ++g) FX_GXE(g);
     }
 
     if (owner) {
@@ -754,6 +837,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
     TRACE_AT(0, 7);
   }
 #undef FX_GX
+#undef FX_GXE
 }
 
 // ---------------------------------------------------------------------------
@@ -1860,8 +1944,8 @@ static bool fwd_fused_ok(int T, int B, int H, int ndir, int D, int* CHX) {
   { const char* e = getenv("DANET_LSTM_FWD_FUSED");
     if (e && atoi(e) == 0) return false;
     if (!(e && atoi(e) == 1) && B < 24) return false; }
-  const int per_wave = cdiv(cdiv(D, 16), 4);
-  if (CHX) *CHX = per_wave <= 3 ? 3 : 10;
+  // k-groups: 4 * window + 2 * early >= D / 16  (see lstm_fwd_fx_kernel)
+  if (CHX) *CHX = D <= 160 ? 2 : (D <= 320 ? 4 : (D <= 608 ? 8 : 9));
   return true;
 }
 
@@ -1914,15 +1998,20 @@ extern "C" int danet_lstm_fwd_fused(danet_stream_t stream_, int T, int B, int H,
     DANET_CHECK_HIP(fl.launch(stream));
   }
   const int nblk = ndir * a.G * a.P;
-  if (CHX == 3) {
-    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_fx_kernel<3>,
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lstm_fwd_fx_kernel<3><<<nblk, 256, lds, stream>>>(a);
-  } else {
-    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_fx_kernel<10>,
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lstm_fwd_fx_kernel<10><<<nblk, 256, lds, stream>>>(a);
-  }
+#define FX_LAUNCH(W_, E_)                                                                \
+  do {                                                                                   \
+    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_fx_kernel<W_, E_>,         \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
+    lstm_fwd_fx_kernel<W_, E_><<<nblk, 256, lds, stream>>>(a);                           \
+  } while (0)
+  // the early groups must fit the gate phase (~0.5 us = 4-5 groups), the window groups the
+  // exchange wait (~1 us = 9 groups); measured at D = 600: 7 + 6 loses 0.27 us per step at the
+  // closing barrier, 8 + 3 has slack on both sides
+  if (CHX == 2) FX_LAUNCH(2, 1);          // D <= 160: 8 + 2 k-groups
+  else if (CHX == 4) FX_LAUNCH(4, 2);     // D <= 320: 16 + 4
+  else if (CHX == 8) FX_LAUNCH(8, 3);     // D <= 608: 32 + 6
+  else FX_LAUNCH(8, 4);                   // D <= 640: 32 + 8
+#undef FX_LAUNCH
   DANET_CHECK_LAUNCH();
   return DANET_OK;
 }
