@@ -10,7 +10,7 @@ g.load_package()
 from danet_amd.model import Model
 
 class A: batch=32; layers=3; hdim=300; frames=128
-hp = bench.setup_hparams(A)
+hp = bench.setup_hparams(A, bench.CONFIGS["cfg2"])
 dev = torch.device('cuda', 0)
 batches = bench.make_batches(hp, 0, 2, dev)
 model = Model('h', device=dev).build()

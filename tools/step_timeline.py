@@ -6,7 +6,7 @@
     python tools/step_timeline.py /tmp/tl/.../tl_kernel_trace.csv [step_index [v]]
 
 (bench.py records HIP events only on timed steps 0, 4, 8, ...: pick an un-instrumented one,
-e.g. step_index = warmup + 5.)  Prints, for the chosen step (adam_clip_kernel to adam_clip_kernel), every kernel
+e.g. step_index = warmup + 5.)  Prints, for the chosen step (frontend_kernel to frontend_kernel), every kernel
 with start offset / duration / queue, the busy time of the union of all kernels and the
 idle gaps (no kernel running at all).'''
 import csv
@@ -20,9 +20,11 @@ def main():
         ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0][:44],
                    r.get('Queue_Id', '?')))
     ev.sort()
-    adam = [i for i, e in enumerate(ev) if e[2].startswith('adam_clip')]
-    k = int(sys.argv[2]) if len(sys.argv) > 2 else len(adam) - 1     # which step (its adam)
-    i0, i1 = adam[k - 1] + 1, adam[k] + 1
+    # a step starts at its front-end kernel (the optimizer update is issued in pieces, the
+    # first of them in the middle of backward, so adam_clip no longer delimits steps)
+    first = [i for i, e in enumerate(ev) if e[2].startswith('frontend_kernel')]
+    k = int(sys.argv[2]) if len(sys.argv) > 2 else len(first) - 2     # which step
+    i0, i1 = first[k], first[k + 1]
     step = ev[i0:i1]
     t0 = step[0][0]
     print('step: %d kernels, %.1f us wall' % (len(step), (step[-1][1] - t0) / 1e3))
