@@ -216,7 +216,139 @@ __device__ __forceinline__ void gemm_kloop(const float* __restrict__ Ap, int lda
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same k-loop with the operands moved global -> LDS by the DMA path (buffer_load ... lds):
+// no staging registers, no LDS store instructions, no edge masks in the loop.  Eligible (host:
+// dma_ok) when both operands are 16-byte aligned with ld % 4 == 0 and every K-contiguous operand
+// has K % 4 == 0, so that a 16-byte vector never straddles a row's end in the k direction (what
+// a vector drags in past the mn edge only reaches output rows / columns that are never stored).
+// Out-of-range lanes of a DMA load WRITE ZEROS to LDS (tools/csrc: dma probe), which is what the
+// k edge needs.  The LDS image of a DMA load is lane-linear (wave-uniform base + lane * 16), so
+// the layout is made by choosing which global vector each lane fetches:
+//   mn-contiguous operand: [16 k][128 mn], odd k rows rotated by 32 floats -- the two half-waves
+//     of a fragment read (k = 2 kk + lane / 32) then hit disjoint banks;
+//   k-contiguous operand: [128 mn][16 k], the four 16-byte slots of a row XOR-ed with
+//     (row / 4) % 4 -- 32 rows of one k spread over 16 bank groups (2-way instead of 8-way).
+// Fragment order (k = 2 kk + lane / 32) and therefore every sum is identical to gemm_kloop.
+template <bool KCONTIG>
+__device__ __forceinline__ void dma_lane(int chunk, int lane, int ld, unsigned& off, int& mn, int& kpos) {
+  if (KCONTIG) {
+    const int row = 16 * chunk + (lane >> 2);
+    const int kq = (lane & 3) ^ ((row >> 2) & 3);
+    mn = row; kpos = kq * 4;
+    off = (unsigned)(row * ld + kq * 4) * 4u;
+  } else {
+    const int k = 2 * chunk + (lane >> 5);
+    const int col = (((lane & 31) * 4) + ((k & 1) ? 96 : 0)) & 127;
+    mn = col; kpos = k;
+    off = (unsigned)(k * ld + col) * 4u;
+  }
+}
+
+// float offset of fragment element (tile row/col t + 32 f, k = 2 kk + fk) inside an operand image
+template <bool KCONTIG>
+__device__ __forceinline__ int frag_off(int t, int f, int kk, int fk) {
+  if (KCONTIG) {
+    const int sw = (t >> 2) & 3;                       // (t + 32 f) / 4 % 4 == t / 4 % 4
+    return (t + 32 * f) * 16 + (((kk >> 1) ^ sw) << 2) + 2 * (kk & 1) + fk;
+  }
+  return (2 * kk + fk) * 128 + ((t + 32 * f + 32 * fk) & 127);
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
 template <bool A_KCONTIG, bool B_KCONTIG>
+__device__ __forceinline__ void gemm_kloop_dma(const float* __restrict__ Ap, int lda,
+                                               const float* __restrict__ Bp, int ldb,
+                                               int M, int N, int m0, int n0, int kbeg, int kend,
+                                               float* smem, f32x16 (&acc)[2][2], int yield) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk <= 0) return;
+  float* const sA = smem;
+  float* const sB = smem + NSTAGE * STG;
+  const float* pa = Ap + (A_KCONTIG ? (size_t)m0 * lda + kbeg : (size_t)kbeg * lda + m0);
+  const float* pb = Bp + (B_KCONTIG ? (size_t)n0 * ldb + kbeg : (size_t)kbeg * ldb + n0);
+  const unsigned sta = (A_KCONTIG ? BK : BK * lda) * 4u;
+  const unsigned stb = (B_KCONTIG ? BK : BK * ldb) * 4u;
+  const int mrem = M - m0, nrem = N - n0;
+  const float* enda = Ap + (A_KCONTIG ? (size_t)(M - 1) * lda + kend : (size_t)(kend - 1) * lda + M);
+  const float* endb = Bp + (B_KCONTIG ? (size_t)(N - 1) * ldb + kend : (size_t)(kend - 1) * ldb + N);
+  const __amdgpu_buffer_rsrc_t rsa = tile_rsrc(pa, enda), rsb = tile_rsrc(pb, endb);
+
+  // this wave moves chunks {wave, wave + 4} (1 KB each) of both operand images
+  unsigned oa[2], ob[2];
+  int ka[2], kb[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int mn;
+    dma_lane<A_KCONTIG>(wave + 4 * j, lane, lda, oa[j], mn, ka[j]);
+    if (mn >= mrem) oa[j] = GEMM_OOB;
+    dma_lane<B_KCONTIG>(wave + 4 * j, lane, ldb, ob[j], mn, kb[j]);
+    if (mn >= nrem) ob[j] = GEMM_OOB;
+  }
+#define DMA_A(j, stage_off, adv, krem)                                                              \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr_t)(sA + (stage_off) + (wave + 4 * (j)) * 256), 16, \
+      (oa[j] != GEMM_OOB && ka[j] < (krem)) ? oa[j] + (adv) : GEMM_OOB, 0, 0, 0)
+#define DMA_B(j, stage_off, adv, krem)                                                              \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_ptr_t)(sB + (stage_off) + (wave + 4 * (j)) * 256), 16, \
+      (ob[j] != GEMM_OOB && kb[j] < (krem)) ? ob[j] + (adv) : GEMM_OOB, 0, 0, 0)
+  DMA_A(0, 0, 0u, kend - kbeg); DMA_A(1, 0, 0u, kend - kbeg);
+  DMA_B(0, 0, 0u, kend - kbeg); DMA_B(1, 0, 0u, kend - kbeg);
+  if (nk > 1) {
+    DMA_A(0, STG, sta, kend - kbeg - BK); DMA_A(1, STG, sta, kend - kbeg - BK);
+    DMA_B(0, STG, stb, kend - kbeg - BK); DMA_B(1, STG, stb, kend - kbeg - BK);
+  }
+  unsigned adva = 2 * sta, advb = 2 * stb;     // k-tile kt + 2
+  __syncthreads();
+
+  const int ta = wm * 64 + (lane & 31);   // fragment row / column within the tile
+  const int tb = wn * 64 + (lane & 31);
+  const int fk = lane >> 5;
+  int s_cur = 0, s_nxt = STG, s_fill = 2 * STG;
+  float a0 = sA[frag_off<A_KCONTIG>(ta, 0, 0, fk)], a1 = sA[frag_off<A_KCONTIG>(ta, 1, 0, fk)];
+  float b0 = sB[frag_off<B_KCONTIG>(tb, 0, 0, fk)], b1 = sB[frag_off<B_KCONTIG>(tb, 1, 0, fk)];
+
+  for (int kt = 0; kt < nk; ++kt) {
+    float a0n, a1n, b0n, b1n;
+    const int k2rem = kend - kbeg - (kt + 2) * BK;   // <= 0 past the last tile: every lane out of range
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      {
+        const int s = (kk + 1 < BK / 2) ? s_cur : s_nxt, k1 = (kk + 1 < BK / 2) ? kk + 1 : 0;
+        a0n = sA[s + frag_off<A_KCONTIG>(ta, 0, k1, fk)]; a1n = sA[s + frag_off<A_KCONTIG>(ta, 1, k1, fk)];
+        b0n = sB[s + frag_off<B_KCONTIG>(tb, 0, k1, fk)]; b1n = sB[s + frag_off<B_KCONTIG>(tb, 1, k1, fk)];
+      }
+      if (kk == 0) DMA_A(0, s_fill, adva, k2rem);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      if (kk == 0) DMA_A(1, s_fill, adva, k2rem);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      if (kk == 0) DMA_B(0, s_fill, advb, k2rem);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      if (kk == 0) DMA_B(1, s_fill, advb, k2rem);
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
+    }
+    if (yield == 1) __builtin_amdgcn_s_sleep(1);
+    else if (yield == 2) __builtin_amdgcn_s_sleep(2);
+    else if (yield == 4) __builtin_amdgcn_s_sleep(4);
+    else if (yield >= 8) __builtin_amdgcn_s_sleep(8);
+    __syncthreads();   // (with a DMA load in flight the compiler waits vmcnt(0) here) publishes s_fill
+    const int t = s_cur; s_cur = s_nxt; s_nxt = s_fill; s_fill = t;
+    adva += sta; advb += stb;
+  }
+#undef DMA_A
+#undef DMA_B
+}
+
+template <bool A_KCONTIG, bool B_KCONTIG, bool DMA>
 __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // GEMM_SMEM_BYTES
   // layout: see gemm_kloop
@@ -253,8 +385,8 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  gemm_kloop<A_KCONTIG, B_KCONTIG>(Ap, lda, Bp, ldb, g.M, g.N, m0, n0, kbeg, kend,
-                                   smem, acc, 0);
+  if (DMA) gemm_kloop_dma<A_KCONTIG, B_KCONTIG>(Ap, lda, Bp, ldb, g.M, g.N, m0, n0, kbeg, kend, smem, acc, 0);
+  else gemm_kloop<A_KCONTIG, B_KCONTIG>(Ap, lda, Bp, ldb, g.M, g.N, m0, n0, kbeg, kend, smem, acc, 0);
 
   // epilogue.  D layout (32x32): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int col_l = lane & 31, row_l = 4 * (lane >> 5);
@@ -306,12 +438,30 @@ static void gemm_allow_lds(KernelT k) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)GEMM_SMEM_BYTES);
 }
+#define GEMM_FOR_ALL_VARIANTS(K_, F_)                                                     \
+  F_((K_<true, false, false>)); F_((K_<true, true, false>)); F_((K_<false, false, false>)); \
+  F_((K_<false, true, false>)); F_((K_<true, false, true>)); F_((K_<true, true, true>));    \
+  F_((K_<false, false, true>)); F_((K_<false, true, true>))
 static void gemm_init_once() {
   static bool done = false;
   if (done) return;
   done = true;
-  gemm_allow_lds(gemm_f32_kernel<true, false>); gemm_allow_lds(gemm_f32_kernel<true, true>);
-  gemm_allow_lds(gemm_f32_kernel<false, false>); gemm_allow_lds(gemm_f32_kernel<false, true>);
+  GEMM_FOR_ALL_VARIANTS(gemm_f32_kernel, gemm_allow_lds);
+}
+
+// DMA staging (gemm_kloop_dma) needs 16-byte aligned operands with ld % 4 == 0, and K % 4 == 0
+// for an operand that is contiguous along k.  DANET_GEMM_DMA is a bit mask: 1 = tile-per-workgroup
+// launches, 2 = stream-K / grouped launches that have the GPU to themselves, 4 = grouped launches
+// capped to one workgroup per CU (the ones that run beside a BPTT kernel).
+// Default 3: beside a BPTT kernel the DMA group is 12 % faster but costs that kernel more than
+// it saves (cfg 2: BPTT 450 -> 478 us per launch, 3.37 -> 3.50 ms per step).  Read per launch
+// (tests flip it).
+static bool dma_env(int bit) {
+  const char* e = getenv("DANET_GEMM_DMA");
+  return ((e ? atoi(e) : 3) & bit) != 0;
+}
+static bool dma_operand_ok(const float* p, int ld, bool kcontig, int K) {
+  return (((uintptr_t)p & 15) == 0) && (ld % 4 == 0) && (!kcontig || K % 4 == 0);
 }
 
 static int choose_splitk(int M, int N, int K) {
@@ -404,10 +554,17 @@ static int gemm_launch(hipStream_t stream, int transA, int transB, int M, int N,
   if (max_workgroups > 0 && nblocks > max_workgroups) nblocks = max_workgroups;
   dim3 grid(nblocks, 1, 1), block(256);
   const bool ak = !transA, bk = (transB != 0);
-  if (ak && !bk) gemm_f32_kernel<true, false><<<grid, block, GEMM_SMEM_BYTES, stream>>>(g);
-  else if (ak && bk) gemm_f32_kernel<true, true><<<grid, block, GEMM_SMEM_BYTES, stream>>>(g);
-  else if (!ak && !bk) gemm_f32_kernel<false, false><<<grid, block, GEMM_SMEM_BYTES, stream>>>(g);
-  else gemm_f32_kernel<false, true><<<grid, block, GEMM_SMEM_BYTES, stream>>>(g);
+  const bool dma = dma_env(1) && dma_operand_ok(A, lda, ak, K) && dma_operand_ok(B, ldb, bk, K) &&
+                   (K2 == 0 || (dma_operand_ok(A2, lda2, ak, K2) && dma_operand_ok(B2, ldb2, bk, K2)));
+#define GEMM_LAUNCH(D_)                                                                          \
+  do {                                                                                           \
+    if (ak && !bk) gemm_f32_kernel<true, false, D_><<<grid, block, GEMM_SMEM_BYTES, stream>>>(g);        \
+    else if (ak && bk) gemm_f32_kernel<true, true, D_><<<grid, block, GEMM_SMEM_BYTES, stream>>>(g);     \
+    else if (!ak && !bk) gemm_f32_kernel<false, false, D_><<<grid, block, GEMM_SMEM_BYTES, stream>>>(g); \
+    else gemm_f32_kernel<false, true, D_><<<grid, block, GEMM_SMEM_BYTES, stream>>>(g);                  \
+  } while (0)
+  if (dma) GEMM_LAUNCH(true); else GEMM_LAUNCH(false);
+#undef GEMM_LAUNCH
   DANET_CHECK_LAUNCH();
   if (splitk > 1) {
     const int64_t total = (int64_t)M * N;
@@ -488,7 +645,7 @@ struct SkArgs {
 
 #define SK_SPIN_LIMIT (1u << 22)
 
-template <bool A_KCONTIG, bool B_KCONTIG>
+template <bool A_KCONTIG, bool B_KCONTIG, bool DMA>
 __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(SkArgs sk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // GEMM_SMEM_BYTES
   // layout: see gemm_kloop
@@ -534,8 +691,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(SkArgs sk) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
-    gemm_kloop<A_KCONTIG, B_KCONTIG>(g.A, g.lda, g.B, g.ldb, g.M, g.N, m0, n0,
-                                     kb * BK, min(g.K, ke * BK), smem, acc, sk.yield);
+    if (DMA) gemm_kloop_dma<A_KCONTIG, B_KCONTIG>(g.A, g.lda, g.B, g.ldb, g.M, g.N, m0, n0,
+                                                  kb * BK, min(g.K, ke * BK), smem, acc, sk.yield);
+    else gemm_kloop<A_KCONTIG, B_KCONTIG>(g.A, g.lda, g.B, g.ldb, g.M, g.N, m0, n0,
+                                          kb * BK, min(g.K, ke * BK), smem, acc, sk.yield);
 
     if (ke < sk.nk) {
       // contributor: the tile's later k-segments belong to higher workgroups
@@ -655,8 +814,7 @@ extern "C" int danet_gemm_f32_streamk_grouped(danet_stream_t stream_, int transA
   static bool lds_ok = false;
   if (!lds_ok) {
     lds_ok = true;
-    gemm_allow_lds(gemm_f32_sk_kernel<true, false>); gemm_allow_lds(gemm_f32_sk_kernel<true, true>);
-    gemm_allow_lds(gemm_f32_sk_kernel<false, false>); gemm_allow_lds(gemm_f32_sk_kernel<false, true>);
+    GEMM_FOR_ALL_VARIANTS(gemm_f32_sk_kernel, gemm_allow_lds);
   }
   hipStream_t stream = (hipStream_t)stream_;
   DANET_CHECK_ARG(probs && nprob >= 1 && nprob <= SK_MAX_PROBLEMS, "gemm group: 1..%d problems",
@@ -696,10 +854,18 @@ extern "C" int danet_gemm_f32_streamk_grouped(danet_stream_t stream_, int transA
   sk.yield = (max_workgroups > 0 && max_workgroups <= 256) ? sk_env("DANET_GEMM_YIELD", 0) : 0;
   dim3 grid(gsz, 1, 1), block(256);
   const bool ak = !transA, bk = (transB != 0);
-  if (ak && !bk) gemm_f32_sk_kernel<true, false><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);
-  else if (ak && bk) gemm_f32_sk_kernel<true, true><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);
-  else if (!ak && !bk) gemm_f32_sk_kernel<false, false><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);
-  else gemm_f32_sk_kernel<false, true><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);
+  bool dma = dma_env((max_workgroups > 0 && max_workgroups <= 256) ? 4 : 2);
+  for (int i = 0; i < nprob; ++i)
+    dma = dma && dma_operand_ok(probs[i].A, probs[i].lda, ak, K) && dma_operand_ok(probs[i].B, probs[i].ldb, bk, K);
+#define SK_LAUNCH(D_)                                                                              \
+  do {                                                                                             \
+    if (ak && !bk) gemm_f32_sk_kernel<true, false, D_><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);        \
+    else if (ak && bk) gemm_f32_sk_kernel<true, true, D_><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);     \
+    else if (!ak && !bk) gemm_f32_sk_kernel<false, false, D_><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk); \
+    else gemm_f32_sk_kernel<false, true, D_><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);                  \
+  } while (0)
+  if (dma) SK_LAUNCH(true); else SK_LAUNCH(false);
+#undef SK_LAUNCH
   DANET_CHECK_LAUNCH();
   return DANET_OK;
 }

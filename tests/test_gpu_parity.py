@@ -218,6 +218,37 @@ def test_gemm_ragged_operands_next_to_poison(M, N, K, ta, tb):
     assert relerr(C3.cpu().numpy(), ref) < 2e-5
 
 
+@pytest.mark.parametrize('M,N,K,ta,tb', [(4096, 600, 1200, 0, 1), (600, 1200, 4096, 1, 0),
+                                         (300, 260, 600, 0, 0), (129, 1200, 4096, 1, 0), (200, 136, 1032, 1, 1)])
+def test_gemm_dma_staging_is_bit_identical(M, N, K, ta, tb, monkeypatch):
+    '''buffer_load ... lds staging (gemm_kloop_dma: swizzled / rotated LDS images, no staging
+    registers) keeps the fragment order of the register path, so every launch flavour -- tiles,
+    split-K, stream-K, the capped grouped launch -- returns the same bits with DANET_GEMM_DMA
+    0 and 7'''
+    from danet_amd import ops
+    rng = np.random.RandomState(M + N + K)
+    A = cu(rng.randn(K, M) if ta else rng.randn(M, K))
+    Bm = cu(rng.randn(N, K) if tb else rng.randn(K, N))
+    ref = ((A.T if ta else A).double() @ (Bm.T if tb else Bm).double()).cpu().numpy()
+    outs = {}
+    for mode in ('0', '7'):
+        monkeypatch.setenv('DANET_GEMM_DMA', mode)
+        got = []
+        C = torch.empty(M, N, device='cuda')
+        ops.gemm(A, Bm, C, M, N, K, A.shape[1], Bm.shape[1], N, transA=ta, transB=tb)
+        got.append(C.clone())
+        ops.gemm(A, Bm, C, M, N, K, A.shape[1], Bm.shape[1], N, transA=ta, transB=tb, streamk=True)
+        got.append(C.clone())
+        ops.gemm_group([(A, A.shape[1], Bm, Bm.shape[1], C, N, M, N, 0.0)], K, transA=ta, transB=tb,
+                       max_workgroups=256)
+        got.append(C.clone())
+        outs[mode] = got
+        for g_ in got:
+            assert relerr(g_.cpu().numpy(), ref) < 2e-5
+    for a, b in zip(outs['0'], outs['7']):
+        assert torch.equal(a, b)
+
+
 def test_gemm_rejects_operands_of_2gib():
     '''operands are addressed through 32-bit buffer views: a span of 2 GiB or more is an
     argument error, not a wrong product (nothing is launched, the pointers are never read)'''
