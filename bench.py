@@ -357,16 +357,13 @@ def run_train(args, cfg, hp, device, rank, world, use_dist):
     # allocator pools are grown on first use (a 0.15 s one-off that must not land in the
     # timed region when the caller asks for W = 0)
     model.train_step(batches[0])
-    # ... and the GPU is brought to its steady power state: about one run in five had ONE 17-33 ms
-    # step 50-100 ms after the process's first GPU work (whatever W is), i.e. inside a short
-    # timed region; it does not recur (tools/step_jitter.py).  DANET_BENCH_SETTLE_S, default 0.5 s
-    # of untimed steps.
-    t_settle = time.perf_counter() + float(os.environ.get('DANET_BENCH_SETTLE_S', '0.5'))
-    i = 0
-    while time.perf_counter() < t_settle:
+    # ... and the GPU is brought to its steady state: about one run in five had ONE 17-33 ms
+    # step shortly after the process's first GPU work (whatever W is), i.e. inside a short timed
+    # region; with this phase 1 run in 40 (it does not recur later: tools/step_jitter.py).
+    # A FIXED number of untimed steps (every rank must issue the same collectives).
+    for i in range(int(os.environ.get('DANET_BENCH_SETTLE_STEPS', '128'))):
         model.train_step(batches[i % len(batches)])
-        i += 1
-        if i % 8 == 0:
+        if i % 8 == 7:
             torch.cuda.synchronize(device)
     torch.cuda.synchronize(device)
     for i in range(args.warmup):
@@ -554,6 +551,11 @@ def run_infer(args, cfg, hp, device, rank, world, use_dist):
 
     y = step(waves[0])
     assert tuple(y.shape) == (hp.MAX_N_SIGNAL, T * S), y.shape
+    for i in range(int(os.environ.get('DANET_BENCH_SETTLE_STEPS', '128')) // 2):   # see run_train
+        step(waves[i % len(waves)])
+        if i % 8 == 7:
+            torch.cuda.synchronize(device)
+    torch.cuda.synchronize(device)
     for i in range(args.warmup):
         step(waves[i % len(waves)])
     barrier()
