@@ -348,6 +348,74 @@ __device__ __forceinline__ void gemm_kloop_dma(const float* __restrict__ Ap, int
 #undef DMA_B
 }
 
+// Epilogue: out[row][col] = acc (+ bias[col]) (+ beta * out[row][col]) for the tile at (m0, n0).
+// The MFMA result layout (a lane holds one column of 16 rows) would make every store a 4-byte
+// access -- 64 store instructions per thread, 128 bytes per row segment (12 us per tile with
+// three workgroups per CU).  When the destination allows 16-byte accesses the tile goes through
+// the (now free) LDS ring in two halves of 64 rows and leaves as full 512-byte row segments:
+// 16 x 16-byte stores per thread.  Same additions in the same order either way.
+__device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], float* smem,
+                                           float* __restrict__ dst, int ldd, int m0, int n0,
+                                           int M, int N, const float* __restrict__ bias, float beta) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // D layout (32x32): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+  const bool vec = (ldd % 4 == 0) && (((uintptr_t)dst & 15) == 0) &&
+                   ((N - n0) >= BN || (N - n0) % 4 == 0);          // uniform
+  if (!vec) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int col = n0 + wn * 64 + nt * 32 + col_l;
+        if (col >= N) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+          if (row >= M) continue;
+          float* c = dst + (size_t)row * ldd + col;
+          float v = acc[mt][nt][r] + bv;
+          if (beta != 0.f) v += *c;
+          *c = v;
+        }
+      }
+    return;
+  }
+  const int c4 = tid & 31, rr = tid >> 5;
+  const int col = n0 + c4 * 4;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias && col < N) { bv.x = bias[col]; bv.y = bias[col + 1]; bv.z = bias[col + 2]; bv.w = bias[col + 3]; }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            smem[(mt * 32 + (r & 3) + 8 * (r >> 2) + row_l) * LDT + wn * 64 + nt * 32 + col_l] = acc[mt][nt][r];
+    }
+    __syncthreads();
+    if (col < N) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = m0 + half * 64 + rr + 8 * i;
+        if (row < M) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(&smem[(rr + 8 * i) * LDT + c4 * 4]);
+          float* c = dst + (size_t)row * ldd + col;
+          v += bv;
+          if (beta != 0.f) v += *reinterpret_cast<const f32x4*>(c);
+          *reinterpret_cast<f32x4*>(c) = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <bool A_KCONTIG, bool B_KCONTIG, bool DMA>
 __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // GEMM_SMEM_BYTES
@@ -388,30 +456,8 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
   if (DMA) gemm_kloop_dma<A_KCONTIG, B_KCONTIG>(Ap, lda, Bp, ldb, g.M, g.N, m0, n0, kbeg, kend, smem, acc, 0);
   else gemm_kloop<A_KCONTIG, B_KCONTIG>(Ap, lda, Bp, ldb, g.M, g.N, m0, n0, kbeg, kend, smem, acc, 0);
 
-  // epilogue.  D layout (32x32): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int col_l = lane & 31, row_l = 4 * (lane >> 5);
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int col = n0 + wn * 64 + nt * 32 + col_l;
-      if (col >= g.N) continue;
-      const float bv = (g.bias && g.splitk == 1) ? g.bias[col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + row_l;
-        if (row >= g.M) continue;
-        float v = acc[mt][nt][r];
-        if (g.splitk == 1) {
-          float* c = g.C + (size_t)row * g.ldc + col;
-          v += bv;
-          if (g.beta != 0.f) v += *c;
-          *c = v;
-        } else {
-          g.slab[((size_t)z * g.M + row) * g.N + col] = v;
-        }
-      }
-    }
+  if (g.splitk == 1) store_tile(acc, smem, g.C, g.ldc, m0, n0, g.M, g.N, g.bias, g.beta);
+  else store_tile(acc, smem, g.slab + (size_t)z * g.M * g.N, g.N, m0, n0, g.M, g.N, nullptr, 0.f);
   }  // work-item loop (the k-loop above ends with a barrier, so LDS reuse is safe)
 }
 
@@ -750,25 +796,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(SkArgs sk) {
           }
         }
       }
-      // epilogue.  D layout (32x32): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-      const int col_l = lane & 31, row_l = 4 * (lane >> 5);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const int col = n0 + wn * 64 + nt * 32 + col_l;
-          if (col >= g.N) continue;
-          const float bv = g.bias ? g.bias[col] : 0.f;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + row_l;
-            if (row >= g.M) continue;
-            float* c = g.C + (size_t)row * g.ldc + col;
-            float v = acc[mt][nt][r] + bv;
-            if (g.beta != 0.f) v += *c;
-            *c = v;
-          }
-        }
+      store_tile(acc, smem, g.C, g.ldc, m0, n0, g.M, g.N, g.bias, g.beta);
     }
     it = tbase + kb;
   }
