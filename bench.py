@@ -357,13 +357,17 @@ def run_train(args, cfg, hp, device, rank, world, use_dist):
     # allocator pools are grown on first use (a 0.15 s one-off that must not land in the
     # timed region when the caller asks for W = 0)
     model.train_step(batches[0])
-    # ... and the GPU is brought to its steady state: about one run in five had ONE 17-33 ms
-    # step shortly after the process's first GPU work (whatever W is), i.e. inside a short timed
-    # region; with this phase 1 run in 40 (it does not recur later: tools/step_jitter.py).
-    # A FIXED number of untimed steps (every rank must issue the same collectives).
+    # ... and so must the runtime's one-off reaction to the host running far ahead of the GPU for
+    # the first time.  The host enqueues a step in ~1.2 ms, the GPU runs it in 3.4 ms; the first
+    # time the host gets 8-9 steps ahead (it then blocks for 6-16 ms in a launch), the recurrent
+    # kernel that is running at that moment takes 13-19 ms instead of 0.4 (tools/catch_stall.py:
+    # one `lstm_fwd` / `lstm_bwd` call, always 3-4 steps after a synchronisation, once per
+    # process, never under rocprofv3 where the host is slower).  It hit one benchmark run in five
+    # -- with K = 20 that is +1.2 ms per step.  A FIXED number (every rank must issue the same
+    # collectives) of un-synchronised untimed steps takes it here: 0 of 90 runs afterwards.
     for i in range(int(os.environ.get('DANET_BENCH_SETTLE_STEPS', '128'))):
         model.train_step(batches[i % len(batches)])
-        if i % 8 == 7:
+        if os.environ.get('DANET_BENCH_SETTLE_SYNC', '0') == '1' and i % 8 == 7:
             torch.cuda.synchronize(device)
     torch.cuda.synchronize(device)
     for i in range(args.warmup):
