@@ -209,7 +209,7 @@ __device__ __forceinline__ void gemm_kloop(const float* __restrict__ Ap, int lda
     if (yield == 1) __builtin_amdgcn_s_sleep(1);
     else if (yield == 2) __builtin_amdgcn_s_sleep(2);
     else if (yield == 4) __builtin_amdgcn_s_sleep(4);
-    else if (yield >= 8) __builtin_amdgcn_s_sleep(8);
+    else for (int z = 0; z < (yield >> 3); ++z) __builtin_amdgcn_s_sleep(8);   // yield x 64 clocks
     __syncthreads();   // publishes stage s_fill; also makes the ring reusable by the next segment
     const int t = s_cur; s_cur = s_nxt; s_nxt = s_fill; s_fill = t;
     adva += sta; advb += stb;
@@ -339,7 +339,7 @@ __device__ __forceinline__ void gemm_kloop_dma(const float* __restrict__ Ap, int
     if (yield == 1) __builtin_amdgcn_s_sleep(1);
     else if (yield == 2) __builtin_amdgcn_s_sleep(2);
     else if (yield == 4) __builtin_amdgcn_s_sleep(4);
-    else if (yield >= 8) __builtin_amdgcn_s_sleep(8);
+    else for (int z = 0; z < (yield >> 3); ++z) __builtin_amdgcn_s_sleep(8);   // yield x 64 clocks
     __syncthreads();   // (with a DMA load in flight the compiler waits vmcnt(0) here) publishes s_fill
     const int t = s_cur; s_cur = s_nxt; s_nxt = s_fill; s_fill = t;
     adva += sta; advb += stb;
@@ -685,7 +685,7 @@ struct SkArgs {
   float* slab;          // [G][16][256][4] partial accumulators
   unsigned* flags;      // [G] launch sequence number when slab[w] is valid
   unsigned seq;
-  int yield;            // > 0: s_sleep(yield) after every k-tile (32 MFMAs per wave): a group that
+  int yield;            // > 0: yield x 64 clocks asleep after every k-tile (32 MFMAs per wave): a group that
                         // runs UNDER a latency-bound recurrent kernel leaves issue slots to it
 };
 
@@ -878,8 +878,12 @@ extern "C" int danet_gemm_f32_streamk_grouped(danet_stream_t stream_, int transA
   sk.flags = (unsigned*)ws;
   sk.slab = (float*)((char*)ws + SK_HEADER);
   sk.seq = __atomic_add_fetch(&launch_seq, 1u, __ATOMIC_RELAXED);
-  // DANET_GEMM_YIELD=n: capped (overlapped) group launches sleep n*64 clocks after every k-tile
-  sk.yield = (max_workgroups > 0 && max_workgroups <= 256) ? sk_env("DANET_GEMM_YIELD", 0) : 0;
+  // DANET_GEMM_YIELD=n: capped (overlapped) group launches sleep n*64 clocks after every k-tile.
+  // The recurrent kernel beside such a group slows down with the group's MFMA duty
+  // (tools/contention_probe.py: +58 us per BPTT launch beside a 60 % burner, starvation beside a
+  // 100 % one) and the group has slack: it only has to finish before that kernel does.  Measured
+  // at cfg 2: 0 -> 3.338, 8 -> 3.335, 16 -> 3.316, 24 -> 3.319, 32 -> 3.323, 48 -> 3.335 ms per step.
+  sk.yield = (max_workgroups > 0 && max_workgroups <= 256) ? sk_env("DANET_GEMM_YIELD", 16) : 0;
   dim3 grid(gsz, 1, 1), block(256);
   const bool ak = !transA, bk = (transB != 0);
   bool dma = dma_env((max_workgroups > 0 && max_workgroups <= 256) ? 4 : 2);

@@ -22,6 +22,7 @@ L = _lib.load()
 ptr = _lib.ptr
 P = ctypes.CDLL(os.path.join(ROOT, 'tools', 'csrc', 'libprobe.so'))
 P.probe_mfma.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+P.probe_mfma_duty.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
 P.probe_mem.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                         ctypes.c_long, ctypes.c_int]
 
@@ -64,6 +65,11 @@ def main():
         'alone': None,
         'mfma burner x256': lambda: P.probe_mfma(side.cuda_stream, 256, ptr(sink), 60000),
         'mfma burner x512': lambda: P.probe_mfma(side.cuda_stream, 512, ptr(sink), 30000),
+        # same MFMA duty (~60 %: 8 x 64 or 16 x 32 clocks of MFMA, then 5 x 64 clocks asleep), two granularities
+        'duty 60% 32x32x2 x256': lambda: P.probe_mfma_duty(side.cuda_stream, 256, ptr(sink), 0, 1500, 8, 5),
+        'duty 60% 16x16x4 x256': lambda: P.probe_mfma_duty(side.cuda_stream, 256, ptr(sink), 1, 1500, 16, 5),
+        'duty 60% 32x32x2 fine  ': lambda: P.probe_mfma_duty(side.cuda_stream, 256, ptr(sink), 0, 6000, 2, 1),
+        'duty 60% 16x16x4 fine  ': lambda: P.probe_mfma_duty(side.cuda_stream, 256, ptr(sink), 1, 6000, 4, 1),
         'HBM streamer x256': lambda: P.probe_mem(side.cuda_stream, 256, ptr(big), ptr(sink), big.numel() // 4, 12),
         'L2 streamer x256': lambda: P.probe_mem(side.cuda_stream, 256, ptr(small), ptr(sink), small.numel() // 4, 700),
     }

@@ -39,6 +39,32 @@ extern "C" int probe_mem(void* stream, int wgs, const void* in, float* out, long
   return (int)hipGetLastError();
 }
 
+// MFMA burner with a duty cycle: `mf` back-to-back MFMAs (SHAPE 0: 32x32x2 = 64 clocks each,
+// SHAPE 1: 16x16x4 = 32 clocks each) followed by `idle` x 64 clocks of s_sleep, repeated.  Does the
+// GRANULARITY of a neighbour's MFMAs matter to a latency-bound kernel that shares the SIMD?
+typedef float f32x4p __attribute__((ext_vector_type(4)));
+template <int SHAPE>
+__global__ __launch_bounds__(256) void mfma_duty_kernel(float* out, int iters, int mf, int idle) {
+  f32x16 a32[2]; f32x4p a16[4];
+  for (int i = 0; i < 2; ++i) for (int r = 0; r < 16; ++r) a32[i][r] = 0.f;
+  for (int i = 0; i < 4; ++i) a16[i] = (f32x4p){0.f, 0.f, 0.f, 0.f};
+  const float a = threadIdx.x * 1e-3f + 0.5f, b = 1.0f + threadIdx.x * 1e-4f;
+  for (int it = 0; it < iters; ++it) {
+    for (int m = 0; m < mf; ++m) {
+      if (SHAPE == 0) a32[m & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, a32[m & 1], 0, 0, 0);
+      else a16[m & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, a16[m & 3], 0, 0, 0);
+    }
+    for (int z = 0; z < idle; ++z) __builtin_amdgcn_s_sleep(1);
+  }
+  float s = a32[0][0] + a32[1][0] + a16[0][0] + a16[1][0] + a16[2][0] + a16[3][0];
+  if (s == 123.456f) out[0] = s;
+}
+extern "C" int probe_mfma_duty(void* stream, int wgs, float* out, int shape, int iters, int mf, int idle) {
+  if (shape == 0) mfma_duty_kernel<0><<<wgs, 256, 0, (hipStream_t)stream>>>(out, iters, mf, idle);
+  else mfma_duty_kernel<1><<<wgs, 256, 0, (hipStream_t)stream>>>(out, iters, mf, idle);
+  return (int)hipGetLastError();
+}
+
 // ---- CU-masked streams (tools/cumask_probe.py) ---------------------------------------------
 extern "C" int probe_stream_create_cumask(const unsigned* mask, int nwords, void** stream) {
   hipStream_t s;
