@@ -133,13 +133,19 @@ __device__ __forceinline__ bool spin_fail(unsigned& spins, int* status, int lane
 // ---------------------------------------------------------------------------
 // NW waves per workgroup split K (4 = one per SIMD; 8 / 16 shorten each wave's
 // chain of sc1 exchange loads, which is what bounds the exchange phase).
-template <int MT, int NW>
+// UN hidden units per workgroup (x 4 gates = NCOL columns = NT MFMA column tiles).  UN = 8 is the
+// default; UN = 12 serves wide layers (H = 600): 50 instead of 75 workgroups per cluster make
+// 16-row clusters fit the GPU (200 workgroups), which halves the h_{t-1} payload every workgroup
+// reads per step (38 instead of 77 KB) and its MFMA count (120 instead of 160 per wave).
+template <int MT, int NW, int UN>
 __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
   constexpr int CH = (FWD_CH * 4 + NW - 1) / NW;
+  constexpr int NCOL = 4 * UN, NT = NCOL / 16;
+  static_assert(NCOL % 16 == 0 && 16 * MT * UN <= 64 * NW, "ownership map: one thread per (row, unit)");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // smem: weights [KP/4][32][4] | red [NW waves][16*MT][33]
+  // smem: weights [KP/4][NCOL][4] | red [NW waves][16*MT][NCOL+1]
   float* Wl = smem;
-  float* red = smem + (size_t)a.KP * 32;
+  float* red = smem + (size_t)a.KP * NCOL;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bid = blockIdx.x;
@@ -149,18 +155,18 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
   const int dir = cl / a.G, grp = cl % a.G;
   const int p = a.xmap ? bid / ncl : bid % a.P;
   const int H = a.H, B = a.B, T = a.T;
-  const int u0 = p * LSTM_UNITS_FWD;
+  const int u0 = p * UN;
   const int b0 = grp * (16 * MT);
 
-  // ---- stationary weights: Wl[(k/4)*32 + n][k%4], n = gate*8 + u ----------
+  // ---- stationary weights: Wl[(k/4)*NCOL + n][k%4], n = gate*UN + u ----------
   {
     const float* W = a.Wh[dir];
-    for (int idx = tid; idx < a.KP * 32; idx += 64 * NW) {
-      const int k = idx >> 5, n = idx & 31;
-      const int gate = n >> 3, u = u0 + (n & 7);
+    for (int idx = tid; idx < a.KP * NCOL; idx += 64 * NW) {
+      const int k = idx / NCOL, n = idx % NCOL;
+      const int gate = n / UN, u = u0 + (n % UN);
       float v = 0.f;
       if (k < H && u < H) v = W[(size_t)k * a.ldw + gate * H + u];
-      Wl[((k >> 2) * 32 + n) * 4 + (k & 3)] = v;
+      Wl[((k >> 2) * NCOL + n) * 4 + (k & 3)] = v;
     }
   }
   __syncthreads();
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
   const __amdgpu_buffer_rsrc_t yres = make_rsrc(a.ypad, ybytes);
 
   // gate-math ownership: thread -> (batch row bl, unit u)
-  const int bl = tid >> 3, ul = tid & 7;
+  const int bl = tid / UN, ul = tid % UN;
   const bool owner = (bl < 16 * MT) && (b0 + bl < B) && (u0 + ul < H);
   const int bg = b0 + bl, unit = u0 + ul;
   float c_state = 0.f;
@@ -182,13 +188,14 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
   // CH k-groups go to registers ONCE (2*CH float4), so the per-step MFMA
   // chain never waits on an LDS read (measured: MFMA phase 0.93 -> see
   // profiles/README.md); later chunks (H > 320) still read LDS.
-  f32x4 wreg[CH][2];
+  f32x4 wreg[CH][NT];
 #pragma unroll
   for (int g = 0; g < CH; ++g) {
     const int kg = g * NW + wave;
     const int k4 = (kg < NG ? kg : 0) * 4 + fq;
-    wreg[g][0] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + fr) * 4]);
-    wreg[g][1] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + 16 + fr) * 4]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      wreg[g][nt] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * NCOL + nt * 16 + fr) * 4]);
   }
 
   for (int s = 0; s < T; ++s) {
@@ -204,11 +211,11 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
       for (int gte = 0; gte < 4; ++gte) gxv[gte] = gp[gte * H];
     }
 
-    f32x4 acc[MT][2];
+    f32x4 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // step 0 multiplies the zero initial state (main.py:108-123): skip it.
     // This wave's k-groups are wave, wave+4, ...; all of a chunk's 16-B loads
@@ -243,23 +250,25 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
         // basic blocks and the compiler then moves the accumulators AGPR<->VGPR
         // around every group (measured 2x on the MFMA phase).  Groups past NG
         // multiply zeros (their loads were out of range) by finite weights.
-        f32x4 wq[CH][2];
+        f32x4 wq[CH][NT];
         if (g0 == 0) {
 #pragma unroll
-          for (int g = 0; g < CH; ++g) { wq[g][0] = wreg[g][0]; wq[g][1] = wreg[g][1]; }
+          for (int g = 0; g < CH; ++g)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wq[g][nt] = wreg[g][nt];
         } else {
 #pragma unroll
           for (int g = 0; g < CH; ++g) {
             const int kg = (g0 + g) * NW + wave;
             const int k4 = (kg < NG ? kg : 0) * 4 + fq;
-            wq[g][0] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + fr) * 4]);
-            wq[g][1] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + 16 + fr) * 4]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              wq[g][nt] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * NCOL + nt * 16 + fr) * 4]);
           }
         }
 #pragma unroll
         for (int g = 0; g < CH; ++g) {
           {
-            const f32x4 w0 = wq[g][0], w1 = wq[g][1];
             // NB: bit_cast the WHOLE vector -- __builtin_bit_cast(float, vec[j])
             // on a vector element reads element 0 for every j (hipcc 7.2)
             f32x4 af[MT];
@@ -268,10 +277,10 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
-              for (int mt = 0; mt < MT; ++mt) {
-                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], w0[j], acc[mt][0], 0, 0, 0);
-                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], w1[j], acc[mt][1], 0, 0, 0);
-              }
+              for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], wq[g][nt][j], acc[mt][nt], 0, 0, 0);
             }
           }
         }
@@ -283,10 +292,10 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          red[(wave * 16 * MT + mt * 16 + 4 * fq + r) * 33 + nt * 16 + fr] = acc[mt][nt][r];
+          red[(wave * 16 * MT + mt * 16 + 4 * fq + r) * (NCOL + 1) + nt * 16 + fr] = acc[mt][nt][r];
     __syncthreads();
     TRACE(3);
 
@@ -296,7 +305,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
       for (int gte = 0; gte < 4; ++gte) {
         float v = gxv[gte];
 #pragma unroll
-        for (int w = 0; w < NW; ++w) v += red[(w * 16 * MT + bl) * 33 + gte * 8 + ul];
+        for (int w = 0; w < NW; ++w) v += red[(w * 16 * MT + bl) * (NCOL + 1) + gte * UN + ul];
         pre[gte] = v;
       }
       const float g = pre[0];                 // linear candidate (ops.py:143)
@@ -1732,7 +1741,7 @@ struct FillList {
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-struct LstmPlan { int MT, G, P, KP, NW; size_t lds; };
+struct LstmPlan { int MT, G, P, KP, NW, UN; size_t lds; };
 
 // compute units of the current device (one persistent workgroup per CU must be co-resident);
 // gfx950 = 256, also the fallback when no device is visible (size queries on a CPU-only host)
@@ -1756,20 +1765,33 @@ static int num_cus() {
 // override the choice (A/B experiments).
 static LstmPlan make_plan(int B, int H, int ndir, bool bwd) {
   LstmPlan pl;
-  pl.P = cdiv(H, bwd ? LSTM_UNITS_BWD : LSTM_UNITS_FWD);
+  pl.UN = bwd ? LSTM_UNITS_BWD : LSTM_UNITS_FWD;
+  pl.P = cdiv(H, pl.UN);
   pl.KP = cdiv(H, 16) * 16;
   pl.MT = (ndir * cdiv(B, 16) * pl.P > num_cus()) ? 2 : 1;
   const char* force = getenv(bwd ? "DANET_LSTM_BWD_MT" : "DANET_LSTM_FWD_MT");
   if (force && (force[0] == '1' || force[0] == '2')) pl.MT = force[0] - '0';
+  // forward, wide layers: 12 units per workgroup keep 16-row clusters on the GPU where 8 units
+  // would need 32-row clusters (cfg 4 as written, H = 600: 200 workgroups of 16 rows instead of
+  // 150 of 32: 5.8 -> 4.6 us per timestep, 12.15 -> 11.55 ms per cfg-4h600 step).
+  // DANET_LSTM_FWD_UN=8|12 overrides.
+  if (!bwd && B > 4) {
+    const char* eu = getenv("DANET_LSTM_FWD_UN");
+    const int want = eu ? atoi(eu) : 0;
+    const bool fits12 = ndir * cdiv(B, 16) * cdiv(H, 12) <= num_cus();
+    if ((want == 12 || (want != 8 && pl.MT == 2 && !(force && force[0] == '2'))) && fits12) {
+      pl.UN = 12; pl.P = cdiv(H, 12); pl.MT = 1;
+    }
+  }
   pl.G = cdiv(B, 16 * pl.MT);
   // waves per workgroup: more waves = shorter per-wave exchange-load chains
   pl.NW = bwd ? 8 : 4;
   const char* fnw = getenv(bwd ? "DANET_LSTM_BWD_NW" : "DANET_LSTM_FWD_NW");
   if (fnw && (atoi(fnw) == 4 || atoi(fnw) == 8 || atoi(fnw) == 16)) pl.NW = atoi(fnw);
-  if (pl.MT == 2 && pl.NW > 4) pl.NW = 4;          // ownership map assumes <= 256 threads
+  if ((pl.MT == 2 || pl.UN == 12) && pl.NW > 4) pl.NW = 4;   // ownership map: 256 threads
   for (;;) {
     pl.lds = bwd ? ((size_t)4 * H * 16 + (size_t)pl.NW * 16 * pl.MT * 17) * sizeof(float)
-                 : ((size_t)pl.KP * 32 + (size_t)pl.NW * 16 * pl.MT * 33) * sizeof(float);
+                 : ((size_t)pl.KP * 4 * pl.UN + (size_t)pl.NW * 16 * pl.MT * (4 * pl.UN + 1)) * sizeof(float);
     if (pl.lds <= 160 * 1024 || pl.NW == 4) break;
     pl.NW /= 2;
   }
@@ -1902,11 +1924,11 @@ extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int n
     fl.add((char*)ypad + (size_t)(T + 1) * blk, blk, 0u);
     DANET_CHECK_HIP(fl.launch(stream));
   }
-#define LAUNCH_FWD(MTV, NWV)                                                         \
+#define LAUNCH_FWD(MTV, NWV, UNV)                                                    \
   do {                                                                               \
-    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_kernel<MTV, NWV>,       \
+    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_kernel<MTV, NWV, UNV>,  \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));                   \
-    lstm_fwd_kernel<MTV, NWV><<<nblk, 64 * NWV, pl.lds, stream>>>(a);                \
+    lstm_fwd_kernel<MTV, NWV, UNV><<<nblk, 64 * NWV, pl.lds, stream>>>(a);           \
   } while (0)
   // tiny batch (the B = 1 demo / inference path): GEMV on the vector ALU instead of 1/16-used
   // MFMA tiles.  DANET_LSTM_FWD_SMALL=0 keeps the MFMA kernel.
@@ -1922,10 +1944,11 @@ extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int n
     DANET_CHECK_LAUNCH();
     return DANET_OK;
   }
-  if (pl.MT == 2) LAUNCH_FWD(2, 4);
-  else if (pl.NW == 16) LAUNCH_FWD(1, 16);
-  else if (pl.NW == 8) LAUNCH_FWD(1, 8);
-  else LAUNCH_FWD(1, 4);
+  if (pl.UN == 12) LAUNCH_FWD(1, 4, 12);
+  else if (pl.MT == 2) LAUNCH_FWD(2, 4, 8);
+  else if (pl.NW == 16) LAUNCH_FWD(1, 16, 8);
+  else if (pl.NW == 8) LAUNCH_FWD(1, 8, 8);
+  else LAUNCH_FWD(1, 4, 8);
   DANET_CHECK_LAUNCH();
   return DANET_OK;
 }

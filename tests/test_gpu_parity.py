@@ -767,6 +767,40 @@ def test_lstm_layer_shape_envelope(B, T, D, H, ndir):
         assert relerr(params[2 * d + 1].grad.cpu().numpy(), rdb[d]) < TOL
 
 
+@pytest.mark.parametrize('B,T,D,H,ndir,force', [
+    (32, 6, 40, 600, 2, None),     # cfg 4 as written: chosen by itself (200 workgroups of 16 rows)
+    (20, 5, 16, 36, 2, '12'),      # 3 groups of 12 units, ragged batch
+    (33, 4, 12, 40, 2, '12'),      # last group has 4 of 12 units, 3 row clusters
+    (16, 7, 24, 132, 1, '12'),     # 11 groups, one direction
+    (32, 6, 40, 600, 2, '8'),      # and the 8-unit / 32-row geometry it replaces
+])
+def test_lstm_forward_12_units_per_workgroup(B, T, D, H, ndir, force, monkeypatch):
+    '''lstm_fwd_kernel<1, 4, 12>: 48 gate columns (3 MFMA column tiles) per workgroup -- the
+    geometry wide layers use so that 16-row clusters fit the GPU -- against the oracle, forward and
+    (through the unchanged BPTT) backward.  The fused forward is off: this is the hoisted kernel.'''
+    from danet_amd import ops
+    monkeypatch.setenv('DANET_LSTM_FWD_FUSED', '0')
+    if force:
+        monkeypatch.setenv('DANET_LSTM_FWD_UN', force)
+    rng = np.random.RandomState(B + 7 * T + H)
+    r = 0.75 / np.sqrt(H)
+    x = rng.randn(B, T, D) * 0.7
+    Ws = [rng.uniform(-r, r, size=(D + H, 4 * H)) * 2 for _ in range(ndir)]
+    bs = [O.lstm_bias_init(H) + rng.randn(4 * H) * 0.1 for _ in range(ndir)]
+    dy = rng.randn(B, T, ndir * H)
+    ry, rdx, rdW, rdb = _lstm_ref(x, Ws, bs, H, dy)
+    xc = cu(x).requires_grad_(True)
+    params = []
+    for W, b in zip(Ws, bs):
+        params += [cu(W).requires_grad_(True), cu(b).requires_grad_(True)]
+    y = ops.LstmLayerFn.apply(xc, H, *params)
+    assert relerr(y.detach().cpu().numpy(), ry) < TOL
+    y.backward(cu(dy))
+    assert relerr(xc.grad.cpu().numpy(), rdx) < TOL
+    for d in range(ndir):
+        assert relerr(params[2 * d].grad.cpu().numpy(), rdW[d]) < TOL
+
+
 def test_lstm_unsupported_shapes_fail_loudly():
     '''outside the compiled envelope the library refuses (no silent fallback)'''
     from danet_amd import ops, _lib
