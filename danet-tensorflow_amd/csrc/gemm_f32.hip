@@ -421,10 +421,6 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // GEMM_SMEM_BYTES
   // layout: see gemm_kloop
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-
   // XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs
   // (private L2 each); give each XCD a contiguous band of N-tiles of one
   // M-row-band so neighbours share the A panel in that XCD's L2.
@@ -696,8 +692,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(SkArgs sk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // GEMM_SMEM_BYTES
   // layout: see gemm_kloop
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
 
   const int G8 = gridDim.x >> 3;                 // workgroups per XCD band
   const int band = blockIdx.x & 7, j = blockIdx.x >> 3;
