@@ -107,7 +107,12 @@ int danet_center(danet_stream_t stream, int B, int T, int D,
  * transB=0: B stored [K][ldb];  transB=1: B stored [N][ldb] (op(B)=B^T)
  * Replaces the tf.matmul inside ops.lyr_linear (app/ops.py:66-68,72-78) for
  * the hoisted LSTM input projections and the encoder output projection, and
- * all their backward products.  `ws` is used for deterministic split-K.    */
+ * all their backward products.  `ws` is used for deterministic split-K.
+ * Every GEMM entry point below: an operand (A or B as stored, first to last element)
+ * must span less than 2 GiB (DANET_ERR_ARG otherwise); any 4-byte aligned pointer and
+ * leading dimension are accepted -- 16-byte aligned operands with ld % 4 == 0 (and
+ * K % 4 == 0 for an operand stored contiguous along K) take the faster DMA staging
+ * path, with bit-identical results.                                            */
 size_t danet_gemm_f32_workspace_bytes(int M, int N, int K);
 int danet_gemm_f32(danet_stream_t stream, int transA, int transB,
                    int M, int N, int K,
