@@ -76,7 +76,8 @@ def test_cfg2_full_size_pit_loss_and_gradients_ignore_speaker_order(hp):
     assert float((g2 - 3.0 * g0).abs().max()) <= 2e-5 * 3.0 * gmax
 
 
-@pytest.mark.parametrize('B,T,D,H', [(32, 128, 600, 300), (32, 128, 129, 300), (32, 24, 1200, 600)])
+@pytest.mark.parametrize('B,T,D,H', [(32, 128, 600, 300), (32, 128, 129, 300), (32, 24, 1200, 600),
+                                     (1, 1251, 600, 300)])     # cfg 5: the B = 1 GEMV kernel, full length
 def test_bilstm_time_reversal_symmetry(B, T, D, H):
     '''a BiLSTM whose two directions swap their weights, fed the time-reversed input, returns the
     time-reversed output with the two halves swapped -- bit for bit in forward, to summation-order
