@@ -3,7 +3,8 @@ Golden-vector capture -- runs ONLY in the build container, where the reference
 is mounted read-only at /root/reference.  Nothing here travels to the GPU box
 except the resulting .npz fixtures (data only: inputs + reference outputs).
 
-What is executed from the reference: `app/utils.py` (istft, random_zeropad) and
+What is executed from the reference: `app/utils.py` (istft, random_zeropad, load_wavfile,
+save_wavfile) and
 its STFT call expression `scipy.signal.stft(x, window=FFT_WND, nperseg=N,
 noverlap=N-S)[2].astype(COMPLEXX).T` (app/utils.py:117-122; same call at
 app/datasets/TIMIT/process.py:93-97).  The model path needs TensorFlow 1.x and
@@ -104,6 +105,30 @@ def main():
     out['istft512_L160000_tail'] = y[-1024:]
     out['istft512_L160000_sum'] = np.asarray(y.sum())
     out['istft512_L160000_abs_sum'] = np.asarray(np.abs(y).sum())
+
+    # ---- G6 / G7: the demo path's wav I/O (app/utils.py:95-135) -------------------
+    # load_wavfile: int16 wav at the model's rate and at two others (FFT resampling to 8 kHz
+    # with scipy.signal.resample, ceil'ed length) -> STFT; save_wavfile: iSTFT -> wav
+    import tempfile
+    import scipy.io.wavfile
+    utils, hp = load_reference_utils(256, 64)
+    tmp = tempfile.mkdtemp(prefix='danet_golden_')
+    for rate, n in ((8000, 3000), (11025, 4100), (16000, 6001)):
+        rs = np.random.RandomState(rate)
+        t = np.arange(n) / float(rate)
+        wave = (3000.0 * np.sin(2 * np.pi * 440.0 * t) * (0.5 + 0.5 * np.sin(2 * np.pi * 3.0 * t))
+                + 300.0 * rs.randn(n)).astype(np.int16)
+        fn = os.path.join(tmp, 'in_%d.wav' % rate)
+        scipy.io.wavfile.write(fn, rate, wave)
+        out['wav_in_%d' % rate] = wave
+        out['wav_load_%d' % rate] = utils.load_wavfile(fn)
+    feat = out['wav_load_11025']
+    fn = os.path.join(tmp, 'out.wav')
+    utils.save_wavfile(fn, feat)
+    sr, back = scipy.io.wavfile.read(fn)
+    out['wav_save_rate'] = np.asarray(sr)
+    out['wav_save_dtype'] = np.asarray(str(back.dtype))
+    out['wav_save_data'] = back
 
     path = os.path.join(OUT, 'frontend_ref.npz')
     np.savez_compressed(path, **out)

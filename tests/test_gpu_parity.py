@@ -567,6 +567,33 @@ def test_stft_against_reference_golden(hp):
         assert relerr(Xb[i], O.stft(xs[i], w256, 256, 64)) < 1e-5
 
 
+def test_wav_io_against_reference_golden(hp, tmp_path):
+    '''G6 / G7: the demo path's wav I/O -- utils.load_wavfile (scipy FFT resampling to SMPRATE
+    with the reference's ceil'ed length, then the HIP STFT) and utils.save_wavfile (HIP iSTFT, wav
+    of the same dtype / rate) against what the reference's own app/utils.py:95-135 returned for
+    the same files (tests/golden/make_golden.py)'''
+    import scipy.io.wavfile
+    from danet_amd import utils
+    hp.load(dict(FFT_SIZE=256, FFT_STRIDE=64, SMPRATE=8000))
+    hp.digest()
+    g = np.load(GOLD)
+    for rate in (8000, 11025, 16000):
+        fn = str(tmp_path / ('in_%d.wav' % rate))
+        scipy.io.wavfile.write(fn, rate, g['wav_in_%d' % rate])
+        X = utils.load_wavfile(fn)
+        ref = g['wav_load_%d' % rate]
+        assert X.shape == ref.shape and X.dtype == ref.dtype
+        assert relerr(X, ref) < 1e-5
+    fn = str(tmp_path / 'out.wav')
+    utils.save_wavfile(fn, g['wav_load_11025'])
+    sr, back = scipy.io.wavfile.read(fn)
+    assert sr == int(g['wav_save_rate']) and str(back.dtype) == str(g['wav_save_dtype'])
+    assert back.shape == g['wav_save_data'].shape
+    assert relerr(back, g['wav_save_data']) < 1e-5
+    with pytest.raises(IOError):
+        utils.load_wavfile(None)
+
+
 def test_stft_512_long_utterance_golden():
     from danet_amd import ops
     g = np.load(GOLD)
