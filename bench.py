@@ -223,18 +223,43 @@ def pmc_traffic(kernel):
     return None, None
 
 
-def mask_mse_vs_oracle(hp, model, src, n_check=2):
-    '''SDR-proxy: MSE between the HIP path's masks and the float64 oracle's on
-    the first `n_check` mixtures of the batch (mixtures are independent).'''
-    from oracle import torch_ref as R
+def parity_vs_oracle(hp, model, src, n_check=4):
+    '''SDR-proxy + parity gate at the parameters the benchmark ends with (TRAINED for as
+    many steps as the run took): masks / embedding / attractors / separated magnitudes of
+    the first `n_check` mixtures (mixtures are independent) against the float64 oracle,
+    with the float32 oracle's own distance to it as the noise floor (oracle/parity.py):
+    ok = err(HIP, f64) <= max(1e-4, 2 * err(f32 oracle, f64)) for every tensor.'''
+    from oracle import parity as P
+    from danet_amd import ops
+    B, E = hp.BATCH_SIZE, hp.EMBED_SIZE
+    act = 0 if hp.SEPARATOR_TYPE == 'dot-softmax-orig' else 1
     with torch.no_grad():
         out = model.forward(src)
-    masks = (out['sep_pwr'] / out['mix_pwr'][:, None].clamp_min(1e-30))[:n_check].double().cpu()
-    tp = {k: torch.tensor(v, dtype=torch.float64) for k, v in model.param_dict().items()}
-    with torch.no_grad():
-        r = R.model_forward(src[:n_check].cpu().to(torch.complex128), tp, oracle_cfg(hp))
-    ref = r['masks'].permute(0, 3, 1, 2)
-    return float(((masks - ref) ** 2).mean()), float((masks - ref).abs().max())
+        _, masks = ops.SeparateFn.apply(out['mix_pwr'], out['attrs'],
+                                        out['embed'].reshape(B, -1, E), act, True)
+    n = n_check
+    got = dict(embed=out['embed'][:n].cpu().numpy(), attrs=out['attrs'][:n].cpu().numpy(),
+               masks=masks[:n].cpu().numpy(), sep_pwr=out['sep_pwr'][:n].cpu().numpy(),
+               perm_idx=out['perm_idx'][:n].cpu().numpy())
+    rep = P.parity_report(got, src[:n].cpu().numpy(), model.param_dict(), oracle_cfg(hp))
+    return rep, rep['masks']['hip_vs_f64']['mse']
+
+
+def _fill_parity(res, rep, mse, model):
+    log('parity at the final parameters (%d train steps): %s' % (model.step_count, json.dumps(rep)))
+    res['train_steps_before_mask_check'] = model.step_count
+    res['mask_mse_vs_oracle'] = mse
+    res['mask_max_abs_err_vs_oracle'] = rep['masks']['hip_vs_f64']['max_rel']
+    res['mask_err_f32_oracle'] = rep['masks']['f32_vs_f64']['max_rel']
+    res['mask_rms_rel_err_vs_oracle'] = rep['masks']['hip_vs_f64']['rms_rel']
+    res['parity_ok'] = rep['ok']
+    res['parity'] = dict(
+        rule='err(HIP,f64) <= max(1e-4, 2*err(f32 oracle,f64)); err = max|a-b|/max|b|; '
+             '4 mixtures of batch 0 at the final (trained) parameters',
+        **{k: dict(hip=rep[k]['hip_vs_f64']['max_rel'], f32=rep[k]['f32_vs_f64']['max_rel'],
+                   hip_rms=rep[k]['hip_vs_f64']['rms_rel'], f32_rms=rep[k]['f32_vs_f64']['rms_rel'],
+                   ok=rep[k]['ok']) for k in ('embed', 'attrs', 'masks', 'sep_pwr')},
+        perm_idx_equal=rep['perm_idx_equal'])
 
 
 def free_port():
@@ -276,9 +301,14 @@ def main():
     ap.add_argument('--layers', type=int)
     ap.add_argument('--hdim', type=int)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity-check', action='store_true',
+                    help='diagnostic sweeps only: skip the oracle comparison (parity_ok = null)')
     ap.add_argument('--step-times', action='store_true',
                     help='diagnostic: one HIP event per timed step, per-step GPU times to stderr')
     ap.add_argument('--cpu-sample', type=int)
+    ap.add_argument('--allreduce-schedule', choices=['0', 'tail', '1'], default=None,
+                    help="gradient reduction schedule under data parallelism (Model.grad_schedule; "
+                         "default '0' = ONE all-reduce per step)")
     args = ap.parse_args()
     maybe_spawn(args)
     cfg = CONFIGS[args.config]
@@ -301,6 +331,8 @@ def main():
         # the side streams must exist before the RCCL communicator (ops.prepare_streams)
         ops.prepare_streams(device)
         torch.distributed.init_process_group('nccl', device_id=device)
+        assert torch.distributed.get_world_size() == args.gpus, \
+            'RCCL group has %d ranks, --gpus %d' % (torch.distributed.get_world_size(), args.gpus)
     hp = setup_hparams(args, cfg)
     if cfg['kind'] == 'infer':
         res = run_infer(args, cfg, hp, device, rank, world, use_dist)
@@ -309,6 +341,8 @@ def main():
     if use_dist:
         torch.distributed.destroy_process_group()
     if rank == 0:
+        if args.gpus > 1:
+            assert res.get('rccl_ranks') == args.gpus, (res.get('rccl_ranks'), args.gpus)
         # RCCL writes a version banner to the C stdout of the process; flush it first so
         # that the JSON line is the LAST line of stdout
         sys.stdout.flush()
@@ -318,6 +352,10 @@ def main():
         except OSError:
             pass
         print(json.dumps(res), flush=True)
+        if res.get('parity_ok') is False:
+            # the line above is still the record; a parity failure fails the run
+            log('PARITY FAILED: %s' % json.dumps(res.get('parity')))
+            sys.exit(4)
 
 
 def make_barrier(use_dist):
@@ -349,7 +387,7 @@ def run_train(args, cfg, hp, device, rank, world, use_dist):
     from danet_amd import _lib, ops
     from danet_amd.model import Model
     batches = make_batches(hp, rank, 4, device)
-    model = Model('bench', device=device, seed=1337).build()
+    model = Model('bench', device=device, seed=1337, grad_schedule=args.allreduce_schedule).build()
     log('built: %d params' % model.parameter_count())
     barrier = make_barrier(use_dist)
 
@@ -365,10 +403,12 @@ def run_train(args, cfg, hp, device, rank, world, use_dist):
     # process, never under rocprofv3 where the host is slower).  It hit one benchmark run in five
     # -- with K = 20 that is +1.2 ms per step.  A FIXED number (every rank must issue the same
     # collectives) of un-synchronised untimed steps takes it here: 0 of 90 runs afterwards.
-    for i in range(int(os.environ.get('DANET_BENCH_SETTLE_STEPS', '128'))):
+    # Round 3: Model.train_step bounds the host's run-ahead (ops.MAX_STEPS_IN_FLIGHT steps),
+    # so that situation no longer arises and the settle phase is 8 steps (was 128); the record
+    # carries every untimed step (`init_steps`, `settle_steps`, `warmup`).
+    settle = int(os.environ.get('DANET_BENCH_SETTLE_STEPS', '8'))
+    for i in range(settle):
         model.train_step(batches[i % len(batches)])
-        if os.environ.get('DANET_BENCH_SETTLE_SYNC', '0') == '1' and i % 8 == 7:
-            torch.cuda.synchronize(device)
     torch.cuda.synchronize(device)
     for i in range(args.warmup):
         model.train_step(batches[i % len(batches)])
@@ -510,18 +550,22 @@ def run_train(args, cfg, hp, device, rank, world, use_dist):
                                        ' (A=%d)' % hp.NUM_ANCHOR if est == 'anchor' else '',
                                        hp.SEPARATOR_TYPE.replace('-orig', ''), B),
                            global_batch=B * world, parallelism='dp%d' % world,
-                           grad_allreduce_bytes=int(model._flat_grad.numel() * 4),
-                           grad_allreduce_schedule=os.environ.get('DANET_OVERLAP_ALLREDUCE', 'tail')),
+                           grad_allreduce_bytes=int(model._grad_store.numel() * 4),
+                           grad_allreduce_schedule=model.grad_schedule,
+                           collectives_per_step=model.collectives_per_step()),
+               init_steps=1, settle_steps=settle,
+               untimed_steps_total=1 + settle + args.warmup,
+               max_steps_in_flight=ops.MAX_STEPS_IN_FLIGHT,
                rccl_ranks=(torch.distributed.get_world_size() if use_dist else 0),
                allreduce_ms_standalone=(round(allreduce_ms, 4) if allreduce_ms is not None else None),
                roofline=roofline, kernels=kernels_table(prof_all, nb), host=host_info())
     if world == 1:
         torch.set_num_threads(min(os.cpu_count() or 1, 16))
-        nchk = 2 if H <= 300 else 1
-        mse, mx = mask_mse_vs_oracle(hp, model, batches[0], nchk)
-        log('mask mse vs oracle %.3e (max abs %.3e)' % (mse, mx))
-        res['mask_mse_vs_oracle'] = mse
-        res['mask_max_abs_err_vs_oracle'] = mx
+        rep, mse = (None, None) if args.no_parity_check else parity_vs_oracle(hp, model, batches[0], 4)
+        if rep is None:
+            res['parity_ok'] = None
+        else:
+            _fill_parity(res, rep, mse, model)
         if not args.no_cpu_baseline:
             sample = args.cpu_sample or (B if (H <= 300 and L <= 3) else max(2, B // 8))
             res['cpu_baseline'] = cpu_baseline(hp, model.param_dict(), sample)
@@ -555,10 +599,9 @@ def run_infer(args, cfg, hp, device, rank, world, use_dist):
 
     y = step(waves[0])
     assert tuple(y.shape) == (hp.MAX_N_SIGNAL, T * S), y.shape
-    for i in range(int(os.environ.get('DANET_BENCH_SETTLE_STEPS', '128')) // 2):   # see run_train
+    settle = int(os.environ.get('DANET_BENCH_SETTLE_STEPS', '8'))                  # see run_train
+    for i in range(settle):
         step(waves[i % len(waves)])
-        if i % 8 == 7:
-            torch.cuda.synchronize(device)
     torch.cuda.synchronize(device)
     for i in range(args.warmup):
         step(waves[i % len(waves)])
@@ -615,6 +658,8 @@ def run_infer(args, cfg, hp, device, rank, world, use_dist):
                                      % (args.config, hp.SMPRATE, hp.MAX_N_SIGNAL, mix_s, N, S, F, T, L, H,
                                         E, hp.INFER_ESTIMATOR_METHOD),
                             global_batch=world, parallelism='replicas%d' % world),
+                init_steps=1, settle_steps=settle, untimed_steps_total=1 + settle + args.warmup,
+                max_steps_in_flight=ops.MAX_STEPS_IN_FLIGHT,
                 rccl_ranks=(torch.distributed.get_world_size() if use_dist else 0),
                 roofline=roofline, kernels=kernels_table(prof_all, nb), host=host_info())
 

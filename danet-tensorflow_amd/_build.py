@@ -87,8 +87,26 @@ def build_trace():
     return out
 
 
+def build_variant(name, defs):
+    '''A/B variant csrc/libdanet_hip_<name>.so compiled with extra -D switches (e.g.
+    name='accmath', defs=['-DDANET_LSTM_ACCURATE_MATH']); loaded instead of the product
+    library when DANET_LIB_PATH points at it (tests / tools only).'''
+    out = os.path.join(CSRC, 'libdanet_hip_%s.so' % name)
+    srcs = [os.path.join(CSRC, f) for f in _sources()]
+    cmd = [HIPCC] + FLAGS + list(defs) + ['-shared', '-o', out]
+    for sp in srcs:
+        cmd += (['-x', 'hip', sp] if sp.endswith('.hip') else ['-x', 'c++', sp])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('variant build failed:\n%s\n%s' % (r.stdout, r.stderr))
+    return out
+
+
 if __name__ == '__main__':
     if '--trace' in sys.argv:
         print(build_trace())
+    elif '--variant' in sys.argv:
+        i = sys.argv.index('--variant')
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
     else:
         build(force='--force' in sys.argv)

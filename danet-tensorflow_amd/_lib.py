@@ -12,7 +12,8 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libdanet_hip.so')
+# DANET_LIB_PATH: an A/B build of the same sources (_build.build_variant), never a different backend
+LIB_PATH = os.environ.get('DANET_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libdanet_hip.so')
 
 c_int, c_i64, c_f32, c_sz, c_p = (ctypes.c_int, ctypes.c_int64, ctypes.c_float,
                                   ctypes.c_size_t, ctypes.c_void_p)

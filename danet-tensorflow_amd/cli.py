@@ -146,25 +146,57 @@ def evaluate(model, dataset, subset, out=sys.stdout):
         out.write('.')
         out.flush()
     _dict_mul(rep, 1. / (i_batch + 1))
+    # a hand-off timeout in any step of the sweep invalidates its metrics: surface it here
+    # (blocking; collective under data parallelism -- every rank reaches this line)
+    model.check_status()
     return rep
 
 
-def demo(model, args, out=sys.stdout):
-    '''wav -> separated wavs (main.py:655-696)'''
-    feat = utils.load_wavfile(args.input_file)                       # [T, F] complex
+def _draw_aligned_sources(dataset, shuffle=False):
+    '''one data point of hparams.MAX_N_SIGNAL single-speaker spectra from the test subset,
+    each zero-padded at a random position of the time axis (utils.random_zeropad) to the
+    longest of them rounded up to a multiple of hparams.LENGTH_ALIGN -- main.py:662-672
+    (demo) and :719-727 (debug).  Returns complex [C, T, F].'''
+    src_signals = []
+    for src_signals in dataset.epoch('test', hparams.MAX_N_SIGNAL, shuffle=shuffle):
+        break
+    max_len = max(map(len, src_signals[0]))
+    max_len += (-max_len) % hparams.LENGTH_ALIGN                     # main.py:668 / :724
+    return np.stack([utils.random_zeropad(x, max_len - len(x), axis=-2) for x in src_signals[0]])
+
+
+def demo(model, args, dataset=None, out=sys.stdout):
+    '''wav -> separated wavs (main.py:655-696).  Without `-if` the mixture is made from
+    MAX_N_SIGNAL utterances of the dataset's test subset and written to demo.wav first
+    (main.py:662-672).'''
+    if args.input_file is None:
+        if dataset is None:
+            raise ValueError('demo mode without an input file needs a dataset')
+        filename = 'demo.wav'
+        src_signals = _draw_aligned_sources(dataset)
+        feat = np.sum(src_signals, axis=0)                           # raw_mixture, main.py:673
+        utils.save_wavfile(filename, feat)
+        out.write('wrote %s\n' % filename)
+    else:
+        filename = args.input_file
+        feat = utils.load_wavfile(args.input_file)                   # [T, F] complex
     x = torch.as_tensor(feat.astype(np.complex64)).to(model.device)[None]
     sep = model.infer(x)[0].cpu().numpy()                            # [C, T, F]
-    base = os.path.splitext(args.input_file)[0]
+    model.check_status()          # never write wavs computed from a timed-out launch
+    base, ext = os.path.splitext(filename)
     for i, s in enumerate(sep):
-        fn = '%s_separated_%d.wav' % (base, i + 1)
+        fn = '%s_separated_%d%s' % (base, i + 1, ext)                # main.py:692-694
         utils.save_wavfile(fn, s)
         out.write('wrote %s\n' % fn)
 
 
 def debug(model, dataset, out=sys.stdout):
-    '''dump the debug fetches to debug/debug_data.npz (main.py:717-737 writes a .mat)'''
-    data_pt = next(iter(dataset.epoch('train', hparams.BATCH_SIZE * hparams.MAX_N_SIGNAL)))
-    fetch = model.debug_fetch(_to_batch(data_pt, model.device))
+    '''dump the debug fetches to debug/debug_data.npz (main.py:717-737 writes a .mat):
+    ONE data point (BATCH_SIZE is forced to 1, main.py:623-629) of MAX_N_SIGNAL test
+    utterances, drawn shuffled, aligned and randomly zero-padded (main.py:719-727)'''
+    input_ = _draw_aligned_sources(dataset, shuffle=True)[None]      # [1, C, T, F]
+    fetch = model.debug_fetch(torch.as_tensor(input_.astype(np.complex64)).to(model.device))
+    model.check_status()
     os.makedirs('debug', exist_ok=True)
     np.savez('debug/debug_data.npz',
              **{k: v.detach().cpu().numpy() for k, v in fetch.items() if torch.is_tensor(v)})
@@ -202,8 +234,10 @@ def main(argv=None, out=sys.stdout):
         hparams.DATASET_TYPE = args.dataset
     if args.batch_size is not None:
         hparams.BATCH_SIZE = args.batch_size
-    if args.mode == 'demo':
+    if args.mode in ('demo', 'debug'):
         hparams.BATCH_SIZE = 1                                        # main.py:623-627
+        if args.mode == 'debug':
+            hparams.DEBUG = True                                      # main.py:628-629
     hparams.digest()
 
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -212,12 +246,10 @@ def main(argv=None, out=sys.stdout):
     dist.init_from_env('nccl', device)
     np.random.seed(dist.shard_seed(1337))
 
-    dataset = None
-    if args.mode != 'demo':
-        out.write('Preparing dataset "%s" ... ' % hparams.DATASET_TYPE)
-        dataset = hparams.get_dataset()()
-        dataset.install_and_load()
-        out.write('done\n')
+    out.write('Preparing dataset "%s" ... ' % hparams.DATASET_TYPE)      # main.py:607-612
+    dataset = hparams.get_dataset()()
+    dataset.install_and_load()
+    out.write('done\n')
     out.write('Building model ... ')
     model = Model(name=args.name, device=device).build()
     out.write('done (%d parameters)\n' % model.parameter_count())
@@ -232,7 +264,7 @@ def main(argv=None, out=sys.stdout):
         rep = evaluate(model, dataset, args.mode, out)
         out.write('\n%s: %s\n' % (args.mode.capitalize(), _dict_format(rep)))
     elif args.mode == 'demo':
-        demo(model, args, out)
+        demo(model, args, dataset, out)
     elif args.mode == 'debug':
         debug(model, dataset, out)
     else:

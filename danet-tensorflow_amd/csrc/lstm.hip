@@ -99,7 +99,7 @@ __device__ __forceinline__ bool spin_fail(unsigned& spins, int* status, int lane
   if ((spins & 255u) == 0) {
     if (__hip_atomic_load(status, RLX_AGENT) != 0) return true;   // someone gave up
     if (spins >= limit) {
-      if (lane == 0) __hip_atomic_store(status, 1, RLX_AGENT);
+      if (lane == 0) __hip_atomic_store(status, (int)DANET_STATUS_TIMEOUT, RLX_AGENT);
       return true;
     }
   }

@@ -28,7 +28,16 @@ from . import dist
 class Model(object):
     '''Base class for a fully trainable model (main.py:61-548)'''
 
-    def __init__(self, name='BaseModel', device=None, seed=1337):
+    def __init__(self, name='BaseModel', device=None, seed=1337, grad_schedule=None):
+        '''grad_schedule (data parallelism only; default: env DANET_OVERLAP_ALLREDUCE or '0'):
+        '0' = ONE all-reduce of the flat gradient bucket after backward (the north_star
+        form, the default); 'tail' = two collectives (everything outside the bottom encoder
+        layer under that layer's weight-gradient GEMMs, the rest after backward); '1' =
+        per-layer buckets under the remaining BPTT kernels.  The overlapped forms are opt-in
+        until a multi-GPU measurement justifies them (tools/scale_sweep.sh).'''
+        self.grad_schedule = str(grad_schedule if grad_schedule is not None else
+                                 os.environ.get('DANET_OVERLAP_ALLREDUCE', '0'))
+        assert self.grad_schedule in ('0', 'tail', '1'), self.grad_schedule
         self.name = name
         self.device = torch.device(device if device is not None else
                                    'cuda:%d' % torch.cuda.current_device())
@@ -110,7 +119,10 @@ class Model(object):
     def _flatten(self):
         n = sum(self.vars[k].numel() for k in self._order)
         flat = torch.empty(n, device=self.device)
-        grad = torch.zeros(n, device=self.device)
+        # 4 spare floats behind the gradients: under data parallelism they carry the
+        # persistent kernels' hand-off status through the gradient all-reduce (ops.py)
+        self._grad_store = torch.zeros(n + 4, device=self.device)
+        grad = self._grad_store[:n]
         off = 0
         for k in self._order:
             v = self.vars[k]
@@ -134,12 +146,10 @@ class Model(object):
                 m._grads_clean = False
         for k in self._order:
             self.vars[k].register_post_accumulate_grad_hook(_mark_dirty)
-        # gradient reduction schedule (dist.py): 'tail' (default) = everything but the
-        # bottom encoder layer is all-reduced under that layer's weight-gradient GEMMs, the
-        # rest after backward; '1' = per-layer buckets under the remaining BPTT kernels
-        # (opt-in); '0' = one all-reduce after backward
+        # gradient reduction schedule (dist.py, see __init__): '0' (default) = one all-reduce
+        # after backward; 'tail' / '1' = overlapped pieces (opt-in)
         self._buckets = None
-        mode = os.environ.get('DANET_OVERLAP_ALLREDUCE', 'tail')
+        mode = self.grad_schedule
         offs, off = {}, 0
         for k in self._order:
             v = self.vars[k]
@@ -148,7 +158,7 @@ class Model(object):
         self._offs = offs
         if mode in ('1', 'tail'):
             cls = dist.GradBuckets if mode == '1' else dist.TailOverlap
-            self._buckets = cls(grad, offs)
+            self._buckets = cls(self._grad_store if dist.is_dist() else grad, offs)
             ops.add_grad_ready_hook(self._buckets.hook)
         # early optimizer step (DANET_EARLY_ADAM=0 turns it off): once the bottom encoder layer's
         # BPTT kernel has been issued every other gradient is final (and, under data parallelism
@@ -157,6 +167,11 @@ class Model(object):
         # bottom layer's range is left (5 instead of 34 us at the tail of a cfg-2 step).  The update
         # is elementwise and nothing reads those parameters again in this step.
         self._early_adam = os.environ.get('DANET_EARLY_ADAM', '1') == '1'
+        if dist.is_dist():
+            # the status word rides in the gradient all-reduce: every rank sees the same value
+            ops.set_status_word(self.device, self._grad_store[n:].view(torch.int32))
+        elif ops.status_word(self.device).is_cuda and ops.STATUS_HOST:
+            ops.set_status_word(self.device, None)     # a previous data-parallel model's word
         self._early = None          # (ranges, stream) of this step's early update
         self.early_steps = 0        # steps that took the early path (diagnostics / tests)
         self._in_step = False
@@ -234,18 +249,25 @@ class Model(object):
         '''one `g_sess.run(train_fetches)` (main.py:430-431): forward, backward,
         gradient all-reduce, value clip, Adam.  Returns dict(loss, SNR, LR) of
         device scalars (no host sync unless the caller reads them).'''
-        ops.poll_status(self.device)       # raises if an earlier launch reported a timeout
+        # bounded run-ahead + status of the steps that have completed (raises DanetHipError
+        # at most ops.MAX_STEPS_IN_FLIGHT steps after a hand-off timeout)
+        ops.poll_status(self.device)
         if not self._grads_clean:
             self._flat_grad.zero_()
         out = self.forward(s_src_signals)
         self._early, self._in_step = None, True
+        # from here until the final optimiser piece has been issued the bucket holds partial
+        # sums: an exception in between (launch error, collective failure, KeyboardInterrupt)
+        # must not leave it marked clean (fast_backward bypasses autograd's accumulate hook)
+        self._grads_clean = False
         try:
             with ops.fast_backward():          # kernels add straight into the flat bucket
                 out['loss'].backward(self._one)    # (a persistent 1: no ones_like fill per step)
                 if self._buckets is not None:
                     grad_scale = self._buckets.finish()            # pieces launched during backward
-                else:
-                    grad_scale = dist.allreduce_grads_(self._flat_grad)    # ONE RCCL all-reduce / step
+                else:                                              # ONE RCCL all-reduce / step
+                    grad_scale = dist.allreduce_grads_(
+                        self._grad_store if dist.is_dist() else self._flat_grad)
         finally:
             self._in_step = False
         self.step_count += 1
@@ -262,13 +284,22 @@ class Model(object):
             # put a 20 us bubble in front of the last kernel of the step)
             torch.cuda.current_stream(self.device).wait_stream(early_stream)
         self._grads_clean = not self.keep_grads
+        ops.step_done(self.device)
         return dict(loss=out['loss'].detach(), SNR=out['SNR'], LR=self.learn_rate)
+
+    def collectives_per_step(self):
+        '''data-path collectives a train step issues under data parallelism (0 without)'''
+        if not dist.is_dist():
+            return 0
+        return {'0': 1, 'tail': 2}.get(self.grad_schedule,
+                                       1 + hparams.NUM_LSTM_LAYERS + 1)   # '1': per-layer buckets
 
     def valid_step(self, s_src_signals):
         '''`g_sess.run(valid_fetches)` (main.py:499-500)'''
         ops.poll_status(self.device)
         with torch.no_grad():
             out = self.forward(s_src_signals, with_valid=True, with_train=False)
+        ops.step_done(self.device, collective_consistent=not dist.is_dist())
         return dict(loss=out['valid_loss'], SNR=out['valid_SNR'])
 
     def infer(self, s_mixed_signals):
@@ -282,7 +313,9 @@ class Model(object):
             s_embed = self.encoder(fe['mix_log'])
             s_attr = self.valid_estimator(s_embed, s_mix_pwr=fe['mix_pwr'])
             s_sep = self.separator(fe['mix_pwr'], s_attr, s_embed.reshape(B, -1, E))
-            return ops.reattach_phase(s_sep, fe['phasor'])
+            res = ops.reattach_phase(s_sep, fe['phasor'])
+        ops.step_done(self.device, collective_consistent=not dist.is_dist())
+        return res
 
     # ------------------------------------------------------- misc (main.py)
     def set_learn_rate(self, lr):
@@ -292,8 +325,9 @@ class Model(object):
         return self.learn_rate
 
     def check_status(self):
-        '''blocking check of the persistent kernels' hand-off status (end of an epoch /
-        before parameters are saved); raises DanetHipError after a timeout'''
+        '''blocking check of the persistent kernels' hand-off status (end of an epoch / a
+        sweep, before parameters or separated signals are written); raises DanetHipError
+        after a timeout -- on every rank together under data parallelism'''
         ops.check_status(self.device)
 
     def zero_grad(self):

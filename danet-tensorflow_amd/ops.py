@@ -217,27 +217,49 @@ class _LayerCtx(object):
                  'Ws', 'bs')
 
 
-# ---- hand-off status of the persistent kernels ------------------------------
-# ONE sticky int32 per device (include/danet_hip.h: `status` of danet_lstm_fwd/bwd): the
-# kernels set it when a bounded inter-workgroup wait times out.  The product path reads it
-# back without a per-step synchronisation: every STATUS_POLL_EVERY calls of `poll_status`
-# an asynchronous 4-byte copy into pinned host memory is enqueued, and the previous copy is
-# inspected once its event has completed; `check_status` is the blocking form (end of an
-# epoch, tests, bench).  No launch workspace is ever retained.
-STATUS_POLL_EVERY = int(__import__('os').environ.get('DANET_STATUS_POLL_EVERY', '16'))
+# ---- hand-off status of the persistent kernels + bounded host run-ahead -------
+# ONE sticky 4-byte word per device (include/danet_hip.h: `status` of danet_lstm_fwd/bwd):
+# the kernels store DANET_STATUS_TIMEOUT (the bit pattern of 1.0f) into it when a bounded
+# inter-workgroup wait times out.  Where it lives:
+#   * single process: in PINNED, device-mapped host memory -- the kernels write it across
+#     the bus (only on a timeout; they read it once per 256 failed polls), the host reads
+#     it directly once a step's event has completed.  No copy, no extra launch.
+#   * data parallel: Model points it at the 4 spare floats behind its flat gradient bucket,
+#     so the word rides in the step's gradient all-reduce (SUM of 1.0f per timed-out rank):
+#     after the reduction every rank holds the same value and they all raise at the same
+#     step instead of one rank leaving the others hanging in the next collective.  The
+#     reduced word is copied to pinned memory asynchronously once per step.
+# `StepFence` bounds how far the host may run ahead of the GPU: Model.train_step /
+# valid_step / infer record an event when a step has been enqueued and wait for the event
+# of the step MAX_STEPS_IN_FLIGHT back before enqueuing the next.  A step whose event has
+# completed is "retired": its status is inspected then, so a timeout raises DanetHipError
+# at most MAX_STEPS_IN_FLIGHT steps later (round 2 polled every 16 calls).  Bounding the
+# run-ahead also keeps the host from ever sitting 8-9 steps (30 ms of queued kernels)
+# ahead of the GPU -- the situation in which the one-off 13-19 ms recurrent-kernel stall
+# of DESIGN.md 5 was observed.
+import collections as _collections
+import os as _os
+
+MAX_STEPS_IN_FLIGHT = int(_os.environ.get('DANET_MAX_STEPS_IN_FLIGHT', '4'))
+STATUS_HOST = _os.environ.get('DANET_STATUS_HOST', '1') == '1'
 TIMEOUT_MSG = ('persistent LSTM kernel: an inter-workgroup hand-off timed out -- the outputs of '
                'that launch (and everything computed from them) are invalid')
 
 
 class _DeviceStatus(object):
-    __slots__ = ('word', 'host', 'event', 'pending', 'calls')
+    __slots__ = ('dev', 'word', 'own', 'host_mapped', 'slots', 'queue', 'n', 'retired')
 
     def __init__(self, dev):
-        self.word = torch.zeros(4, dtype=torch.int32, device=dev)
-        self.host = torch.zeros(4, dtype=torch.int32).pin_memory()
-        self.event = torch.cuda.Event()
-        self.pending = False
-        self.calls = 0
+        self.dev = dev
+        if STATUS_HOST:
+            self.own = torch.zeros(4, dtype=torch.int32).pin_memory()
+        else:
+            self.own = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.word, self.host_mapped = self.own, STATUS_HOST
+        self.slots = torch.zeros(MAX_STEPS_IN_FLIGHT + 2, 4, dtype=torch.int32).pin_memory()
+        self.queue = _collections.deque()     # (event, slot or -1, may_raise)
+        self.n = 0
+        self.retired = 0
 
 
 _status = {}
@@ -252,36 +274,92 @@ def _dev_status(dev):
 
 
 def status_word(dev):
-    '''the device's sticky int32 status tensor (element 0 = LSTM hand-off)'''
+    '''the device's sticky 4 x int32 status tensor (element 0 = LSTM hand-off) that the
+    launches are given; pinned host memory or device memory (see above)'''
     return _dev_status(dev).word
 
 
+def set_status_word(dev, word=None):
+    '''point the device's status word at caller-owned DEVICE memory (an int32 view of 4
+    elements; Model uses the tail of its gradient bucket under data parallelism); None
+    restores the process-owned word'''
+    st = _dev_status(dev)
+    torch.cuda.synchronize(st.dev)
+    st.queue.clear()
+    if word is None:
+        st.word, st.host_mapped = st.own, STATUS_HOST
+    else:
+        assert word.is_cuda and word.dtype == torch.int32 and word.numel() == 4
+        st.word, st.host_mapped = word, False
+
+
+def _word_flag(st):
+    '''current value of word 0 (caller has synchronised what it needs)'''
+    return int(st.word[0].item())
+
+
 def _raise_timeout(st):
+    torch.cuda.synchronize(st.dev)
     st.word.zero_()              # so the caller may restore parameters and go on
-    st.pending = False
+    st.queue.clear()
     raise _lib.DanetHipError(TIMEOUT_MSG)
 
 
+def _retire(st, block):
+    ev, slot, may_raise = st.queue[0]
+    if block:
+        ev.synchronize()
+    elif not ev.query():
+        return False
+    st.queue.popleft()
+    st.retired += 1
+    flag = int(st.slots[slot, 0]) if slot >= 0 else int(st.word[0])
+    if flag != 0 and may_raise:
+        _raise_timeout(st)
+    return True
+
+
 def poll_status(dev):
-    '''non-blocking check (see above); raises DanetHipError one poll period after a
-    timeout at the latest.  Called by Model.train_step / valid_step / infer.'''
+    '''admission of a new step (called first by Model.train_step / valid_step / infer):
+    retire every completed step, wait until fewer than MAX_STEPS_IN_FLIGHT are in flight;
+    raises DanetHipError when a retired step recorded a hand-off timeout'''
     st = _dev_status(dev)
-    if st.pending and st.event.query():
-        st.pending = False
-        if int(st.host[0]) != 0:
-            _raise_timeout(st)
-    st.calls += 1
-    if not st.pending and st.calls % max(STATUS_POLL_EVERY, 1) == 0:
-        st.host.copy_(st.word, non_blocking=True)
-        st.event.record()
-        st.pending = True
+    while st.queue and _retire(st, block=False):
+        pass
+    while len(st.queue) >= max(MAX_STEPS_IN_FLIGHT, 1):
+        _retire(st, block=True)
+
+
+def step_done(dev, collective_consistent=True):
+    '''a step has been enqueued on the current stream: record its event (and, for a
+    device-resident word, an asynchronous 16-byte snapshot into pinned memory).
+    collective_consistent=False (data parallel, a step without a gradient all-reduce): the
+    word is rank-local, so retiring the step does not raise -- `check_status` does, on
+    every rank together.'''
+    st = _dev_status(dev)
+    slot = -1
+    if not st.host_mapped:
+        slot = st.n % st.slots.shape[0]
+        st.slots[slot].copy_(st.word, non_blocking=True)
+    st.n += 1
+    ev = torch.cuda.Event()
+    ev.record()
+    st.queue.append((ev, slot, collective_consistent))
 
 
 def check_status(dev=None):
-    '''blocking check of the status word; raises DanetHipError on a recorded timeout'''
+    '''blocking check (end of an epoch / a sweep, before results are written, tests);
+    raises DanetHipError on a recorded timeout.  Under torch.distributed the flag is
+    MAX-reduced first, so every rank raises (or none does).'''
     for st in ([_dev_status(dev)] if dev is not None else list(_status.values())):
-        st.pending = False
-        if int(st.word[0].item()) != 0:
+        torch.cuda.synchronize(st.dev)
+        st.queue.clear()
+        flag = 1 if _word_flag(st) != 0 else 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            t = torch.tensor([flag], dtype=torch.int32, device=st.dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            flag = int(t.item())
+        if flag != 0:
             _raise_timeout(st)
 
 
@@ -290,8 +368,9 @@ def lstm_status_ok():
     inter-workgroup timeout (clears the word).  Synchronises.'''
     ok = True
     for st in _status.values():
-        st.pending = False
-        if int(st.word[0].item()) != 0:
+        torch.cuda.synchronize(st.dev)
+        st.queue.clear()
+        if _word_flag(st) != 0:
             ok = False
             st.word.zero_()
     return ok

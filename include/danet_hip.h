@@ -201,7 +201,13 @@ size_t danet_colsum_f32_workspace_bytes(int M, int N);
  * clears it, so one word can serve every launch of a training run and be read
  * back once in a while (later launches that find it non-zero give up their
  * waits early instead of spinning to the bound).  status == NULL: ws word 0 is
- * used instead and is zeroed by the call.                                  */
+ * used instead and is zeroed by the call.  The value stored on a timeout is
+ * DANET_STATUS_TIMEOUT, the bit pattern of 1.0f: the word may therefore live
+ * inside a float32 buffer that is SUM-all-reduced across ranks (a data-parallel
+ * host puts it behind its gradient bucket, so every rank learns of a timeout on
+ * any rank from the collective it issues anyway).  The word may also be pinned,
+ * device-mapped HOST memory: the kernels touch it only on the timeout path.   */
+#define DANET_STATUS_TIMEOUT 0x3F800000
 size_t danet_lstm_workspace_bytes(int T, int B, int H, int ndir);
 int danet_lstm_fwd(danet_stream_t stream, int T, int B, int H, int ndir,
                    const float* gx_f, const float* gx_b,

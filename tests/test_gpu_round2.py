@@ -90,13 +90,16 @@ def test_train_soak_memory_flat(hp):
     assert m1 <= m0 + (1 << 20), (m0, m1)
     assert np.isfinite(float(out['loss']))
     assert len(ops._status) == 1 and ops.status_word(model.device).numel() == 4
+    # the host never runs more than MAX_STEPS_IN_FLIGHT steps ahead of the GPU
+    assert len(ops._dev_status(model.device).queue) <= ops.MAX_STEPS_IN_FLIGHT
+    assert ops._dev_status(model.device).retired >= 2000 - ops.MAX_STEPS_IN_FLIGHT
     model.check_status()
 
 
 def test_injected_handoff_timeout_raises_from_train_step(hp, monkeypatch):
     '''a hand-off timeout inside a persistent LSTM launch (forced: workgroup 0 of every
     launch exits without publishing) surfaces as DanetHipError from Model.train_step
-    within one poll period, and the model is usable again afterwards'''
+    within ops.MAX_STEPS_IN_FLIGHT steps, and the model is usable again afterwards'''
     from danet_amd import ops, _lib
     model = _small_model(hp)
     src = torch.as_tensor(_rand_src(hp, 10)).cuda()
@@ -104,11 +107,9 @@ def test_injected_handoff_timeout_raises_from_train_step(hp, monkeypatch):
     model.check_status()
     monkeypatch.setenv('DANET_LSTM_FAULT_INJECT', '1')
     monkeypatch.setenv('DANET_LSTM_SPIN_LIMIT', '2048')
-    monkeypatch.setattr(ops, 'STATUS_POLL_EVERY', 2)
     with pytest.raises(_lib.DanetHipError, match='hand-off timed out'):
-        for _ in range(8):
+        for _ in range(ops.MAX_STEPS_IN_FLIGHT + 2):      # no synchronisation: the fence finds it
             model.train_step(src)
-            torch.cuda.synchronize()
     monkeypatch.delenv('DANET_LSTM_FAULT_INJECT')
     monkeypatch.delenv('DANET_LSTM_SPIN_LIMIT')
     torch.cuda.synchronize()

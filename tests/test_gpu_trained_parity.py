@@ -1,0 +1,99 @@
+'''
+Parity at TRAINED parameters (run with -m gpu).
+
+Every other model-level GPU test compares the HIP path with the oracle at freshly
+initialised parameters, where the softmax masks are soft and errors small.  After
+training the masks sharpen and rounding differences in the embedding are amplified --
+the regime the driver's bench line is measured in.  This test trains BASELINE cfg 2
+(B = 32, T = 128, 3 x 300 BiLSTM, anchor estimator, dot-softmax) for 200 steps on fixed
+batches through Model.train_step, then compares masks / embeddings / attractors /
+separated magnitudes of 4 mixtures with
+
+  (i)  the float64 oracle             (the parity authority), and
+  (ii) the float32 oracle             (the reference's own FLOATX arithmetic,
+                                       default.json:2 -- the noise floor of ANY fp32 path)
+
+at the same parameters, and asserts (oracle/parity.py)
+
+    err(HIP, f64) <= max(1e-4, 2 * err(f32 oracle, f64)).
+
+Reference lines: main.py:208-337, app/modules.py:207-260,490-603, app/ops.py:139-147.
+'''
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import parity as P
+
+pytestmark = pytest.mark.gpu
+
+N_STEPS = int(os.environ.get('DANET_TRAINED_PARITY_STEPS', '200'))
+N_CHECK = 4
+
+
+def _setup(hp, B):
+    from danet_amd.model import Model
+    hp.load(dict(BATCH_SIZE=B, MAX_N_SIGNAL=2, FFT_SIZE=256, FFT_STRIDE=64, SMPRATE=8000,
+                 EMBED_SIZE=20, NUM_LSTM_LAYERS=3, LSTM_HDIM=300, NUM_ANCHOR=6,
+                 MAX_TRAIN_LEN=128, ENCODER_TYPE='bilstm-orig',
+                 TRAIN_ESTIMATOR_METHOD='anchor', INFER_ESTIMATOR_METHOD='anchor',
+                 SEPARATOR_TYPE='dot-softmax-orig'))
+    hp.digest()
+    return Model('trained', device='cuda', seed=1337).build()
+
+
+def _batches(hp, n):
+    from danet_amd import datasets, utils
+    B, C, T = hp.BATCH_SIZE, hp.MAX_N_SIGNAL, hp.MAX_TRAIN_LEN
+    out = []
+    for i in range(n):
+        waves = datasets.synth_waves(1337 + 1000 * i, B * C, T)
+        spec = utils.stft(torch.as_tensor(waves).cuda())
+        out.append(spec.reshape(B, C, T, hp.FEATURE_SIZE).contiguous())
+    return out
+
+
+def product_outputs(model, hp, src, n):
+    '''embed / attrs / masks / sep_pwr / perm_idx of the first n mixtures (numpy)'''
+    from danet_amd import ops
+    with torch.no_grad():
+        out = model.forward(src)
+        B, E = hp.BATCH_SIZE, hp.EMBED_SIZE
+        _, masks = ops.SeparateFn.apply(out['mix_pwr'], out['attrs'],
+                                        out['embed'].reshape(B, -1, E), 0, True)
+    torch.cuda.synchronize()
+    return dict(embed=out['embed'][:n].cpu().numpy(), attrs=out['attrs'][:n].cpu().numpy(),
+                masks=masks[:n].cpu().numpy(), sep_pwr=out['sep_pwr'][:n].cpu().numpy(),
+                perm_idx=out['perm_idx'][:n].cpu().numpy())
+
+
+def test_cfg2_parity_after_training(hp):
+    from danet_amd import ops
+    model = _setup(hp, 32)
+    batches = _batches(hp, 4)
+    losses = []
+    for i in range(N_STEPS):
+        o = model.train_step(batches[i % 4])
+        if i % 50 == 0 or i == N_STEPS - 1:
+            losses.append(float(o['loss']))
+    torch.cuda.synchronize()
+    assert ops.lstm_status_ok()
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    got = product_outputs(model, hp, batches[0], N_CHECK)
+    cfg = dict(H=300, L=3, E=20, C=2, A=6, train_est='anchor', infer_est='anchor',
+               separator='dot-softmax-orig')
+    rep = P.parity_report(got, batches[0][:N_CHECK].cpu().numpy(), model.param_dict(), cfg)
+    rep['losses'] = losses
+    rep['train_steps'] = N_STEPS
+    print('\nTRAINED-PARITY ' + json.dumps(rep))
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open('gpurun_out/trained_parity.json', 'w') as f:
+        json.dump(rep, f, indent=1)
+    for k in P.KEYS:
+        assert rep[k]['ok'], (k, rep[k])
+    assert rep['perm_idx_equal']
+    # the masks are a simplex: the max error is an absolute error in [0, 1]
+    assert rep['masks']['hip_vs_f64']['max_rel'] <= max(1e-4, 2 * rep['masks']['f32_vs_f64']['max_rel'])

@@ -266,3 +266,26 @@ def test_lstm_orig_restatements_agree():
     a = O.lstm_encoder(x, p, H, L, E)
     b = R.lstm_encoder(torch.tensor(x), {k: torch.tensor(v) for k, v in p.items()}, H, L, E).numpy()
     assert np.abs(a - b).max() < 1e-12
+
+
+# ----------------------------------------------------- G5: the oracle is frozen
+@pytest.mark.parametrize('name', sorted(__import__('oracle.g5', fromlist=['CASES']).CASES))
+def test_g5_live_oracle_matches_committed_fixtures(name):
+    '''SURVEY 8c G5 (debug_fetches keys main.py:389-397, app/modules.py:540-543,571,600):
+    the LIVE oracle must reproduce the committed oracle-generated fixtures.  Integer
+    tensors exactly; float64 tensors to 1e-11 of the tensor maximum -- the result of a
+    float64 matmul may differ in the last bits between BLAS builds / CPU types, while any
+    edit of the restated arithmetic moves results by many orders more.  An intended oracle
+    change regenerates the fixtures with tests/golden/make_oracle_g5.py.'''
+    from oracle import g5
+    fix = dict(np.load(os.path.join(os.path.dirname(__file__), 'golden', 'oracle_g5_%s.npz' % name)))
+    assert 'NOT produced by the reference' in str(fix.pop('_label'))
+    live = g5.case_outputs(name)
+    errs = g5.compare(fix, live, 1e-11)
+    need = {'embed', 'attrs', 'masks', 'asets', 'subset_choice', 'output', 'loss', 'SNR',
+            'perm_idx'}
+    have = {k.split('__')[0] for k in errs}
+    assert need <= have, need - have
+    assert any(k.startswith('grad:') for k in errs)
+    bad = {k: e for k, e in errs.items() if not e <= 1e-11}
+    assert not bad, bad

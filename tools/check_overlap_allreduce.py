@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-'''1-rank RCCL check of the gradient-reduction schedules (dist.py): after 3 train steps the
-parameters of 'tail' (default: everything but the bottom layer reduced under the bottom
+'''1-rank RCCL check of the gradient-reduction schedules (dist.py): after N train steps (argv[1], default 3) the
+parameters of 'tail' (opt-in: everything but the bottom layer reduced under the bottom
 layer's weight-gradient GEMMs) and '1' (per-layer buckets) must be bit-identical to '0' (one
 all-reduce after backward), and the expected number of asynchronous pieces must have been
 launched from the gradient-ready hooks.  (A 1-rank all-reduce is an identity, so the STREAM
@@ -25,23 +25,26 @@ torch.distributed.init_process_group('nccl', device_id=dev)
 class A: batch = 32; layers = 3; hdim = 300; frames = 128
 hp = bench.setup_hparams(A, bench.CONFIGS['cfg2'])
 batches = bench.make_batches(hp, 0, 2, dev)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 res = {}
 for mode in ('0', 'tail', '1'):
-    os.environ['DANET_OVERLAP_ALLREDUCE'] = mode
-    m = Model('o' + mode, device=dev, seed=5).build()
+    m = Model('o' + mode, device=dev, seed=5, grad_schedule=mode).build()
     assert (m._buckets is not None) == (mode != '0')
-    for k in range(3):
+    assert m.collectives_per_step() == {'0': 1, 'tail': 2, '1': 5}[mode]
+    for k in range(N):
         m.train_step(batches[k % 2])
     torch.cuda.synchronize()
     if m._buckets is not None:
-        print('mode', mode, 'asynchronous pieces launched from hooks in 3 steps:', m._buckets.launched)
-        assert m._buckets.launched == (3 if mode == 'tail' else 3 * 4), m._buckets.launched
+        print('mode', mode, 'asynchronous pieces launched from hooks in %d steps:' % N, m._buckets.launched)
+        assert m._buckets.launched == (N if mode == 'tail' else N * 4), m._buckets.launched
+    # the early optimizer piece runs behind the tail all-reduce only in the 'tail' schedule
+    assert m.early_steps == (N if mode == 'tail' else 0), (mode, m.early_steps)
     res[mode] = m.param_dict()
     del m
 assert ops.lstm_status_ok()
 for mode in ('tail', '1'):
     worst = max(np.abs(res['0'][k] - res[mode][k]).max() for k in res['0'])
-    print('max |param diff| %s vs single all-reduce after 3 steps:' % mode, worst)
+    print('max |param diff| %s vs single all-reduce after %d steps:' % (mode, N), worst)
     assert worst == 0.0
 torch.distributed.destroy_process_group()
 print('OK')
