@@ -498,7 +498,7 @@ def run_train(args, cfg, hp, device, rank, world, use_dist):
     # kernel symbol behind the label (csrc/lstm.hip)
     ksym = {'lstm_fwd': 'lstm_fwd_fx_kernel' if any(fwd_fused) else 'lstm_fwd_kernel',
             'lstm_bwd': 'lstm_bwd_rsw_kernel' if any(bwd_fused) else
-                        ('lstm_bwd_kernel' if os.environ.get('DANET_LSTM_BWD_RS') == '0'
+                        ('lstm_bwd_kernel' if _lib.get_option('lstm_bwd_rs') == 0
                          else 'lstm_bwd_rs_kernel')}[dom]
     traffic, tsrc = pmc_traffic(ksym)
     if tsrc is not None and tsrc.get('workload', 'cfg2') != args.config:

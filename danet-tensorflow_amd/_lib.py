@@ -28,6 +28,11 @@ class GemmProblem(ctypes.Structure):
 PROTOTYPES = {
     'danet_abi_version': (c_int, []),
     'danet_last_error': (ctypes.c_char_p, []),
+    'danet_set_option': (c_int, [ctypes.c_char_p, c_int]),
+    'danet_get_option': (c_int, [ctypes.c_char_p, ctypes.POINTER(c_int)]),
+    'danet_reset_options': (None, []),
+    'danet_option_count': (c_int, []),
+    'danet_option_name': (ctypes.c_char_p, [c_int]),
     'danet_stft_num_frames': (c_int, [c_i64, c_int, c_int]),
     'danet_stft': (c_int, [c_p, c_int, c_i64, c_int, c_int, c_p, c_p, c_p]),
     'danet_istft_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int]),
@@ -50,6 +55,9 @@ PROTOTYPES = {
                                        c_p, c_int, c_p, c_f32, c_p, c_sz]),
     'danet_gemm_f32_streamk_grouped': (c_int, [c_p, c_int, c_int, c_int, c_int,
                                                ctypes.POINTER(GemmProblem), c_int, c_p, c_sz]),
+    'danet_gemm_f32_streamk_kcat': (c_int, [c_p, c_int, c_int, c_int, c_int,
+                                            c_int, c_p, c_int, c_p, c_int, c_int, c_p, c_int, c_p, c_int,
+                                            c_p, c_int, c_p, c_f32, c_p, c_sz]),
     'danet_colsum_f32_workspace_bytes': (c_sz, [c_int, c_int]),
     'danet_colsum_f32': (c_int, [c_p, c_int, c_int, c_p, c_int, c_p, c_f32, c_p, c_sz]),
     'danet_lstm_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int]),
@@ -82,6 +90,11 @@ PROTOTYPES = {
     'danet_separate_bwd_workspace_bytes': (c_sz, [c_int, c_int, c_i64, c_int]),
     'danet_separate_bwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p, c_p,
                                    c_p, c_p, c_p, c_sz]),
+    'danet_separate_pit_workspace_bytes': (c_sz, [c_int, c_int, c_i64, c_int]),
+    'danet_separate_pit_fwd': (c_int, [c_p, c_int, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p,
+                                       c_p, c_p, c_f32, c_p, c_p, c_p, c_p, c_p, c_sz]),
+    'danet_separate_pit_bwd': (c_int, [c_p, c_int, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p,
+                                       c_p, c_p, c_p, c_f32, c_p, c_p, c_p, c_p, c_sz]),
     'danet_pit_mse_workspace_bytes': (c_sz, [c_int, c_int, c_i64]),
     'danet_pit_mse_fwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_p, c_p, c_p, c_f32, c_p,
                                   c_p, c_p, c_p, c_sz]),
@@ -119,10 +132,40 @@ def load():
             fn = getattr(lib, name)      # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.danet_abi_version() != 2:
+        if lib.danet_abi_version() != 3:
             raise DanetHipError('libdanet_hip.so ABI version mismatch')
         _lib = lib
+        apply_env_options()
     return _lib
+
+
+# ---- library options ---------------------------------------------------------
+# The C library never reads the environment (include/danet_hip.h); the DANET_* overrides of
+# its options live HERE: option `lstm_fwd_fused` <- env DANET_LSTM_FWD_FUSED, applied when the
+# library is loaded (and by apply_env_options(), which tests call to restore the defaults).
+def option_names():
+    lib = _lib
+    return [lib.danet_option_name(i).decode() for i in range(lib.danet_option_count())]
+
+
+def apply_env_options():
+    '''reset every option to its default, then apply DANET_<NAME> from the environment'''
+    lib = _lib
+    lib.danet_reset_options()
+    for name in option_names():
+        v = os.environ.get('DANET_' + name.upper())
+        if v is not None and v.strip() != '':
+            check(lib.danet_set_option(name.encode(), int(v)))
+
+
+def set_option(name, value):
+    check(load().danet_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    v = c_int(0)
+    check(load().danet_get_option(name.encode(), ctypes.byref(v)))
+    return v.value
 
 
 def check(rc):

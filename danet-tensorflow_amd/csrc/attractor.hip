@@ -11,11 +11,12 @@
 // assignment tensor (63 MB x2, app/modules.py:513-516): soft assignments for a
 // 128-bin tile are formed in LDS and contracted against the tile immediately.
 #include "common.h"
+#include "options.h"
+#include "pit_common.h"
 #include <stdlib.h>
 
 #define CHUNK_N 2048       // bins per workgroup (reduction granularity; 512 / 1024 measured: the
                            // backward kernels gain 4 us, the chunk sums lose as much)
-#define MAXC 4
 #define MAXA 8
 #define MAXP 70            // C(8,4)
 
@@ -330,11 +331,208 @@ __global__ void sum_chunks_kernel(int nch, int C, int E, int EP,
   const int b = blockIdx.x;
   for (int i = threadIdx.x; i < C * E; i += blockDim.x) {
     const int c = i / E, e = i % E;
-    float s = 0.f;
-    for (int ch = 0; ch < nch; ++ch)
-      s += partial[(((int64_t)b * nch + ch) * C + c) * EP + e];
-    out[((int64_t)b * C + c) * E + e] = s;
+    // 4 independent partial sums: the chunk loads are in flight together instead of one
+    // dependent load per add (fixed combination order: deterministic)
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* pp = partial + ((int64_t)b * nch * C + c) * EP + e;
+    int ch = 0;
+    for (; ch + 4 <= nch; ch += 4)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[u] += pp[(int64_t)(ch + u) * C * EP];
+    for (; ch < nch; ++ch) s[0] += pp[(int64_t)ch * C * EP];
+    out[((int64_t)b * C + c) * E + e] = (s[0] + s[1]) + (s[2] + s[3]);
   }
+}
+
+// =========================================================================
+// separator + PIT loss in one pass (training): app/modules.py:548-603 -> main.py:281-290,
+// 308-309 -> app/ops.py:374-431.  The masks, the separated magnitudes and (in backward) the
+// loss gradient w.r.t. them exist only in registers: logits -> softmax / sigmoid -> x |mix| ->
+// cross-error partials (forward); the same chain recomputed + dL/dsep -> dL/dlogit -> dembed
+// and dattr partials (backward).  `out` (separated magnitudes) is written only when asked for.
+// =========================================================================
+template <int EP, int CP>
+__device__ __forceinline__ void sep_masks(int act, const float (&x)[EP], const float (&st)[CP][EP],
+                                          float (&m)[CP]) {
+#pragma unroll
+  for (int c = 0; c < CP; ++c) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < EP; ++e) s += x[e] * st[c][e];          // modules.py:558-560
+    m[c] = s;
+  }
+  if (act == 0) {                                               // softmax, modules.py:595
+    float mx = m[0];
+#pragma unroll
+    for (int c = 1; c < CP; ++c) mx = fmaxf(mx, m[c]);
+    float den = 0.f;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) { m[c] = expf(m[c] - mx); den += m[c]; }
+#pragma unroll
+    for (int c = 0; c < CP; ++c) m[c] = m[c] / den;
+  } else {                                                      // sigmoid, modules.py:566
+#pragma unroll
+    for (int c = 0; c < CP; ++c) m[c] = sigmoid_acc(m[c]);
+  }
+}
+
+// the same with the attractor table read from LDS (broadcast reads): in the forward kernel the
+// scalar-register copy spills (CP*EP > ~40 SGPRs) and costs more than it saves
+template <int EP, int CP>
+__device__ __forceinline__ void sep_masks_lds(int act, const float (&x)[EP], const float* tab,
+                                              float (&m)[CP]) {
+#pragma unroll
+  for (int c = 0; c < CP; ++c) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < EP; ++e) s += x[e] * tab[c * EP + e];
+    m[c] = s;
+  }
+  if (act == 0) {
+    float mx = m[0];
+#pragma unroll
+    for (int c = 1; c < CP; ++c) mx = fmaxf(mx, m[c]);
+    float den = 0.f;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) { m[c] = expf(m[c] - mx); den += m[c]; }
+#pragma unroll
+    for (int c = 0; c < CP; ++c) m[c] = m[c] / den;
+  } else {
+#pragma unroll
+    for (int c = 0; c < CP; ++c) m[c] = sigmoid_acc(m[c]);
+  }
+}
+
+template <int EP, int CP>
+__global__ __launch_bounds__(256) void sep_pit_fwd_kernel(
+    int act, int mode, int64_t N, int E, const float* __restrict__ mix_pwr,
+    const float* __restrict__ attr, const float* __restrict__ embed,
+    const float2* __restrict__ src, const float2* __restrict__ phasor,
+    float* __restrict__ out /* optional [B][C][N] */, float* __restrict__ partial /* [B][nch][REC] */) {
+  constexpr int C = CP;
+  __shared__ float tab[CP * EP];
+  __shared__ float red[4 * REC];
+  const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  for (int i = threadIdx.x; i < C * EP; i += 256) {
+    const int c = i / EP, e = i % EP;
+    tab[i] = (e < E) ? attr[((int64_t)b * C + c) * E + e] : 0.f;
+  }
+  __syncthreads();
+  const int64_t n0 = (int64_t)ch * CHUNK_N, n1 = min(N, n0 + CHUNK_N);
+  const float* eb = embed + (int64_t)b * N * E;
+  float acc[REC];
+#pragma unroll
+  for (int i = 0; i < REC; ++i) acc[i] = 0.f;
+  for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
+    float x[EP];
+    load_row<EP>(eb + n * E, E, x);
+    const float mp = mix_pwr[(int64_t)b * N + n];
+    const float2 ph = phasor[(int64_t)b * N + n];
+    float2 s[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) s[c] = src[((int64_t)b * C + c) * N + n];
+    float m[CP], p[CP];
+    sep_masks_lds<EP, CP>(act, x, tab, m);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      p[c] = mp * m[c];                                          // modules.py:567-574
+      if (out) out[((int64_t)b * C + c) * N + n] = p[c];
+    }
+    pit_accumulate<C>(mode, s, p, ph, acc);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < REC; ++i) {
+    const float v = wave_sum(acc[i]);
+    if (lane == 0) red[wave * REC + i] = v;
+  }
+  __syncthreads();
+  float* po = partial + ((int64_t)b * nch + ch) * REC;
+  for (int i = threadIdx.x; i < REC; i += 256)
+    po[i] = red[i] + red[REC + i] + red[2 * REC + i] + red[3 * REC + i];
+}
+
+template <int EP, int CP>
+__global__ __launch_bounds__(256) void sep_pit_bwd_kernel(
+    int act, int mode, int B, int64_t N, int E, const float* __restrict__ mix_pwr,
+    const float* __restrict__ attr, const float* __restrict__ embed,
+    const float2* __restrict__ src, const float2* __restrict__ phasor,
+    const int32_t* __restrict__ perm_idx, float dloss, const float* __restrict__ dloss_dev,
+    float* __restrict__ dembed, float* __restrict__ partial /* [B][nch][C][EP] */) {
+  constexpr int C = CP;
+  __shared__ float tab[CP * EP];
+  __shared__ float red[4 * EP];
+  const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  for (int i = threadIdx.x; i < C * EP; i += 256) {
+    const int c = i / EP, e = i % EP;
+    tab[i] = (e < E) ? attr[((int64_t)b * C + c) * E + e] : 0.f;
+  }
+  __syncthreads();
+  float st[CP][EP];
+#pragma unroll
+  for (int c = 0; c < CP; ++c)
+#pragma unroll
+    for (int e = 0; e < EP; ++e) st[c][e] = uniform(tab[c * EP + e]);
+  int perm[MAXC], inv[MAXC];
+  nth_perm(C, perm_idx[b], perm);
+  for (int i = 0; i < C; ++i) inv[perm[i]] = i;   // estimate j is paired with truth inv[j]
+  const float scale = dloss * (dloss_dev ? *dloss_dev : 1.f) * 2.f / ((float)B * (float)N);
+  const int64_t n0 = (int64_t)ch * CHUNK_N, n1 = min(N, n0 + CHUNK_N);
+  const float* eb = embed + (int64_t)b * N * E;
+  float* db = dembed + (int64_t)b * N * E;
+  float accs[CP][EP];
+#pragma unroll
+  for (int c = 0; c < CP; ++c)
+#pragma unroll
+    for (int e = 0; e < EP; ++e) accs[c][e] = 0.f;
+  for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
+    float x[EP];
+    load_row<EP>(eb + n * E, E, x);
+    const float mp = mix_pwr[(int64_t)b * N + n];
+    const float2 ph = phasor[(int64_t)b * N + n];
+    float2 s[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) s[c] = src[((int64_t)b * C + c) * N + n];
+    float m[CP], dl[CP];
+    sep_masks<EP, CP>(act, x, st, m);
+    // dL/dsep (ops.py:412-430 differentiated; the estimate j is compared with truth inv[j])
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      float2 t = s[0];
+#pragma unroll
+      for (int q = 1; q < C; ++q) t = (inv[j] == q) ? s[q] : t;
+      const float p = mp * m[j];
+      float g;
+      if (mode == 1) g = p - hypotf(t.x, t.y);
+      else g = p * (ph.x * ph.x + ph.y * ph.y) - (ph.x * t.x + ph.y * t.y);
+      dl[j] = (scale * g) * mp;                                  // dL/dmask
+    }
+    if (act == 0) {
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) dot += m[c] * dl[c];
+#pragma unroll
+      for (int c = 0; c < C; ++c) dl[c] = m[c] * (dl[c] - dot);
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c) dl[c] = dl[c] * m[c] * (1.f - m[c]);
+    }
+    float dx[EP];
+#pragma unroll
+    for (int e = 0; e < EP; ++e) dx[e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+      for (int e = 0; e < EP; ++e) {
+        dx[e] += dl[c] * st[c][e];
+        accs[c][e] += dl[c] * x[e];
+      }
+    }
+    store_row<EP>(db + n * E, E, dx);
+  }
+  float* po = partial + ((int64_t)b * nch + ch) * C * EP;
+#pragma unroll
+  for (int c = 0; c < CP; ++c) block_reduce_store<EP>(accs[c], EP, red, po + c * EP);
 }
 
 // =========================================================================
@@ -735,34 +933,44 @@ __global__ __launch_bounds__(256) void anchor_bwd_final_kernel(
     int B, int C, int E, int EP, int A, int nch, AnchorCombos cb,
     const float* __restrict__ partial, const int32_t* __restrict__ choice,
     float* __restrict__ danchors, float beta) {
-  // one block per anchor; thread = (e, 1 of 4 utterance lanes); fixed summation
-  // order => deterministic scatter over utterances
-  __shared__ float red[4][64];
+  // one block per anchor.  Phase 1: the (utterance, e) pairs of a tile of 64 utterances are
+  // spread over all 256 threads (each sums the chunk partials of its pair with the loads in
+  // flight together); phase 2: thread e adds the tile's utterances in ascending order --
+  // fixed summation order => deterministic scatter over utterances.  (One thread per e walking
+  // 8 utterances serially, each behind a dependent `choice` load, took 12.7 us at cfg 2.)
+  __shared__ float vals[64][65];
   const int a = blockIdx.x;
-  const int e = threadIdx.x & 63, bl = threadIdx.x >> 6;
-  float s = 0.f;
-  if (e < E) {
-    for (int b = bl; b < B; b += 4) {
-      const int p = choice[b];
-      for (int c = 0; c < C; ++c) {
-        if (cb.idx[p][c] != a) continue;
-        float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // loads in flight together
-        const float* pp = partial + ((int64_t)b * nch * C + c) * EP + e;
-        int ch = 0;
-        for (; ch + 8 <= nch; ch += 8)
+  float acc = 0.f;
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    for (int idx = threadIdx.x; idx < 64 * E; idx += 256) {
+      const int bb = idx / E, e = idx % E, b = b0 + bb;
+      float v = 0.f;
+      if (b < B) {
+        const int p = choice[b];
+        for (int c = 0; c < C; ++c) {
+          if (cb.idx[p][c] != a) continue;
+          float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // loads in flight together
+          const float* pp = partial + ((int64_t)b * nch * C + c) * EP + e;
+          int ch = 0;
+          for (; ch + 8 <= nch; ch += 8)
 #pragma unroll
-          for (int u = 0; u < 8; ++u) t[u] += pp[(int64_t)(ch + u) * C * EP];
-        for (; ch < nch; ++ch) t[0] += pp[(int64_t)ch * C * EP];
-        s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+            for (int u = 0; u < 8; ++u) t[u] += pp[(int64_t)(ch + u) * C * EP];
+          for (; ch < nch; ++ch) t[0] += pp[(int64_t)ch * C * EP];
+          v += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        }
       }
+      vals[bb][e] = v;
     }
+    __syncthreads();
+    if ((int)threadIdx.x < E) {
+      const int nb = min(64, B - b0);
+      for (int bb = 0; bb < nb; ++bb) acc += vals[bb][threadIdx.x];
+    }
+    __syncthreads();
   }
-  red[bl][e] = s;
-  __syncthreads();
-  if (bl == 0 && e < E) {
-    float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-    if (beta != 0.f) v += danchors[a * E + e];
-    danchors[a * E + e] = v;
+  if ((int)threadIdx.x < E) {
+    const int e = threadIdx.x;
+    danchors[a * E + e] = (beta != 0.f) ? danchors[a * E + e] + acc : acc;
   }
 }
 
@@ -905,6 +1113,66 @@ extern "C" int danet_separate_bwd(danet_stream_t stream_, int act, int B, int C,
   return DANET_OK;
 }
 
+extern "C" size_t danet_separate_pit_workspace_bytes(int B, int C, int64_t N, int E) {
+  const size_t fwd = (size_t)B * n_chunks(N) * REC * sizeof(float);
+  const size_t bwd = (size_t)B * n_chunks(N) * C * pick_ep(E) * sizeof(float);
+  return fwd > bwd ? fwd : bwd;
+}
+
+extern "C" int danet_separate_pit_fwd(danet_stream_t stream_, int act, int mode, int B, int C,
+                                      int64_t N, int E, const float* mix_pwr, const float* attr,
+                                      const float* embed, const float* src_c64,
+                                      const float* phasor, float eps, float* sep_pwr_out,
+                                      float* loss, float* snr, int32_t* perm_idx, void* ws,
+                                      size_t ws_bytes) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_common("separate_pit_fwd", B, C, N, E);
+  if (rc) return rc;
+  DANET_CHECK_ARG((act == 0 || act == 1) && (mode == 0 || mode == 1), "separate_pit_fwd: act / mode");
+  DANET_CHECK_ARG(mix_pwr && attr && embed && src_c64 && phasor && loss && perm_idx,
+                  "separate_pit_fwd: null pointer");
+  if (!ws || ws_bytes < danet_separate_pit_workspace_bytes(B, C, N, E)) {
+    danet_set_error("separate_pit_fwd: workspace too small");
+    return DANET_ERR_WORKSPACE;
+  }
+  const int nch = n_chunks(N), EPV = pick_ep(E);
+  dim3 grid(nch, B);
+  DISPATCH_EP(EPV, DISPATCH_CP(C, (sep_pit_fwd_kernel<EP, CP><<<grid, 256, 0, stream>>>(
+                       act, mode, N, E, mix_pwr, attr, embed, (const float2*)src_c64,
+                       (const float2*)phasor, sep_pwr_out, (float*)ws))));
+  DANET_CHECK_LAUNCH();
+  pit_final_kernel<<<1, PIT_FINAL_THREADS, 0, stream>>>(B, C, N, nch, eps, (const float*)ws, loss, snr, perm_idx);
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
+
+extern "C" int danet_separate_pit_bwd(danet_stream_t stream_, int act, int mode, int B, int C,
+                                      int64_t N, int E, const float* mix_pwr, const float* attr,
+                                      const float* embed, const float* src_c64,
+                                      const float* phasor, const int32_t* perm_idx, float dloss,
+                                      const float* dloss_dev, float* dembed, float* dattr,
+                                      void* ws, size_t ws_bytes) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_common("separate_pit_bwd", B, C, N, E);
+  if (rc) return rc;
+  DANET_CHECK_ARG((act == 0 || act == 1) && (mode == 0 || mode == 1), "separate_pit_bwd: act / mode");
+  DANET_CHECK_ARG(mix_pwr && attr && embed && src_c64 && phasor && perm_idx && dembed && dattr,
+                  "separate_pit_bwd: null pointer");
+  if (!ws || ws_bytes < danet_separate_pit_workspace_bytes(B, C, N, E)) {
+    danet_set_error("separate_pit_bwd: workspace too small");
+    return DANET_ERR_WORKSPACE;
+  }
+  const int nch = n_chunks(N), EPV = pick_ep(E);
+  dim3 grid(nch, B);
+  DISPATCH_EP(EPV, DISPATCH_CP(C, (sep_pit_bwd_kernel<EP, CP><<<grid, 256, 0, stream>>>(
+                       act, mode, B, N, E, mix_pwr, attr, embed, (const float2*)src_c64,
+                       (const float2*)phasor, perm_idx, dloss, dloss_dev, dembed, (float*)ws))));
+  DANET_CHECK_LAUNCH();
+  sum_chunks_kernel<<<B, 128, 0, stream>>>(nch, C, E, EPV, (const float*)ws, dattr);
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
+
 static int anchor_check(const char* who, int B, int C, int64_t N, int E, int A) {
   int rc = check_common(who, B, C, N, E);
   if (rc) return rc;
@@ -951,7 +1219,7 @@ extern "C" int danet_attractor_anchor_fwd(danet_stream_t stream_, int B, int C, 
   const int nch = n_chunks_anchor_fwd(N);
   // the [PC][EPA] contraction runs on the matrix cores when it fits 2 x 2 tiles of 32 x 32
   int RT = 0, CT = 0;
-  if (PC <= 64 && EPA <= 64 && !getenv("DANET_ANCHOR_SCALAR")) { RT = cdiv(PC, 32); CT = cdiv(EPA, 32); }
+  if (PC <= 64 && EPA <= 64 && danet_opt(OPT_ANCHOR_SCALAR) == 0) { RT = cdiv(PC, 32); CT = cdiv(EPA, 32); }
   size_t lds = ((size_t)ANCH_TN * EPA + (size_t)ANCH_TN * (PC + 1) + (size_t)A * EPV + 64) * sizeof(float);
   const size_t lds_red = (size_t)4 * RT * 32 * CT * 32 * sizeof(float);
   if (lds_red > lds) lds = lds_red;

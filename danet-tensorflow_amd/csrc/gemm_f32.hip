@@ -11,6 +11,8 @@
 // itself between the MFMAs of consecutive k-tiles).  Small-output / long-K products (weight gradients) use a
 // deterministic split-K: per-slice slabs in `ws`, summed by a second kernel.
 #include "common.h"
+#include "options.h"
+#include <atomic>
 #include <stdlib.h>
 
 #define BM 128
@@ -485,10 +487,9 @@ static void gemm_allow_lds(KernelT k) {
   F_((K_<false, true, false>)); F_((K_<true, false, true>)); F_((K_<true, true, true>));    \
   F_((K_<false, false, true>)); F_((K_<false, true, true>))
 static void gemm_init_once() {
-  static bool done = false;
-  if (done) return;
-  done = true;
-  GEMM_FOR_ALL_VARIANTS(gemm_f32_kernel, gemm_allow_lds);
+  // function-local static: initialised exactly once, thread-safe (C++11)
+  static const bool done = [] { GEMM_FOR_ALL_VARIANTS(gemm_f32_kernel, gemm_allow_lds); return true; }();
+  (void)done;
 }
 
 // DMA staging (gemm_kloop_dma) needs 16-byte aligned operands with ld % 4 == 0, and K % 4 == 0
@@ -498,10 +499,7 @@ static void gemm_init_once() {
 // Default 3: beside a BPTT kernel the DMA group is 12 % faster but costs that kernel more than
 // it saves (cfg 2: BPTT 450 -> 478 us per launch, 3.37 -> 3.50 ms per step).  Read per launch
 // (tests flip it).
-static bool dma_env(int bit) {
-  const char* e = getenv("DANET_GEMM_DMA");
-  return ((e ? atoi(e) : 3) & bit) != 0;
-}
+static bool dma_env(int bit) { return (danet_opt(OPT_GEMM_DMA) & bit) != 0; }
 static bool dma_operand_ok(const float* p, int ld, bool kcontig, int K) {
   return (((uintptr_t)p & 15) == 0) && (ld % 4 == 0) && (!kcontig || K % 4 == 0);
 }
@@ -512,8 +510,7 @@ static int choose_splitk(int M, int N, int K) {
   // Fill the 256 CUs ~twice over: 160-tile products (dX, dYc: N = 600) gain 1.4-1.9x
   // from 4 slices; the cost is one M*N slab write + read per slice in the reduce
   // kernel, so the slice count is capped (it was 8% of the train step at s = 18).
-  static int target = 0;
-  if (!target) { const char* e = getenv("DANET_SPLITK_TARGET"); target = e ? atoi(e) : 512; }
+  const int target = danet_opt(OPT_SPLITK_TARGET) > 0 ? danet_opt(OPT_SPLITK_TARGET) : 512;
   int s = cdiv(target, tiles);
   const int maxs = K / 256;
   if (s > maxs) s = maxs;
@@ -670,6 +667,8 @@ extern "C" int danet_gemm_f32_kcat(danet_stream_t stream_, int transA, int trans
 #define SK_MAX_PROBLEMS 6
 struct SkProblem {
   const float* A; const float* B; float* C; const float* bias;
+  const float* A2; const float* B2;   // optional second operand pair (K-concatenated product)
+  int lda2, ldb2;
   int M, N, lda, ldb, ldc;
   int tiles_n;     // N tiles of this problem
   int tile0;       // first global tile index of this problem
@@ -678,6 +677,8 @@ struct SkProblem {
 struct SkArgs {
   SkProblem p[SK_MAX_PROBLEMS];   // a group shares K and the transpose flags
   int nprob, K, nk, tiles;        // nk = k-iterations (of BK) per tile; tiles = total
+  int K2, nk1;                    // K-concatenated products: k-iterations [0, nk1) take pair 1 (K),
+                                  // [nk1, nk) pair 2 (K2); nk1 == nk without a second pair
   float* slab;          // [G][16][256][4] partial accumulators
   unsigned* flags;      // [G] launch sequence number when slab[w] is valid
   unsigned seq;
@@ -697,19 +698,39 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(SkArgs sk) {
   const int band = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int tiles = sk.tiles;
   const int tb0 = (int)((int64_t)tiles * band / 8), tb1 = (int)((int64_t)tiles * (band + 1) / 8);
-  const int64_t I = (int64_t)(tb1 - tb0) * sk.nk;   // (tile, k-iteration) items of the band
+  // HYBRID schedule: every workgroup of the band first owns F = floor(band tiles / G8) WHOLE
+  // tiles (data-parallel: nothing is cut, nothing to fix up); only the R = band tiles - F * G8
+  // tiles of the ragged last round are cut stream-K style into G8 equal (tile, k-iteration)
+  // ranges.  With fewer tiles than workgroups (weight-gradient groups) F = 0 and the launch is
+  // pure stream-K as before; with a multiple of G8 tiles nothing is cut at all.
+  const int F = (tb1 - tb0) / G8;
+  const int rb0 = tb0 + F * G8;                    // first remainder tile of the band
+  const int64_t I = (int64_t)(tb1 - rb0) * sk.nk;  // (tile, k-iteration) items of the remainder
   const int64_t lo = I * j / G8, hi = I * (j + 1) / G8;
 
   const unsigned slab_bytes = gridDim.x * 65536u;
   const __amdgpu_buffer_rsrc_t sres =
       __builtin_amdgcn_make_buffer_rsrc(sk.slab, 0, (int)slab_bytes, 0x00020000);
 
+  // phase 0: the remainder range, walked from its END backwards (what is owed to a higher-
+  // numbered owner first, the own cut tile last); phases 1..F: the whole tiles
   int64_t it = hi;
-  while (it > lo) {
-    const int tl = (int)((it - 1) / sk.nk);              // band-local tile
-    const int64_t tbase = (int64_t)tl * sk.nk;
-    const int kb = (int)((lo > tbase ? lo : tbase) - tbase), ke = (int)(it - tbase);
-    const int tile = tb0 + tl;
+  int fdone = 0;
+  for (;;) {
+    int tile, kb, ke;
+    int64_t tbase = 0;
+    const bool rem = it > lo;
+    if (rem) {
+      const int tl = (int)((it - 1) / sk.nk);              // remainder-local tile
+      tbase = (int64_t)tl * sk.nk;
+      kb = (int)((lo > tbase ? lo : tbase) - tbase); ke = (int)(it - tbase);
+      tile = rb0 + tl;
+    } else {
+      if (fdone >= F) break;
+      tile = tb0 + j * F + fdone;
+      kb = 0; ke = sk.nk;
+      ++fdone;
+    }
     int pi = sk.nprob - 1;
     while (pi > 0 && tile < sk.p[pi].tile0) --pi;
     const SkProblem& pr = sk.p[pi];
@@ -731,10 +752,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(SkArgs sk) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
-    if (DMA) gemm_kloop_dma<A_KCONTIG, B_KCONTIG>(g.A, g.lda, g.B, g.ldb, g.M, g.N, m0, n0,
-                                                  kb * BK, min(g.K, ke * BK), smem, acc, sk.yield);
-    else gemm_kloop<A_KCONTIG, B_KCONTIG>(g.A, g.lda, g.B, g.ldb, g.M, g.N, m0, n0,
-                                          kb * BK, min(g.K, ke * BK), smem, acc, sk.yield);
+    if (kb < sk.nk1) {       // the part of the segment inside the first operand pair
+      const int ke1 = ke < sk.nk1 ? ke : sk.nk1;
+      if (DMA) gemm_kloop_dma<A_KCONTIG, B_KCONTIG>(g.A, g.lda, g.B, g.ldb, g.M, g.N, m0, n0,
+                                                    kb * BK, min(g.K, ke1 * BK), smem, acc, sk.yield);
+      else gemm_kloop<A_KCONTIG, B_KCONTIG>(g.A, g.lda, g.B, g.ldb, g.M, g.N, m0, n0,
+                                            kb * BK, min(g.K, ke1 * BK), smem, acc, sk.yield);
+    }
+    if (ke > sk.nk1) {       // ... and inside the second (same accumulators)
+      const int kb2 = (kb > sk.nk1 ? kb : sk.nk1) - sk.nk1, ke2 = ke - sk.nk1;
+      if (DMA) gemm_kloop_dma<A_KCONTIG, B_KCONTIG>(pr.A2, pr.lda2, pr.B2, pr.ldb2, g.M, g.N, m0, n0,
+                                                    kb2 * BK, min(sk.K2, ke2 * BK), smem, acc, sk.yield);
+      else gemm_kloop<A_KCONTIG, B_KCONTIG>(pr.A2, pr.lda2, pr.B2, pr.ldb2, g.M, g.N, m0, n0,
+                                            kb2 * BK, min(sk.K2, ke2 * BK), smem, acc, sk.yield);
+    }
 
     if (ke < sk.nk) {
       // contributor: the tile's later k-segments belong to higher workgroups
@@ -792,7 +823,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(SkArgs sk) {
       }
       store_tile(acc, smem, g.C, g.ldc, m0, n0, g.M, g.N, g.bias, g.beta);
     }
-    it = tbase + kb;
+    if (rem) it = tbase + kb;
   }
 }
 
@@ -802,16 +833,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(SkArgs sk) {
 //   - otherwise at most DANET_GEMM_MAXSPLIT (8) workgroups share a tile, so the owner's
 //     serial fix-up stays short; few-tile / long-K products (weight gradients) then run
 //     on fewer, longer workgroups -- they are overlapped with other kernels anyway.
-static int sk_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static int sk_grid(int tiles, int nk, int max_workgroups) {
-  static int gmax = 0, maxsplit = 0;
-  if (!gmax) {
-    gmax = sk_env("DANET_GEMM_WGS", 512) & ~7;
-    if (gmax < 8) gmax = 8;
-    if (gmax > 1024) gmax = 1024;
-    maxsplit = sk_env("DANET_GEMM_MAXSPLIT", 8);
-    if (maxsplit < 1) maxsplit = 1;
-  }
+  int gmax = danet_opt(OPT_GEMM_WGS) & ~7;
+  if (gmax < 8) gmax = 8;
+  if (gmax > 1024) gmax = 1024;
+  int maxsplit = danet_opt(OPT_GEMM_MAXSPLIT);
+  if (maxsplit < 1) maxsplit = 1;
   int lim = gmax;
   if (max_workgroups > 0 && max_workgroups < lim) lim = max_workgroups & ~7;
   if (lim < 8) lim = 8;
@@ -829,19 +856,22 @@ extern "C" size_t danet_gemm_f32_streamk_workspace_bytes(int M, int N, int K) {
   return SK_HEADER + (size_t)SK_MAX_GRID * 65536;   // flags + one partial tile per workgroup
 }
 
-extern "C" int danet_gemm_f32_streamk_grouped(danet_stream_t stream_, int transA, int transB,
-                                              int K, int nprob, const danet_gemm_problem_t* probs,
-                                              int max_workgroups, void* ws, size_t ws_bytes) {
-  static unsigned launch_seq = 0x5eed0000u;   // flag value of the next launch
-  static bool lds_ok = false;
-  if (!lds_ok) {
-    lds_ok = true;
-    GEMM_FOR_ALL_VARIANTS(gemm_f32_sk_kernel, gemm_allow_lds);
-  }
+// second: optional per-problem second operand pairs {A2, lda2, B2, ldb2} contracted over K2
+struct SkSecond { const float* A2; int lda2; const float* B2; int ldb2; };
+static int sk_launch(danet_stream_t stream_, int transA, int transB, int K, int K2, int nprob,
+                     const danet_gemm_problem_t* probs, const SkSecond* second,
+                     int max_workgroups, void* ws, size_t ws_bytes) {
+  // flag value of the next launch: process-wide, atomically incremented, so launches from any
+  // number of host threads get distinct values (a workspace only ever holds earlier ones)
+  static std::atomic<unsigned> launch_seq{0x5eed0000u};
+  static const bool lds_ok = [] { GEMM_FOR_ALL_VARIANTS(gemm_f32_sk_kernel, gemm_allow_lds); return true; }();
+  (void)lds_ok;
   hipStream_t stream = (hipStream_t)stream_;
   DANET_CHECK_ARG(probs && nprob >= 1 && nprob <= SK_MAX_PROBLEMS, "gemm group: 1..%d problems",
                   SK_MAX_PROBLEMS);
-  DANET_CHECK_ARG(K > 0, "gemm: non-positive K %d", K);
+  DANET_CHECK_ARG(K > 0 && K2 >= 0, "gemm: non-positive K %d", K);
+  DANET_CHECK_ARG(K2 == 0 || (second && K % BK == 0),
+                  "gemm: a K-concatenated stream-K product needs K1 %% %d == 0", BK);
   SkArgs sk;
   int tiles = 0;
   for (int i = 0; i < nprob; ++i) {
@@ -857,12 +887,23 @@ extern "C" int danet_gemm_f32_streamk_grouped(danet_stream_t stream_, int transA
     SkProblem& p = sk.p[i];
     p.A = q.A; p.B = q.B; p.C = q.C; p.bias = q.bias;
     p.M = q.M; p.N = q.N; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.beta = q.beta;
+    p.A2 = nullptr; p.B2 = nullptr; p.lda2 = p.ldb2 = 0;
+    if (K2 > 0) {
+      const SkSecond& e = second[i];
+      DANET_CHECK_ARG(e.A2 && e.B2 && e.lda2 >= (transA ? q.M : K2) && e.ldb2 >= (transB ? K2 : q.N),
+                      "gemm: bad second operand pair");
+      DANET_CHECK_ARG(operand_fits(transA ? K2 : q.M, transA ? q.M : K2, e.lda2) &&
+                      operand_fits(transB ? q.N : K2, transB ? K2 : q.N, e.ldb2),
+                      "gemm: an operand spans 2 GiB or more");
+      p.A2 = e.A2; p.B2 = e.B2; p.lda2 = e.lda2; p.ldb2 = e.ldb2;
+    }
     p.tiles_n = cdiv(q.N, BN);
     p.tile0 = tiles;
     tiles += cdiv(q.M, BM) * p.tiles_n;
   }
   for (int i = nprob; i < SK_MAX_PROBLEMS; ++i) sk.p[i] = sk.p[0];
-  sk.nprob = nprob; sk.K = K; sk.nk = cdiv(K, BK); sk.tiles = tiles;
+  sk.nprob = nprob; sk.K = K; sk.K2 = K2; sk.nk1 = cdiv(K, BK); sk.nk = sk.nk1 + cdiv(K2, BK);
+  sk.tiles = tiles;
   const int gsz = sk_grid(tiles, sk.nk, max_workgroups);
   const size_t need = SK_HEADER + (size_t)gsz * 65536;
   if (!ws || ws_bytes < need || ((uintptr_t)ws & 15) != 0) {
@@ -871,18 +912,22 @@ extern "C" int danet_gemm_f32_streamk_grouped(danet_stream_t stream_, int transA
   }
   sk.flags = (unsigned*)ws;
   sk.slab = (float*)((char*)ws + SK_HEADER);
-  sk.seq = __atomic_add_fetch(&launch_seq, 1u, __ATOMIC_RELAXED);
+  sk.seq = launch_seq.fetch_add(1u, std::memory_order_relaxed) + 1u;
   // DANET_GEMM_YIELD=n: capped (overlapped) group launches sleep n*64 clocks after every k-tile.
   // The recurrent kernel beside such a group slows down with the group's MFMA duty
   // (tools/contention_probe.py: +58 us per BPTT launch beside a 60 % burner, starvation beside a
   // 100 % one) and the group has slack: it only has to finish before that kernel does.  Measured
   // at cfg 2: 0 -> 3.338, 8 -> 3.335, 16 -> 3.316, 24 -> 3.319, 32 -> 3.323, 48 -> 3.335 ms per step.
-  sk.yield = (max_workgroups > 0 && max_workgroups <= 256) ? sk_env("DANET_GEMM_YIELD", 16) : 0;
+  sk.yield = (max_workgroups > 0 && max_workgroups <= 256) ? danet_opt(OPT_GEMM_YIELD) : 0;
   dim3 grid(gsz, 1, 1), block(256);
   const bool ak = !transA, bk = (transB != 0);
   bool dma = dma_env((max_workgroups > 0 && max_workgroups <= 256) ? 4 : 2);
-  for (int i = 0; i < nprob; ++i)
+  for (int i = 0; i < nprob; ++i) {
     dma = dma && dma_operand_ok(probs[i].A, probs[i].lda, ak, K) && dma_operand_ok(probs[i].B, probs[i].ldb, bk, K);
+    if (K2 > 0)
+      dma = dma && dma_operand_ok(second[i].A2, second[i].lda2, ak, K2) &&
+            dma_operand_ok(second[i].B2, second[i].ldb2, bk, K2);
+  }
 #define SK_LAUNCH(D_)                                                                              \
   do {                                                                                             \
     if (ak && !bk) gemm_f32_sk_kernel<true, false, D_><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);        \
@@ -894,6 +939,30 @@ extern "C" int danet_gemm_f32_streamk_grouped(danet_stream_t stream_, int transA
 #undef SK_LAUNCH
   DANET_CHECK_LAUNCH();
   return DANET_OK;
+}
+
+extern "C" int danet_gemm_f32_streamk_grouped(danet_stream_t stream_, int transA, int transB,
+                                              int K, int nprob, const danet_gemm_problem_t* probs,
+                                              int max_workgroups, void* ws, size_t ws_bytes) {
+  return sk_launch(stream_, transA, transB, K, 0, nprob, probs, nullptr, max_workgroups, ws, ws_bytes);
+}
+
+// C = op(A1) op(B1) + op(A2) op(B2) (+bias) (+beta C) on the hybrid stream-K schedule: the two
+// operand pairs are one K-concatenated contraction (k-iterations of pair 1, then of pair 2,
+// continuing the same accumulators), so there are no per-pair slabs and no reduce kernel.
+// K1 must be a multiple of 16.  Workspace: danet_gemm_f32_streamk_workspace_bytes.
+extern "C" int danet_gemm_f32_streamk_kcat(danet_stream_t stream_, int transA, int transB, int M, int N,
+                                           int K1, const float* A1, int lda1, const float* B1, int ldb1,
+                                           int K2, const float* A2, int lda2, const float* B2, int ldb2,
+                                           float* C, int ldc, const float* bias, float beta,
+                                           void* ws, size_t ws_bytes) {
+  DANET_CHECK_ARG(K2 > 0, "gemm_streamk_kcat: K2 must be positive");
+  danet_gemm_problem_t q;
+  q.A = A1; q.lda = lda1; q.B = B1; q.ldb = ldb1; q.C = C; q.ldc = ldc; q.M = M; q.N = N;
+  q.bias = bias; q.beta = beta;
+  SkSecond e;
+  e.A2 = A2; e.lda2 = lda2; e.B2 = B2; e.ldb2 = ldb2;
+  return sk_launch(stream_, transA, transB, K1, K2, 1, &q, &e, 0, ws, ws_bytes);
 }
 
 extern "C" int danet_gemm_f32_streamk(danet_stream_t stream_, int transA, int transB,

@@ -9,15 +9,12 @@
 // is fused: the complex estimate phasor*sep_pwr is never written to HBM here.
 #include "common.h"
 
-#define MAXC 4
+#include "pit_common.h"
 #define LOSS_CHUNK 4096
 
 __host__ __device__ static inline int loss_chunks(int64_t N) {
   return (int)((N + LOSS_CHUNK - 1) / LOSS_CHUNK);
 }
-
-// per-chunk record: crossL[C*C] | crossS[C*C] | sig  (padded to 2*16+1)
-#define REC 33
 
 template <int CP>
 __global__ __launch_bounds__(256) void pit_cross_kernel(
@@ -38,24 +35,8 @@ __global__ __launch_bounds__(256) void pit_cross_kernel(
     for (int c = 0; c < C; ++c) {
       s[c] = src[((int64_t)b * C + c) * N + n];
       p[c] = sep_pwr[((int64_t)b * C + c) * N + n];
-      acc[32] += s[c].x * s[c].x + s[c].y * s[c].y;          // |src|^2 (ops.py:209,213)
     }
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-      const float mag = (mode == 1) ? hypotf(s[i].x, s[i].y) : 0.f;
-#pragma unroll
-      for (int j = 0; j < C; ++j) {
-        const float dr = s[i].x - ph.x * p[j], di = s[i].y - ph.y * p[j];
-        const float cs = dr * dr + di * di;                  // ops.py:415-418
-        acc[16 + i * C + j] += cs;
-        if (mode == 1) {
-          const float d = mag - p[j];                        // ops.py:420-421
-          acc[i * C + j] += d * d;
-        } else {
-          acc[i * C + j] += cs;
-        }
-      }
-    }
+    pit_accumulate<C>(mode, s, p, ph, acc);
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -67,61 +48,6 @@ __global__ __launch_bounds__(256) void pit_cross_kernel(
   float* out = partial + ((int64_t)b * nch + ch) * REC;
   for (int i = threadIdx.x; i < REC; i += 256)
     out[i] = red[i] + red[REC + i] + red[2 * REC + i] + red[3 * REC + i];
-}
-
-__device__ __forceinline__ void nth_perm(int C, int p, int* out) {
-  int avail[MAXC] = {0, 1, 2, 3};
-  int fact = 1;
-  for (int i = 2; i < C; ++i) fact *= i;
-  int n = C;
-  for (int i = 0; i < C; ++i) {
-    const int q = p / fact;
-    p -= q * fact;
-    out[i] = avail[q];
-    for (int j = q; j < n - 1; ++j) avail[j] = avail[j + 1];
-    --n;
-    if (n > 1) fact /= n;
-  }
-}
-
-// single block: per-utterance permutation search, batch means
-__global__ void pit_final_kernel(int B, int C, int64_t N, int nch, float eps,
-                                 const float* __restrict__ partial, float* __restrict__ loss,
-                                 float* __restrict__ snr, int32_t* __restrict__ perm_idx) {
-  __shared__ float red[16];
-  int nperm = 1;
-  for (int i = 2; i <= C; ++i) nperm *= i;
-  float my_loss = 0.f, my_snr = 0.f;
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    float rec[REC];
-    for (int i = 0; i < REC; ++i) rec[i] = 0.f;
-    for (int ch = 0; ch < nch; ++ch)
-      for (int i = 0; i < REC; ++i) rec[i] += partial[((int64_t)b * nch + ch) * REC + i];
-    const float invN = 1.f / (float)N;                       // reduce_mean over T*F
-    int best = 0;
-    float best_v = 0.f, best_s = 0.f;
-    for (int p = 0; p < nperm; ++p) {
-      int perm[MAXC];
-      nth_perm(C, p, perm);
-      float v = 0.f, sv = 0.f;
-      for (int i = 0; i < C; ++i) {                          // ops.py:422-423
-        v += rec[i * C + perm[i]] * invN;
-        sv += rec[16 + i * C + perm[i]] * invN;
-      }
-      if (p == 0 || v < best_v) { best = p; best_v = v; best_s = sv; }   // ops.py:424
-    }
-    perm_idx[b] = best;
-    my_loss += best_v;
-    const float sig_pwr = rec[32] * invN / (float)C;         // mean over (C,T,F)
-    const float noise_pwr = best_s / (float)C;
-    my_snr += 4.342944819f * (logf(sig_pwr + eps) - logf(noise_pwr + eps));   // ops.py:221-222
-  }
-  const float tl = block_sum(my_loss, red);
-  const float ts = block_sum(my_snr, red);
-  if (threadIdx.x == 0) {
-    loss[0] = tl / (float)B;                                 // ops.py:430
-    if (snr) snr[0] = ts / (float)B;                         // main.py:308-309
-  }
 }
 
 template <int CP>
@@ -189,7 +115,7 @@ extern "C" int danet_pit_mse_fwd(danet_stream_t stream_, int mode, int B, int C,
                     mode, N, (const float2*)src_c64, sep_pwr, (const float2*)phasor,
                     (float*)ws)));
   DANET_CHECK_LAUNCH();
-  pit_final_kernel<<<1, 256, 0, stream>>>(B, C, N, nch, eps, (const float*)ws, loss, snr,
+  pit_final_kernel<<<1, PIT_FINAL_THREADS, 0, stream>>>(B, C, N, nch, eps, (const float*)ws, loss, snr,
                                           perm_idx);
   DANET_CHECK_LAUNCH();
   return DANET_OK;

@@ -33,6 +33,8 @@
 // drain + barrier + flag + poll + load.  Every spin is bounded; a timeout sets
 // the status word (ws word 0) instead of hanging.
 #include "common.h"
+#include "options.h"
+#include <atomic>
 #include <stdlib.h>
 
 #define LSTM_UNITS_FWD 8    // hidden units per workgroup (x4 gates = 32 columns)
@@ -1103,9 +1105,23 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
   const int ncl = a.ndir * a.G;
   // xmap: consecutive block ids cycle over the clusters (so a cluster's workgroups
   // share their id modulo 8 = their XCD whenever ncl divides 8 or vice versa)
-  const int cl = a.xmap ? bid % ncl : bid / (P * S);
-  const int m = a.xmap ? bid / ncl : bid % (P * S);
-  const int p = m / S, tw = m % S;
+  int cl, p, tw;
+  if (a.xmap == 2) {
+    // twins on ONE XCD (workgroup id % 8 = XCD): the S twins of a group re-read the same
+    // gates / cell / dy lines every step -- in one XCD's L2 the second and third read hit.
+    // XCD x = cl + ncl * (p % npar), npar = 8 / ncl; slot j = (p / npar) * S + tw; bid = x + 8 j.
+    // (grid = 8 * ceil(P / npar) * S: the few slots with p >= P exit at once)
+    const int npar = 8 / ncl;
+    const int x = bid & 7, j = bid >> 3;
+    cl = x % ncl;
+    tw = j % S;
+    p = (j / S) * npar + x / ncl;
+    if (p >= P) return;
+  } else {
+    cl = a.xmap ? bid % ncl : bid / (P * S);
+    const int m = a.xmap ? bid / ncl : bid % (P * S);
+    p = m / S; tw = m % S;
+  }
   const int dir = cl / a.G, grp = cl % a.G;
   const int u0 = p * U, b0 = grp * 16;
   const int fr = lane & 15, fq = lane >> 4;
@@ -1746,17 +1762,17 @@ struct LstmPlan { int MT, G, P, KP, NW, UN; size_t lds; };
 // compute units of the current device (one persistent workgroup per CU must be co-resident);
 // gfx950 = 256, also the fallback when no device is visible (size queries on a CPU-only host)
 static int num_cus() {
-  static int n = 0;
-  if (n) return n;
+  static std::atomic<int> n{0};          // cached once a device answered (idempotent: benign race)
+  int c = n.load(std::memory_order_relaxed);
+  if (c) return c;
   int dev = 0, v = 0;
   if (hipGetDevice(&dev) == hipSuccess &&
-      hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-    n = v;
-  else {
-    (void)hipGetLastError();
-    return 256;
+      hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) {
+    n.store(v, std::memory_order_relaxed);
+    return v;
   }
-  return n;
+  (void)hipGetLastError();
+  return 256;
 }
 
 // MT=1 (16-row clusters) halves the per-step MFMA time and the payload per
@@ -1769,25 +1785,24 @@ static LstmPlan make_plan(int B, int H, int ndir, bool bwd) {
   pl.P = cdiv(H, pl.UN);
   pl.KP = cdiv(H, 16) * 16;
   pl.MT = (ndir * cdiv(B, 16) * pl.P > num_cus()) ? 2 : 1;
-  const char* force = getenv(bwd ? "DANET_LSTM_BWD_MT" : "DANET_LSTM_FWD_MT");
-  if (force && (force[0] == '1' || force[0] == '2')) pl.MT = force[0] - '0';
+  const int force = danet_opt(bwd ? OPT_LSTM_BWD_MT : OPT_LSTM_FWD_MT);
+  if (force == 1 || force == 2) pl.MT = force;
   // forward, wide layers: 12 units per workgroup keep 16-row clusters on the GPU where 8 units
   // would need 32-row clusters (cfg 4 as written, H = 600: 200 workgroups of 16 rows instead of
   // 150 of 32: 5.8 -> 4.6 us per timestep, 12.15 -> 11.55 ms per cfg-4h600 step).
   // DANET_LSTM_FWD_UN=8|12 overrides.
   if (!bwd && B > 4) {
-    const char* eu = getenv("DANET_LSTM_FWD_UN");
-    const int want = eu ? atoi(eu) : 0;
+    const int want = danet_opt(OPT_LSTM_FWD_UN);
     const bool fits12 = ndir * cdiv(B, 16) * cdiv(H, 12) <= num_cus();
-    if ((want == 12 || (want != 8 && pl.MT == 2 && !(force && force[0] == '2'))) && fits12) {
+    if ((want == 12 || (want != 8 && pl.MT == 2 && force != 2)) && fits12) {
       pl.UN = 12; pl.P = cdiv(H, 12); pl.MT = 1;
     }
   }
   pl.G = cdiv(B, 16 * pl.MT);
   // waves per workgroup: more waves = shorter per-wave exchange-load chains
   pl.NW = bwd ? 8 : 4;
-  const char* fnw = getenv(bwd ? "DANET_LSTM_BWD_NW" : "DANET_LSTM_FWD_NW");
-  if (fnw && (atoi(fnw) == 4 || atoi(fnw) == 8 || atoi(fnw) == 16)) pl.NW = atoi(fnw);
+  const int fnw = danet_opt(bwd ? OPT_LSTM_BWD_NW : OPT_LSTM_FWD_NW);
+  if (fnw == 4 || fnw == 8 || fnw == 16) pl.NW = fnw;
   if ((pl.MT == 2 || pl.UN == 12) && pl.NW > 4) pl.NW = 4;   // ownership map: 256 threads
   for (;;) {
     pl.lds = bwd ? ((size_t)4 * H * 16 + (size_t)pl.NW * 16 * pl.MT * 17) * sizeof(float)
@@ -1813,8 +1828,8 @@ static RsPlan make_rs_plan(int B, int H, int ndir, int U) {
   r.S = smax;
   for (int sv = 1; sv <= smax; ++sv)
     if (cdiv(r.NT, sv) <= 8) { r.S = sv; break; }
-  { const char* es = getenv("DANET_LSTM_BWD_S");
-    if (es && atoi(es) >= 1 && atoi(es) <= smax) r.S = atoi(es); }
+  { const int es = danet_opt(OPT_LSTM_BWD_S);
+    if (es >= 1 && es <= smax) r.S = es; }
   r.NTW = r.S > 0 ? cdiv(cdiv(r.NT, r.S), 8) : 99;
   r.ring_bytes = (size_t)r.D * ncl * r.P * r.NT * 1024;
   r.ok = (H % 4 == 0) && smax >= 1 && r.NTW <= 5 && r.NI <= RS_NI_MAX &&
@@ -1824,10 +1839,8 @@ static RsPlan make_rs_plan(int B, int H, int ndir, int U) {
 // DANET_LSTM_BWD_RS=0 selects the all-gather kernel; DANET_LSTM_BWD_U=8|16|32 pins U
 static RsPlan choose_rs_plan(int B, int H, int ndir) {
   RsPlan none; none.ok = false; none.ring_bytes = 0;
-  const char* e = getenv("DANET_LSTM_BWD_RS");
-  if (e && atoi(e) == 0) return none;
-  const char* eu = getenv("DANET_LSTM_BWD_U");
-  const int pin = eu ? atoi(eu) : 0;
+  if (danet_opt(OPT_LSTM_BWD_RS) == 0) return none;
+  const int pin = danet_opt(OPT_LSTM_BWD_U);
   // fewest MFMAs per SIMD and step (tiles of a workgroup spread over 4 SIMDs, 4U/4
   // k-steps each); ties go to the smaller U (shorter dependent chains).  Measured at
   // cfg 2: U=16,S=3 2.4 us/step; U=32,S=5 2.8; U=8,S=1 3.0 (all-gather kernel: 3.5)
@@ -1850,11 +1863,10 @@ static size_t ring_offset(int T) { return (64 + TRACE_BYTES(T) + 255) / 256 * 25
 // DANET_LSTM_SPIN_LIMIT overrides the wait bound, DANET_LSTM_FAULT_INJECT=1 makes workgroup 0
 // of every launch exit without publishing (tests of the timeout path only)
 static unsigned spin_limit_env() {
-  const char* e = getenv("DANET_LSTM_SPIN_LIMIT");
-  const long v = e ? atol(e) : 0;
+  const long v = danet_opt(OPT_LSTM_SPIN_LIMIT);
   return v >= 256 ? (unsigned)v : SPIN_LIMIT;
 }
-static int fault_env() { const char* e = getenv("DANET_LSTM_FAULT_INJECT"); return e && atoi(e) == 1; }
+static int fault_env() { return danet_opt(OPT_LSTM_FAULT_INJECT) == 1; }
 
 extern "C" size_t danet_lstm_workspace_bytes(int T, int B, int H, int ndir) {
   // status word (+ padding) (+ trace records) + partial-dh ring of the BPTT kernel
@@ -1912,7 +1924,7 @@ extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int n
   a.spin_limit = spin_limit_env(); a.fault = fault_env();
   a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.ldy = ldy; a.ldw = ldw;
   a.P = pl.P; a.G = pl.G; a.KP = pl.KP;
-  a.xmap = getenv("DANET_LSTM_XMAP") ? atoi(getenv("DANET_LSTM_XMAP")) : 1;
+  a.xmap = (danet_opt(OPT_LSTM_XMAP) >= 0 ? danet_opt(OPT_LSTM_XMAP) : 1);
   // status word; "not yet published" sentinel in the T interior blocks of ypad; the
   // zero initial state in pad blocks 0 and T+1 (main.py:108-123) -- one launch
   const size_t blk = (size_t)B * ldy * sizeof(float);
@@ -1932,8 +1944,7 @@ extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int n
   } while (0)
   // tiny batch (the B = 1 demo / inference path): GEMV on the vector ALU instead of 1/16-used
   // MFMA tiles.  DANET_LSTM_FWD_SMALL=0 keeps the MFMA kernel.
-  const char* esm = getenv("DANET_LSTM_FWD_SMALL");
-  if (B <= 4 && H <= 16 * FWD_CH * 4 && !(esm && atoi(esm) == 0)) {
+  if (B <= 4 && H <= 16 * FWD_CH * 4 && danet_opt(OPT_LSTM_FWD_SMALL) != 0) {
     const size_t lds = ((size_t)pl.KP * 32 + (size_t)4 * 4 * 33) * sizeof(float);
     DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_small_kernel<4>,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1964,9 +1975,9 @@ static bool fwd_fused_ok(int T, int B, int H, int ndir, int D, int* CHX) {
   // (measured, profiles/r02_d_fused_fwd_trace.txt), the hoisted GEMM costs ~1.15 us * B/32 *
   // D/600 per step (80 TFLOP/s) -- i.e. from about B >= 24 on; B = 1 inference (cfg 5) stays
   // on the hoisted path (2.66 vs 1.84 us per step).
-  { const char* e = getenv("DANET_LSTM_FWD_FUSED");
-    if (e && atoi(e) == 0) return false;
-    if (!(e && atoi(e) == 1) && B < 24) return false; }
+  { const int e = danet_opt(OPT_LSTM_FWD_FUSED);
+    if (e == 0) return false;
+    if (e != 1 && B < 24) return false; }
   // k-groups: 4 * window + 2 * early >= D / 16  (see lstm_fwd_fx_kernel)
   if (CHX) *CHX = D <= 160 ? 2 : (D <= 320 ? 4 : (D <= 608 ? 8 : 9));
   return true;
@@ -2005,11 +2016,11 @@ extern "C" int danet_lstm_fwd_fused(danet_stream_t stream_, int T, int B, int H,
   a.gates[0] = gates_f; a.gates[1] = gates_b; a.cell[0] = cell_f; a.cell[1] = cell_b;
   a.ypad = ypad; a.status = status ? (int*)status : (int*)ws; a.status_ws = ws;
   a.spin_limit = spin_limit_env(); a.fault = fault_env();
-  a.mode = getenv("DANET_LSTM_FX_MODE") ? atoi(getenv("DANET_LSTM_FX_MODE")) : 0;
+  a.mode = danet_opt(OPT_LSTM_FX_MODE);
   a.T = T; a.B = B; a.H = H; a.D = D; a.ndir = ndir; a.ldx = ldx; a.ldy = ldy; a.ldw = ldw;
   a.P = cdiv(H, LSTM_UNITS_FWD); a.G = cdiv(B, 16); a.KP = cdiv(H, 16) * 16;
   a.DP = cdiv(D, 16) * 16;
-  a.xmap = getenv("DANET_LSTM_XMAP") ? atoi(getenv("DANET_LSTM_XMAP")) : 1;
+  a.xmap = (danet_opt(OPT_LSTM_XMAP) >= 0 ? danet_opt(OPT_LSTM_XMAP) : 1);
   const size_t lds = ((size_t)a.KP * 32 + (size_t)4 * 16 * 33) * sizeof(float);
   const size_t blk = (size_t)B * ldy * sizeof(float);
   {
@@ -2050,8 +2061,8 @@ static RswPlan make_rsw_plan(int B, int H, int ndir, int D) {
   // step with all layers fused) -- the 80 weight-gradient MFMAs per SIMD and step run at 22 ns
   // instead of the 15 ns the pipe can do and make the step MFMA-bound at 3.6 us.  Fusing only
   // the bottom layer (whose group has nothing to hide under) LOSES: the layer-1 group then runs
-  // beside an MFMA-heavy kernel (3.82 ms).  DANET_LSTM_BWD_FUSED=0 turns the kernel off.
-  { const char* e = getenv("DANET_LSTM_BWD_FUSED"); if (e && e[0] == '0' && e[1] == 0) return w; }
+  // beside an MFMA-heavy kernel (3.82 ms).  option lstm_bwd_fused_kernel = 0 turns the kernel off.
+  if (danet_opt(OPT_LSTM_BWD_FUSED_KERNEL) == 0) return w;
   if (!w.rs.ok || D <= 0) return w;
   if (w.rs.U != 8 && w.rs.U != 16) return w;
   if (w.rs.NTW > 2 || w.rs.NI > RSW_NI_MAX) return w;
@@ -2127,7 +2138,7 @@ extern "C" int danet_lstm_bwd_fused(danet_stream_t stream_, int T, int B, int H,
   a.ring = (float*)((char*)ws + ring_offset(T));
   a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.P = rs.P; a.G = rs.G; a.S = rs.S;
   a.NT = rs.NT; a.NI = rs.NI; a.D = rs.D;
-  a.xmap = getenv("DANET_LSTM_XMAP") ? atoi(getenv("DANET_LSTM_XMAP")) : 1;
+  a.xmap = (danet_opt(OPT_LSTM_XMAP) >= 0 ? danet_opt(OPT_LSTM_XMAP) : 1);
   a.dbslab = nullptr;
   aa.x = x; aa.ypad = ypad; aa.ldx = ldx; aa.ldy = ldy; aa.Din = D; aa.Dp = cdiv(D, 16) * 16;
   aa.NFt = w.NFt; aa.NFP = w.NFP;
@@ -2225,7 +2236,7 @@ static int lstm_bwd_impl(danet_stream_t stream_, int T, int B, int H, int ndir,
     a.ring = (float*)((char*)ws + ring_offset(T));
     a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.P = rs.P; a.G = rs.G; a.S = rs.S;
     a.NT = rs.NT; a.NI = rs.NI; a.D = rs.D;
-    a.xmap = getenv("DANET_LSTM_XMAP") ? atoi(getenv("DANET_LSTM_XMAP")) : 1;
+    a.xmap = (danet_opt(OPT_LSTM_XMAP) >= 0 ? danet_opt(OPT_LSTM_XMAP) : 1);
     a.dbslab = db_f ? (float*)((char*)ws + align_up(ring_offset(T) + rs.ring_bytes, 256)) : nullptr;
     {
       FillList fl;
@@ -2233,8 +2244,29 @@ static int lstm_bwd_impl(danet_stream_t stream_, int T, int B, int H, int ndir,
       fl.add(a.ring, rs.ring_bytes, 1u);   // phase 1 in bit 0 of every word
       DANET_CHECK_HIP(fl.launch(stream));
     }
-    const int nblk = ndir * rs.G * rs.P * rs.S;
-#define LAUNCH_RS(UV, NTWV) lstm_bwd_rs_kernel<UV, NTWV><<<nblk, 512, 0, stream>>>(a)
+    int nblk = ndir * rs.G * rs.P * rs.S;
+    {
+      // twin-co-located order (xmap 2) where the clusters divide the 8 XCDs and the padded grid
+      // still fits one workgroup per CU
+      const int ncl = ndir * rs.G;
+      if (a.xmap == 2) a.xmap = 1;
+      if (danet_opt(OPT_LSTM_BWD_TWIN_XCD) == 1 && a.xmap == 1 && ncl <= 8 && 8 % ncl == 0 && rs.S > 1) {
+        const int npar = 8 / ncl;
+        const int g2 = 8 * cdiv(rs.P, npar) * rs.S;
+        if (g2 <= num_cus()) { a.xmap = 2; nblk = g2; }
+      }
+    }
+    // lstm_bwd_lds_pad (bytes, experiment): extra dynamic LDS the kernel never touches -- with
+    // ~100 KB a GEMM workgroup (50 KB of LDS) cannot become co-resident on a CU that carries a
+    // BPTT workgroup, so an overlapped weight-gradient group only lands on the CUs BPTT leaves free
+    const int pad = danet_opt(OPT_LSTM_BWD_LDS_PAD);
+#define LAUNCH_RS(UV, NTWV)                                                                     \
+    do {                                                                                        \
+      if (pad > 0)                                                                              \
+        DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_bwd_rs_kernel<UV, NTWV>,          \
+            hipFuncAttributeMaxDynamicSharedMemorySize, pad));                                  \
+      lstm_bwd_rs_kernel<UV, NTWV><<<nblk, 512, pad > 0 ? pad : 0, stream>>>(a);                \
+    } while (0)
 #define LAUNCH_RS_U(UV)                                          \
     switch (rs.NTW) {                                            \
       case 1: LAUNCH_RS(UV, 1); break; case 2: LAUNCH_RS(UV, 2); break; \
@@ -2260,7 +2292,7 @@ static int lstm_bwd_impl(danet_stream_t stream_, int T, int B, int H, int ndir,
   // used whenever one workgroup per CU still fits.  DANET_LSTM_BWD_ROWS=16 overrides.
   int R = 16 * pl.MT;
   if (pl.MT == 1 && ndir * cdiv(B, 8) * pl.P <= num_cus()) R = 8;
-  { const char* er = getenv("DANET_LSTM_BWD_ROWS"); if (er && pl.MT == 1 && atoi(er) == 16) R = 16; }
+  if (pl.MT == 1 && danet_opt(OPT_LSTM_BWD_ROWS) == 16) R = 16;
   const int G = cdiv(B, R);
   const int nblk = ndir * G * pl.P;
   if (nblk > num_cus()) {
@@ -2273,7 +2305,7 @@ static int lstm_bwd_impl(danet_stream_t stream_, int T, int B, int H, int ndir,
   a.da[0] = da_f; a.da[1] = da_b; a.status = status ? (int*)status : (int*)ws;
   a.spin_limit = spin_limit_env(); a.fault = fault_env();
   a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.P = pl.P; a.G = G; a.R = R;
-  a.xmap = getenv("DANET_LSTM_XMAP") ? atoi(getenv("DANET_LSTM_XMAP")) : 0;
+  a.xmap = (danet_opt(OPT_LSTM_XMAP) >= 0 ? danet_opt(OPT_LSTM_XMAP) : 0);
   const size_t dbytes = (size_t)T * B * 4 * H * sizeof(float);
   {
     FillList fl;

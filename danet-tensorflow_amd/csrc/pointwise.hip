@@ -110,32 +110,46 @@ __device__ __forceinline__ int64_t center_index(int layout, int B, int T, int ld
 
 // Both kernels walk whole rows (t) with the threads striding over d: no per-element
 // 64-bit division, coalesced row segments.
+// The per-utterance sum is accumulated in DOUBLE: the mean is subtracted from every element, so
+// its rounding error is a common-mode error of all T*D inputs of the stack (coherent through the
+// first layer's 129-term products), and a float32 tree sum of 16512 values of magnitude ~3 is
+// off by 3e-7 .. 5e-7 -- more than the rounding of any single input.  Measured at trained cfg-2
+// parameters (tools/parity_decompose.py): centred-input error 3.2e-7 rms with the float32 sum vs
+// 1.9e-7 for numpy's float32 pairwise mean; with the double sum the mean is the correctly
+// rounded float32 value.  16512 adds per utterance: free.
 __global__ void center_sum_kernel(int B, int T, int D, const float* __restrict__ in,
-                                  int layout, int ld, float* __restrict__ partial) {
-  __shared__ float red[16];
+                                  int layout, int ld, double* __restrict__ partial) {
+  __shared__ double redd[16];
   const int b = blockIdx.y, ch = blockIdx.x;
   const int tper = cdiv(T, CENTER_CHUNKS);
   const int t0 = ch * tper, t1 = min(T, t0 + tper);
-  float s0 = 0.f, s1 = 0.f;
+  double s0 = 0.0, s1 = 0.0;
   for (int t = t0; t < t1; ++t) {
     const float* row = in + center_index(layout, B, T, ld, b, t);
     int d = threadIdx.x;
-    for (; d + (int)blockDim.x < D; d += 2 * blockDim.x) { s0 += row[d]; s1 += row[d + blockDim.x]; }
-    if (d < D) s0 += row[d];
+    for (; d + (int)blockDim.x < D; d += 2 * blockDim.x) { s0 += (double)row[d]; s1 += (double)row[d + blockDim.x]; }
+    if (d < D) s0 += (double)row[d];
   }
-  const float s = block_sum(s0 + s1, red);
-  if (threadIdx.x == 0) partial[b * CENTER_CHUNKS + ch] = s;
+  double v = wave_sum_d(s0 + s1);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) redd[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < nw; ++i) s += redd[i];
+    partial[b * CENTER_CHUNKS + ch] = s;
+  }
 }
 
 __global__ void center_apply_kernel(int B, int T, int D, const float* __restrict__ in,
                                     int in_layout, int ld_in, float* __restrict__ out,
                                     int out_layout, int ld_out,
-                                    const float* __restrict__ partial,
+                                    const double* __restrict__ partial,
                                     float* __restrict__ mean_out) {
   const int b = blockIdx.y;
-  float s = 0.f;
+  double s = 0.0;
   for (int i = 0; i < CENTER_CHUNKS; ++i) s += partial[b * CENTER_CHUNKS + i];
-  const float mean = s / (float)((int64_t)T * D);
+  const float mean = (float)(s / (double)((int64_t)T * D));
   if (mean_out && blockIdx.x == 0 && threadIdx.x == 0) mean_out[b] = mean;
   for (int t = blockIdx.x; t < T; t += gridDim.x) {
     const float* src = in + center_index(in_layout, B, T, ld_in, b, t);
@@ -145,9 +159,9 @@ __global__ void center_apply_kernel(int B, int T, int D, const float* __restrict
   }
 }
 
-// `mean` doubles as scratch: [B] means followed by [B][CENTER_CHUNKS] partial
-// sums (keeps the ABI allocation-free and re-entrant).
-extern "C" int danet_center_mean_elems(int B) { return B * (1 + CENTER_CHUNKS); }
+// `mean` doubles as scratch: [B] means (padded to an even count) followed by
+// [B][CENTER_CHUNKS] DOUBLE partial sums (keeps the ABI allocation-free and re-entrant).
+extern "C" int danet_center_mean_elems(int B) { return ((B + 1) & ~1) + 2 * B * CENTER_CHUNKS; }
 
 extern "C" int danet_center(danet_stream_t stream, int B, int T, int D, const float* in,
                             int in_layout, int ld_in, float* out, int out_layout,
@@ -155,7 +169,8 @@ extern "C" int danet_center(danet_stream_t stream, int B, int T, int D, const fl
   DANET_CHECK_ARG(B > 0 && T > 0 && D > 0 && in && out && mean, "center: bad args (mean scratch is required)");
   DANET_CHECK_ARG(ld_in >= D && ld_out >= D, "center: ld < D");
   DANET_CHECK_ARG((in_layout | 1) == 1 && (out_layout | 1) == 1, "center: layout must be 0/1");
-  float* partial = mean + B;
+  DANET_CHECK_ARG(((uintptr_t)mean & 7) == 0, "center: mean scratch must be 8-byte aligned");
+  double* partial = reinterpret_cast<double*>(mean + ((B + 1) & ~1));
   dim3 g1(CENTER_CHUNKS, B);
   center_sum_kernel<<<g1, 256, 0, (hipStream_t)stream>>>(B, T, D, in, in_layout, ld_in, partial);
   DANET_CHECK_LAUNCH();

@@ -52,6 +52,8 @@ class Model(object):
         # True: gradients stay readable after train_step (grad_dict); costs one fill
         # kernel per step.  False: the optimiser kernel zeroes them after use.
         self.keep_grads = False
+        # train_step: separator + PIT loss as one fused kernel pair (DANET_FUSE_HEADS=0: off)
+        self.fuse_heads = os.environ.get('DANET_FUSE_HEADS', '1') == '1'
 
     # ------------------------------------------------------------ variables
     def get_variable(self, name, shape, init):
@@ -195,8 +197,13 @@ class Model(object):
         self.early_steps += 1
 
     # -------------------------------------------------------------- forward
-    def forward(self, s_src_signals, with_valid=False, with_train=True):
-        '''main.py:215-337.  s_src_signals complex64 [B, C, T, F].'''
+    def forward(self, s_src_signals, with_valid=False, with_train=True, fuse_heads=False):
+        '''main.py:215-337.  s_src_signals complex64 [B, C, T, F].
+        fuse_heads (train_step): separator + phase re-attach + PIT loss + SNR run as ONE
+        kernel forward and ONE backward (ops.SeparatePitFn); the separated magnitudes then
+        exist only in registers and `sep_pwr` is not in the returned dict.  Needs a separator
+        that exposes its activation (`ACT`, the dot-product separators); others take the
+        unfused path.'''
         B, E = hparams.BATCH_SIZE, hparams.EMBED_SIZE
         eps = float(hparams.EPS)
         fe = ops.frontend(s_src_signals)                       # main.py:233-240
@@ -207,11 +214,18 @@ class Model(object):
         if with_train:
             s_attractors = self.estimator(                     # main.py:251-254
                 s_embed, s_src_pwr=fe['src_pwr'], s_mix_pwr=fe['mix_pwr'])
-            s_sep_pwr = self.separator(fe['mix_pwr'], s_attractors, s_embed_flat)  # :271-272
-            loss, perms, idx, snr = ops.pit_mse_loss(          # main.py:289-290, 308-309
-                s_src_signals, s_sep_pwr, phasor, mode=0, eps=eps)
-            out.update(attrs=s_attractors, sep_pwr=s_sep_pwr, loss=loss, SNR=snr,
-                       perm_idx=idx, perms=perms)
+            act = getattr(self.separator, 'ACT', None)
+            if fuse_heads and act is not None and not hparams.DEBUG and not with_valid:
+                loss, perms, idx, snr = ops.separate_pit_loss(      # :271-272 + :281-290, 308-309
+                    fe['mix_pwr'], s_attractors, s_embed_flat, s_src_signals, phasor, act,
+                    mode=0, eps=eps)
+                out.update(attrs=s_attractors, loss=loss, SNR=snr, perm_idx=idx, perms=perms)
+            else:
+                s_sep_pwr = self.separator(fe['mix_pwr'], s_attractors, s_embed_flat)  # :271-272
+                loss, perms, idx, snr = ops.pit_mse_loss(          # main.py:289-290, 308-309
+                    s_src_signals, s_sep_pwr, phasor, mode=0, eps=eps)
+                out.update(attrs=s_attractors, sep_pwr=s_sep_pwr, loss=loss, SNR=snr,
+                           perm_idx=idx, perms=perms)
         if with_valid:
             if self.using_same_method and with_train:
                 s_vattr, s_vsep = out['attrs'], out['sep_pwr']
@@ -254,7 +268,7 @@ class Model(object):
         ops.poll_status(self.device)
         if not self._grads_clean:
             self._flat_grad.zero_()
-        out = self.forward(s_src_signals)
+        out = self.forward(s_src_signals, fuse_heads=self.fuse_heads)
         self._early, self._in_step = None, True
         # from here until the final optimiser piece has been issued the bucket holds partial
         # sums: an exception in between (launch error, collective failure, KeyboardInterrupt)

@@ -34,11 +34,14 @@ def _ws(nbytes, dev):
 # ---------------------------------------------------------------------------
 # raw wrappers (no autograd)
 # ---------------------------------------------------------------------------
-# stream-K schedule for single products on the critical path: opt-in bit mask
-# (1: dYc / unidirectional dX, 2: output projection).  Alone on the GPU they gain up to
-# 1.75x (tools/bench_gemm.py); in the train step dYc drops 164 -> 148 us but the step time
-# does not move (3.95 ms either way), so the default stays the split-K launch.
-STREAMK = int(__import__('os').environ.get('DANET_STREAMK', '0'))
+# stream-K schedule (danet_gemm_f32_streamk*: persistent workgroups, whole tiles data-parallel,
+# the ragged last round cut along K, deterministic in-kernel fix-up) for single products on the
+# critical path -- bit mask: 1 = dYc / unidirectional dX, 2 = output projection, 4 = the
+# K-concatenated dX of a BiLSTM layer.  Default 5.  Round 3, in-step at cfg 2 (us per launch /
+# ms per step): dX 133 -> 117 (3.273 -> 3.241), dYc 142 -> 125 (-> 3.265), both 3.228; the
+# output projection (672 tiles, K = 600) LOSES on it (126 -> 132: two workgroups per CU instead
+# of three, and 160 of its tiles need a fix-up) and stays on the tile kernel.
+STREAMK = int(__import__('os').environ.get('DANET_STREAMK', '5'))
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, beta=0.0,
@@ -68,9 +71,20 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None,
 
 
 def gemm_kcat(A1, lda1, B1, ldb1, K1, A2, lda2, B2, ldb2, K2, C, M, N, ldc,
-              transA=False, transB=False, bias=None, beta=0.0, tag=None):
-    '''C[M,N] = op(A1) op(B1) + op(A2) op(B2) (+bias) (+beta*C) in one launch'''
+              transA=False, transB=False, bias=None, beta=0.0, tag=None, streamk=False):
+    '''C[M,N] = op(A1) op(B1) + op(A2) op(B2) (+bias) (+beta*C) in one launch.
+    streamk: the hybrid stream-K schedule (no slabs / reduce kernel; K1 % 16 == 0)'''
     L = _L()
+    if streamk and K1 % 16 == 0:
+        w = _lib.workspace(L.danet_gemm_f32_streamk_workspace_bytes(M, N, K1 + K2), C.device,
+                           tag='gemm_sk')
+        with _lib.timed('gemm_f32', tag):
+            check(L.danet_gemm_f32_streamk_kcat(_lib.stream(), int(transA), int(transB), M, N,
+                                                K1, ptr(_f32(A1)), lda1, ptr(_f32(B1)), ldb1,
+                                                K2, ptr(_f32(A2)), lda2, ptr(_f32(B2)), ldb2,
+                                                ptr(_f32(C)), ldc, ptr(bias), float(beta),
+                                                ptr(w), w.numel()))
+        return C
     w, wn = _ws(L.danet_gemm_f32_kcat_workspace_bytes(M, N, K1, K2), C.device)
     with _lib.timed('gemm_f32', tag):
         check(L.danet_gemm_f32_kcat(_lib.stream(), int(transA), int(transB), M, N,
@@ -545,10 +559,14 @@ def join_deferred():
             main.wait_stream(s)
 
 
-def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs):
+def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs, x_pad_zero=False):
     '''x: time-major [T*B rows, ldx] tensor (data_ptr = row 0), D valid columns.
     Ws[d]: [D+H, 4H] (reference layout, rows 0..D-1 input, D.. recurrent),
-    bs[d]: [4H].  Returns ctx with ypad [T+2, B, ndir*H].'''
+    bs[d]: [4H].  Returns ctx with ypad [T+2, B, ndir*H].
+    x_pad_zero: the caller guarantees that columns D..ldx-1 of x hold finite values (zeros).
+    The fused-input kernel loads whole float4 groups of a row and masks only W for k >= D,
+    so with D % 4 != 0 a non-finite pad value would poison the gates (0 * NaN); without the
+    guarantee such inputs take the hoisted GEMM path, which never reads the pad.'''
     ndir = len(Ws)
     dev = x.device
     L = _L()
@@ -556,7 +574,7 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs):
     cells = [torch.empty(T * B, H, device=dev) for _ in range(ndir)]
     ypad = torch.empty(T + 2, B, ndir * H, device=dev)
     ws, wn = _lstm_ws(T, B, H, ndir, dev)
-    fused = (ldx % 4 == 0 and x.data_ptr() % 16 == 0 and
+    fused = (ldx % 4 == 0 and x.data_ptr() % 16 == 0 and (D % 4 == 0 or x_pad_zero) and
              all(W.stride(0) == 4 * H and W.stride(1) == 1 for W in Ws) and
              L.danet_lstm_fwd_fused_supported(T, B, H, ndir, D) == 1)
     if fused:
@@ -594,6 +612,8 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs):
     return c
 
 
+# (Python-side POLICY; the library's own kill-switch for that kernel is the separate option
+# `lstm_bwd_fused_kernel`, env DANET_LSTM_BWD_FUSED_KERNEL.)
 # Where BPTT accumulates dW / db inside the persistent kernel (danet_lstm_bwd_fused): '0'
 # (default) = nowhere; '1' = every layer inside the kernel's envelope; 'bottom' = only the
 # layer whose input needs no gradient.  Measured at cfg 2 / cfg 4 (ms per step): '0' 3.60 /
@@ -733,7 +753,7 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False):
         if ndir == 2:
             # dX = da_f Wx_f^T + da_b Wx_b^T: one K-concatenated launch
             gemm_kcat(das[0], 4 * H, c.Ws[0], 4 * H, 4 * H, das[1], 4 * H, c.Ws[1], 4 * H, 4 * H,
-                      dx, T * B, D, D, transB=True, tag='dX')
+                      dx, T * B, D, D, transB=True, tag='dX', streamk=(STREAMK & 4) != 0)
             return
         for d in range(ndir):
             # dX += da Wx^T
@@ -841,7 +861,9 @@ class RnnEncoderFn(torch.autograd.Function):
         for l in range(L):                                    # modules.py:223-242
             Ws = [params[(l * ndir + d) * 2] for d in range(ndir)]
             bs = [params[(l * ndir + d) * 2 + 1] for d in range(ndir)]
-            c = lstm_layer_fwd(cur, ld, D, T, B, H, Ws, bs)
+            # (the centre kernel zero-fills the float4 pad of layer 0's rows; deeper layers
+            # read ypad, whose row length is a multiple of 4)
+            c = lstm_layer_fwd(cur, ld, D, T, B, H, Ws, bs, x_pad_zero=True)
             ctxs.append(c)
             cur, ld, D = c.ypad[1:], ndir * H, ndir * H
         # y - mean_{t,h}(y), back to batch-major                modules.py:244-245
@@ -1170,6 +1192,74 @@ class PitMseFn(torch.autograd.Function):
                                      ptr(torch.view_as_real(src)), ptr(sep_pwr), ptr(phasor),
                                      ptr(perm_idx), 1.0, ptr(_f32(dloss.contiguous())), ptr(dsep)))
         return None, dsep, None, None, None
+
+
+class SeparatePitFn(torch.autograd.Function):
+    '''Separator + phase re-attach + PIT-MSE + SNR in ONE pass over the embedding and ONE
+    pass back (danet_separate_pit_fwd / _bwd): the training path of app/modules.py:548-603 ->
+    main.py:281-290, 308-309 -> app/ops.py:374-431.  Same arithmetic as SeparateFn followed by
+    PitMseFn; the masks, the separated magnitudes and dL/dsep never touch HBM.
+    (mix_pwr [B,T,F], attr [B,C,E], embed_flat [B,N,E], src complex64 [B,C,T,F],
+    phasor [B,T,F,2]) -> (loss, snr, perm_idx)'''
+
+    @staticmethod
+    def forward(ctx, mix_pwr, attr, embed_flat, src, phasor, act, mode, eps):
+        assert src.dtype == torch.complex64
+        B, T, F = mix_pwr.shape
+        C, E = attr.shape[1], attr.shape[2]
+        N = T * F
+        dev = mix_pwr.device
+        mix_pwr = _f32(mix_pwr.contiguous())
+        attr_c = _f32(attr.contiguous())
+        embed_flat = _f32(embed_flat.contiguous())
+        src = src.contiguous()
+        phasor = _f32(phasor.contiguous())
+        loss, snr = torch.empty((), device=dev), torch.empty((), device=dev)
+        perm_idx = torch.empty(B, dtype=torch.int32, device=dev)
+        L = _L()
+        w, wn = _ws(L.danet_separate_pit_workspace_bytes(B, C, N, E), dev)
+        check(L.danet_separate_pit_fwd(_lib.stream(), act, mode, B, C, N, E, ptr(mix_pwr),
+                                       ptr(attr_c), ptr(embed_flat), ptr(torch.view_as_real(src)),
+                                       ptr(phasor), eps, None, ptr(loss), ptr(snr), ptr(perm_idx),
+                                       ptr(w), wn))
+        ctx.save_for_backward(mix_pwr, attr_c, embed_flat, src, phasor, perm_idx)
+        ctx.args = (act, mode, B, C, N, E)
+        ctx.token = getattr(attr, '_danet_dembed_token', None)
+        ctx.mark_non_differentiable(snr, perm_idx)
+        ctx.set_materialize_grads(False)
+        return loss, snr, perm_idx
+
+    @staticmethod
+    def backward(ctx, dloss, _dsnr, _dperm):
+        if dloss is None:
+            return (None,) * 8
+        mix_pwr, attr, embed_flat, src, phasor, perm_idx = ctx.saved_tensors
+        act, mode, B, C, N, E = ctx.args
+        dev = dloss.device
+        dembed = torch.empty(B, N, E, device=dev)
+        dattr = torch.empty(B, C, E, device=dev)
+        L = _L()
+        w, wn = _ws(L.danet_separate_pit_workspace_bytes(B, C, N, E), dev)
+        # dloss is a device scalar: the kernel reads it (no host sync, no extra pass)
+        check(L.danet_separate_pit_bwd(_lib.stream(), act, mode, B, C, N, E, ptr(mix_pwr),
+                                       ptr(attr), ptr(embed_flat), ptr(torch.view_as_real(src)),
+                                       ptr(phasor), ptr(perm_idx), 1.0,
+                                       ptr(_f32(dloss.contiguous())), ptr(dembed), ptr(dattr),
+                                       ptr(w), wn))
+        if ctx.token is not None and ctx.needs_input_grad[1]:
+            # the estimator that made `attr` runs its backward next and adds into `dembed`
+            ctx.token.dembed = dembed
+        return None, dattr, dembed, None, None, None, None, None
+
+
+def separate_pit_loss(s_mix_pwr, s_attractors, s_embed_flat, s_x, phasor, act, mode=0, eps=1e-7):
+    '''fused separator + pit_mse_loss; returns (s_loss, v_perms, s_loss_sets_idx, snr) like
+    pit_mse_loss'''
+    C = s_attractors.shape[1]
+    loss, snr, idx = SeparatePitFn.apply(s_mix_pwr, s_attractors, s_embed_flat, s_x, phasor,
+                                         act, mode, eps)
+    v_perms = torch.tensor(list(itertools.permutations(range(C))), dtype=torch.int32)
+    return loss, v_perms, idx, snr
 
 
 def pit_mse_loss(s_x, s_y_pwr, phasor, mode=0, eps=1e-7):

@@ -17,8 +17,13 @@
  *    `*_workspace_bytes(...)` bytes; contents are clobbered.
  *  - return value: 0 = DANET_OK, negative = error (no exceptions cross the
  *    ABI); `danet_last_error()` returns a thread-local message.
- *  - all launches are asynchronous on `stream`; no global state, re-entrant
- *    per stream (each concurrent call needs its own `ws`).
+ *  - all launches are asynchronous on `stream`; calls are re-entrant per stream
+ *    and may come from several host threads (each concurrent call needs its own
+ *    `ws`).  Process-wide state is limited to: (1) the tuning/diagnostic option
+ *    table below (ints in atomics, changed only through danet_set_option --
+ *    the library never reads the process environment), (2) an atomic launch
+ *    counter that numbers stream-K launches, (3) one-time per-kernel
+ *    attribute setup (thread-safe), (4) the thread-local error string.
  *  - symbols: B batch (mixtures), C speakers, T frames, F bins, E embedding,
  *    H hidden units per LSTM direction, N = T*F time-frequency bins,
  *    A anchors, P = C(A,C) anchor subsets.
@@ -40,12 +45,29 @@ extern "C" {
 #define DANET_ERR_UNSUPPORTED (-3)  /* shape outside the compiled envelope     */
 #define DANET_ERR_WORKSPACE (-4)    /* ws too small                            */
 
-#define DANET_ABI_VERSION 2
+#define DANET_ABI_VERSION 3
 
 typedef void* danet_stream_t;
 
 int danet_abi_version(void);
 const char* danet_last_error(void);
+
+/* Options: kernel-variant selection and diagnostics that round 2 read from
+ * DANET_* environment variables inside the library.  Every launch reads the
+ * current value; defaults are the shipped configuration.  Names (value meaning
+ * in csrc/options.h): gemm_dma, splitk_target, gemm_wgs, gemm_maxsplit,
+ * gemm_yield, anchor_scalar, lstm_fwd_mt, lstm_bwd_mt, lstm_fwd_un,
+ * lstm_fwd_nw, lstm_bwd_nw, lstm_bwd_s, lstm_bwd_rs, lstm_bwd_u,
+ * lstm_bwd_rows, lstm_spin_limit, lstm_fault_inject, lstm_xmap,
+ * lstm_fwd_small, lstm_fwd_fused, lstm_fx_mode, lstm_bwd_fused_kernel,
+ * lstm_bwd_twin_xcd, lstm_bwd_lds_pad.
+ * danet_set_option / danet_get_option return DANET_ERR_ARG for an unknown
+ * name; danet_option_name(i), 0 <= i < danet_option_count(), enumerates.   */
+int danet_set_option(const char* name, int value);
+int danet_get_option(const char* name, int* value);
+void danet_reset_options(void);
+int danet_option_count(void);
+const char* danet_option_name(int index);
 
 /* ---------------------------------------------------------------- a1 / a2
  * STFT: replaces scipy.signal.stft(x, window=FFT_WND, nperseg=N,
@@ -92,8 +114,11 @@ int danet_reattach_phase(danet_stream_t stream, int B, int C, int64_t N,
  * 1 = time-major [T][B][ld]; in/out layouts are independent (this is where
  * the encoder switches between the API's batch-major tensors and the LSTM
  * stack's time-major ones).  Columns D..ld_out-1 of `out` are zero-filled.
- * `mean` is REQUIRED scratch+output of danet_center_mean_elems(B) floats: the
- * first B hold the per-utterance means, the rest per-chunk partial sums.
+ * `mean` is REQUIRED scratch+output of danet_center_mean_elems(B) floats,
+ * 8-byte aligned: the first B hold the per-utterance means, the rest per-chunk
+ * partial sums.  The sum is accumulated in double and the mean is its correctly
+ * rounded float32 value (the mean's error is a common-mode error of every
+ * element; a float32 tree sum is off by more than any single element's rounding).
  * The same call is its own backward.                                        */
 int danet_center_mean_elems(int B);
 int danet_center(danet_stream_t stream, int B, int T, int D,
@@ -170,6 +195,14 @@ typedef struct {
 int danet_gemm_f32_streamk_grouped(danet_stream_t stream, int transA, int transB,
                                    int K, int nprob, const danet_gemm_problem_t* probs,
                                    int max_workgroups, void* ws, size_t ws_bytes);
+/* K-concatenated product C = op(A1) op(B1) + op(A2) op(B2) on the stream-K schedule (one
+ * launch, no slabs, no reduce kernel; K1 % 16 == 0).  Same result as danet_gemm_f32_kcat up to
+ * summation order.  Workspace: danet_gemm_f32_streamk_workspace_bytes.                    */
+int danet_gemm_f32_streamk_kcat(danet_stream_t stream, int transA, int transB, int M, int N,
+                                int K1, const float* A1, int lda1, const float* B1, int ldb1,
+                                int K2, const float* A2, int lda2, const float* B2, int ldb2,
+                                float* C, int ldc, const float* bias, float beta,
+                                void* ws, size_t ws_bytes);
 
 /* out[N] = sum_m A[m][n] (+ beta*out): bias gradients.                     */
 int danet_colsum_f32(danet_stream_t stream, int M, int N, const float* A,
@@ -348,6 +381,28 @@ int danet_separate_bwd(danet_stream_t stream, int act, int B, int C,
                        const float* attr, const float* embed,
                        const float* dout, float* dembed, float* dattr,
                        void* ws, size_t ws_bytes);
+
+/* ------------------------------------------------- a12 + a13 + a14 + a15 fused
+ * Separator + phase re-attach + PIT-MSE + SNR in ONE pass over the embedding (the
+ * training path: app/modules.py:548-603 -> main.py:281-290, 308-309 ->
+ * app/ops.py:374-431, 191-222).  Same arithmetic as danet_separate_fwd followed
+ * by danet_pit_mse_fwd, but the masks and separated magnitudes stay in registers
+ * (sep_pwr_out may be NULL; if given, [B][C][N] is written as well).  `act` 0
+ * softmax / 1 sigmoid; `mode` 0 complex MSE (train) / 1 magnitude MSE (valid).
+ * The backward recomputes the masks and returns the gradient w.r.t. the
+ * embedding (dembed [B][N][E], overwritten) and the attractors (dattr [B][C][E]):
+ * danet_pit_mse_bwd + danet_separate_bwd without the dsep round trip.        */
+size_t danet_separate_pit_workspace_bytes(int B, int C, int64_t N, int E);
+int danet_separate_pit_fwd(danet_stream_t stream, int act, int mode, int B, int C, int64_t N,
+                           int E, const float* mix_pwr, const float* attr, const float* embed,
+                           const float* src_c64, const float* phasor, float eps,
+                           float* sep_pwr_out, float* loss, float* snr, int32_t* perm_idx,
+                           void* ws, size_t ws_bytes);
+int danet_separate_pit_bwd(danet_stream_t stream, int act, int mode, int B, int C, int64_t N,
+                           int E, const float* mix_pwr, const float* attr, const float* embed,
+                           const float* src_c64, const float* phasor, const int32_t* perm_idx,
+                           float dloss, const float* dloss_dev, float* dembed, float* dattr,
+                           void* ws, size_t ws_bytes);
 
 /* ---------------------------------------------------------------- a14/a15
  * PIT-MSE loss + SNR (app/ops.py:374-431, :191-222; main.py:289-337).

@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- \
-    python ${GRAFT_REPO_ROOT:-/root/repo}/bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" \
+    python ${GRAFT_REPO_ROOT:-/root/repo}/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-check "$@" \
     > "$OUT/bench.log" 2>&1 < /dev/null
 find /tmp/prof_$TAG -type f < /dev/null | head -20
 for f in $(find /tmp/prof_$TAG -name "*kernel_stats.csv" < /dev/null); do cp "$f" "$OUT/kernel_stats.csv"; done

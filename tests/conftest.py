@@ -32,3 +32,13 @@ def hp():
     hparams.reset()
     yield hparams
     hparams.reset()
+
+
+@pytest.fixture(autouse=True)
+def _restore_library_options():
+    '''tests flip library options with _lib.set_option(); every test starts from and leaves
+    behind the defaults (+ the DANET_* overrides of the process environment)'''
+    yield
+    from danet_amd import _lib
+    if _lib._lib is not None:
+        _lib.apply_env_options()

@@ -33,7 +33,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), 'missing export: ' + s
     assert set(_lib.PROTOTYPES) == set(syms), set(_lib.PROTOTYPES) ^ set(syms)
-    assert lib.danet_abi_version() == 2
+    assert lib.danet_abi_version() == 3
     # pure host-side helpers are callable without a GPU
     assert lib.danet_stft_num_frames(8000, 256, 64) == 126
     assert lib.danet_stft_num_frames(160000, 512, 128) == 1251
@@ -308,3 +308,62 @@ def test_cli_flags_match_reference(hp):
     assert a.no_save_on_epoch and a.no_valid_on_epoch
     assert 'kmeans' in hp.estimator_registry and hp.get_estimator('kmeans').USE_TRUTH is False
     assert hp.KMEANS_ITERS == 10
+
+
+def test_library_never_reads_the_environment_and_options_abi(monkeypatch):
+    '''ABI hygiene (include/danet_hip.h): variant selection is an option table set through
+    danet_set_option, not the process environment; unknown names are errors; values read back;
+    reset restores the defaults; the Python layer is what maps DANET_<NAME> onto the setter'''
+    import ctypes
+    from danet_amd import _lib
+    lib = _lib.load()
+    blob = open(_lib.LIB_PATH, 'rb').read()
+    assert b'getenv' not in blob                # no import of getenv / secure_getenv at all
+    names = _lib.option_names()
+    assert len(names) == lib.danet_option_count() >= 20 and len(set(names)) == len(names)
+    for must in ('gemm_dma', 'lstm_fwd_fused', 'lstm_bwd_rs', 'lstm_spin_limit', 'gemm_yield'):
+        assert must in names
+    assert lib.danet_option_name(lib.danet_option_count()) is None
+    lib.danet_reset_options()
+    assert _lib.get_option('gemm_dma') == 3 and _lib.get_option('lstm_fwd_fused') == -1
+    _lib.set_option('gemm_dma', 7)
+    assert _lib.get_option('gemm_dma') == 7
+    # the envelope query follows the option, not the environment
+    monkeypatch.setenv('DANET_LSTM_FWD_FUSED', '0')
+    assert lib.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 600) == 1
+    _lib.set_option('lstm_fwd_fused', 0)
+    assert lib.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 600) == 0
+    monkeypatch.delenv('DANET_LSTM_FWD_FUSED')
+    # ... and the Python layer applies DANET_<NAME> through the setter
+    monkeypatch.setenv('DANET_GEMM_YIELD', '24')
+    _lib.apply_env_options()
+    assert _lib.get_option('gemm_yield') == 24 and _lib.get_option('gemm_dma') == 3
+    assert _lib.get_option('lstm_fwd_fused') == -1
+    monkeypatch.delenv('DANET_GEMM_YIELD')
+    _lib.apply_env_options()
+    assert _lib.get_option('gemm_yield') == 16
+    assert lib.danet_set_option(b'no_such_option', 1) == -1
+    assert b'unknown option' in lib.danet_last_error()
+    v = ctypes.c_int(0)
+    assert lib.danet_get_option(b'no_such_option', ctypes.byref(v)) == -1
+
+
+def test_options_are_thread_safe():
+    '''two host threads flipping / reading options concurrently never see torn or foreign
+    values (ints in atomics)'''
+    import threading
+    from danet_amd import _lib
+    _lib.load()
+    bad = []
+
+    def worker(name, vals):
+        for i in range(20000):
+            _lib.set_option(name, vals[i % 2])
+            if _lib.get_option(name) not in vals:
+                bad.append((name, _lib.get_option(name)))
+    ts = [threading.Thread(target=worker, args=('gemm_yield', (8, 16))),
+          threading.Thread(target=worker, args=('gemm_wgs', (256, 512)))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not bad
+    _lib.apply_env_options()

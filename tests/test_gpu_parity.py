@@ -225,14 +225,14 @@ def test_gemm_dma_staging_is_bit_identical(M, N, K, ta, tb, monkeypatch):
     registers) keeps the fragment order of the register path, so every launch flavour -- tiles,
     split-K, stream-K, the capped grouped launch -- returns the same bits with DANET_GEMM_DMA
     0 and 7'''
-    from danet_amd import ops
+    from danet_amd import ops, _lib
     rng = np.random.RandomState(M + N + K)
     A = cu(rng.randn(K, M) if ta else rng.randn(M, K))
     Bm = cu(rng.randn(N, K) if tb else rng.randn(K, N))
     ref = ((A.T if ta else A).double() @ (Bm.T if tb else Bm).double()).cpu().numpy()
     outs = {}
     for mode in ('0', '7'):
-        monkeypatch.setenv('DANET_GEMM_DMA', mode)
+        _lib.set_option('gemm_dma', int(mode))
         got = []
         C = torch.empty(M, N, device='cuda')
         ops.gemm(A, Bm, C, M, N, K, A.shape[1], Bm.shape[1], N, transA=ta, transB=tb)
@@ -806,9 +806,10 @@ def test_lstm_forward_12_units_per_workgroup(B, T, D, H, ndir, force, monkeypatc
     geometry wide layers use so that 16-row clusters fit the GPU -- against the oracle, forward and
     (through the unchanged BPTT) backward.  The fused forward is off: this is the hoisted kernel.'''
     from danet_amd import ops
-    monkeypatch.setenv('DANET_LSTM_FWD_FUSED', '0')
+    from danet_amd import _lib
+    _lib.set_option('lstm_fwd_fused', 0)
     if force:
-        monkeypatch.setenv('DANET_LSTM_FWD_UN', force)
+        _lib.set_option('lstm_fwd_un', int(force))
     rng = np.random.RandomState(B + 7 * T + H)
     r = 0.75 / np.sqrt(H)
     x = rng.randn(B, T, D) * 0.7
@@ -875,17 +876,13 @@ def test_lstm_bwd_handoff_under_uneven_load(B, T, H):
                                     ptr(das[0]), ptr(das[1]), ptr(w), n, None))
         return das, w
 
-    old = os.environ.get('DANET_LSTM_BWD_RS')
-    os.environ['DANET_LSTM_BWD_RS'] = '0'
+    _lib.set_option('lstm_bwd_rs', 0)              # the all-gather kernel as the reference
     try:
         ref, w = bwd()
         torch.cuda.synchronize()
         assert int(w[:4].view(torch.int32)[0]) == 0
     finally:
-        if old is None:
-            del os.environ['DANET_LSTM_BWD_RS']
-        else:
-            os.environ['DANET_LSTM_BWD_RS'] = old
+        _lib.set_option('lstm_bwd_rs', 1)
     scale = max(float(r.abs().max()) for r in ref)
     side = torch.cuda.Stream()
     a = torch.randn(2048, 2048, device=dev)

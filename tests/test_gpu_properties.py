@@ -103,7 +103,8 @@ def test_bilstm_time_reversal_symmetry(B, T, D, H):
     swap = lambda t: torch.cat([t[..., H:], t[..., :H]], dim=-1)
     y2, dx2, g2 = run(x.flip(1).contiguous(), [Wb, bb, Wf, bf], swap(dy).flip(1).contiguous())
     from danet_amd import _lib
-    if _lib.load().danet_lstm_fwd_fused_supported(T, B, H, 2, D) == 1:
+    # (LstmLayerFn hands the kernel rows of length D: the fused forward needs D % 4 == 0)
+    if D % 4 == 0 and _lib.load().danet_lstm_fwd_fused_supported(T, B, H, 2, D) == 1:
         assert torch.equal(swap(y2).flip(1), y1)           # whole cell in one kernel: same arithmetic
     else:
         # hoisted input projection: both directions' products are ONE grouped stream-K launch whose
@@ -112,7 +113,8 @@ def test_bilstm_time_reversal_symmetry(B, T, D, H):
     # dX = da_f Wx_f^T + da_b Wx_b^T is one K-concatenated product: swapping the directions swaps
     # the order of its two halves -> rounding only (da itself is bit-exact, or y's test above and
     # the weight gradients below would not hold)
-    assert float((dx2.flip(1) - dx1).abs().max()) <= 2e-6 * float(dx1.abs().max())
+    # (2400-term float32 sums in two different orders, the stream-K launch cuts them at other k)
+    assert float((dx2.flip(1) - dx1).abs().max()) <= 5e-6 * float(dx1.abs().max())
     # weight gradients: same products, the K (time) order of the GEMM reversed -> rounding only
     for a, b in ((g1[0], g2[2]), (g1[1], g2[3]), (g1[2], g2[0]), (g1[3], g2[1])):
         assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())

@@ -105,21 +105,21 @@ def test_injected_handoff_timeout_raises_from_train_step(hp, monkeypatch):
     src = torch.as_tensor(_rand_src(hp, 10)).cuda()
     model.train_step(src)
     model.check_status()
-    monkeypatch.setenv('DANET_LSTM_FAULT_INJECT', '1')
-    monkeypatch.setenv('DANET_LSTM_SPIN_LIMIT', '2048')
+    _lib.set_option('lstm_fault_inject', 1)
+    _lib.set_option('lstm_spin_limit', 2048)
     with pytest.raises(_lib.DanetHipError, match='hand-off timed out'):
         for _ in range(ops.MAX_STEPS_IN_FLIGHT + 2):      # no synchronisation: the fence finds it
             model.train_step(src)
-    monkeypatch.delenv('DANET_LSTM_FAULT_INJECT')
-    monkeypatch.delenv('DANET_LSTM_SPIN_LIMIT')
+    _lib.set_option('lstm_fault_inject', 0)
+    _lib.set_option('lstm_spin_limit', 0)
     torch.cuda.synchronize()
     ops.lstm_status_ok()                        # clear what the faulty launches left behind
     # blocking form
-    monkeypatch.setenv('DANET_LSTM_FAULT_INJECT', '1')
-    monkeypatch.setenv('DANET_LSTM_SPIN_LIMIT', '2048')
+    _lib.set_option('lstm_fault_inject', 1)
+    _lib.set_option('lstm_spin_limit', 2048)
     with torch.no_grad():
         model.forward(src)
-    monkeypatch.delenv('DANET_LSTM_FAULT_INJECT')
+    _lib.set_option('lstm_fault_inject', 0)
     with pytest.raises(_lib.DanetHipError):
         model.check_status()
     model.load_param_dict({k: np.where(np.isfinite(v), v, 0.0) for k, v in model.param_dict().items()})
@@ -204,7 +204,7 @@ def test_fast_backward_equals_plain_autograd(hp):
     gets ordinary gradient tensors (torch.autograd.grad works) -- same numbers'''
     model = _small_model(hp, TRAIN_ESTIMATOR_METHOD='truth-weighted')
     src = torch.as_tensor(_rand_src(hp, 9, 2)).cuda()
-    out = model.forward(src)
+    out = model.forward(src, fuse_heads=model.fuse_heads)     # the kernels train_step runs
     names = [k for k in model._order]
     plist = [model.vars[k] for k in names]
     gs = torch.autograd.grad(out['loss'], plist, allow_unused=True)
@@ -627,8 +627,8 @@ def test_lstm_forward_fused_input_projection(B, T, D, H, ndir, fused, monkeypatc
     hoisted-GEMM / separate-GEMM paths on the other: both give the oracle's outputs and
     gradients; the envelope queries decide which one runs'''
     from danet_amd import ops, _lib
-    monkeypatch.setenv('DANET_LSTM_FWD_FUSED', fused)
-    monkeypatch.setenv('DANET_LSTM_BWD_FUSED', fused)      # BPTT with fused dW / db alongside
+    _lib.set_option('lstm_fwd_fused', int(fused))
+    _lib.set_option('lstm_bwd_fused_kernel', int(fused))   # BPTT with fused dW / db alongside
     monkeypatch.setattr(ops, 'BWD_FUSED', fused)
     assert _lib.load().danet_lstm_fwd_fused_supported(T, B, H, ndir, D) == int(fused)
     bwd_fused = _lib.load().danet_lstm_bwd_fused_supported(T, B, H, ndir, D)
@@ -659,8 +659,7 @@ def test_lstm_forward_fused_input_projection(B, T, D, H, ndir, fused, monkeypatc
 def test_lstm_fused_envelope_query(monkeypatch):
     from danet_amd import _lib
     L = _lib.load()
-    monkeypatch.delenv('DANET_LSTM_FWD_FUSED', raising=False)
-    monkeypatch.delenv('DANET_LSTM_BWD_FUSED', raising=False)
+    L.danet_reset_options()
     assert L.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 600) == 1      # default: B >= 24
     assert L.danet_lstm_fwd_fused_supported(1251, 1, 300, 2, 600) == 0      # B = 1: hoisted GEMM
     assert L.danet_lstm_bwd_fused_supported(128, 32, 300, 2, 600) == 1      # envelope
@@ -670,11 +669,11 @@ def test_lstm_fused_envelope_query(monkeypatch):
     monkeypatch.setattr(ops, 'BWD_FUSED', 'bottom')
     assert ops.bptt_fused(128, 32, 300, 2, 129, need_dx=False) is True
     assert ops.bptt_fused(128, 32, 300, 2, 600, need_dx=True) is False
-    monkeypatch.setenv('DANET_LSTM_BWD_FUSED', '0')
+    _lib.set_option('lstm_bwd_fused_kernel', 0)
     assert L.danet_lstm_bwd_fused_supported(128, 32, 300, 2, 600) == 0
-    monkeypatch.setenv('DANET_LSTM_BWD_FUSED', '1')
+    _lib.set_option('lstm_bwd_fused_kernel', 1)
     assert L.danet_lstm_bwd_fused_supported(128, 32, 600, 2, 1200) == 0     # U = 32 geometry
-    monkeypatch.setenv('DANET_LSTM_FWD_FUSED', '1')
+    _lib.set_option('lstm_fwd_fused', 1)
     assert L.danet_lstm_fwd_fused_supported(1251, 1, 300, 2, 600) == 1
     assert L.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 129) == 1
     assert L.danet_lstm_fwd_fused_supported(128, 32, 600, 2, 1200) == 0     # H > 320

@@ -1,0 +1,231 @@
+'''
+Round-3 GPU tests (run with -m gpu): ABI hygiene under host threads, the status word in
+pinned host memory, the bounded run-ahead.
+'''
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_host_threads_launch_concurrently():
+    '''Two host threads, each on its own HIP stream with its own workspace, launch stream-K
+    grouped GEMMs (the launches that number themselves from the process-wide atomic counter and
+    hand partial tiles over through flags in their workspace) and persistent LSTM layers at the
+    same time; every result equals the single-threaded one bit for bit.'''
+    from danet_amd import ops, _lib
+    _lib.load()
+    dev = torch.device('cuda')
+    rng = np.random.RandomState(0)
+    M, N, K = 300, 1200, 4096
+    A = torch.as_tensor(rng.randn(K, M).astype(np.float32)).cuda()
+    Bm = torch.as_tensor(rng.randn(K, N).astype(np.float32)).cuda()
+    T, B, D, H = 24, 16, 40, 64
+    x = torch.as_tensor(rng.randn(T * B, D).astype(np.float32)).cuda()
+    Ws = [torch.as_tensor((rng.randn(D + H, 4 * H) * 0.1).astype(np.float32)).cuda() for _ in range(2)]
+    bs = [torch.as_tensor((rng.randn(4 * H) * 0.1).astype(np.float32)).cuda() for _ in range(2)]
+
+    def work(n_iter):
+        outs = []
+        for _ in range(n_iter):
+            C = torch.empty(M, N, device=dev)
+            ops.gemm_group([(A, M, Bm, N, C, N, M, N, 0.0)], K, transA=True, max_workgroups=256)
+            c = ops.lstm_layer_fwd(x, D, D, T, B, H, Ws, bs)
+            outs.append((C, c.ypad[1:T + 1].clone()))
+        return outs
+
+    ref = work(1)[0]
+    torch.cuda.synchronize()
+    results, errors = {}, []
+
+    def thread_main(tid):
+        try:
+            s = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(s):
+                results[tid] = work(12)
+            s.synchronize()
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=thread_main, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    torch.cuda.synchronize()
+    assert not errors, errors
+    assert ops.lstm_status_ok()
+    for tid in (0, 1):
+        for C, y in results[tid]:
+            assert torch.equal(C, ref[0]) and torch.equal(y, ref[1])
+
+
+def test_status_word_lives_in_pinned_host_memory_and_kernels_can_write_it(hp):
+    '''single process: the persistent kernels' status word is pinned, device-mapped host
+    memory (no per-step copy); a forced timeout is written by the GPU and read by the host
+    directly, with the DANET_STATUS_TIMEOUT bit pattern (1.0f)'''
+    from danet_amd import ops, _lib
+    dev = torch.device('cuda')
+    w = ops.status_word(dev)
+    assert not w.is_cuda and w.is_pinned() and w.numel() == 4
+    rng = np.random.RandomState(1)
+    T, B, D, H = 8, 16, 16, 32
+    x = torch.as_tensor(rng.randn(T * B, D).astype(np.float32)).cuda()
+    Ws = [torch.as_tensor((rng.randn(D + H, 4 * H) * 0.1).astype(np.float32)).cuda() for _ in range(2)]
+    bs = [torch.zeros(4 * H, device=dev) for _ in range(2)]
+    ops.lstm_layer_fwd(x, D, D, T, B, H, Ws, bs)
+    torch.cuda.synchronize()
+    assert int(w[0]) == 0
+    _lib.set_option('lstm_fault_inject', 1)
+    _lib.set_option('lstm_spin_limit', 2048)
+    ops.lstm_layer_fwd(x, D, D, T, B, H, Ws, bs)
+    torch.cuda.synchronize()
+    assert int(w[0]) == 0x3F800000
+    assert w.view(torch.float32)[0].item() == 1.0
+    assert not ops.lstm_status_ok() and int(w[0]) == 0
+
+
+@pytest.mark.parametrize('act', [0, 1])
+@pytest.mark.parametrize('mode', [0, 1])
+@pytest.mark.parametrize('B,C,T,F,E', [(3, 2, 9, 33, 20), (2, 3, 17, 129, 40), (1, 1, 5, 7, 4),
+                                       (2, 2, 40, 129, 20)])
+def test_fused_separator_pit_matches_unfused_and_oracle(act, mode, B, C, T, F, E):
+    '''danet_separate_pit_fwd / _bwd (separator + phase re-attach + PIT-MSE + SNR in one pass,
+    app/modules.py:548-603 -> main.py:281-290 -> app/ops.py:374-431) against (i) the two-kernel
+    HIP path -- same arithmetic per bin, so loss / SNR agree to reduction-order rounding and
+    the permutation index and dembed / dattr match tightly -- and (ii) the float64 oracle'''
+    from danet_amd import ops
+    from oracle import danet_oracle as O
+    rng = np.random.RandomState(B * 1000 + C * 100 + T + E + act * 7 + mode)
+    N = T * F
+    embed = (rng.randn(B, N, E) * 0.7).astype(np.float32)
+    attr = (rng.randn(B, C, E) * 0.8).astype(np.float32)
+    src = ((rng.randn(B, C, T, F) + 1j * rng.randn(B, C, T, F)) * 4).astype(np.complex64)
+    src[:, :, 0] = 0                                       # an all-zero frame (padded batches)
+    fe = O.frontend(src)
+    cu = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
+    mix_pwr = cu(fe['mix_pwr'].astype(np.float32))
+    ph = np.stack([np.cos(fe['phase']), np.sin(fe['phase'])], -1).astype(np.float32)
+    phasor = cu(ph)
+    s_src = cu(src)
+
+    def run(fused):
+        e = cu(embed).requires_grad_(True)
+        a = cu(attr).requires_grad_(True)
+        if fused:
+            loss, _, idx, snr = ops.separate_pit_loss(mix_pwr, a, e, s_src, phasor, act, mode=mode, eps=1e-7)
+        else:
+            sep, _ = ops.SeparateFn.apply(mix_pwr, a, e, act, False)
+            loss, _, idx, snr = ops.pit_mse_loss(s_src, sep, phasor, mode=mode, eps=1e-7)
+        loss.backward()
+        torch.cuda.synchronize()
+        return (float(loss), float(snr), idx.cpu().numpy(), e.grad.cpu().numpy(), a.grad.cpu().numpy())
+
+    lf, sf, pf, def_, daf = run(True)
+    lu, su, pu, deu, dau = run(False)
+    assert np.array_equal(pf, pu)
+    assert abs(lf - lu) <= 2e-6 * abs(lu) and abs(sf - su) <= 1e-5 * max(abs(su), 1.0), (lf, lu, sf, su)
+    # (C = 1: the softmax mask is identically 1 and both gradients are exact zeros up to
+    # cancellation noise -- compare on the scale of the incoming gradient instead)
+    gscale = float(np.abs(src).max()) / (B * N)
+    assert np.abs(def_ - deu).max() <= 1e-6 * np.abs(deu).max() + 1e-6 * gscale, \
+        (np.abs(def_ - deu).max(), np.abs(deu).max())
+    assert np.abs(daf - dau).max() <= 2e-5 * np.abs(dau).max() + 1e-5 * gscale * N ** 0.5, \
+        (np.abs(daf - dau).max(), np.abs(dau).max())
+    # oracle (float64): loss and permutation
+    sep64, _ = O.sep_dot(fe['mix_pwr'], attr.astype(np.float64), embed.astype(np.float64),
+                         'softmax' if act == 0 else 'sigmoid', return_masks=True)
+    if mode == 0:
+        est = O.reattach_phase(sep64, fe['phase'])
+        lo, _, io, _ = O.pit_mse_loss(src.astype(np.complex128), est)
+    else:
+        lo, _, io, _ = O.pit_mse_loss(fe['src_pwr'], sep64)
+    # (C = 1, mode 0: estimate == mixture == the one source, the loss is rounding noise)
+    assert abs(lf - lo) <= 1e-4 * abs(lo) + 1e-9 * float(np.mean(np.abs(src) ** 2))
+    assert np.array_equal(pf, io)
+
+
+def test_train_step_uses_fused_heads_and_matches_unfused(hp):
+    '''Model.train_step takes the fused separator + loss kernels; three steps give the same
+    parameters as the unfused path to rounding'''
+    from danet_amd.model import Model
+    res = []
+    for fuse in (True, False):
+        hp.reset()
+        hp.load(dict(BATCH_SIZE=3, MAX_N_SIGNAL=2, FFT_SIZE=32, FFT_STRIDE=8, EMBED_SIZE=8,
+                     NUM_LSTM_LAYERS=2, LSTM_HDIM=16, NUM_ANCHOR=4, ENCODER_TYPE='bilstm-orig',
+                     TRAIN_ESTIMATOR_METHOD='anchor', INFER_ESTIMATOR_METHOD='anchor',
+                     SEPARATOR_TYPE='dot-softmax-orig'))
+        hp.digest()
+        model = Model('fh', device='cuda', seed=11).build()
+        model.fuse_heads = fuse
+        rng = np.random.RandomState(3)
+        src = torch.as_tensor(((rng.randn(3, 2, 10, 17) + 1j * rng.randn(3, 2, 10, 17)) * 5)
+                              .astype(np.complex64)).cuda()
+        out = None
+        for _ in range(3):
+            out = model.train_step(src)
+        res.append((float(out['loss']), model.param_dict()))
+        if fuse:
+            o = model.forward(src, fuse_heads=True)
+            assert 'sep_pwr' not in o and 'loss' in o
+    assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[1][0])
+    for k in res[0][1]:
+        a, b = res[0][1][k], res[1][1][k]
+        assert np.abs(a - b).max() <= 1e-4 * (np.abs(b).max() + 1e-12), k
+
+
+@pytest.mark.parametrize('M,N,K1,K2,ta,tb', [(4096, 600, 1200, 1200, 0, 1), (4096, 1200, 2400, 2400, 0, 1),
+                                             (130, 70, 32, 500, 0, 0), (64, 300, 16, 17, 1, 0),
+                                             (257, 129, 704, 90, 1, 1), (700, 2600, 48, 33, 0, 0)])
+def test_gemm_streamk_kcat(M, N, K1, K2, ta, tb):
+    '''danet_gemm_f32_streamk_kcat: C = A1 B1 + A2 B2 (+bias)(+beta C) on the hybrid stream-K
+    schedule (whole tiles data-parallel, the ragged last round cut along K; the two operand
+    pairs are one concatenated contraction): correct, bit-reproducible'''
+    from danet_amd import ops
+    rng = np.random.RandomState(M + N + K1 + K2)
+    cu = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    mk = lambda K: (rng.randn(K, M) if ta else rng.randn(M, K), rng.randn(N, K) if tb else rng.randn(K, N))
+    (A1, B1), (A2, B2) = mk(K1), mk(K2)
+    op = lambda A, Bm: (A.T if ta else A) @ (Bm.T if tb else Bm)
+    ref = op(A1, B1) + op(A2, B2)
+    bias, C0 = rng.randn(N), rng.randn(M, N)
+    d = [cu(x) for x in (A1, B1, A2, B2)]
+    outs = []
+    for _ in range(2):
+        C = torch.empty(M, N, device='cuda')
+        ops.gemm_kcat(d[0], d[0].shape[1], d[1], d[1].shape[1], K1, d[2], d[2].shape[1], d[3],
+                      d[3].shape[1], K2, C, M, N, N, transA=ta, transB=tb, streamk=True)
+        outs.append(C)
+    err = np.abs(outs[0].cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err < 2e-5, err
+    assert torch.equal(outs[0], outs[1])
+    C = cu(C0)
+    ops.gemm_kcat(d[0], d[0].shape[1], d[1], d[1].shape[1], K1, d[2], d[2].shape[1], d[3],
+                  d[3].shape[1], K2, C, M, N, N, transA=ta, transB=tb, bias=cu(bias), beta=1.0,
+                  streamk=True)
+    assert np.abs(C.cpu().numpy() - (ref + bias + C0)).max() / np.abs(ref).max() < 2e-5
+
+
+@pytest.mark.parametrize('M,N,K', [(4096, 2580, 600), (4096, 600, 2580), (4096, 5160, 1200), (2100, 3000, 50),
+                                   (1030, 1300, 70)])
+def test_gemm_hybrid_streamk_many_tiles(M, N, K):
+    '''products with more tiles than workgroups: every workgroup owns whole tiles and only the
+    ragged last round is cut along K -- correct, reproducible, identical under a capped grid
+    of a different size only up to summation order'''
+    from danet_amd import ops
+    rng = np.random.RandomState(M + N + K)
+    A = torch.as_tensor(rng.randn(M, K).astype(np.float32)).cuda()
+    Bm = torch.as_tensor(rng.randn(K, N).astype(np.float32)).cuda()
+    ref = (A.double() @ Bm.double()).cpu().numpy()
+    outs = []
+    for _ in range(2):
+        C = torch.full((M, N), float('nan'), device='cuda')
+        ops.gemm(A, Bm, C, M, N, K, K, N, N, streamk=True)
+        outs.append(C)
+    assert np.abs(outs[0].cpu().numpy() - ref).max() / np.abs(ref).max() < 2e-5
+    assert torch.equal(outs[0], outs[1])
+    C = torch.full((M, N), float('nan'), device='cuda')
+    ops.gemm_group([(A, K, Bm, N, C, N, M, N, 0.0)], K, max_workgroups=104)
+    assert np.abs(C.cpu().numpy() - ref).max() / np.abs(ref).max() < 2e-5

@@ -67,9 +67,9 @@ def main():
     modes.append(dict(DANET_LSTM_BWD_U='32', DANET_LSTM_BWD_S='5', DANET_LSTM_XMAP='0'))
     modes.append(dict(DANET_LSTM_BWD_RS='0'))
     for m in modes:
-        for k in ('DANET_LSTM_BWD_RS', 'DANET_LSTM_BWD_U', 'DANET_LSTM_XMAP', 'DANET_LSTM_BWD_S'):
-            os.environ.pop(k, None)
-        os.environ.update(m)
+        _lib.apply_env_options()          # defaults (+ process environment), then this mode
+        for k, v in m.items():
+            _lib.set_option(k[len('DANET_'):].lower(), int(v))
         tf, tb = [], []
         for it in range(12):
             a, ypad, gates, cells = fwd()

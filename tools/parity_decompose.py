@@ -84,6 +84,88 @@ def main():
     ops.gemm(yc, model.vars['global/encoder/output/W'], out, n * 128, W.shape[1], 600, 600, W.shape[1], W.shape[1])
     print('projection of the f64 stack output by the HIP GEMM vs f64     : %.3e' %
           mx(out.cpu().numpy().reshape(r64['embed'].shape), r64['embed']))
+    # the HIP stack, layer by layer (activations kept by the encoder's autograd node)
+    with torch.enable_grad():
+        fe = ops.frontend(batches[0])
+        emb = model.encoder(fe['mix_log'])
+    node = emb.grad_fn
+    while node is not None and not hasattr(node, 'ctxs'):
+        node = node.next_functions[0][0] if node.next_functions else None
+    T = 128
+    for l, c in enumerate(node.ctxs):
+        yh = c.ypad[1:T + 1].transpose(0, 1)[:n].cpu().numpy()          # [n, T, 2H]
+        print('layer %d output: HIP vs f64 max abs %.3e rms %.3e | f32 oracle %.3e rms %.3e' % (
+            l, mx(yh, acts64[l]), np.sqrt(((yh - acts64[l]) ** 2).mean()),
+            mx(acts32[l], acts64[l]), np.sqrt(((acts32[l].astype(np.float64) - acts64[l]) ** 2).mean())))
+    # the SAME parameters through the hoisted forward (input GEMM + recurrent kernel)
+    from danet_amd import _lib
+    _lib.set_option('lstm_fwd_fused', 0)
+    with torch.enable_grad():
+        emb2 = model.encoder(fe['mix_log'])
+    node2 = emb2.grad_fn
+    while node2 is not None and not hasattr(node2, 'ctxs'):
+        node2 = node2.next_functions[0][0] if node2.next_functions else None
+    for l, c in enumerate(node2.ctxs):
+        yh = c.ypad[1:T + 1].transpose(0, 1)[:n].cpu().numpy()
+        print('layer %d output, HOISTED forward at the same parameters: HIP vs f64 max abs %.3e rms %.3e' % (
+            l, mx(yh, acts64[l]), np.sqrt(((yh - acts64[l]) ** 2).mean())))
+    print('embed, hoisted forward: HIP vs f64 max abs %.3e' % mx(emb2[:n].detach().cpu().numpy(), r64['embed']))
+    _lib.apply_env_options()
+    # input centring: the per-utterance mean (a COMMON-MODE error of every input of layer 0)
+    ml64 = r64['mix_log']
+    mean64 = ml64.mean(axis=(1, 2))
+    mean32 = r32['mix_log'].mean(axis=(1, 2), dtype=np.float32)
+    xin = torch.zeros(B, T, 129, device='cuda'); xin[:n] = torch.as_tensor(ml64.astype(np.float32)).cuda()
+    xc = torch.empty(T, B, 132, device='cuda')
+    mean_hip = ops.center(xin, B, T, 129, 0, 129, xc, 1, 132)[:n].cpu().numpy()
+    print('input mean: f64 %s' % mean64)
+    print('input mean error: HIP %s | numpy f32 %s' % (mean_hip - mean64, mean32 - mean64))
+    xc64 = (ml64 - mean64[:, None, None])
+    print('centred input: HIP vs f64 max %.3e rms %.3e | numpy f32 max %.3e rms %.3e' % (
+        mx(xc.transpose(0, 1)[:n, :, :129].cpu().numpy(), xc64),
+        np.sqrt(((xc.transpose(0, 1)[:n, :, :129].cpu().numpy() - xc64) ** 2).mean()),
+        mx((r32['mix_log'] - mean32[:, None, None]).astype(np.float32), xc64),
+        np.sqrt((((r32['mix_log'] - mean32[:, None, None]).astype(np.float32) - xc64) ** 2).mean())))
+    # layer 0 in isolation on the exactly centred input (rounded to float32)
+    x0 = xc64.astype(np.float32)
+    names0 = ['global/encoder/lstm0_%s/LSTM/linear/%s' % (d, w) for d in ('fwd', 'bwd') for w in ('W', 'B')]
+    W0f, b0f, W0b, b0b = [p[k] for k in names0]
+    ref0 = O.lyr_bilstm(x0.astype(np.float64), W0f.astype(np.float64), b0f.astype(np.float64),
+                        W0b.astype(np.float64), b0b.astype(np.float64), 300)
+    np0 = O.lyr_bilstm(x0, W0f, b0f, W0b, b0b, 300)
+    xb0 = torch.zeros(B, T, 129, device='cuda'); xb0[:n] = torch.as_tensor(x0).cuda()
+    with torch.no_grad():
+        y0 = ops.LstmLayerFn.apply(xb0, 300, *[model.vars[k] for k in names0])[:n].cpu().numpy()
+    print('layer 0 alone (exact centred input): HIP max %.3e rms %.3e | numpy f32 max %.3e rms %.3e' % (
+        mx(y0, ref0), np.sqrt(((y0 - ref0) ** 2).mean()), mx(np0, ref0), np.sqrt(((np0 - ref0) ** 2).mean())))
+    # layer 1 in ISOLATION: the float64 oracle's layer-0 output (rounded to float32) through
+    # layer 1 only -- intrinsic noise of one layer: HIP fused / HIP hoisted / numpy float32
+    x1 = acts64[0].astype(np.float32)                                  # [n, T, 2H]
+    names = ['global/encoder/lstm1_%s/LSTM/linear/%s' % (d, w) for d in ('fwd', 'bwd') for w in ('W', 'B')]
+    Wf, bf, Wb, bb = [p[k] for k in names]
+    ref1 = O.lyr_bilstm(x1.astype(np.float64), Wf.astype(np.float64), bf.astype(np.float64),
+                        Wb.astype(np.float64), bb.astype(np.float64), 300)
+    np32 = O.lyr_bilstm(x1, Wf, bf, Wb, bb, 300)
+    print('layer 1 alone: numpy f32 vs f64 max %.3e rms %.3e' % (mx(np32, ref1), np.sqrt(((np32 - ref1) ** 2).mean())))
+    xb = torch.zeros(B, T, 600, device='cuda'); xb[:n] = torch.as_tensor(x1).cuda()
+    prm = [model.vars[k] for k in names]
+    for fused in (1, 0):
+        _lib.set_option('lstm_fwd_fused', fused)
+        with torch.no_grad():
+            yh = ops.LstmLayerFn.apply(xb, 300, *prm)[:n].cpu().numpy()
+        print('layer 1 alone: HIP (fused=%d) vs f64 max %.3e rms %.3e' % (
+            fused, mx(yh, ref1), np.sqrt(((yh - ref1) ** 2).mean())))
+        et = np.abs(yh - ref1).max(axis=(0, 2))
+        print('   max error by time step (every 16th): ' + ' '.join('%.1e' % v for v in et[::16]))
+    et = np.abs(np32 - ref1).max(axis=(0, 2))
+    print('   numpy f32, by time step (every 16th):   ' + ' '.join('%.1e' % v for v in et[::16]))
+    _lib.apply_env_options()
+    ych = node.yc[:n].cpu().numpy()
+    print('centred stack output: HIP vs f64 max abs %.3e | f32 oracle %.3e' % (mx(ych, y64), mx(y32, y64)))
+    print('f64 projection of the HIP stack output vs f64 embed: %.3e' %
+          mx((ych.astype(np.float64) @ W.astype(np.float64)).reshape(r64['embed'].shape), r64['embed']))
+    xin = (r64['mix_log'] - r64['mix_log'].mean(axis=(1, 2), keepdims=True))
+    print('front-end: mix_log HIP vs f64 %.3e' % mx(fe['mix_log'][:n].cpu().numpy(), r64['mix_log']))
     d = np.abs(got['masks'].astype(np.float64) - m64)
     idx = np.unravel_index(d.argmax(), d.shape)
     b, t, f, c = idx

@@ -131,7 +131,7 @@ def bwd_fused(B, T, H, D):
 
 def main():
     B, T, H = (int(x) for x in sys.argv[1:4]) if len(sys.argv) >= 4 else (32, 128, 300)
-    if os.environ.get('DANET_LSTM_FWD_FUSED') == '1':
+    if _lib.get_option('lstm_fwd_fused') == 1:
         fused(B, T, H, 2 * H)
         fused(B, T, H, 132)
     bwd_fused(B, T, H, 2 * H)
