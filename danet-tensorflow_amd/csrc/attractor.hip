@@ -457,12 +457,44 @@ __global__ __launch_bounds__(256) void sep_pit_bwd_kernel(
     int act, int mode, int B, int64_t N, int E, const float* __restrict__ mix_pwr,
     const float* __restrict__ attr, const float* __restrict__ embed,
     const float2* __restrict__ src, const float2* __restrict__ phasor,
-    const int32_t* __restrict__ perm_idx, float dloss, const float* __restrict__ dloss_dev,
+    const int32_t* __restrict__ perm_idx, const float* __restrict__ records,
+    float dloss, const float* __restrict__ dloss_dev,
     float* __restrict__ dembed, float* __restrict__ partial /* [B][nch][C][EP] */) {
   constexpr int C = CP;
   __shared__ float tab[CP * EP];
   __shared__ float red[4 * EP];
+  __shared__ float rec_s[REC + 1];
+  __shared__ int perm_s;
   const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  if (records != nullptr) {
+    // this utterance's permutation from the forward's records: the sums and the search of
+    // pit_final_kernel (ascending chunks, first minimum), so the same index -- without waiting
+    // for that kernel
+    if (threadIdx.x < REC) {
+      const float* pp = records + (int64_t)b * nch * REC + threadIdx.x;
+      float sacc = 0.f;
+      for (int c2 = 0; c2 < nch; ++c2) sacc += pp[(int64_t)c2 * REC];
+      rec_s[threadIdx.x] = sacc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int nperm = 1;
+      for (int i = 2; i <= C; ++i) nperm *= i;
+      const float invN = 1.f / (float)N;
+      int best = 0;
+      float best_v = 0.f;
+      for (int pq = 0; pq < nperm; ++pq) {
+        int pm[MAXC];
+        nth_perm(C, pq, pm);
+        float v = 0.f;
+        for (int i = 0; i < C; ++i) v += rec_s[i * C + pm[i]] * invN;
+        if (pq == 0 || v < best_v) { best = pq; best_v = v; }
+      }
+      perm_s = best;
+    }
+  } else if (threadIdx.x == 0) {
+    perm_s = perm_idx[b];
+  }
   for (int i = threadIdx.x; i < C * EP; i += 256) {
     const int c = i / EP, e = i % EP;
     tab[i] = (e < E) ? attr[((int64_t)b * C + c) * E + e] : 0.f;
@@ -474,7 +506,7 @@ __global__ __launch_bounds__(256) void sep_pit_bwd_kernel(
 #pragma unroll
     for (int e = 0; e < EP; ++e) st[c][e] = uniform(tab[c * EP + e]);
   int perm[MAXC], inv[MAXC];
-  nth_perm(C, perm_idx[b], perm);
+  nth_perm(C, perm_s, perm);       // (published by the barrier behind the table load above)
   for (int i = 0; i < C; ++i) inv[perm[i]] = i;   // estimate j is paired with truth inv[j]
   const float scale = dloss * (dloss_dev ? *dloss_dev : 1.f) * 2.f / ((float)B * (float)N);
   const int64_t n0 = (int64_t)ch * CHUNK_N, n1 = min(N, n0 + CHUNK_N);
@@ -1119,45 +1151,77 @@ extern "C" size_t danet_separate_pit_workspace_bytes(int B, int C, int64_t N, in
   return fwd > bwd ? fwd : bwd;
 }
 
+// The forward in two stream-ordered parts: part 1 writes the per-chunk cross-error records
+// (`records`, danet_separate_pit_records_bytes, caller-owned: the backward reads them again),
+// part 2 turns them into loss / SNR / permutation index.  The backward derives each utterance's
+// permutation from the records itself (same sums, same order), so part 2 is not on the
+// critical path between forward and backward: a host may issue it on another stream.
+extern "C" size_t danet_separate_pit_records_bytes(int B, int64_t N) {
+  return (size_t)B * n_chunks(N) * REC * sizeof(float);
+}
+
+extern "C" int danet_separate_pit_fwd_records(danet_stream_t stream_, int act, int mode, int B,
+                                              int C, int64_t N, int E, const float* mix_pwr,
+                                              const float* attr, const float* embed,
+                                              const float* src_c64, const float* phasor,
+                                              float* sep_pwr_out, float* records) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_common("separate_pit_fwd", B, C, N, E);
+  if (rc) return rc;
+  DANET_CHECK_ARG((act == 0 || act == 1) && (mode == 0 || mode == 1), "separate_pit_fwd: act / mode");
+  DANET_CHECK_ARG(mix_pwr && attr && embed && src_c64 && phasor && records,
+                  "separate_pit_fwd: null pointer");
+  const int nch = n_chunks(N), EPV = pick_ep(E);
+  dim3 grid(nch, B);
+  DISPATCH_EP(EPV, DISPATCH_CP(C, (sep_pit_fwd_kernel<EP, CP><<<grid, 256, 0, stream>>>(
+                       act, mode, N, E, mix_pwr, attr, embed, (const float2*)src_c64,
+                       (const float2*)phasor, sep_pwr_out, records))));
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
+
+extern "C" int danet_separate_pit_final(danet_stream_t stream_, int B, int C, int64_t N, float eps,
+                                        const float* records, float* loss, float* snr,
+                                        int32_t* perm_idx) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DANET_CHECK_ARG(B > 0 && C > 0 && C <= MAXC && N > 0 && records && loss && perm_idx,
+                  "separate_pit_final: bad argument");
+  pit_final_kernel<<<1, PIT_FINAL_THREADS, 0, stream>>>(B, C, N, n_chunks(N), eps, records, loss, snr,
+                                                        perm_idx);
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
+
 extern "C" int danet_separate_pit_fwd(danet_stream_t stream_, int act, int mode, int B, int C,
                                       int64_t N, int E, const float* mix_pwr, const float* attr,
                                       const float* embed, const float* src_c64,
                                       const float* phasor, float eps, float* sep_pwr_out,
                                       float* loss, float* snr, int32_t* perm_idx, void* ws,
                                       size_t ws_bytes) {
-  hipStream_t stream = (hipStream_t)stream_;
-  int rc = check_common("separate_pit_fwd", B, C, N, E);
-  if (rc) return rc;
-  DANET_CHECK_ARG((act == 0 || act == 1) && (mode == 0 || mode == 1), "separate_pit_fwd: act / mode");
-  DANET_CHECK_ARG(mix_pwr && attr && embed && src_c64 && phasor && loss && perm_idx,
-                  "separate_pit_fwd: null pointer");
+  DANET_CHECK_ARG(loss && perm_idx, "separate_pit_fwd: null pointer");
   if (!ws || ws_bytes < danet_separate_pit_workspace_bytes(B, C, N, E)) {
     danet_set_error("separate_pit_fwd: workspace too small");
     return DANET_ERR_WORKSPACE;
   }
-  const int nch = n_chunks(N), EPV = pick_ep(E);
-  dim3 grid(nch, B);
-  DISPATCH_EP(EPV, DISPATCH_CP(C, (sep_pit_fwd_kernel<EP, CP><<<grid, 256, 0, stream>>>(
-                       act, mode, N, E, mix_pwr, attr, embed, (const float2*)src_c64,
-                       (const float2*)phasor, sep_pwr_out, (float*)ws))));
-  DANET_CHECK_LAUNCH();
-  pit_final_kernel<<<1, PIT_FINAL_THREADS, 0, stream>>>(B, C, N, nch, eps, (const float*)ws, loss, snr, perm_idx);
-  DANET_CHECK_LAUNCH();
-  return DANET_OK;
+  int rc = danet_separate_pit_fwd_records(stream_, act, mode, B, C, N, E, mix_pwr, attr, embed,
+                                          src_c64, phasor, sep_pwr_out, (float*)ws);
+  if (rc) return rc;
+  return danet_separate_pit_final(stream_, B, C, N, eps, (const float*)ws, loss, snr, perm_idx);
 }
 
 extern "C" int danet_separate_pit_bwd(danet_stream_t stream_, int act, int mode, int B, int C,
                                       int64_t N, int E, const float* mix_pwr, const float* attr,
                                       const float* embed, const float* src_c64,
-                                      const float* phasor, const int32_t* perm_idx, float dloss,
+                                      const float* phasor, const int32_t* perm_idx,
+                                      const float* records, float dloss,
                                       const float* dloss_dev, float* dembed, float* dattr,
                                       void* ws, size_t ws_bytes) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_common("separate_pit_bwd", B, C, N, E);
   if (rc) return rc;
   DANET_CHECK_ARG((act == 0 || act == 1) && (mode == 0 || mode == 1), "separate_pit_bwd: act / mode");
-  DANET_CHECK_ARG(mix_pwr && attr && embed && src_c64 && phasor && perm_idx && dembed && dattr,
-                  "separate_pit_bwd: null pointer");
+  DANET_CHECK_ARG(mix_pwr && attr && embed && src_c64 && phasor && (perm_idx || records) && dembed && dattr,
+                  "separate_pit_bwd: null pointer (one of perm_idx / records is required)");
   if (!ws || ws_bytes < danet_separate_pit_workspace_bytes(B, C, N, E)) {
     danet_set_error("separate_pit_bwd: workspace too small");
     return DANET_ERR_WORKSPACE;
@@ -1166,7 +1230,8 @@ extern "C" int danet_separate_pit_bwd(danet_stream_t stream_, int act, int mode,
   dim3 grid(nch, B);
   DISPATCH_EP(EPV, DISPATCH_CP(C, (sep_pit_bwd_kernel<EP, CP><<<grid, 256, 0, stream>>>(
                        act, mode, B, N, E, mix_pwr, attr, embed, (const float2*)src_c64,
-                       (const float2*)phasor, perm_idx, dloss, dloss_dev, dembed, (float*)ws))));
+                       (const float2*)phasor, perm_idx, records, dloss, dloss_dev, dembed,
+                       (float*)ws))));
   DANET_CHECK_LAUNCH();
   sum_chunks_kernel<<<B, 128, 0, stream>>>(nch, C, E, EPV, (const float*)ws, dattr);
   DANET_CHECK_LAUNCH();
@@ -1242,16 +1307,19 @@ extern "C" int danet_attractor_anchor_fwd(danet_stream_t stream_, int B, int C, 
   return DANET_OK;
 }
 
-extern "C" int danet_attractor_anchor_bwd(danet_stream_t stream_, int B, int C, int64_t N, int E,
-                                          int A, const float* dattr, const float* embed,
-                                          const float* anchors, const float* attr,
-                                          const float* asum, const int32_t* choice,
-                                          float* dembed, float* danchors, void* ws,
-                                          size_t ws_bytes, float danchors_beta) {
+// Backward in two stream-ordered parts so that a host may issue the second one elsewhere: part 1
+// (everything the rest of backward waits for: dembed += ...; per-chunk anchor-gradient partials
+// into `ws`) and part 2 (danchors from the partials: only the optimiser needs it).
+extern "C" int danet_attractor_anchor_bwd_embed(danet_stream_t stream_, int B, int C, int64_t N,
+                                                int E, int A, const float* dattr,
+                                                const float* embed, const float* anchors,
+                                                const float* attr, const float* asum,
+                                                const int32_t* choice, float* dembed, void* ws,
+                                                size_t ws_bytes) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = anchor_check("attractor_anchor_bwd", B, C, N, E, A);
   if (rc) return rc;
-  DANET_CHECK_ARG(dattr && embed && anchors && attr && asum && choice && dembed && danchors,
+  DANET_CHECK_ARG(dattr && embed && anchors && attr && asum && choice && dembed,
                   "attractor_anchor_bwd: null pointer");
   if (!ws || ws_bytes < danet_attractor_anchor_workspace_bytes(B, C, N, E, A)) {
     danet_set_error("attractor_anchor_bwd: workspace too small");
@@ -1265,9 +1333,41 @@ extern "C" int danet_attractor_anchor_bwd(danet_stream_t stream_, int B, int C, 
                        C, N, E, A, cb, dattr, embed, anchors, attr, asum, choice, dembed,
                        (float*)ws))));
   DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
+
+extern "C" int danet_attractor_anchor_bwd_anchors(danet_stream_t stream_, int B, int C, int64_t N,
+                                                  int E, int A, const int32_t* choice,
+                                                  float* danchors, const void* ws,
+                                                  size_t ws_bytes, float danchors_beta) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = anchor_check("attractor_anchor_bwd", B, C, N, E, A);
+  if (rc) return rc;
+  DANET_CHECK_ARG(choice && danchors, "attractor_anchor_bwd: null pointer");
   DANET_CHECK_ARG(danchors_beta == 0.f || danchors_beta == 1.f, "attractor_anchor_bwd: beta must be 0 or 1");
+  if (!ws || ws_bytes < danet_attractor_anchor_workspace_bytes(B, C, N, E, A)) {
+    danet_set_error("attractor_anchor_bwd: workspace too small");
+    return DANET_ERR_WORKSPACE;
+  }
+  AnchorCombos cb;
+  make_combos(A, C, cb);
+  const int nch = n_chunks(N), EPV = pick_ep(E);
   anchor_bwd_final_kernel<<<A, 256, 0, stream>>>(B, C, E, EPV, A, nch, cb, (const float*)ws,
                                                  choice, danchors, danchors_beta);
   DANET_CHECK_LAUNCH();
   return DANET_OK;
+}
+
+extern "C" int danet_attractor_anchor_bwd(danet_stream_t stream_, int B, int C, int64_t N, int E,
+                                          int A, const float* dattr, const float* embed,
+                                          const float* anchors, const float* attr,
+                                          const float* asum, const int32_t* choice,
+                                          float* dembed, float* danchors, void* ws,
+                                          size_t ws_bytes, float danchors_beta) {
+  DANET_CHECK_ARG(danchors, "attractor_anchor_bwd: null pointer");
+  int rc = danet_attractor_anchor_bwd_embed(stream_, B, C, N, E, A, dattr, embed, anchors, attr, asum,
+                                            choice, dembed, ws, ws_bytes);
+  if (rc) return rc;
+  return danet_attractor_anchor_bwd_anchors(stream_, B, C, N, E, A, choice, danchors, ws, ws_bytes,
+                                            danchors_beta);
 }

@@ -28,7 +28,7 @@ enum DanetOpt {
   OPT_LSTM_FWD_FUSED,        // -1 auto (B >= 24) | 0 off | 1 whenever supported
   OPT_LSTM_FX_MODE,          // diagnostic modes of the fused forward kernel
   OPT_LSTM_BWD_FUSED_KERNEL, // 1 the dW-fusing BPTT kernel may be used | 0 never
-  OPT_LSTM_BWD_TWIN_XCD,     // 1: the twins of a BPTT group share an XCD (L2 hits on their re-reads)
+  OPT_LSTM_BWD_TWIN_XCD,     // 1 (default): the twins of a BPTT group share an XCD (L2 hits on their re-reads) | 0
   OPT_LSTM_BWD_LDS_PAD,      // bytes of unused dynamic LDS of the BPTT kernel (CU exclusivity experiment)
   OPT_COUNT
 };

@@ -268,7 +268,13 @@ class Model(object):
         ops.poll_status(self.device)
         if not self._grads_clean:
             self._flat_grad.zero_()
-        out = self.forward(s_src_signals, fuse_heads=self.fuse_heads)
+        chain = ops.heads_chain()        # small finalize kernels go to the side stream (ops.py)
+        chain.__enter__()
+        try:
+            out = self.forward(s_src_signals, fuse_heads=self.fuse_heads)
+        except BaseException:
+            chain.__exit__(None, None, None)
+            raise
         self._early, self._in_step = None, True
         # from here until the final optimiser piece has been issued the bucket holds partial
         # sums: an exception in between (launch error, collective failure, KeyboardInterrupt)
@@ -277,6 +283,9 @@ class Model(object):
         try:
             with ops.fast_backward():          # kernels add straight into the flat bucket
                 out['loss'].backward(self._one)    # (a persistent 1: no ones_like fill per step)
+                # side-stream finalizers (loss / SNR, anchor gradients) join the main stream
+                # BEFORE the gradient reduction reads the bucket
+                ops.join_deferred()
                 if self._buckets is not None:
                     grad_scale = self._buckets.finish()            # pieces launched during backward
                 else:                                              # ONE RCCL all-reduce / step
@@ -284,6 +293,8 @@ class Model(object):
                         self._grad_store if dist.is_dist() else self._flat_grad)
         finally:
             self._in_step = False
+            chain.__exit__(None, None, None)
+            ops.join_deferred()        # (no-op after a clean backward; an exception path still joins)
         self.step_count += 1
         ranges, early_stream = None, None
         if self._early is not None:            # everything but the bottom layer is already stepped

@@ -991,6 +991,38 @@ TRUTH_MODES = {'truth': 0, 'truth-threshold': 1, 'truth-weighted': 2}
 FUSE_DEMBED = int(__import__('os').environ.get('DANET_FUSE_DEMBED', '1'))
 
 
+# "Heads chain" scope (entered by Model.train_step around forward + backward): inside it the two
+# reductions nobody on the critical path waits for are issued on the side stream --
+#   * the loss / SNR / permutation finalize of SeparatePitFn (the backward kernel derives the
+#     permutation from the chunk records itself), and
+#   * the anchors' gradient finalize of AnchorAttractorFn (only the optimiser reads it)
+# -- and joined by `join_deferred()` (RnnEncoderFn.backward ends with it; train_step calls it
+# again before the optimiser).  Outside the scope both run in stream order, so a caller that
+# reads `loss` right after forward needs no join.
+_chain_depth = [0]
+
+
+class heads_chain(object):
+    def __enter__(self):
+        _chain_depth[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _chain_depth[0] -= 1
+        return False
+
+
+def _chain():
+    return _chain_depth[0] > 0 and SIDE_STREAMS > 0
+
+
+def _on_side(dev, fn, keep=()):
+    '''run fn() on the side stream behind everything issued on the main stream so far; the main
+    stream joins it at the next join_deferred()'''
+    with _Fork(dev, 2, defer=True, keep=keep) as f:
+        f.run(1, fn)
+
+
 class _DembedToken(object):
     '''links an estimator's autograd node to the separator node that consumes its
     attractors: created in the estimator's forward, carried on the attractor tensor
@@ -1098,11 +1130,24 @@ class AnchorAttractorFn(torch.autograd.Function):
         # fast backward: add straight into the parameter's .grad (no autograd accumulate kernel)
         danchors, direct = _grad_target(ctx.anchors_param, (A, E), dev)
         L = _L()
-        w, wn = _ws(L.danet_attractor_anchor_workspace_bytes(B, C, N, E, A), dev)
-        check(L.danet_attractor_anchor_bwd(
-            _lib.stream(), B, C, N, E, A, ptr(_f32(dattr.contiguous())), ptr(embed),
-            ptr(anchors), ptr(attr), ptr(asum), ptr(choice), ptr(dembed), ptr(danchors),
-            ptr(w), wn, 1.0 if direct else 0.0))
+        nbytes = L.danet_attractor_anchor_workspace_bytes(B, C, N, E, A)
+        dattr = _f32(dattr.contiguous())
+        if _chain():
+            # part 1 (dembed) on this stream; part 2 (danchors, from the chunk partials) on the
+            # side stream: its own scratch, kept alive until the join
+            w = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            check(L.danet_attractor_anchor_bwd_embed(
+                _lib.stream(), B, C, N, E, A, ptr(dattr), ptr(embed), ptr(anchors), ptr(attr),
+                ptr(asum), ptr(choice), ptr(dembed), ptr(w), nbytes))
+            _on_side(dev, lambda: check(L.danet_attractor_anchor_bwd_anchors(
+                _lib.stream(), B, C, N, E, A, ptr(choice), ptr(danchors), ptr(w), nbytes,
+                1.0 if direct else 0.0)), keep=(w, choice, danchors))
+        else:
+            w, wn = _ws(nbytes, dev)
+            check(L.danet_attractor_anchor_bwd(
+                _lib.stream(), B, C, N, E, A, ptr(dattr), ptr(embed),
+                ptr(anchors), ptr(attr), ptr(asum), ptr(choice), ptr(dembed), ptr(danchors),
+                ptr(w), wn, 1.0 if direct else 0.0))
         return (None if shared is not None else dembed), (None if direct else danchors), None
 
 
@@ -1217,11 +1262,19 @@ class SeparatePitFn(torch.autograd.Function):
         loss, snr = torch.empty((), device=dev), torch.empty((), device=dev)
         perm_idx = torch.empty(B, dtype=torch.int32, device=dev)
         L = _L()
-        w, wn = _ws(L.danet_separate_pit_workspace_bytes(B, C, N, E), dev)
-        check(L.danet_separate_pit_fwd(_lib.stream(), act, mode, B, C, N, E, ptr(mix_pwr),
-                                       ptr(attr_c), ptr(embed_flat), ptr(torch.view_as_real(src)),
-                                       ptr(phasor), eps, None, ptr(loss), ptr(snr), ptr(perm_idx),
-                                       ptr(w), wn))
+        records = torch.empty(L.danet_separate_pit_records_bytes(B, N) // 4, device=dev)
+        check(L.danet_separate_pit_fwd_records(
+            _lib.stream(), act, mode, B, C, N, E, ptr(mix_pwr), ptr(attr_c), ptr(embed_flat),
+            ptr(torch.view_as_real(src)), ptr(phasor), None, ptr(records)))
+
+        def final():
+            check(L.danet_separate_pit_final(_lib.stream(), B, C, N, eps, ptr(records), ptr(loss),
+                                             ptr(snr), ptr(perm_idx)))
+        if _chain():
+            _on_side(dev, final, keep=(records, loss, snr, perm_idx))   # the backward does not wait for it
+        else:
+            final()
+        ctx.records = records
         ctx.save_for_backward(mix_pwr, attr_c, embed_flat, src, phasor, perm_idx)
         ctx.args = (act, mode, B, C, N, E)
         ctx.token = getattr(attr, '_danet_dembed_token', None)
@@ -1235,6 +1288,7 @@ class SeparatePitFn(torch.autograd.Function):
             return (None,) * 8
         mix_pwr, attr, embed_flat, src, phasor, perm_idx = ctx.saved_tensors
         act, mode, B, C, N, E = ctx.args
+        records, ctx.records = ctx.records, None
         dev = dloss.device
         dembed = torch.empty(B, N, E, device=dev)
         dattr = torch.empty(B, C, E, device=dev)
@@ -1243,7 +1297,7 @@ class SeparatePitFn(torch.autograd.Function):
         # dloss is a device scalar: the kernel reads it (no host sync, no extra pass)
         check(L.danet_separate_pit_bwd(_lib.stream(), act, mode, B, C, N, E, ptr(mix_pwr),
                                        ptr(attr), ptr(embed_flat), ptr(torch.view_as_real(src)),
-                                       ptr(phasor), ptr(perm_idx), 1.0,
+                                       ptr(phasor), None, ptr(records), 1.0,
                                        ptr(_f32(dloss.contiguous())), ptr(dembed), ptr(dattr),
                                        ptr(w), wn))
         if ctx.token is not None and ctx.needs_input_grad[1]:

@@ -365,6 +365,16 @@ int danet_attractor_anchor_bwd(danet_stream_t stream, int B, int C, int64_t N,
                                const int32_t* choice, float* dembed,
                                float* danchors, void* ws, size_t ws_bytes,
                                float danchors_beta);
+/* The same backward in two stream-ordered parts: `_embed` does everything the rest of backward
+ * waits for (dembed += ..., per-chunk anchor-gradient partials into ws), `_anchors` reduces the
+ * partials in ws to danchors (only the optimiser needs it; ws must stay untouched in between). */
+int danet_attractor_anchor_bwd_embed(danet_stream_t stream, int B, int C, int64_t N, int E, int A,
+                                     const float* dattr, const float* embed, const float* anchors,
+                                     const float* attr, const float* asum, const int32_t* choice,
+                                     float* dembed, void* ws, size_t ws_bytes);
+int danet_attractor_anchor_bwd_anchors(danet_stream_t stream, int B, int C, int64_t N, int E, int A,
+                                       const int32_t* choice, float* danchors, const void* ws,
+                                       size_t ws_bytes, float danchors_beta);
 
 /* ---------------------------------------------------------------- a12
  * Dot-product separators (app/modules.py:548-603). act 0 = softmax over C
@@ -398,11 +408,24 @@ int danet_separate_pit_fwd(danet_stream_t stream, int act, int mode, int B, int 
                            const float* src_c64, const float* phasor, float eps,
                            float* sep_pwr_out, float* loss, float* snr, int32_t* perm_idx,
                            void* ws, size_t ws_bytes);
+/* The forward in two stream-ordered parts.  Part 1 writes the per-chunk cross-error `records`
+ * (danet_separate_pit_records_bytes, caller-owned); part 2 reduces them to loss / SNR /
+ * permutation index.  danet_separate_pit_bwd accepts `records` INSTEAD of perm_idx (pass
+ * perm_idx = NULL) and derives each utterance's permutation from them itself -- the same sums
+ * in the same order, hence the same index -- so part 2 is off the forward -> backward critical
+ * path and a host may issue it on another stream.                                          */
+size_t danet_separate_pit_records_bytes(int B, int64_t N);
+int danet_separate_pit_fwd_records(danet_stream_t stream, int act, int mode, int B, int C,
+                                   int64_t N, int E, const float* mix_pwr, const float* attr,
+                                   const float* embed, const float* src_c64, const float* phasor,
+                                   float* sep_pwr_out, float* records);
+int danet_separate_pit_final(danet_stream_t stream, int B, int C, int64_t N, float eps,
+                             const float* records, float* loss, float* snr, int32_t* perm_idx);
 int danet_separate_pit_bwd(danet_stream_t stream, int act, int mode, int B, int C, int64_t N,
                            int E, const float* mix_pwr, const float* attr, const float* embed,
                            const float* src_c64, const float* phasor, const int32_t* perm_idx,
-                           float dloss, const float* dloss_dev, float* dembed, float* dattr,
-                           void* ws, size_t ws_bytes);
+                           const float* records, float dloss, const float* dloss_dev,
+                           float* dembed, float* dattr, void* ws, size_t ws_bytes);
 
 /* ---------------------------------------------------------------- a14/a15
  * PIT-MSE loss + SNR (app/ops.py:374-431, :191-222; main.py:289-337).
