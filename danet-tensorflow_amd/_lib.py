@@ -62,15 +62,19 @@ PROTOTYPES = {
     'danet_colsum_f32': (c_int, [c_p, c_int, c_int, c_p, c_int, c_p, c_f32, c_p, c_sz]),
     'danet_lstm_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int]),
     'danet_lstm_fwd': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_int,
-                               c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+                               c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_sz, c_p, c_int]),
+    'danet_lstm_fwd_prefill': (c_int, [c_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_p),
+                                       ctypes.POINTER(c_p)]),
+    'danet_lstm_bwd_prefill': (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_p)]),
     'danet_lstm_fwd_fused_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'danet_lstm_fwd_fused': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_int, c_p, c_p,
-                                     c_int, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+                                     c_int, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_sz, c_p,
+                                     c_int]),
     'danet_lstm_bwd': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_int,
                                c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     'danet_lstm_bwd_db_supported': (c_int, [c_int, c_int, c_int, c_int]),
     'danet_lstm_bwd_db': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_int,
-                                  c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_sz, c_p]),
+                                  c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_sz, c_p, c_int]),
     'danet_lstm_bwd_fused_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'danet_lstm_bwd_fused_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     'danet_lstm_bwd_fused': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_int,

@@ -686,7 +686,9 @@ __global__ __launch_bounds__(256) void anchor_fwd_kernel(
         for (int a = 1; a < MAXA; ++a) if (a < A) dmax = fmaxf(dmax, d[a]);
         float ea[MAXA];
 #pragma unroll
-        for (int a = 0; a < MAXA; ++a) ea[a] = (a < A) ? expf(d[a] - dmax) : 0.f;
+        // (hardware exponential: arguments are <= 0 after the max subtraction; ~1e-7 relative in a
+        // soft assignment, far inside the 1e-4 bar, and 6 x ~20 fewer vector instructions per bin)
+        for (int a = 0; a < MAXA; ++a) ea[a] = (a < A) ? __expf(d[a] - dmax) : 0.f;
         if constexpr (AT > 0) {
           constexpr CombosCE<AT, CTT> tb{};
 #pragma unroll
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(256) void anchor_fwd_kernel(
 #pragma unroll
               for (int c = 0; c < CTT; ++c) { lg[c] = expf(d[tb.idx[p][c]] - mx); den += lg[c]; }
             }
-            const float inv = 1.0f / den;
+            const float inv = __frcp_rn(den);
 #pragma unroll
             for (int c = 0; c < CTT; ++c) Ss[tid * lds + p * CTT + c] = lg[c] * inv;   // modules.py:516
           }

@@ -1717,19 +1717,18 @@ __global__ __launch_bounds__(256) void lstm_dw_reduce_kernel(
 // (hipMemsetAsync with a byte value lowers to a fill kernel PLUS copy kernels on this
 // runtime, and each memset is its own node on the critical path of the layer)
 // ---------------------------------------------------------------------------
+#define FILL_MAXSEG 16
 struct FillArgs {
-  void* ptr[4];
-  unsigned long long n16[4];   // 16-byte words per segment
-  unsigned value[4];
+  void* ptr[FILL_MAXSEG];
+  unsigned long long n16[FILL_MAXSEG];   // 16-byte words per segment
+  unsigned value[FILL_MAXSEG];
   int nseg;
 };
 
 __global__ __launch_bounds__(256) void multi_fill_kernel(FillArgs a) {
   const unsigned long long tid = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
   const unsigned long long stride = (unsigned long long)gridDim.x * 256;
-#pragma unroll
-  for (int sgi = 0; sgi < 4; ++sgi) {
-    if (sgi >= a.nseg) break;
+  for (int sgi = 0; sgi < a.nseg; ++sgi) {
     const unsigned v = a.value[sgi];
     const v4u w = {v, v, v, v};
     v4u* p = reinterpret_cast<v4u*>(a.ptr[sgi]);
@@ -1740,6 +1739,7 @@ __global__ __launch_bounds__(256) void multi_fill_kernel(FillArgs a) {
 struct FillList {
   FillArgs a;
   FillList() { a.nseg = 0; }
+  bool full() const { return a.nseg >= FILL_MAXSEG; }
   void add(void* p, size_t bytes, unsigned value) {
     a.ptr[a.nseg] = p; a.n16[a.nseg] = bytes / 16; a.value[a.nseg] = value; ++a.nseg;
   }
@@ -1893,12 +1893,56 @@ static int lstm_check_common(int T, int B, int H, int ndir, void* ws, size_t ws_
   return DANET_OK;
 }
 
+// ---- prefill of several launches' buffers in ONE fill launch ----------------------------------
+// Every forward launch needs its output buffer prefilled with the "not yet published" sentinel
+// (+ zero pad blocks), every reduce-scatter BPTT launch its partial-dh ring prefilled with phase
+// 1.  Inside the entry points that is one fill launch per call (~6 us each: 6 per cfg-2 train
+// step); a host that allocates the buffers of all layers up front prefills them with ONE call
+// here and passes DANET_LSTM_PREFILLED to the launches.
+extern "C" int danet_lstm_fwd_prefill(danet_stream_t stream_, int T, int B, int ldy, int n,
+                                      float* const* ypads, void* const* wss) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DANET_CHECK_ARG(T > 0 && B > 0 && ldy > 0 && ldy % 4 == 0 && n > 0 && ypads, "lstm_fwd_prefill: bad argument");
+  const size_t blk = (size_t)B * ldy * sizeof(float);
+  FillList fl;
+  for (int i = 0; i < n; ++i) {
+    DANET_CHECK_ARG(ypads[i] && ((uintptr_t)ypads[i] & 15) == 0, "lstm_fwd_prefill: ypad %d null / misaligned", i);
+    if (fl.a.nseg + 4 > FILL_MAXSEG) { DANET_CHECK_HIP(fl.launch(stream)); fl = FillList(); }
+    if (wss && wss[i]) fl.add(wss[i], 64 + TRACE_BYTES(T), 0u);
+    fl.add((char*)ypads[i] + blk, (size_t)T * blk, SENTINEL);
+    fl.add(ypads[i], blk, 0u);
+    fl.add((char*)ypads[i] + (size_t)(T + 1) * blk, blk, 0u);
+  }
+  if (fl.a.nseg) DANET_CHECK_HIP(fl.launch(stream));
+  return DANET_OK;
+}
+
+extern "C" int danet_lstm_bwd_prefill(danet_stream_t stream_, int T, int B, int H, int ndir, int n,
+                                      void* const* wss) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DANET_CHECK_ARG(T > 0 && B > 0 && H > 0 && (ndir == 1 || ndir == 2) && n > 0 && wss, "lstm_bwd_prefill: bad argument");
+  const RsPlan rs = choose_rs_plan(B, H, ndir);
+  if (!rs.ok) {
+    danet_set_error("lstm_bwd_prefill: B=%d H=%d outside the reduce-scatter geometry", B, H);
+    return DANET_ERR_UNSUPPORTED;
+  }
+  FillList fl;
+  for (int i = 0; i < n; ++i) {
+    DANET_CHECK_ARG(wss[i] && ((uintptr_t)wss[i] & 15) == 0, "lstm_bwd_prefill: ws %d null / misaligned", i);
+    if (fl.a.nseg + 2 > FILL_MAXSEG) { DANET_CHECK_HIP(fl.launch(stream)); fl = FillList(); }
+    fl.add(wss[i], 64 + TRACE_BYTES(T), 0u);
+    fl.add((char*)wss[i] + ring_offset(T), rs.ring_bytes, 1u);   // phase 1 in bit 0 of every word
+  }
+  if (fl.a.nseg) DANET_CHECK_HIP(fl.launch(stream));
+  return DANET_OK;
+}
+
 extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int ndir,
                               const float* gx_f, const float* gx_b,
                               const float* Wh_f, const float* Wh_b, int ldw,
                               float* ypad, int ldy, float* gates_f, float* gates_b,
                               float* cell_f, float* cell_b, void* ws, size_t ws_bytes,
-                              int32_t* status) {
+                              int32_t* status, int flags) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = lstm_check_common(T, B, H, ndir, ws, ws_bytes);
   if (rc) return rc;
@@ -1928,7 +1972,7 @@ extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int n
   // status word; "not yet published" sentinel in the T interior blocks of ypad; the
   // zero initial state in pad blocks 0 and T+1 (main.py:108-123) -- one launch
   const size_t blk = (size_t)B * ldy * sizeof(float);
-  {
+  if (!(flags & DANET_LSTM_PREFILLED)) {
     FillList fl;
     fl.add(ws, 64 + TRACE_BYTES(T), 0u);
     fl.add((char*)ypad + blk, (size_t)T * blk, SENTINEL);
@@ -1993,7 +2037,7 @@ extern "C" int danet_lstm_fwd_fused(danet_stream_t stream_, int T, int B, int H,
                                     const float* bias_f, const float* bias_b,
                                     float* ypad, int ldy, float* gates_f, float* gates_b,
                                     float* cell_f, float* cell_b, void* ws, size_t ws_bytes,
-                                    int32_t* status) {
+                                    int32_t* status, int flags) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = lstm_check_common(T, B, H, ndir, ws, ws_bytes);
   if (rc) return rc;
@@ -2023,7 +2067,7 @@ extern "C" int danet_lstm_fwd_fused(danet_stream_t stream_, int T, int B, int H,
   a.xmap = (danet_opt(OPT_LSTM_XMAP) >= 0 ? danet_opt(OPT_LSTM_XMAP) : 1);
   const size_t lds = ((size_t)a.KP * 32 + (size_t)4 * 16 * 33) * sizeof(float);
   const size_t blk = (size_t)B * ldy * sizeof(float);
-  {
+  if (!(flags & DANET_LSTM_PREFILLED)) {
     FillList fl;
     fl.add(ws, 64 + TRACE_BYTES(T), 0u);
     fl.add((char*)ypad + blk, (size_t)T * blk, SENTINEL);
@@ -2174,7 +2218,7 @@ static int lstm_bwd_impl(danet_stream_t stream_, int T, int B, int H, int ndir,
                          const float* gates_f, const float* gates_b,
                          const float* cell_f, const float* cell_b,
                          float* da_f, float* da_b, void* ws, size_t ws_bytes,
-                         int32_t* status, float* db_f, float* db_b, float beta);
+                         int32_t* status, float* db_f, float* db_b, float beta, int flags);
 
 extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int ndir,
                               const float* dy, int lddy,
@@ -2184,7 +2228,7 @@ extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int n
                               float* da_f, float* da_b, void* ws, size_t ws_bytes,
                               int32_t* status) {
   return lstm_bwd_impl(stream_, T, B, H, ndir, dy, lddy, Wh_f, Wh_b, ldw, gates_f, gates_b,
-                       cell_f, cell_b, da_f, da_b, ws, ws_bytes, status, nullptr, nullptr, 0.f);
+                       cell_f, cell_b, da_f, da_b, ws, ws_bytes, status, nullptr, nullptr, 0.f, 0);
 }
 
 extern "C" int danet_lstm_bwd_db_supported(int T, int B, int H, int ndir) {
@@ -2198,7 +2242,7 @@ extern "C" int danet_lstm_bwd_db(danet_stream_t stream_, int T, int B, int H, in
                                  const float* gates_f, const float* gates_b,
                                  const float* cell_f, const float* cell_b,
                                  float* da_f, float* da_b, float* db_f, float* db_b, float beta,
-                                 void* ws, size_t ws_bytes, int32_t* status) {
+                                 void* ws, size_t ws_bytes, int32_t* status, int flags) {
   DANET_CHECK_ARG(db_f && (ndir == 1 || db_b), "lstm_bwd_db: null db pointer");
   DANET_CHECK_ARG((((uintptr_t)db_f | (uintptr_t)db_b) & 15) == 0, "lstm_bwd_db: db must be 16-B aligned");
   DANET_CHECK_ARG(beta == 0.f || beta == 1.f, "lstm_bwd_db: beta must be 0 or 1");
@@ -2207,7 +2251,7 @@ extern "C" int danet_lstm_bwd_db(danet_stream_t stream_, int T, int B, int H, in
     return DANET_ERR_UNSUPPORTED;
   }
   return lstm_bwd_impl(stream_, T, B, H, ndir, dy, lddy, Wh_f, Wh_b, ldw, gates_f, gates_b,
-                       cell_f, cell_b, da_f, da_b, ws, ws_bytes, status, db_f, db_b, beta);
+                       cell_f, cell_b, da_f, da_b, ws, ws_bytes, status, db_f, db_b, beta, flags);
 }
 
 static int lstm_bwd_impl(danet_stream_t stream_, int T, int B, int H, int ndir,
@@ -2216,7 +2260,7 @@ static int lstm_bwd_impl(danet_stream_t stream_, int T, int B, int H, int ndir,
                          const float* gates_f, const float* gates_b,
                          const float* cell_f, const float* cell_b,
                          float* da_f, float* da_b, void* ws, size_t ws_bytes,
-                         int32_t* status, float* db_f, float* db_b, float beta) {
+                         int32_t* status, float* db_f, float* db_b, float beta, int flags) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = lstm_check_common(T, B, H, ndir, ws, ws_bytes);
   if (rc) return rc;
@@ -2238,7 +2282,7 @@ static int lstm_bwd_impl(danet_stream_t stream_, int T, int B, int H, int ndir,
     a.NT = rs.NT; a.NI = rs.NI; a.D = rs.D;
     a.xmap = (danet_opt(OPT_LSTM_XMAP) >= 0 ? danet_opt(OPT_LSTM_XMAP) : 1);
     a.dbslab = db_f ? (float*)((char*)ws + align_up(ring_offset(T) + rs.ring_bytes, 256)) : nullptr;
-    {
+    if (!(flags & DANET_LSTM_PREFILLED)) {
       FillList fl;
       fl.add(ws, 64 + TRACE_BYTES(T), 0u);
       fl.add(a.ring, rs.ring_bytes, 1u);   // phase 1 in bit 0 of every word

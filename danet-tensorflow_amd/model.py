@@ -162,13 +162,17 @@ class Model(object):
             cls = dist.GradBuckets if mode == '1' else dist.TailOverlap
             self._buckets = cls(self._grad_store if dist.is_dist() else grad, offs)
             ops.add_grad_ready_hook(self._buckets.hook)
-        # early optimizer step (DANET_EARLY_ADAM=0 turns it off): once the bottom encoder layer's
-        # BPTT kernel has been issued every other gradient is final (and, under data parallelism
-        # with the 'tail' schedule, reduced), so clip + Adam over everything outside that layer's
-        # range runs on the side stream under the bottom layer's kernels; after backward only the
-        # bottom layer's range is left (5 instead of 34 us at the tail of a cfg-2 step).  The update
-        # is elementwise and nothing reads those parameters again in this step.
-        self._early_adam = os.environ.get('DANET_EARLY_ADAM', '1') == '1'
+        # early optimizer step (opt-in: DANET_EARLY_ADAM=1): once the bottom encoder layer's BPTT
+        # kernel has been issued every other gradient is final (and, under data parallelism with
+        # the 'tail' schedule, reduced), so clip + Adam over everything outside that layer's range
+        # can run on the side stream under the bottom layer's kernels; after backward only the
+        # bottom layer's range is left.  The update is elementwise and nothing reads those
+        # parameters again in this step (bit-identical parameters, tested).  Round 2 measured
+        # -35 us per cfg-2 step; with round 3's shorter tail it LOSES 27 us (3.166 vs 3.192 ms:
+        # the 188 MB Adam stream beside the bottom layer's weight-gradient group costs the group
+        # more than the 33 us the single update takes afterwards) -> off by default.
+        self._early_hooked = False
+        self._early_adam = os.environ.get('DANET_EARLY_ADAM', '0') == '1'
         if dist.is_dist():
             # the status word rides in the gradient all-reduce: every rank sees the same value
             ops.set_status_word(self.device, self._grad_store[n:].view(torch.int32))
@@ -177,7 +181,19 @@ class Model(object):
         self._early = None          # (ranges, stream) of this step's early update
         self.early_steps = 0        # steps that took the early path (diagnostics / tests)
         self._in_step = False
-        ops.add_grad_ready_hook(self._grad_ready)     # after the bucket's hook: it launches first
+
+    # (the gradient-ready hook is registered only when the early step is wanted: with no hook at
+    # all ops does not fire the 'rest' event, whose cross-stream wait costs the main stream ~10 us)
+    @property
+    def _early_adam(self):
+        return self._early_adam_on
+
+    @_early_adam.setter
+    def _early_adam(self, on):
+        self._early_adam_on = bool(on)
+        if on and not self._early_hooked:
+            ops.add_grad_ready_hook(self._grad_ready)     # after the bucket's hook: it launches first
+            self._early_hooked = True
 
     def _grad_ready(self, tag, params):
         if tag[0] != 'rest' or not self._early_adam or not self._in_step or self._early is not None:

@@ -456,6 +456,9 @@ class _Fork(object):
         s = self.sides[(chain - 1) % len(self.sides)]
         self.used.add(s)
         with torch.cuda.stream(s):
+            if _lazy:
+                self.keep = tuple(self.keep) + tuple(k for _f, k in _lazy)
+                _flush_lazy()          # queued small kernels ride on this fork's event
             return fn()
 
     def after_all(self, fn, wait_main=False):
@@ -552,14 +555,36 @@ def _grad_target(param, shape, dev):
 
 
 def join_deferred():
-    '''main stream waits for every deferred side chain'''
+    '''main stream waits for every deferred side chain -- ONE wait per distinct side stream
+    (each wait is an event record + a barrier packet: four of them in a row put a 17 us bubble
+    in front of the optimiser kernel)'''
+    _flush_lazy()                      # nothing forked since they were queued: run them here
+    waits = {}
     while _deferred:
         main, used, _keep = _deferred.pop()
         for s in used:
-            main.wait_stream(s)
+            waits.setdefault((main.cuda_stream, s.cuda_stream), (main, s))
+    for main, s in waits.values():
+        main.wait_stream(s)
 
 
-def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs, x_pad_zero=False):
+def lstm_prefill_fwd(T, B, ldy, ypads, wss):
+    '''ONE fill launch for the output buffers (+ workspaces) of several forward launches'''
+    n = len(ypads)
+    yp = (_lib.c_p * n)(*[ptr(y) for y in ypads])
+    wp = (_lib.c_p * n)(*[ptr(w) for w in wss])
+    check(_L().danet_lstm_fwd_prefill(_lib.stream(), T, B, ldy, n, yp, wp))
+
+
+def lstm_prefill_bwd(T, B, H, ndir, wss):
+    '''ONE fill launch for the partial-dh rings of several BPTT launches; False when the shape
+    takes the all-gather kernel (which prefills its own exchange medium)'''
+    n = len(wss)
+    wp = (_lib.c_p * n)(*[ptr(w) for w in wss])
+    return _L().danet_lstm_bwd_prefill(_lib.stream(), T, B, H, ndir, n, wp) == 0
+
+
+def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs, x_pad_zero=False, ypad=None, ws=None):
     '''x: time-major [T*B rows, ldx] tensor (data_ptr = row 0), D valid columns.
     Ws[d]: [D+H, 4H] (reference layout, rows 0..D-1 input, D.. recurrent),
     bs[d]: [4H].  Returns ctx with ypad [T+2, B, ndir*H].
@@ -572,8 +597,13 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs, x_pad_zero=False):
     L = _L()
     gates = [torch.empty(T * B, 4 * H, device=dev) for _ in range(ndir)]
     cells = [torch.empty(T * B, H, device=dev) for _ in range(ndir)]
-    ypad = torch.empty(T + 2, B, ndir * H, device=dev)
-    ws, wn = _lstm_ws(T, B, H, ndir, dev)
+    flags = 0
+    if ypad is None:
+        ypad = torch.empty(T + 2, B, ndir * H, device=dev)
+        ws, wn = _lstm_ws(T, B, H, ndir, dev)
+    else:                    # allocated and prefilled by the caller (lstm_prefill_fwd)
+        wn = ws.numel()
+        flags = 1            # DANET_LSTM_PREFILLED
     fused = (ldx % 4 == 0 and x.data_ptr() % 16 == 0 and (D % 4 == 0 or x_pad_zero) and
              all(W.stride(0) == 4 * H and W.stride(1) == 1 for W in Ws) and
              L.danet_lstm_fwd_fused_supported(T, B, H, ndir, D) == 1)
@@ -585,7 +615,7 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs, x_pad_zero=False):
                 _lib.stream(), T, B, H, ndir, ptr(_f32(x)), ldx, D,
                 ptr(Ws[0]), ptr(Ws[-1]), 4 * H, ptr(bs[0]), ptr(bs[-1]), ptr(ypad), ndir * H,
                 ptr(gates[0]), ptr(gates[-1]), ptr(cells[0]), ptr(cells[-1]), ptr(ws), wn,
-                ptr(status_word(dev))))
+                ptr(status_word(dev)), flags))
     else:
         if GROUPED_GX and ndir == 2:
             # hoisted input half of ops.lyr_lstm_flat's [x,h]W+b (app/ops.py:139-142) of both
@@ -605,7 +635,7 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs, x_pad_zero=False):
                 _lib.stream(), T, B, H, ndir, ptr(gates[0]), ptr(gates[-1]),
                 ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(ypad), ndir * H,
                 ptr(gates[0]), ptr(gates[-1]), ptr(cells[0]), ptr(cells[-1]), ptr(ws), wn,
-                ptr(status_word(dev))))
+                ptr(status_word(dev)), flags))
     c = _LayerCtx()
     c.x, c.ldx, c.D, c.T, c.B, c.H, c.ndir = x, ldx, D, T, B, H, ndir
     c.ypad, c.gates, c.cells, c.Ws, c.bs = ypad, gates, cells, Ws, bs
@@ -654,8 +684,9 @@ def bptt_fused(T, B, H, ndir, D, need_dx, is_top=False):
     return use and _L().danet_lstm_bwd_fused_supported(T, B, H, ndir, D) == 1
 
 
-def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False):
-    '''dy: [T, B, ndir*H] contiguous.  Returns (dx [T*B, D] or None, dWs, dbs).'''
+def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=None):
+    '''dy: [T, B, ndir*H] contiguous.  Returns (dx [T*B, D] or None, dWs, dbs).
+    ws_prefilled: a workspace whose ring the caller prefilled (lstm_prefill_bwd)'''
     T, B, H, D, ndir = c.T, c.B, c.H, c.D, c.ndir
     dev = dy.device
     das = [torch.empty(T * B, 4 * H, device=dev) for _ in range(ndir)]
@@ -689,7 +720,10 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False):
                 ptr(das[0]), ptr(das[-1]), ptr(dWs[0]), ptr(dWs[-1]), ptr(dbs[0]), ptr(dbs[-1]),
                 1.0 if all_direct else 0.0, ptr(ws), wn, ptr(status_word(dev))))
     else:
-        ws, wn = _lstm_ws(T, B, H, ndir, dev)
+        if ws_prefilled is not None:
+            ws, wn = ws_prefilled, ws_prefilled.numel()
+        else:
+            ws, wn = _lstm_ws(T, B, H, ndir, dev)
         Whs = [W[D:] for W in c.Ws]
         b_direct = [okb for _, okb in direct]
         db_in_kernel = (BWD_DB and (all(b_direct) or not any(b_direct)) and
@@ -702,7 +736,7 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False):
                     ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(c.gates[0]), ptr(c.gates[-1]),
                     ptr(c.cells[0]), ptr(c.cells[-1]), ptr(das[0]), ptr(das[-1]),
                     ptr(dbs[0]), ptr(dbs[-1]), 1.0 if all(b_direct) else 0.0, ptr(ws), wn,
-                    ptr(status_word(dev))))
+                    ptr(status_word(dev)), 1 if ws_prefilled is not None else 0))
             else:
                 check(L.danet_lstm_bwd(
                     _lib.stream(), T, B, H, ndir, ptr(_f32(dy)), ndir * H,
@@ -858,12 +892,17 @@ class RnnEncoderFn(torch.autograd.Function):
         center(x, B, T, F, 0, F, xc, 1, Fp)                  # modules.py:209-210
         ctxs = []
         cur, ld, D = xc, Fp, F
+        # output buffers + workspaces of ALL layers, prefilled by one fill launch
+        ypads = [torch.empty(T + 2, B, ndir * H, device=dev) for _ in range(L)]
+        wss = [_lstm_ws(T, B, H, ndir, dev)[0] for _ in range(L)]
+        lstm_prefill_fwd(T, B, ndir * H, ypads, wss)
         for l in range(L):                                    # modules.py:223-242
             Ws = [params[(l * ndir + d) * 2] for d in range(ndir)]
             bs = [params[(l * ndir + d) * 2 + 1] for d in range(ndir)]
             # (the centre kernel zero-fills the float4 pad of layer 0's rows; deeper layers
             # read ypad, whose row length is a multiple of 4)
-            c = lstm_layer_fwd(cur, ld, D, T, B, H, Ws, bs, x_pad_zero=True)
+            c = lstm_layer_fwd(cur, ld, D, T, B, H, Ws, bs, x_pad_zero=True, ypad=ypads[l],
+                               ws=wss[l])
             ctxs.append(c)
             cur, ld, D = c.ypad[1:], ndir * H, ndir * H
         # y - mean_{t,h}(y), back to batch-major                modules.py:244-245
@@ -899,9 +938,18 @@ class RnnEncoderFn(torch.autograd.Function):
         dy = torch.empty(T, B, D, device=dev)
         center(dyc, B, T, D, 0, D, dy, 1, D)                 # centre is self-adjoint
         grads = [None] * (2 * L * ndir)
+        # partial-dh rings of all layers' BPTT launches, prefilled by one fill launch (layers
+        # that take the dW-fusing kernel allocate and prefill their own, larger workspace)
+        bwss = [None] * L
+        plain = [l for l in range(L) if not bptt_fused(T, B, H, ndir, ctx.ctxs[l].D, l > 0, l == L - 1)]
+        if plain and BWD_DB and _L().danet_lstm_bwd_db_supported(T, B, H, ndir) == 1:
+            cand = [_lstm_ws(T, B, H, ndir, dev)[0] for _ in plain]
+            if lstm_prefill_bwd(T, B, H, ndir, cand):
+                for l, w in zip(plain, cand):
+                    bwss[l] = w
         for l in reversed(range(L)):
             dx, dWs, dbs = lstm_layer_bwd(ctx.ctxs[l], dy, need_dx=(l > 0), layer_tag=l,
-                                          is_top=(l == L - 1))
+                                          is_top=(l == L - 1), ws_prefilled=bwss[l])
             for d in range(ndir):
                 grads[(l * ndir + d) * 2] = dWs[d]
                 grads[(l * ndir + d) * 2 + 1] = dbs[d]
@@ -1016,11 +1064,23 @@ def _chain():
     return _chain_depth[0] > 0 and SIDE_STREAMS > 0
 
 
+_lazy = []
+
+
 def _on_side(dev, fn, keep=()):
-    '''run fn() on the side stream behind everything issued on the main stream so far; the main
-    stream joins it at the next join_deferred()'''
-    with _Fork(dev, 2, defer=True, keep=keep) as f:
-        f.run(1, fn)
+    '''fn() runs on the side stream at the NEXT fork of the backward pass (behind that fork's
+    event, i.e. behind everything issued on the main stream so far), ahead of the fork's own
+    work; the main stream joins it at the next join_deferred().  No fork of its own: recording
+    an event on the main stream costs it ~8 us (the following kernel cannot overlap the
+    previous one's tail), more than the small kernels moved here take.  Without any fork before
+    the join, fn() runs in stream order at the join.'''
+    _lazy.append((fn, keep))
+
+
+def _flush_lazy():
+    while _lazy:
+        fn, _keep = _lazy.pop(0)
+        fn()
 
 
 class _DembedToken(object):

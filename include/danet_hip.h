@@ -248,7 +248,17 @@ int danet_lstm_fwd(danet_stream_t stream, int T, int B, int H, int ndir,
                    float* ypad, int ldy,
                    float* gates_f, float* gates_b,
                    float* cell_f, float* cell_b,
-                   void* ws, size_t ws_bytes, int32_t* status);
+                   void* ws, size_t ws_bytes, int32_t* status, int flags);
+
+/* `flags` of danet_lstm_fwd / danet_lstm_fwd_fused / danet_lstm_bwd_db: DANET_LSTM_PREFILLED = the
+ * caller has prefilled this launch's buffers with danet_lstm_fwd_prefill / danet_lstm_bwd_prefill
+ * (one fill launch for the buffers of ALL layers instead of one per call); 0 = the call prefills
+ * its own buffers.                                                                          */
+#define DANET_LSTM_PREFILLED 1
+int danet_lstm_fwd_prefill(danet_stream_t stream, int T, int B, int ldy, int n,
+                           float* const* ypads, void* const* wss /* NULL or n workspaces */);
+int danet_lstm_bwd_prefill(danet_stream_t stream, int T, int B, int H, int ndir, int n,
+                           void* const* wss);
 
 /* The same layer forward with the INPUT projection fused (no hoisted GEMM, no gx
  * tensor): the kernel computes a_t = [x_t, h_{t-1}] W + b itself -- x_t*Wx of step t
@@ -271,7 +281,7 @@ int danet_lstm_fwd_fused(danet_stream_t stream, int T, int B, int H, int ndir,
                          float* ypad, int ldy,
                          float* gates_f, float* gates_b,
                          float* cell_f, float* cell_b,
-                         void* ws, size_t ws_bytes, int32_t* status);
+                         void* ws, size_t ws_bytes, int32_t* status, int flags);
 
 /* BPTT of the above.  dy [T][B][lddy] (dir d uses columns [d*H,(d+1)*H)).
  * Outputs da_d [T][B][4H] = dL/d(pre-activation) (16-byte aligned; pre-filled
@@ -298,7 +308,7 @@ int danet_lstm_bwd_db(danet_stream_t stream, int T, int B, int H, int ndir,
                       const float* gates_f, const float* gates_b,
                       const float* cell_f, const float* cell_b,
                       float* da_f, float* da_b, float* db_f, float* db_b, float beta,
-                      void* ws, size_t ws_bytes, int32_t* status);
+                      void* ws, size_t ws_bytes, int32_t* status, int flags);
 
 /* BPTT with the layer's weight and bias gradients FUSED: dW_d = [X | Hprev]^T da_d and
  * db_d = colsum(da_d) are accumulated inside the persistent kernel -- every workgroup owns

@@ -57,7 +57,7 @@ def test_bad_arguments_return_error_codes_not_crashes():
     rc = lib.danet_gemm_f32(None, 0, 0, 0, 4, 4, None, 4, None, 4, None, 4, None, 0.0, None, 0)
     assert rc == -1 and b'gemm' in lib.danet_last_error()
     rc = lib.danet_lstm_fwd(None, 4, 2, 6, 2, None, None, None, None, 24, None, 12,
-                            None, None, None, None, ctypes.c_void_p(8), 64, None)
+                            None, None, None, None, ctypes.c_void_p(8), 64, None, 0)
     assert rc == -3 and b'multiple of 4' in lib.danet_last_error()
     with pytest.raises(_lib.DanetHipError):
         _lib.check(rc)

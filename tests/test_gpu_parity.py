@@ -864,7 +864,7 @@ def test_lstm_bwd_handoff_under_uneven_load(B, T, H):
     ws = torch.zeros(n, dtype=torch.uint8, device=dev)
     _lib.check(L.danet_lstm_fwd(st, T, B, H, 2, ptr(gates[0]), ptr(gates[1]), ptr(Wh[0]), ptr(Wh[1]),
                                 4 * H, ptr(ypad), 2 * H, ptr(gates[0]), ptr(gates[1]),
-                                ptr(cells[0]), ptr(cells[1]), ptr(ws), n, None))
+                                ptr(cells[0]), ptr(cells[1]), ptr(ws), n, None, 0))
     torch.cuda.synchronize()
     assert int(ws[:4].view(torch.int32)[0]) == 0
 

@@ -29,6 +29,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 res = {}
 for mode in ('0', 'tail', '1'):
     m = Model('o' + mode, device=dev, seed=5, grad_schedule=mode).build()
+    m._early_adam = True          # the opt-in early optimizer piece rides behind the tail all-reduce
     assert (m._buckets is not None) == (mode != '0')
     assert m.collectives_per_step() == {'0': 1, 'tail': 2, '1': 5}[mode]
     for k in range(N):

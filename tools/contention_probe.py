@@ -53,7 +53,7 @@ def main():
         return lambda: _lib.check(L.danet_lstm_fwd(
             main_s.cuda_stream, T, B, H, 2, ptr(gates[0]), ptr(gates[1]), ptr(Wh[0]), ptr(Wh[1]),
             4 * H, ptr(ypad), 2 * H, ptr(gates[0]), ptr(gates[1]), ptr(cells[0]), ptr(cells[1]),
-            ptr(ws), n, None))
+            ptr(ws), n, None, 0))
 
     def bwd():
         return lambda: _lib.check(L.danet_lstm_bwd(

@@ -68,7 +68,7 @@ def contention(dev):
     _lib.check(L.danet_lstm_fwd(
         main_s.cuda_stream, T, B, H, 2, ptr(gates[0]), ptr(gates[1]), ptr(Wh[0]), ptr(Wh[1]),
         4 * H, ptr(ypad), 2 * H, ptr(gates[0]), ptr(gates[1]), ptr(cells[0]), ptr(cells[1]),
-        ptr(ws), n, None))
+        ptr(ws), n, None, 0))
     torch.cuda.synchronize()
     x = torch.randn(T * B, D, device=dev)
     h = torch.randn(T * B, H, device=dev)

@@ -76,7 +76,7 @@ def fused(B, T, H, D):
         ws = torch.zeros(n, dtype=torch.uint8, device=dev)
         _lib.check(L.danet_lstm_fwd_fused(st, T, B, H, ndir, ptr(x), D, D, ptr(W[0]), ptr(W[1]), 4 * H,
                                           ptr(b[0]), ptr(b[1]), ptr(ypad), 2 * H, ptr(gates[0]),
-                                          ptr(gates[1]), ptr(cells[0]), ptr(cells[1]), ptr(ws), n, None))
+                                          ptr(gates[1]), ptr(cells[0]), ptr(cells[1]), ptr(ws), n, None, 0))
         torch.cuda.synchronize()
     assert int(ws[:4].view(torch.int32)[0]) == 0
     report_fused('lstm_fwd_fused D=%d' % D, ws, T)
@@ -149,7 +149,7 @@ def main():
         gates = [x.clone() for x in gx]
         _lib.check(L.danet_lstm_fwd(st, T, B, H, ndir, ptr(gates[0]), ptr(gates[1]), ptr(Wh[0]),
                                     ptr(Wh[1]), 4 * H, ptr(ypad), 2 * H, ptr(gates[0]),
-                                    ptr(gates[1]), ptr(cells[0]), ptr(cells[1]), ptr(ws), n, None))
+                                    ptr(gates[1]), ptr(cells[0]), ptr(cells[1]), ptr(ws), n, None, 0))
         torch.cuda.synchronize()
     assert int(ws[:4].view(torch.int32)[0]) == 0
     report('lstm_fwd', ws, T)
