@@ -910,7 +910,11 @@ class RnnEncoderFn(torch.autograd.Function):
         center(cur, B, T, D, 1, D, yc, 0, D)
         O = Wout.shape[1]
         embed = torch.empty(B, T, O, device=dev)
-        gemm(yc, Wout, embed, B * T, O, D, D, O, O, tag='proj', streamk=(STREAMK & 2) != 0)           # modules.py:249-255
+        # (hybrid stream-K pays for the projection only with >= 4 tiles per CU: cfg 4, 1312 tiles,
+        # 248 -> 238 us; cfg 2, 672 tiles, 126 -> 132 us)
+        big = ((B * T + 127) // 128) * ((O + 127) // 128) >= 1024
+        gemm(yc, Wout, embed, B * T, O, D, D, O, O, tag='proj',
+             streamk=(STREAMK & 2) != 0 or (big and STREAMK != 0))           # modules.py:249-255
         ctx.ctxs, ctx.yc, ctx.Wout = ctxs, yc, Wout
         ctx.dims = (B, T, F, H, L, ndir, D, O)
         return embed

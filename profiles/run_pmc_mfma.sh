@@ -14,7 +14,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmcm_$TAG
 timeout 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
-    -d /tmp/pmcm_$TAG -o m -- python $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline \
+    -d /tmp/pmcm_$TAG -o m -- python $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-parity-check \
     > "$OUT/run.log" 2>&1 < /dev/null
 CC=$(find /tmp/pmcm_$TAG -name "*counter_collection.csv" < /dev/null | head -1)
 KT=$(find /tmp/pmcm_$TAG -name "*kernel_trace.csv" < /dev/null | head -1)

@@ -1,9 +1,10 @@
-B="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-parity-check"
-run() { tag=$1; shift; env "$@" $B 2>/dev/null | tail -1 | python -c "
+run() { tag=$1; cfg=$2; shift; shift; env "$@" python bench.py --config $cfg --steps 12 --warmup 3 --no-cpu-baseline --no-parity-check 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['kernels']
-print('$tag', d['ms_per_step'], 'bwd %.1f fwd %.1f group %.1f' % (k['lstm_bwd']['avg_us'], k['lstm_fwd']['avg_us'], k['gemm_f32_group']['avg_us']))" >> gpurun_out/exp3.log 2>&1; }
-rm -f gpurun_out/exp3.log
-run default A=1
-run default A=1
-run early DANET_EARLY_ADAM=1
+print('$tag', '$cfg', d['ms_per_step'], d['value'], 'fwd %.1f' % (k['lstm_fwd']['avg_us']), d['roofline'].get('us_per_timestep'))" >> gpurun_out/exp5.log 2>&1; }
+rm -f gpurun_out/exp5.log
+run xl cfg5 A=1
+run noxl cfg5 DANET_LSTM_FWD_SMALL_XL=0
+run xl cfg5 A=1
+run noxl cfg5 DANET_LSTM_FWD_SMALL_XL=0
+run xl cfg5-kmeans A=1
