@@ -1,10 +1,13 @@
-run() { tag=$1; cfg=$2; shift; shift; env "$@" python bench.py --config $cfg --steps 12 --warmup 3 --no-cpu-baseline --no-parity-check 2>/dev/null | tail -1 | python -c "
+B="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-parity-check"
+run() { tag=$1; shift; env "$@" $B 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['kernels']
-print('$tag', '$cfg', d['ms_per_step'], d['value'], 'fwd %.1f' % (k['lstm_fwd']['avg_us']), d['roofline'].get('us_per_timestep'))" >> gpurun_out/exp5.log 2>&1; }
-rm -f gpurun_out/exp5.log
-run xl cfg5 A=1
-run noxl cfg5 DANET_LSTM_FWD_SMALL_XL=0
-run xl cfg5 A=1
-run noxl cfg5 DANET_LSTM_FWD_SMALL_XL=0
-run xl cfg5-kmeans A=1
+print('$tag', d['ms_per_step'], 'bwd %.1f fwd %.1f group %.1f' % (k['lstm_bwd']['avg_us'], k['lstm_fwd']['avg_us'], k['gemm_f32_group']['avg_us']))" >> gpurun_out/exp6.log 2>&1; }
+rm -f gpurun_out/exp6.log
+run y16 A=1
+run y-16 DANET_GEMM_YIELD=-16
+run y-8 DANET_GEMM_YIELD=-8
+run y-32 DANET_GEMM_YIELD=-32
+run y-4 DANET_GEMM_YIELD=-4
+run y16 A=1
+run y-16 DANET_GEMM_YIELD=-16

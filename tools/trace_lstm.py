@@ -163,6 +163,35 @@ def main():
         torch.cuda.synchronize()
     assert int(ws[:4].view(torch.int32)[0]) == 0
     report('lstm_bwd', ws, T)
+    # the same BPTT launch with a layer's weight-gradient group (4 products, K = T*B, capped to one
+    # workgroup per CU, as in the train step) running beside it on another stream: which phase
+    # pays for the company?
+    from danet_amd import ops
+    D = 2 * H
+    x = torch.randn(T * B, D, device=dev)
+    hp = torch.randn(T * B + 2 * B, 2 * H, device=dev)
+    dWs = [torch.empty(D + H, 4 * H, device=dev) for _ in range(2)]
+    side = torch.cuda.Stream()
+
+    def group():
+        probs = []
+        for d in range(2):
+            probs.append((x, D, das[d], 4 * H, dWs[d], 4 * H, D, 4 * H, 0.0))
+            probs.append((hp, 2 * H, das[d], 4 * H, dWs[d][D:], 4 * H, H, 4 * H, 0.0))
+        ops.gemm_group(probs, T * B, transA=True, max_workgroups=256)
+
+    for variant in ('beside the capped group',):
+        for it in range(3):
+            ws = torch.zeros(n, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                group()
+            _lib.check(L.danet_lstm_bwd(st, T, B, H, ndir, ptr(dy), 2 * H, ptr(Wh[0]), ptr(Wh[1]), 4 * H,
+                                        ptr(gates[0]), ptr(gates[1]), ptr(cells[0]), ptr(cells[1]),
+                                        ptr(das[0]), ptr(das[1]), ptr(ws), n, None))
+            torch.cuda.synchronize()
+        assert int(ws[:4].view(torch.int32)[0]) == 0
+        report('lstm_bwd ' + variant, ws, T)
 
 
 if __name__ == '__main__':
