@@ -135,6 +135,47 @@ __global__ __launch_bounds__(256) void truth_fwd_kernel(
   }
 }
 
+// Single pass over the bins with one accumulator set PER SPEAKER (CP * (EP + 1) <= 128 registers):
+// the multi-pass kernel above walks the chunk once per speaker (3 x the src_pwr reads and the loop
+// overhead at C = 3: 121 us at cfg 4).  A bin adds w * x to its own speaker's set and +0 to the
+// others, so every sum sees the same addends in the same order: bit-identical to the multi-pass form.
+template <int EP, int CP>
+__global__ __launch_bounds__(256) void truth_fwd1_kernel(
+    int mode, int64_t N, int E, const float* __restrict__ embed,
+    const float* __restrict__ src_pwr, const float* __restrict__ mix_pwr,
+    float* __restrict__ partial /* [B][chunks][C][EP+1] */) {
+  constexpr int C = CP;
+  __shared__ float red[4 * (EP + 1)];
+  const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  const int64_t n0 = (int64_t)ch * CHUNK_N, n1 = min(N, n0 + CHUNK_N);
+  const float* eb = embed + (int64_t)b * N * E;
+  const float* sp = src_pwr + (int64_t)b * C * N;
+  const float* mp = mix_pwr + (int64_t)b * N;
+  float* out = partial + ((int64_t)b * nch + ch) * C * (EP + 1);
+  float acc[CP][EP + 1];
+#pragma unroll
+  for (int c = 0; c < CP; ++c)
+#pragma unroll
+    for (int e = 0; e <= EP; ++e) acc[c][e] = 0.f;
+  for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
+    const int idx = argmax_src(sp, C, N, n);
+    const float w = truth_weight(mode, mp[n]);
+    float x[EP];
+    load_row<EP>(eb + n * E, E, x);
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      const float wc = (idx == c) ? w : 0.f;
+      if (idx == c) {
+#pragma unroll
+        for (int e = 0; e < EP; ++e) acc[c][e] += wc * x[e];
+        acc[c][EP] += wc;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CP; ++c) block_reduce_store<EP + 1>(acc[c], EP + 1, red, out + c * (EP + 1));
+}
+
 __global__ void truth_final_kernel(int mode, int C, int E, int EP, int nch, float eps,
                                    const float* __restrict__ partial,
                                    float* __restrict__ attr, float* __restrict__ denom) {
@@ -1077,8 +1118,13 @@ extern "C" int danet_attractor_truth_fwd(danet_stream_t stream_, int mode, int B
   if (mode == 0 && !mix_pwr) mix_pwr = src_pwr;  // never read for its value
   const int nch = n_chunks(N), EPV = pick_ep(E);
   dim3 grid(nch, B);
-  DISPATCH_EP(EPV, (truth_fwd_kernel<EP><<<grid, 256, 0, stream>>>(
-                       mode, C, N, E, embed, src_pwr, mix_pwr, (float*)ws)));
+  if (C * (EPV + 1) <= 128) {
+    DISPATCH_EP(EPV, DISPATCH_CP(C, (truth_fwd1_kernel<EP, CP><<<grid, 256, 0, stream>>>(
+                         mode, N, E, embed, src_pwr, mix_pwr, (float*)ws))));
+  } else {
+    DISPATCH_EP(EPV, (truth_fwd_kernel<EP><<<grid, 256, 0, stream>>>(
+                         mode, C, N, E, embed, src_pwr, mix_pwr, (float*)ws)));
+  }
   DANET_CHECK_LAUNCH();
   truth_final_kernel<<<B, 128, 0, stream>>>(mode, C, E, EPV, nch, eps, (const float*)ws, attr,
                                             denom);
