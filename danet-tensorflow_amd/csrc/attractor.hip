@@ -657,11 +657,15 @@ struct CombosCE {
 
 // LDS: Xs[ANCH_TN][EPA] (embedding tile + ones column), Ss[ANCH_TN][PC+1]
 // AT, CTT > 0: (A, C) specialisation; AT = 0: generic (run-time table in `cb`)
-template <int EP, int AT, int CTT>
+// T11: the contraction is ONE 32 x 32 MFMA tile (PC <= 32, EPA <= 32: cfg 2) known at compile time --
+// one accumulator tile instead of four behind run-time conditions
+template <int EP, int AT, int CTT, bool T11>
 __global__ __launch_bounds__(256) void anchor_fwd_kernel(
     int C, int64_t N, int E, int A, AnchorCombos cb, const float* __restrict__ embed,
     const float* __restrict__ anchors, float* __restrict__ partial /* [B][chunks][PC][EPA] */,
-    int RT, int CT /* MFMA tiling of the [PC][EPA] contraction; RT = 0: scalar path */) {
+    int RT_, int CT_ /* MFMA tiling of the [PC][EPA] contraction; RT = 0: scalar path */) {
+  constexpr int NM = T11 ? 1 : 2;
+  const int RT = T11 ? 1 : RT_, CT = T11 ? 1 : CT_;
   constexpr int EPA = EP + 4;           // + ones column, padded to a float4
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int PC = cb.P * C;
@@ -688,11 +692,11 @@ __global__ __launch_bounds__(256) void anchor_fwd_kernel(
   // v_mfma_f32_32x32x2_f32, the tile's 256 bins split over the 4 waves.  Rows /
   // columns past PC / EPA read whatever follows in LDS: they only ever reach
   // accumulator entries that are never stored.
-  f32x16 macc[2][2];
+  f32x16 macc[NM][NM];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NM; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) macc[i][j][r] = 0.f;
   const int mlane = tid & 63, mwave = tid >> 6;
@@ -732,23 +736,39 @@ __global__ __launch_bounds__(256) void anchor_fwd_kernel(
         for (int a = 0; a < MAXA; ++a) ea[a] = (a < A) ? __expf(d[a] - dmax) : 0.f;
         if constexpr (AT > 0) {
           constexpr CombosCE<AT, CTT> tb{};
+          float* srow = Ss + tid * lds;
+          // branch-free over the subsets; ONE (rare) branch afterwards redoes the subsets all of
+          // whose members underflowed against the global max (15 per-subset branches cost more
+          // exec-mask bookkeeping than the arithmetic they guard)
+          bool under = false;
 #pragma unroll
           for (int p = 0; p < tb.P; ++p) {
-            float lg[CTT];
             float den = 0.f;
 #pragma unroll
-            for (int c = 0; c < CTT; ++c) { lg[c] = ea[tb.idx[p][c]]; den += lg[c]; }
-            if (den < 1e-30f) {      // all members underflowed: redo against the subset's own max
-              float mx = -INFINITY;
-#pragma unroll
-              for (int c = 0; c < CTT; ++c) mx = fmaxf(mx, d[tb.idx[p][c]]);
-              den = 0.f;
-#pragma unroll
-              for (int c = 0; c < CTT; ++c) { lg[c] = expf(d[tb.idx[p][c]] - mx); den += lg[c]; }
-            }
+            for (int c = 0; c < CTT; ++c) den += ea[tb.idx[p][c]];
+            under |= (den < 1e-30f);
             const float inv = __frcp_rn(den);
 #pragma unroll
-            for (int c = 0; c < CTT; ++c) Ss[tid * lds + p * CTT + c] = lg[c] * inv;   // modules.py:516
+            for (int c = 0; c < CTT; ++c) srow[p * CTT + c] = ea[tb.idx[p][c]] * inv;   // modules.py:516
+          }
+          if (under) {
+#pragma unroll
+            for (int p = 0; p < tb.P; ++p) {
+              float den = 0.f;
+#pragma unroll
+              for (int c = 0; c < CTT; ++c) den += ea[tb.idx[p][c]];
+              if (den < 1e-30f) {      // redo against the subset's own max (tf.nn.softmax's formulation)
+                float lg[CTT];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int c = 0; c < CTT; ++c) mx = fmaxf(mx, d[tb.idx[p][c]]);
+                den = 0.f;
+#pragma unroll
+                for (int c = 0; c < CTT; ++c) { lg[c] = expf(d[tb.idx[p][c]] - mx); den += lg[c]; }
+#pragma unroll
+                for (int c = 0; c < CTT; ++c) srow[p * CTT + c] = lg[c] / den;
+              }
+            }
           }
         } else
         for (int p = 0; p < cb.P; ++p) {
@@ -790,16 +810,16 @@ __global__ __launch_bounds__(256) void anchor_fwd_kernel(
 #pragma unroll 4
       for (int ks = 0; ks < ANCH_TN / 8; ++ks) {
         const int r = mwave * (ANCH_TN / 4) + ks * 2 + kl;
-        float av[2], bv[2];
+        float av[NM], bv[NM];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NM; ++i) {
           av[i] = (i < RT) ? Ss[r * lds + i * 32 + il] : 0.f;
           bv[i] = (i < CT) ? Xs[r * EPA + i * 32 + il] : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NM; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < NM; ++j)
             if (i < RT && j < CT)
               macc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], macc[i][j], 0, 0, 0);
       }
@@ -827,9 +847,9 @@ __global__ __launch_bounds__(256) void anchor_fwd_kernel(
     float* red = smem;   // [4 waves][RT*32][CT*32]
     const int ldr = CT * 32;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NM; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NM; ++j)
         if (i < RT && j < CT) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -882,24 +902,34 @@ __global__ void anchor_final_kernel(int C, int E, int EPA, int P, int nch,
   }
   __syncthreads();
   const int EP = EPA - 4;
+  // normalise in place (columns e < E are rewritten, the denominator column EP is only read)
   for (int i = threadIdx.x; i < PC * E; i += blockDim.x) {
     const int pc = i / E, e = i % E;
     const float v = S[pc * EPA + e] / S[pc * EPA + EP];      // modules.py:522-523
     asets[((int64_t)b * PC + pc) * E + e] = v;
+    S[pc * EPA + e] = v;
   }
   for (int i = threadIdx.x; i < PC; i += blockDim.x) asum[(int64_t)b * PC + i] = S[i * EPA + EP];
   __syncthreads();
-  for (int p = threadIdx.x; p < P; p += blockDim.x) {
-    float mx = -INFINITY;
-    for (int c1 = 0; c1 < C; ++c1)
-      for (int c2 = 0; c2 < C; ++c2) {                        // full CxC incl. diagonal (K7)
-        float dot = 0.f;
-        const float d1 = S[(p * C + c1) * EPA + EP], d2 = S[(p * C + c2) * EPA + EP];
-        for (int e = 0; e < E; ++e)
-          dot += (S[(p * C + c1) * EPA + e] / d1) * (S[(p * C + c2) * EPA + e] / d2);
-        mx = fmaxf(mx, dot);
-      }
-    sim[p] = mx;                                              // modules.py:526-530
+  // Gram max over the full C x C matrix incl. the diagonal (K7) of the NORMALISED sets (as the
+  // reference: asets @ asets^T, modules.py:526-530): one thread per (p, c1, c2) entry -- P * C * C
+  // short dot products in parallel instead of P threads walking C * C * E divisions each
+  {
+    float* gram = S + PC * EPA;    // (sim lives there; the Gram entries go behind it)
+    float* ge = gram + P;
+    const int CC = C * C;
+    for (int i = threadIdx.x; i < P * CC; i += blockDim.x) {
+      const int p = i / CC, c1 = (i % CC) / C, c2 = i % C;
+      float dot = 0.f;
+      for (int e = 0; e < E; ++e) dot += S[(p * C + c1) * EPA + e] * S[(p * C + c2) * EPA + e];
+      ge[i] = dot;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+      float mx = -INFINITY;
+      for (int q = 0; q < CC; ++q) mx = fmaxf(mx, ge[p * CC + q]);
+      sim[p] = mx;                                            // modules.py:526-530
+    }
   }
   __syncthreads();
   __shared__ int best_s;
@@ -913,8 +943,7 @@ __global__ void anchor_final_kernel(int C, int E, int EPA, int P, int nch,
   const int best = best_s;
   for (int i = threadIdx.x; i < C * E; i += blockDim.x) {
     const int c = i / E, e = i % E;
-    attr[((int64_t)b * C + c) * E + e] =
-        S[(best * C + c) * EPA + e] / S[(best * C + c) * EPA + EP];   // modules.py:534-537
+    attr[((int64_t)b * C + c) * E + e] = S[(best * C + c) * EPA + e];   // modules.py:534-537 (normalised above)
   }
 }
 
@@ -1337,18 +1366,19 @@ extern "C" int danet_attractor_anchor_fwd(danet_stream_t stream_, int B, int C, 
   const size_t lds_red = (size_t)4 * RT * 32 * CT * 32 * sizeof(float);
   if (lds_red > lds) lds = lds_red;
   dim3 grid(nch, B);
-#define LAUNCH_ANCHOR(AT_, CT_)                                                              \
+#define LAUNCH_ANCHOR(AT_, CT_, T11_)                                                        \
   DISPATCH_EP(EPV, {                                                                         \
-    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)anchor_fwd_kernel<EP, AT_, CT_>,         \
+    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)anchor_fwd_kernel<EP, AT_, CT_, T11_>,   \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                              \
-    anchor_fwd_kernel<EP, AT_, CT_><<<grid, 256, lds, stream>>>(C, N, E, A, cb, embed,        \
+    anchor_fwd_kernel<EP, AT_, CT_, T11_><<<grid, 256, lds, stream>>>(C, N, E, A, cb, embed,  \
                                                                 anchors, (float*)ws, RT, CT); \
   })
-  if (A == 6 && C == 2) { LAUNCH_ANCHOR(6, 2); }          // default.json: NUM_ANCHOR 6, 2 speakers
-  else if (A == 6 && C == 3) { LAUNCH_ANCHOR(6, 3); }     // 3-speaker configs
-  else { LAUNCH_ANCHOR(0, 0); }
+  const bool t11 = (RT == 1 && CT == 1);
+  if (A == 6 && C == 2) { if (t11) { LAUNCH_ANCHOR(6, 2, true); } else { LAUNCH_ANCHOR(6, 2, false); } }   // default.json: NUM_ANCHOR 6, 2 speakers
+  else if (A == 6 && C == 3) { LAUNCH_ANCHOR(6, 3, false); }     // 3-speaker configs
+  else { LAUNCH_ANCHOR(0, 0, false); }
   DANET_CHECK_LAUNCH();
-  const size_t lds2 = ((size_t)PC * EPA + cb.P) * sizeof(float);
+  const size_t lds2 = ((size_t)PC * EPA + cb.P + (size_t)cb.P * C * C) * sizeof(float);
   anchor_final_kernel<<<B, 512, lds2, stream>>>(C, E, EPA, cb.P, nch, (const float*)ws, attr,
                                                 asets, asum, choice);
   DANET_CHECK_LAUNCH();
