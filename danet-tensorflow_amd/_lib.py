@@ -80,6 +80,11 @@ PROTOTYPES = {
     'danet_lstm_bwd_fused': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_int,
                                      c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_p, c_int, c_p, c_p,
                                      c_p, c_p, c_p, c_p, c_f32, c_p, c_sz, c_p]),
+    'danet_lstm_bwd_fused_h_supported': (c_int, [c_int, c_int, c_int, c_int]),
+    'danet_lstm_bwd_fused_h_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int]),
+    'danet_lstm_bwd_fused_h': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_int,
+                                       c_p, c_p, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_p,
+                                       c_f32, c_p, c_sz, c_p]),
     'danet_attractor_truth_workspace_bytes': (c_sz, [c_int, c_int, c_i64, c_int]),
     'danet_attractor_truth_fwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p,
                                           c_f32, c_p, c_p, c_p, c_sz]),

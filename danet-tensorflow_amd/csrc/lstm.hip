@@ -2096,7 +2096,7 @@ extern "C" int danet_lstm_fwd_fused(danet_stream_t stream_, int T, int B, int H,
 
 // ---- BPTT with fused weight gradients: geometry and entry points ---------------------
 struct RswPlan { bool ok; RsPlan rs; int NFt, NFP, NFT; size_t dw_bytes, db_bytes; };
-static RswPlan make_rsw_plan(int B, int H, int ndir, int D) {
+static RswPlan make_rsw_plan(int B, int H, int ndir, int D, bool h_only = false) {
   RswPlan w; w.ok = false; w.NFt = w.NFP = w.NFT = 0; w.dw_bytes = w.db_bytes = 0;
   w.rs = choose_rs_plan(B, H, ndir);
   // Envelope only; WHERE it is used is the caller's policy.  Measured (profiles/
@@ -2107,7 +2107,7 @@ static RswPlan make_rsw_plan(int B, int H, int ndir, int D) {
   // the bottom layer (whose group has nothing to hide under) LOSES: the layer-1 group then runs
   // beside an MFMA-heavy kernel (3.82 ms).  option lstm_bwd_fused_kernel = 0 turns the kernel off.
   if (danet_opt(OPT_LSTM_BWD_FUSED_KERNEL) == 0) return w;
-  if (!w.rs.ok || D <= 0) return w;
+  if (!w.rs.ok || (h_only ? D != 0 : D <= 0)) return w;
   if (w.rs.U != 8 && w.rs.U != 16) return w;
   if (w.rs.NTW > 2 || w.rs.NI > RSW_NI_MAX) return w;
   const int Dp = cdiv(D, 16) * 16, Hp = cdiv(H, 16) * 16;
@@ -2133,34 +2133,37 @@ extern "C" size_t danet_lstm_bwd_fused_workspace_bytes(int T, int B, int H, int 
   return align_up(ring_offset(T) + w.rs.ring_bytes, 256) + w.dw_bytes + w.db_bytes;
 }
 
-extern "C" int danet_lstm_bwd_fused(danet_stream_t stream_, int T, int B, int H, int ndir,
-                                    const float* dy, int lddy,
-                                    const float* W_f, const float* W_b, int ldw,
-                                    const float* gates_f, const float* gates_b,
-                                    const float* cell_f, const float* cell_b,
-                                    const float* x, int ldx, int D,
-                                    const float* ypad, int ldy,
-                                    float* da_f, float* da_b,
-                                    float* dW_f, float* dW_b, float* db_f, float* db_b,
-                                    float beta, void* ws, size_t ws_bytes, int32_t* status) {
+// h_only: only the RECURRENT rows of the weight gradient (dWh = Hprev^T da, K = H per step, 16
+// update MFMAs per wave and step at cfg 2) are accumulated in the kernel; W_f / W_b / dW_f / dW_b
+// then point at the recurrent rows and x is not read (D = 0).
+static int lstm_bwd_fused_impl(danet_stream_t stream_, int T, int B, int H, int ndir,
+                               const float* dy, int lddy,
+                               const float* W_f, const float* W_b, int ldw,
+                               const float* gates_f, const float* gates_b,
+                               const float* cell_f, const float* cell_b,
+                               const float* x, int ldx, int D,
+                               const float* ypad, int ldy,
+                               float* da_f, float* da_b,
+                               float* dW_f, float* dW_b, float* db_f, float* db_b,
+                               float beta, void* ws, size_t ws_bytes, int32_t* status, bool h_only) {
   hipStream_t stream = (hipStream_t)stream_;
-  DANET_CHECK_ARG(T > 0 && B > 0 && H > 0 && D > 0, "lstm_bwd_fused: non-positive shape");
+  DANET_CHECK_ARG(T > 0 && B > 0 && H > 0 && (h_only ? D == 0 : D > 0), "lstm_bwd_fused: non-positive shape");
   DANET_CHECK_ARG(ndir == 1 || ndir == 2, "lstm_bwd_fused: ndir must be 1 or 2");
   if (H % 4 != 0) {
     danet_set_error("lstm: H=%d must be a multiple of 4", H);
     return DANET_ERR_UNSUPPORTED;
   }
-  const RswPlan w = make_rsw_plan(B, H, ndir, D);
+  const RswPlan w = make_rsw_plan(B, H, ndir, D, h_only);
   if (!w.ok) {
     danet_set_error("lstm_bwd_fused: T=%d B=%d H=%d D=%d outside the fused envelope", T, B, H, D);
     return DANET_ERR_UNSUPPORTED;
   }
-  const size_t need = danet_lstm_bwd_fused_workspace_bytes(T, B, H, ndir, D);
+  const size_t need = align_up(ring_offset(T) + w.rs.ring_bytes, 256) + w.dw_bytes + w.db_bytes;
   if (!ws || ((uintptr_t)ws & 15) != 0 || ws_bytes < need) {
     danet_set_error("lstm_bwd_fused: workspace too small or not 16-B aligned");
     return DANET_ERR_WORKSPACE;
   }
-  DANET_CHECK_ARG(dy && W_f && gates_f && cell_f && da_f && x && ypad && dW_f && db_f,
+  DANET_CHECK_ARG(dy && W_f && gates_f && cell_f && da_f && (x || h_only) && ypad && dW_f && db_f,
                   "lstm_bwd_fused: null pointer");
   DANET_CHECK_ARG(ndir == 1 || (W_b && gates_b && cell_b && da_b && dW_b && db_b),
                   "lstm_bwd_fused: null bwd pointer");
@@ -2210,6 +2213,46 @@ extern "C" int danet_lstm_bwd_fused(danet_stream_t stream_, int T, int B, int H,
                                                   rs.G, D, aa.Dp, NF, w.NFP, 4 * H, beta);
   DANET_CHECK_LAUNCH();
   return DANET_OK;
+}
+
+extern "C" int danet_lstm_bwd_fused(danet_stream_t stream_, int T, int B, int H, int ndir,
+                                    const float* dy, int lddy,
+                                    const float* W_f, const float* W_b, int ldw,
+                                    const float* gates_f, const float* gates_b,
+                                    const float* cell_f, const float* cell_b,
+                                    const float* x, int ldx, int D,
+                                    const float* ypad, int ldy,
+                                    float* da_f, float* da_b,
+                                    float* dW_f, float* dW_b, float* db_f, float* db_b,
+                                    float beta, void* ws, size_t ws_bytes, int32_t* status) {
+  return lstm_bwd_fused_impl(stream_, T, B, H, ndir, dy, lddy, W_f, W_b, ldw, gates_f, gates_b, cell_f,
+                             cell_b, x, ldx, D, ypad, ldy, da_f, da_b, dW_f, dW_b, db_f, db_b, beta,
+                             ws, ws_bytes, status, false);
+}
+
+// BPTT with ONLY the recurrent weight gradient (and the bias gradient) fused: dWh_d[H][4H] +=
+// Hprev^T da_d inside the kernel (Wh_d / dWh_d = rows D.. of the layer's W / dW); dWx stays a GEMM.
+extern "C" int danet_lstm_bwd_fused_h_supported(int T, int B, int H, int ndir) {
+  if (T <= 0 || B <= 0 || H <= 0 || H % 4 != 0 || (ndir != 1 && ndir != 2)) return 0;
+  return make_rsw_plan(B, H, ndir, 0, true).ok ? 1 : 0;
+}
+extern "C" size_t danet_lstm_bwd_fused_h_workspace_bytes(int T, int B, int H, int ndir) {
+  const RswPlan w = make_rsw_plan(B, H, ndir, 0, true);
+  if (!w.ok) return 0;
+  return align_up(ring_offset(T) + w.rs.ring_bytes, 256) + w.dw_bytes + w.db_bytes;
+}
+extern "C" int danet_lstm_bwd_fused_h(danet_stream_t stream_, int T, int B, int H, int ndir,
+                                      const float* dy, int lddy,
+                                      const float* Wh_f, const float* Wh_b, int ldw,
+                                      const float* gates_f, const float* gates_b,
+                                      const float* cell_f, const float* cell_b,
+                                      const float* ypad, int ldy,
+                                      float* da_f, float* da_b,
+                                      float* dWh_f, float* dWh_b, float* db_f, float* db_b,
+                                      float beta, void* ws, size_t ws_bytes, int32_t* status) {
+  return lstm_bwd_fused_impl(stream_, T, B, H, ndir, dy, lddy, Wh_f, Wh_b, ldw, gates_f, gates_b, cell_f,
+                             cell_b, nullptr, 4, 0, ypad, ldy, da_f, da_b, dWh_f, dWh_b, db_f, db_b, beta,
+                             ws, ws_bytes, status, true);
 }
 
 static int lstm_bwd_impl(danet_stream_t stream_, int T, int B, int H, int ndir,

@@ -646,7 +646,8 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs, x_pad_zero=False, ypad=None, ws=N
 # `lstm_bwd_fused_kernel`, env DANET_LSTM_BWD_FUSED_KERNEL.)
 # Where BPTT accumulates dW / db inside the persistent kernel (danet_lstm_bwd_fused): '0'
 # (default) = nowhere; '1' = every layer inside the kernel's envelope; 'bottom' = only the
-# layer whose input needs no gradient.  Measured at cfg 2 / cfg 4 (ms per step): '0' 3.60 /
+# layer whose input needs no gradient; 'h' = only dWh (and db) inside the kernel, dWx by the group
+# (round 3: 3.35 vs 3.13 ms per step, profiles/EXPERIMENTS.md).  Measured at cfg 2 / cfg 4 (ms per step): '0' 3.60 /
 # 5.12, '1' 3.61 / 5.27, 'bottom' 3.82 / 5.30 -- the fused kernel runs at 3.4 us per step alone
 # (MFMA block first, all loads behind it) but ~3.9 in the step, what the GEMM path reaches with
 # its contention; a fused bottom layer slows the layer-1 weight-gradient group that runs beside
@@ -707,7 +708,26 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
              all(t.data_ptr() % 16 == 0 for t in dWs + dbs) and
              bptt_fused(T, B, H, ndir, D, need_dx, is_top))
     db_in_kernel = False
-    if fused:
+    # 'h': only the recurrent weight gradient (dWh) and the bias gradient inside the BPTT kernel
+    fused_h = (not fused and BWD_FUSED == 'h' and (all_direct or none_direct) and
+               all(W.stride(0) == 4 * H and W.stride(1) == 1 and W.data_ptr() % 16 == 0 for W in c.Ws) and
+               all(t.data_ptr() % 16 == 0 for t in dbs) and (D * 4 * H) % 4 == 0 and
+               all(dW[D:].data_ptr() % 16 == 0 for dW in dWs) and
+               L.danet_lstm_bwd_fused_h_supported(T, B, H, ndir) == 1)
+    if fused_h:
+        wn = L.danet_lstm_bwd_fused_h_workspace_bytes(T, B, H, ndir)
+        ws = torch.empty(wn, dtype=torch.uint8, device=dev)
+        Whs = [W[D:] for W in c.Ws]
+        dWhs = [dW[D:] for dW in dWs]
+        with _lib.timed('lstm_bwd'):
+            check(L.danet_lstm_bwd_fused_h(
+                _lib.stream(), T, B, H, ndir, ptr(_f32(dy)), ndir * H,
+                ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(c.gates[0]), ptr(c.gates[-1]),
+                ptr(c.cells[0]), ptr(c.cells[-1]), ptr(c.ypad), ldy,
+                ptr(das[0]), ptr(das[-1]), ptr(dWhs[0]), ptr(dWhs[-1]), ptr(dbs[0]), ptr(dbs[-1]),
+                1.0 if all_direct else 0.0, ptr(ws), wn, ptr(status_word(dev))))
+        db_in_kernel = True
+    elif fused:
         # BPTT with dW / db accumulated inside the persistent kernel (csrc/lstm.hip): no
         # weight-gradient GEMMs, no column sums, nothing on a side stream
         wn = L.danet_lstm_bwd_fused_workspace_bytes(T, B, H, ndir, D)
@@ -755,8 +775,9 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
              max_workgroups=cap)
         # dWh = Hprev^T da; Hprev(t) = ypad block t (fwd) / block t+2 (bwd)
         hprev = c.ypad.view(-1)[(0 if d == 0 else 2 * B * ldy + H):]
-        gemm(hprev, das[d], dWs[d][D:], H, 4 * H, T * B, ldy, 4 * H, 4 * H, transA=True, beta=bW,
-             max_workgroups=cap)
+        if not fused_h:
+            gemm(hprev, das[d], dWs[d][D:], H, 4 * H, T * B, ldy, 4 * H, 4 * H, transA=True, beta=bW,
+                 max_workgroups=cap)
         if not db_in_kernel:
             colsum(das[d], T * B, 4 * H, 4 * H, dbs[d], beta=bb)
 
@@ -770,7 +791,8 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
         for d in range(ndir):
             bW = 1.0 if direct[d][0] else 0.0
             probs.append((c.x, c.ldx, das[d], 4 * H, dWs[d], 4 * H, D, 4 * H, bW))
-            probs.append((hprev_of(d), ldy, das[d], 4 * H, dWs[d][D:], 4 * H, H, 4 * H, bW))
+            if not fused_h:          # ('h': dWh came out of the BPTT kernel)
+                probs.append((hprev_of(d), ldy, das[d], 4 * H, dWs[d][D:], 4 * H, H, 4 * H, bW))
         gemm_group(probs, T * B, transA=True, max_workgroups=wgs)
         # (the bias gradients as M = 1 members of the group were measured slower than
         # the two column-sum kernels: +25 us on the group for 128-row tiles with one row)
@@ -945,7 +967,8 @@ class RnnEncoderFn(torch.autograd.Function):
         # partial-dh rings of all layers' BPTT launches, prefilled by one fill launch (layers
         # that take the dW-fusing kernel allocate and prefill their own, larger workspace)
         bwss = [None] * L
-        plain = [l for l in range(L) if not bptt_fused(T, B, H, ndir, ctx.ctxs[l].D, l > 0, l == L - 1)]
+        plain = [] if BWD_FUSED == 'h' else \
+            [l for l in range(L) if not bptt_fused(T, B, H, ndir, ctx.ctxs[l].D, l > 0, l == L - 1)]
         if plain and BWD_DB and _L().danet_lstm_bwd_db_supported(T, B, H, ndir) == 1:
             cand = [_lstm_ws(T, B, H, ndir, dev)[0] for _ in plain]
             if lstm_prefill_bwd(T, B, H, ndir, cand):

@@ -336,6 +336,22 @@ int danet_lstm_bwd_fused(danet_stream_t stream, int T, int B, int H, int ndir,
                          float* dW_f, float* dW_b, float* db_f, float* db_b,
                          float beta, void* ws, size_t ws_bytes, int32_t* status);
 
+/* The same with ONLY the recurrent rows of the weight gradient fused: dWh_d [H][4H] (+)= Hprev^T
+ * da_d and db_d inside the persistent kernel (16 update MFMAs per wave and step at cfg 2, issued in
+ * the exchange wait); Wh_d / dWh_d point at rows D.. of the layer's W / dW, x is not read and
+ * dWx_d = X^T da_d stays a GEMM of the caller.                                              */
+int danet_lstm_bwd_fused_h_supported(int T, int B, int H, int ndir);
+size_t danet_lstm_bwd_fused_h_workspace_bytes(int T, int B, int H, int ndir);
+int danet_lstm_bwd_fused_h(danet_stream_t stream, int T, int B, int H, int ndir,
+                           const float* dy, int lddy,
+                           const float* Wh_f, const float* Wh_b, int ldw,
+                           const float* gates_f, const float* gates_b,
+                           const float* cell_f, const float* cell_b,
+                           const float* ypad, int ldy,
+                           float* da_f, float* da_b,
+                           float* dWh_f, float* dWh_b, float* db_f, float* db_b,
+                           float beta, void* ws, size_t ws_bytes, int32_t* status);
+
 /* ---------------------------------------------------------------- a8-a10
  * Truth-family attractor estimators (app/modules.py:382-487).
  * mode 0 'truth' (w=1, denom count+1), 1 'truth-threshold' (w=[|mix|>5],

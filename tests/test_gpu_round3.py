@@ -229,3 +229,36 @@ def test_gemm_hybrid_streamk_many_tiles(M, N, K):
     C = torch.full((M, N), float('nan'), device='cuda')
     ops.gemm_group([(A, K, Bm, N, C, N, M, N, 0.0)], K, max_workgroups=104)
     assert np.abs(C.cpu().numpy() - ref).max() / np.abs(ref).max() < 2e-5
+
+
+@pytest.mark.parametrize('B,T,D,H', [(32, 40, 600, 300), (32, 24, 132, 300), (16, 12, 64, 64), (20, 9, 36, 40)])
+def test_bptt_with_only_the_recurrent_weight_gradient_fused(B, T, D, H, monkeypatch):
+    '''danet_lstm_bwd_fused_h: dWh = Hprev^T da and db accumulated inside the persistent BPTT
+    kernel, dWx left to the GEMM group -- every gradient equals the unfused path's to
+    summation-order rounding (tf.gradients through main.py:130-131, app/ops.py:139-147)'''
+    from danet_amd import ops, _lib
+    if _lib.load().danet_lstm_bwd_fused_h_supported(T, B, H, 2) != 1:
+        pytest.skip('outside the envelope')
+    rng = np.random.RandomState(B + T + D + H)
+    r = 0.75 / np.sqrt(H)
+    x = torch.as_tensor((rng.randn(B, T, D) * 0.7).astype(np.float32)).cuda()
+    Ws = [torch.as_tensor((rng.uniform(-r, r, size=(D + H, 4 * H)) * 2).astype(np.float32)).cuda() for _ in range(2)]
+    bs = [torch.as_tensor((rng.randn(4 * H) * 0.1).astype(np.float32)).cuda() for _ in range(2)]
+    dy = torch.as_tensor(rng.randn(B, T, 2 * H).astype(np.float32)).cuda()
+
+    def run(policy):
+        monkeypatch.setattr(ops, 'BWD_FUSED', policy)
+        xi = x.clone().requires_grad_(True)
+        ps = []
+        for W, b in zip(Ws, bs):
+            ps += [W.clone().requires_grad_(True), b.clone().requires_grad_(True)]
+        y = ops.LstmLayerFn.apply(xi, H, *ps)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        return [xi.grad] + [p.grad for p in ps]
+
+    ref = run('0')
+    got = run('h')
+    assert ops.lstm_status_ok()
+    for a, b in zip(got, ref):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (a.shape,)
