@@ -110,6 +110,9 @@ PROTOTYPES = {
     'danet_separate_pit_final': (c_int, [c_p, c_int, c_int, c_i64, c_f32, c_p, c_p, c_p, c_p]),
     'danet_attractor_anchor_bwd_embed': (c_int, [c_p, c_int, c_int, c_i64, c_int, c_int, c_p, c_p, c_p,
                                                  c_p, c_p, c_p, c_p, c_p, c_sz]),
+    'danet_attractor_anchor_bwd_embed_sep': (c_int, [c_p, c_int, c_int, c_i64, c_int, c_int, c_p, c_p, c_p,
+                                                     c_p, c_p, c_p, c_int, c_int, c_p, c_p, c_p, c_p, c_p,
+                                                     c_f32, c_p, c_p, c_p, c_sz]),
     'danet_attractor_anchor_bwd_anchors': (c_int, [c_p, c_int, c_int, c_i64, c_int, c_int, c_p, c_p,
                                                    c_p, c_sz, c_f32]),
     'danet_pit_mse_workspace_bytes': (c_sz, [c_int, c_int, c_i64]),

@@ -493,24 +493,45 @@ __global__ __launch_bounds__(256) void sep_pit_fwd_kernel(
     po[i] = red[i] + red[REC + i] + red[2 * REC + i] + red[3 * REC + i];
 }
 
-template <int EP, int CP>
-__global__ __launch_bounds__(256) void sep_pit_bwd_kernel(
-    int act, int mode, int B, int64_t N, int E, const float* __restrict__ mix_pwr,
-    const float* __restrict__ attr, const float* __restrict__ embed,
-    const float2* __restrict__ src, const float2* __restrict__ phasor,
-    const int32_t* __restrict__ perm_idx, const float* __restrict__ records,
-    float dloss, const float* __restrict__ dloss_dev,
-    float* __restrict__ dembed, float* __restrict__ partial /* [B][nch][C][EP] */) {
+// dL/dlogit_c of the fused separator + PIT loss for one bin (masks m, mixture magnitude mp,
+// phasor ph, truth s, inverse permutation inv, scale = dloss * 2 / (B N)); also used by the
+// estimator backward that recomputes the separator's embedding gradient
+template <int CP>
+__device__ __forceinline__ void sep_pit_dlogit(int act, int mode, const float (&m)[CP], float mp,
+                                               float2 ph, const float2 (&s)[CP],
+                                               const int (&inv)[MAXC], float scale, float (&dl)[CP]) {
   constexpr int C = CP;
-  __shared__ float tab[CP * EP];
-  __shared__ float red[4 * EP];
-  __shared__ float rec_s[REC + 1];
-  __shared__ int perm_s;
-  const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    float2 t = s[0];
+#pragma unroll
+    for (int q = 1; q < C; ++q) t = (inv[j] == q) ? s[q] : t;
+    const float p = mp * m[j];
+    float g;
+    if (mode == 1) g = p - hypotf(t.x, t.y);
+    else g = p * (ph.x * ph.x + ph.y * ph.y) - (ph.x * t.x + ph.y * t.y);
+    dl[j] = (scale * g) * mp;                                  // dL/dmask
+  }
+  if (act == 0) {
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) dot += m[c] * dl[c];
+#pragma unroll
+    for (int c = 0; c < C; ++c) dl[c] = m[c] * (dl[c] - dot);
+  } else {
+#pragma unroll
+    for (int c = 0; c < C; ++c) dl[c] = dl[c] * m[c] * (1.f - m[c]);
+  }
+}
+
+// this utterance's permutation from the forward's chunk records (the sums and the search of
+// pit_final_kernel) or from perm_idx; published by the caller's next __syncthreads()
+template <int CP>
+__device__ __forceinline__ void sep_pit_perm(const float* __restrict__ records,
+                                             const int32_t* __restrict__ perm_idx, int b, int nch,
+                                             int64_t N, float* rec_s, int* perm_s) {
+  constexpr int C = CP;
   if (records != nullptr) {
-    // this utterance's permutation from the forward's records: the sums and the search of
-    // pit_final_kernel (ascending chunks, first minimum), so the same index -- without waiting
-    // for that kernel
     if (threadIdx.x < REC) {
       const float* pp = records + (int64_t)b * nch * REC + threadIdx.x;
       float sacc = 0.f;
@@ -531,11 +552,28 @@ __global__ __launch_bounds__(256) void sep_pit_bwd_kernel(
         for (int i = 0; i < C; ++i) v += rec_s[i * C + pm[i]] * invN;
         if (pq == 0 || v < best_v) { best = pq; best_v = v; }
       }
-      perm_s = best;
+      *perm_s = best;
     }
   } else if (threadIdx.x == 0) {
-    perm_s = perm_idx[b];
+    *perm_s = perm_idx[b];
   }
+}
+
+template <int EP, int CP>
+__global__ __launch_bounds__(256) void sep_pit_bwd_kernel(
+    int act, int mode, int B, int64_t N, int E, const float* __restrict__ mix_pwr,
+    const float* __restrict__ attr, const float* __restrict__ embed,
+    const float2* __restrict__ src, const float2* __restrict__ phasor,
+    const int32_t* __restrict__ perm_idx, const float* __restrict__ records,
+    float dloss, const float* __restrict__ dloss_dev,
+    float* __restrict__ dembed, float* __restrict__ partial /* [B][nch][C][EP] */) {
+  constexpr int C = CP;
+  __shared__ float tab[CP * EP];
+  __shared__ float red[4 * EP];
+  __shared__ float rec_s[REC + 1];
+  __shared__ int perm_s;
+  const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  sep_pit_perm<CP>(records, perm_idx, b, nch, N, rec_s, &perm_s);
   for (int i = threadIdx.x; i < C * EP; i += 256) {
     const int c = i / EP, e = i % EP;
     tab[i] = (e < E) ? attr[((int64_t)b * C + c) * E + e] : 0.f;
@@ -569,39 +607,26 @@ __global__ __launch_bounds__(256) void sep_pit_bwd_kernel(
     float m[CP], dl[CP];
     sep_masks<EP, CP>(act, x, st, m);
     // dL/dsep (ops.py:412-430 differentiated; the estimate j is compared with truth inv[j])
+    sep_pit_dlogit<CP>(act, mode, m, mp, ph, s, inv, scale, dl);
+    if (dembed != nullptr) {
+      float dx[EP];
 #pragma unroll
-    for (int j = 0; j < C; ++j) {
-      float2 t = s[0];
+      for (int e = 0; e < EP; ++e) dx[e] = 0.f;
 #pragma unroll
-      for (int q = 1; q < C; ++q) t = (inv[j] == q) ? s[q] : t;
-      const float p = mp * m[j];
-      float g;
-      if (mode == 1) g = p - hypotf(t.x, t.y);
-      else g = p * (ph.x * ph.x + ph.y * ph.y) - (ph.x * t.x + ph.y * t.y);
-      dl[j] = (scale * g) * mp;                                  // dL/dmask
-    }
-    if (act == 0) {
-      float dot = 0.f;
+      for (int c = 0; c < C; ++c) {
 #pragma unroll
-      for (int c = 0; c < C; ++c) dot += m[c] * dl[c];
-#pragma unroll
-      for (int c = 0; c < C; ++c) dl[c] = m[c] * (dl[c] - dot);
-    } else {
-#pragma unroll
-      for (int c = 0; c < C; ++c) dl[c] = dl[c] * m[c] * (1.f - m[c]);
-    }
-    float dx[EP];
-#pragma unroll
-    for (int e = 0; e < EP; ++e) dx[e] = 0.f;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-#pragma unroll
-      for (int e = 0; e < EP; ++e) {
-        dx[e] += dl[c] * st[c][e];
-        accs[c][e] += dl[c] * x[e];
+        for (int e = 0; e < EP; ++e) {
+          dx[e] += dl[c] * st[c][e];
+          accs[c][e] += dl[c] * x[e];
+        }
       }
+      store_row<EP>(db + n * E, E, dx);
+    } else {          // dattr partials only: the estimator's backward recomputes the dx term
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int e = 0; e < EP; ++e) accs[c][e] += dl[c] * x[e];
     }
-    store_row<EP>(db + n * E, E, dx);
   }
   float* po = partial + ((int64_t)b * nch + ch) * C * EP;
 #pragma unroll
@@ -1033,6 +1058,123 @@ __global__ __launch_bounds__(256) void anchor_bwd_kernel(
     if (c < C) block_reduce_store<EP>(accs[c], EP, red, out + c * EP);
 }
 
+// The estimator backward WITH the separator's embedding-gradient term recomputed in place: the
+// fused separator + loss backward (sep_pit_bwd_kernel with dembed == NULL) only produces dattr, and
+// this kernel forms dembed = dL/dembed|separator + dL/dembed|estimator in ONE pass -- the same
+// additions in the same order as sep_pit_bwd_kernel followed by anchor_bwd_kernel, without
+// writing the first term to HBM (42 MB at cfg 2) and reading it back.
+template <int EP, int CP>
+__global__ __launch_bounds__(256) void anchor_sep_bwd_kernel(
+    int64_t N, int E, int A, AnchorCombos cb, const float* __restrict__ dattr,
+    const float* __restrict__ embed, const float* __restrict__ anchors,
+    const float* __restrict__ attr, const float* __restrict__ asum,
+    const int32_t* __restrict__ choice,
+    int act, int mode, int B, const float* __restrict__ mix_pwr,
+    const float2* __restrict__ src, const float2* __restrict__ phasor,
+    const int32_t* __restrict__ perm_idx, const float* __restrict__ records,
+    float dloss, const float* __restrict__ dloss_dev,
+    float* __restrict__ dembed, float* __restrict__ partial /* [B][chunks][C][EP] */) {
+  constexpr int C = CP;
+  __shared__ float An[MAXC * EP];   // chosen anchors
+  __shared__ float G[MAXC * EP];    // dL/dSnum[c][e]
+  __shared__ float g0[MAXC];        // dL/dSden[c]
+  __shared__ float tab[CP * EP];    // attractors (the separator's table)
+  __shared__ float red[4 * EP];
+  __shared__ float rec_s[REC + 1];
+  __shared__ int perm_s;
+  const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  sep_pit_perm<CP>(records, perm_idx, b, nch, N, rec_s, &perm_s);
+  const int pstar = choice[b];
+  for (int i = threadIdx.x; i < C * EP; i += 256) {
+    const int c = i / EP, e = i % EP;
+    const int a = cb.idx[pstar][c];
+    const float den = asum[((int64_t)b * cb.P + pstar) * C + c];
+    An[i] = (e < E) ? anchors[a * E + e] : 0.f;
+    G[i] = (e < E) ? dattr[((int64_t)b * C + c) * E + e] / den : 0.f;
+    tab[i] = (e < E) ? attr[((int64_t)b * C + c) * E + e] : 0.f;
+  }
+  if (threadIdx.x < C) {
+    const int c = threadIdx.x;
+    const float den = asum[((int64_t)b * cb.P + pstar) * C + c];
+    float sacc = 0.f;
+    for (int e = 0; e < E; ++e)
+      sacc += dattr[((int64_t)b * C + c) * E + e] * attr[((int64_t)b * C + c) * E + e];
+    g0[c] = -sacc / den;
+  }
+  __syncthreads();
+  int perm[MAXC], inv[MAXC];
+  nth_perm(C, perm_s, perm);
+  for (int i = 0; i < C; ++i) inv[perm[i]] = i;
+  const float scale = dloss * (dloss_dev ? *dloss_dev : 1.f) * 2.f / ((float)B * (float)N);
+  const int64_t n0 = (int64_t)ch * CHUNK_N, n1 = min(N, n0 + CHUNK_N);
+  const float* eb = embed + (int64_t)b * N * E;
+  float* db = dembed + (int64_t)b * N * E;
+  float sAn[CP][EP], sG[CP][EP], sg0[CP];
+#pragma unroll
+  for (int c = 0; c < CP; ++c) {
+    sg0[c] = uniform(g0[c]);
+#pragma unroll
+    for (int e = 0; e < EP; ++e) { sAn[c][e] = uniform(An[c * EP + e]); sG[c][e] = uniform(G[c * EP + e]); }
+  }
+  float accs[CP][EP];
+#pragma unroll
+  for (int c = 0; c < CP; ++c)
+#pragma unroll
+    for (int e = 0; e < EP; ++e) accs[c][e] = 0.f;
+  for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
+    float x[EP], dx[EP];
+    load_row<EP>(eb + n * E, E, x);
+    // ---- the separator's term (sep_pit_bwd_kernel's arithmetic, attractor table from LDS)
+    {
+      const float mp = mix_pwr[(int64_t)b * N + n];
+      const float2 ph = phasor[(int64_t)b * N + n];
+      float2 sv[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) sv[c] = src[((int64_t)b * C + c) * N + n];
+      float m[CP], dl[CP];
+      sep_masks_lds<EP, CP>(act, x, tab, m);
+      sep_pit_dlogit<CP>(act, mode, m, mp, ph, sv, inv, scale, dl);
+#pragma unroll
+      for (int e = 0; e < EP; ++e) dx[e] = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int e = 0; e < EP; ++e) dx[e] += dl[c] * tab[c * EP + e];
+    }
+    // ---- the estimator's term (anchor_bwd_kernel's arithmetic)
+    float s[CP], ds[CP];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      float v = 0.f, w = 0.f;
+#pragma unroll
+      for (int e = 0; e < EP; ++e) { v += x[e] * sAn[c][e]; w += x[e] * sG[c][e]; }
+      s[c] = v; ds[c] = w + sg0[c];
+      mx = fmaxf(mx, v);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) { s[c] = expf(s[c] - mx); den += s[c]; }
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) { s[c] /= den; dot += s[c] * ds[c]; }
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      const float dl = s[c] * (ds[c] - dot);
+#pragma unroll
+      for (int e = 0; e < EP; ++e) {
+        dx[e] += s[c] * sG[c][e] + dl * sAn[c][e];
+        accs[c][e] += dl * x[e];
+      }
+    }
+    store_row<EP>(db + n * E, E, dx);
+  }
+  float* out = partial + ((int64_t)b * nch + ch) * C * EP;
+#pragma unroll
+  for (int c = 0; c < CP; ++c)
+    if (c < C) block_reduce_store<EP>(accs[c], EP, red, out + c * EP);
+}
+
 __global__ __launch_bounds__(256) void anchor_bwd_final_kernel(
     int B, int C, int E, int EP, int A, int nch, AnchorCombos cb,
     const float* __restrict__ partial, const int32_t* __restrict__ choice,
@@ -1297,7 +1439,9 @@ extern "C" int danet_separate_pit_bwd(danet_stream_t stream_, int act, int mode,
   int rc = check_common("separate_pit_bwd", B, C, N, E);
   if (rc) return rc;
   DANET_CHECK_ARG((act == 0 || act == 1) && (mode == 0 || mode == 1), "separate_pit_bwd: act / mode");
-  DANET_CHECK_ARG(mix_pwr && attr && embed && src_c64 && phasor && (perm_idx || records) && dembed && dattr,
+  // dembed == NULL: only dattr is produced (the caller's estimator backward recomputes the
+  // separator's contribution to dembed: danet_attractor_anchor_bwd_embed_sep)
+  DANET_CHECK_ARG(mix_pwr && attr && embed && src_c64 && phasor && (perm_idx || records) && dattr,
                   "separate_pit_bwd: null pointer (one of perm_idx / records is required)");
   if (!ws || ws_bytes < danet_separate_pit_workspace_bytes(B, C, N, E)) {
     danet_set_error("separate_pit_bwd: workspace too small");
@@ -1410,6 +1554,37 @@ extern "C" int danet_attractor_anchor_bwd_embed(danet_stream_t stream_, int B, i
   DISPATCH_EP(EPV, DISPATCH_CP(C, (anchor_bwd_kernel<EP, CP><<<grid, 256, 0, stream>>>(
                        C, N, E, A, cb, dattr, embed, anchors, attr, asum, choice, dembed,
                        (float*)ws))));
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
+
+// danet_attractor_anchor_bwd_embed + the separator's dembed term recomputed (see
+// anchor_sep_bwd_kernel): dembed is WRITTEN (not accumulated); pair it with
+// danet_separate_pit_bwd(..., dembed = NULL, ...) which then only produces dattr.
+extern "C" int danet_attractor_anchor_bwd_embed_sep(
+    danet_stream_t stream_, int B, int C, int64_t N, int E, int A, const float* dattr,
+    const float* embed, const float* anchors, const float* attr, const float* asum,
+    const int32_t* choice, int act, int mode, const float* mix_pwr, const float* src_c64,
+    const float* phasor, const int32_t* perm_idx, const float* records, float dloss,
+    const float* dloss_dev, float* dembed, void* ws, size_t ws_bytes) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = anchor_check("attractor_anchor_bwd", B, C, N, E, A);
+  if (rc) return rc;
+  DANET_CHECK_ARG(dattr && embed && anchors && attr && asum && choice && dembed && mix_pwr && src_c64 &&
+                  phasor && (perm_idx || records), "attractor_anchor_bwd_embed_sep: null pointer");
+  DANET_CHECK_ARG((act == 0 || act == 1) && (mode == 0 || mode == 1), "attractor_anchor_bwd_embed_sep: act / mode");
+  if (!ws || ws_bytes < danet_attractor_anchor_workspace_bytes(B, C, N, E, A)) {
+    danet_set_error("attractor_anchor_bwd: workspace too small");
+    return DANET_ERR_WORKSPACE;
+  }
+  AnchorCombos cb;
+  make_combos(A, C, cb);
+  const int nch = n_chunks(N), EPV = pick_ep(E);
+  dim3 grid(nch, B);
+  DISPATCH_EP(EPV, DISPATCH_CP(C, (anchor_sep_bwd_kernel<EP, CP><<<grid, 256, 0, stream>>>(
+                       N, E, A, cb, dattr, embed, anchors, attr, asum, choice, act, mode, B, mix_pwr,
+                       (const float2*)src_c64, (const float2*)phasor, perm_idx, records, dloss,
+                       dloss_dev, dembed, (float*)ws))));
   DANET_CHECK_LAUNCH();
   return DANET_OK;
 }

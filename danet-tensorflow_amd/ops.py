@@ -1064,6 +1064,11 @@ TRUTH_MODES = {'truth': 0, 'truth-threshold': 1, 'truth-weighted': 2}
 # estimator's backward -- whose kernels accumulate (`dembed += ...`) -- adds into that
 # buffer in place and returns no gradient of its own.  DANET_FUSE_DEMBED=0 disables.
 FUSE_DEMBED = int(__import__('os').environ.get('DANET_FUSE_DEMBED', '1'))
+# Inside Model.train_step (heads chain) with the anchor estimator: the fused separator + loss
+# backward produces only dattr and the estimator's backward forms the WHOLE embedding gradient in
+# one pass (danet_attractor_anchor_bwd_embed_sep) -- the separator's term is not written to HBM
+# and read back.  DANET_HEADS_RECOMPUTE=0: the two-pass accumulate-in-place form.
+HEADS_RECOMPUTE = int(__import__('os').environ.get('DANET_HEADS_RECOMPUTE', '1'))
 
 
 # "Heads chain" scope (entered by Model.train_step around forward + backward): inside it the two
@@ -1116,10 +1121,12 @@ class _DembedToken(object):
     (`attr._danet_dembed_token`; lost -- and the fusion with it -- if the caller
     transforms the attractors in between), picked up by SeparateFn.forward.  No global
     state, so several models / re-entrant backward passes cannot alias each other.'''
-    __slots__ = ('dembed',)
+    __slots__ = ('dembed', 'kind', 'recipe')
 
     def __init__(self):
         self.dembed = None
+        self.kind = None          # 'anchor': the estimator's backward can recompute the separator's term
+        self.recipe = None        # set by SeparatePitFn.backward when it left that term to the estimator
 
 
 def _new_token(attr):
@@ -1203,6 +1210,8 @@ class AnchorAttractorFn(torch.autograd.Function):
         ctx.mark_non_differentiable(asets, choice)
         ctx.set_materialize_grads(False)
         ctx.token = _new_token(attr)
+        if ctx.token is not None:
+            ctx.token.kind = 'anchor'
         return attr, asets, choice
 
     @staticmethod
@@ -1212,14 +1221,31 @@ class AnchorAttractorFn(torch.autograd.Function):
         embed, anchors, attr, asum, choice = ctx.saved_tensors
         B, C, N, E, A, T, F = ctx.args
         dev = dattr.device
-        shared = _take_dembed(ctx.token, B * T * F * E)
-        dembed = shared if shared is not None else torch.zeros(B, T, F, E, device=dev)
+        recipe = None
+        if ctx.token is not None:
+            recipe, ctx.token.recipe = ctx.token.recipe, None
+        shared = None if recipe is not None else _take_dembed(ctx.token, B * T * F * E)
+        if recipe is not None:
+            dembed = torch.empty(B, T, F, E, device=dev)       # written whole by the kernel
+        else:
+            dembed = shared if shared is not None else torch.zeros(B, T, F, E, device=dev)
         # fast backward: add straight into the parameter's .grad (no autograd accumulate kernel)
         danchors, direct = _grad_target(ctx.anchors_param, (A, E), dev)
         L = _L()
         nbytes = L.danet_attractor_anchor_workspace_bytes(B, C, N, E, A)
         dattr = _f32(dattr.contiguous())
-        if _chain():
+        if recipe is not None:
+            # the separator's embedding-gradient term is recomputed here (one pass, one store)
+            act, mode, mix_pwr, src, phasor, records, dl = recipe
+            w = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            check(L.danet_attractor_anchor_bwd_embed_sep(
+                _lib.stream(), B, C, N, E, A, ptr(dattr), ptr(embed), ptr(anchors), ptr(attr),
+                ptr(asum), ptr(choice), act, mode, ptr(mix_pwr), ptr(torch.view_as_real(src)),
+                ptr(phasor), None, ptr(records), 1.0, ptr(dl), ptr(dembed), ptr(w), nbytes))
+            _on_side(dev, lambda: check(L.danet_attractor_anchor_bwd_anchors(
+                _lib.stream(), B, C, N, E, A, ptr(choice), ptr(danchors), ptr(w), nbytes,
+                1.0 if direct else 0.0)), keep=(w, choice, danchors))
+        elif _chain():
             # part 1 (dembed) on this stream; part 2 (danchors, from the chunk partials) on the
             # side stream: its own scratch, kept alive until the join
             w = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -1377,16 +1403,24 @@ class SeparatePitFn(torch.autograd.Function):
         act, mode, B, C, N, E = ctx.args
         records, ctx.records = ctx.records, None
         dev = dloss.device
-        dembed = torch.empty(B, N, E, device=dev)
+        tok = ctx.token
+        defer = (HEADS_RECOMPUTE and _chain() and tok is not None and tok.kind == 'anchor' and
+                 ctx.needs_input_grad[1] and ctx.needs_input_grad[2])
+        dembed = None if defer else torch.empty(B, N, E, device=dev)
         dattr = torch.empty(B, C, E, device=dev)
+        dl = _f32(dloss.contiguous())
         L = _L()
         w, wn = _ws(L.danet_separate_pit_workspace_bytes(B, C, N, E), dev)
         # dloss is a device scalar: the kernel reads it (no host sync, no extra pass)
         check(L.danet_separate_pit_bwd(_lib.stream(), act, mode, B, C, N, E, ptr(mix_pwr),
                                        ptr(attr), ptr(embed_flat), ptr(torch.view_as_real(src)),
                                        ptr(phasor), None, ptr(records), 1.0,
-                                       ptr(_f32(dloss.contiguous())), ptr(dembed), ptr(dattr),
-                                       ptr(w), wn))
+                                       ptr(dl), ptr(dembed), ptr(dattr), ptr(w), wn))
+        if defer:
+            # the anchor estimator's backward (next node) recomputes this kernel's dembed term
+            # and returns the whole embedding gradient
+            tok.recipe = (act, mode, mix_pwr, src, phasor, records, dl)
+            return None, dattr, None, None, None, None, None, None
         if ctx.token is not None and ctx.needs_input_grad[1]:
             # the estimator that made `attr` runs its backward next and adds into `dembed`
             ctx.token.dembed = dembed

@@ -398,6 +398,16 @@ int danet_attractor_anchor_bwd_embed(danet_stream_t stream, int B, int C, int64_
                                      const float* dattr, const float* embed, const float* anchors,
                                      const float* attr, const float* asum, const int32_t* choice,
                                      float* dembed, void* ws, size_t ws_bytes);
+/* `_embed` with the fused separator + loss backward's dembed term RECOMPUTED in the same pass
+ * (dembed is written, not accumulated): pair it with danet_separate_pit_bwd(dembed = NULL), which
+ * then produces dattr only -- the separator's term is never written to HBM and read back.      */
+int danet_attractor_anchor_bwd_embed_sep(danet_stream_t stream, int B, int C, int64_t N, int E, int A,
+                                         const float* dattr, const float* embed, const float* anchors,
+                                         const float* attr, const float* asum, const int32_t* choice,
+                                         int act, int mode, const float* mix_pwr, const float* src_c64,
+                                         const float* phasor, const int32_t* perm_idx,
+                                         const float* records, float dloss, const float* dloss_dev,
+                                         float* dembed, void* ws, size_t ws_bytes);
 int danet_attractor_anchor_bwd_anchors(danet_stream_t stream, int B, int C, int64_t N, int E, int A,
                                        const int32_t* choice, float* danchors, const void* ws,
                                        size_t ws_bytes, float danchors_beta);

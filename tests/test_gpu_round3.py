@@ -262,3 +262,36 @@ def test_bptt_with_only_the_recurrent_weight_gradient_fused(B, T, D, H, monkeypa
     assert ops.lstm_status_ok()
     for a, b in zip(got, ref):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (a.shape,)
+
+
+def test_estimator_backward_recomputes_the_separator_term(hp, monkeypatch):
+    '''inside train_step with the anchor estimator the fused separator + loss backward only
+    produces dattr and danet_attractor_anchor_bwd_embed_sep forms the whole embedding gradient
+    in one pass (the separator's term is not written to HBM and read back): same additions in the
+    same order -> the parameters after three steps equal the two-pass form's'''
+    from danet_amd.model import Model
+    from danet_amd import ops
+    res = []
+    for recompute in (1, 0):
+        monkeypatch.setattr(ops, 'HEADS_RECOMPUTE', recompute)
+        hp.reset()
+        hp.load(dict(BATCH_SIZE=4, MAX_N_SIGNAL=2, FFT_SIZE=64, FFT_STRIDE=16, EMBED_SIZE=20,
+                     NUM_LSTM_LAYERS=2, LSTM_HDIM=16, NUM_ANCHOR=6, ENCODER_TYPE='bilstm-orig',
+                     TRAIN_ESTIMATOR_METHOD='anchor', INFER_ESTIMATOR_METHOD='anchor',
+                     SEPARATOR_TYPE='dot-softmax-orig'))
+        hp.digest()
+        model = Model('rc', device='cuda', seed=3).build()
+        model.keep_grads = True
+        rng = np.random.RandomState(5)
+        src = torch.as_tensor(((rng.randn(4, 2, 70, 33) + 1j * rng.randn(4, 2, 70, 33)) * 5)
+                              .astype(np.complex64)).cuda()
+        for _ in range(3):
+            out = model.train_step(src)
+        torch.cuda.synchronize()
+        res.append((float(out['loss']), model.param_dict(), model.grad_dict()))
+    assert res[0][0] == res[1][0]
+    for k in res[0][1]:
+        a, b = res[0][2][k], res[1][2][k]
+        assert np.abs(a - b).max() <= 1e-6 * (np.abs(b).max() + 1e-30), ('grad', k)
+        a, b = res[0][1][k], res[1][1][k]
+        assert np.abs(a - b).max() <= 1e-6 * (np.abs(b).max() + 1e-30), ('param', k)
