@@ -90,6 +90,9 @@ PROTOTYPES = {
                                           c_f32, c_p, c_p, c_p, c_sz]),
     'danet_attractor_truth_bwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p,
                                           c_p, c_f32, c_p]),
+    'danet_attractor_truth_bwd_sep': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p, c_p,
+                                              c_f32, c_p, c_p, c_int, c_int, c_p, c_p, c_p, c_p, c_f32,
+                                              c_p, c_p]),
     'danet_attractor_anchor_workspace_bytes': (c_sz, [c_int, c_int, c_i64, c_int, c_int]),
     'danet_attractor_anchor_fwd': (c_int, [c_p, c_int, c_int, c_i64, c_int, c_int, c_p, c_p, c_p,
                                            c_p, c_p, c_p, c_p, c_sz]),

@@ -633,6 +633,65 @@ __global__ __launch_bounds__(256) void sep_pit_bwd_kernel(
   for (int c = 0; c < CP; ++c) block_reduce_store<EP>(accs[c], EP, red, po + c * EP);
 }
 
+// The truth-family estimator backward WITH the fused separator + loss backward's dembed term
+// recomputed in the same pass (see anchor_sep_bwd_kernel): dembed = dL/dembed|separator +
+// w(n) * dattr[idx(n)] / (denom + add), written once.
+template <int EP, int CP>
+__global__ __launch_bounds__(256) void truth_sep_bwd_kernel(
+    int tmode, int64_t N, int E, const float* __restrict__ dattr,
+    const float* __restrict__ src_pwr, const float* __restrict__ mix_pwr,
+    const float* __restrict__ denom, float eps,
+    const float* __restrict__ embed, const float* __restrict__ attr,
+    int act, int mode, int B, const float2* __restrict__ src, const float2* __restrict__ phasor,
+    const int32_t* __restrict__ perm_idx, const float* __restrict__ records,
+    float dloss, const float* __restrict__ dloss_dev, float* __restrict__ dembed) {
+  constexpr int C = CP;
+  __shared__ float dtab[CP * EP];   // dattr / (denom + add)
+  __shared__ float tab[CP * EP];    // attractors (the separator's table)
+  __shared__ float rec_s[REC + 1];
+  __shared__ int perm_s;
+  const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  sep_pit_perm<CP>(records, perm_idx, b, nch, N, rec_s, &perm_s);
+  for (int i = threadIdx.x; i < C * EP; i += 256) {
+    const int c = i / EP, e = i % EP;
+    const float add = (tmode == 0) ? 1.f : eps;
+    dtab[i] = (e < E) ? dattr[((int64_t)b * C + c) * E + e] / (denom[b * C + c] + add) : 0.f;
+    tab[i] = (e < E) ? attr[((int64_t)b * C + c) * E + e] : 0.f;
+  }
+  __syncthreads();
+  int perm[MAXC], inv[MAXC];
+  nth_perm(C, perm_s, perm);
+  for (int i = 0; i < C; ++i) inv[perm[i]] = i;
+  const float scale = dloss * (dloss_dev ? *dloss_dev : 1.f) * 2.f / ((float)B * (float)N);
+  const int64_t n0 = (int64_t)ch * CHUNK_N, n1 = min(N, n0 + CHUNK_N);
+  const float* eb = embed + (int64_t)b * N * E;
+  const float* sp = src_pwr + (int64_t)b * C * N;
+  float* db = dembed + (int64_t)b * N * E;
+  for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
+    float x[EP], dx[EP];
+    load_row<EP>(eb + n * E, E, x);
+    const float mp = mix_pwr[(int64_t)b * N + n];
+    const float2 ph = phasor[(int64_t)b * N + n];
+    float2 sv[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) sv[c] = src[((int64_t)b * C + c) * N + n];
+    float m[CP], dl[CP];
+    sep_masks_lds<EP, CP>(act, x, tab, m);
+    sep_pit_dlogit<CP>(act, mode, m, mp, ph, sv, inv, scale, dl);
+#pragma unroll
+    for (int e = 0; e < EP; ++e) dx[e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int e = 0; e < EP; ++e) dx[e] += dl[c] * tab[c * EP + e];
+    const int cs = argmax_src(sp, C, N, n);
+    const float w = truth_weight(tmode, mp);
+#pragma unroll
+    for (int e = 0; e < EP; ++e) dx[e] += w * dtab[cs * EP + e];
+    store_row<EP>(db + n * E, E, dx);
+  }
+}
+
 // =========================================================================
 // anchor estimator (app/modules.py:501-545)
 // =========================================================================
@@ -1317,6 +1376,33 @@ extern "C" int danet_attractor_truth_bwd(danet_stream_t stream_, int mode, int B
   dim3 grid((unsigned)min((int64_t)64, cdiv64(N, 256)), B);
   DISPATCH_EP(EPV, (truth_bwd_kernel<EP><<<grid, 256, 0, stream>>>(
                        mode, C, N, E, dattr, src_pwr, mix_pwr, denom, eps, dembed)));
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
+
+// danet_attractor_truth_bwd + the separator's dembed term recomputed (truth_sep_bwd_kernel):
+// dembed is WRITTEN; pair it with danet_separate_pit_bwd(dembed = NULL).
+extern "C" int danet_attractor_truth_bwd_sep(danet_stream_t stream_, int tmode, int B, int C,
+                                             int64_t N, int E, const float* dattr,
+                                             const float* src_pwr, const float* mix_pwr,
+                                             const float* denom, float eps, const float* embed,
+                                             const float* attr, int act, int mode,
+                                             const float* src_c64, const float* phasor,
+                                             const int32_t* perm_idx, const float* records,
+                                             float dloss, const float* dloss_dev, float* dembed) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_common("attractor_truth_bwd_sep", B, C, N, E);
+  if (rc) return rc;
+  DANET_CHECK_ARG(dattr && src_pwr && mix_pwr && denom && dembed && embed && attr && src_c64 && phasor &&
+                  (perm_idx || records), "attractor_truth_bwd_sep: null pointer");
+  DANET_CHECK_ARG(tmode >= 0 && tmode <= 2 && (act == 0 || act == 1) && (mode == 0 || mode == 1),
+                  "attractor_truth_bwd_sep: mode");
+  const int nch = n_chunks(N), EPV = pick_ep(E);
+  dim3 grid(nch, B);
+  DISPATCH_EP(EPV, DISPATCH_CP(C, (truth_sep_bwd_kernel<EP, CP><<<grid, 256, 0, stream>>>(
+                       tmode, N, E, dattr, src_pwr, mix_pwr, denom, eps, embed, attr, act, mode, B,
+                       (const float2*)src_c64, (const float2*)phasor, perm_idx, records, dloss,
+                       dloss_dev, dembed))));
   DANET_CHECK_LAUNCH();
   return DANET_OK;
 }

@@ -1165,15 +1165,30 @@ class TruthAttractorFn(torch.autograd.Function):
         check(L.danet_attractor_truth_fwd(_lib.stream(), mode, B, C, N, E, ptr(embed),
                                           ptr(src_pwr), ptr(mix_pwr), eps, ptr(attr),
                                           ptr(denom), ptr(w), wn))
-        ctx.save_for_backward(src_pwr, mix_pwr, denom)
+        ctx.save_for_backward(src_pwr, mix_pwr, denom, embed, attr)
         ctx.args = (mode, eps, B, C, N, E, T, F)
         ctx.token = _new_token(attr)
+        if ctx.token is not None:
+            ctx.token.kind = 'truth'
         return attr
 
     @staticmethod
     def backward(ctx, dattr):
-        src_pwr, mix_pwr, denom = ctx.saved_tensors
+        src_pwr, mix_pwr, denom, embed, attr = ctx.saved_tensors
         mode, eps, B, C, N, E, T, F = ctx.args
+        recipe = None
+        if ctx.token is not None:
+            recipe, ctx.token.recipe = ctx.token.recipe, None
+        if recipe is not None:
+            # the separator's embedding-gradient term is recomputed here (one pass, one store)
+            act, lmode, s_mix, src, phasor, records, dl = recipe
+            dembed = torch.empty(B, T, F, E, device=dattr.device)
+            check(_L().danet_attractor_truth_bwd_sep(
+                _lib.stream(), mode, B, C, N, E, ptr(_f32(dattr.contiguous())), ptr(src_pwr),
+                ptr(s_mix), ptr(denom), eps, ptr(embed), ptr(attr), act, lmode,
+                ptr(torch.view_as_real(src)), ptr(phasor), None, ptr(records), 1.0, ptr(dl),
+                ptr(dembed)))
+            return dembed, None, None, None, None
         shared = _take_dembed(ctx.token, B * T * F * E)
         dembed = shared if shared is not None else torch.zeros(B, T, F, E, device=dattr.device)
         check(_L().danet_attractor_truth_bwd(
@@ -1404,7 +1419,7 @@ class SeparatePitFn(torch.autograd.Function):
         records, ctx.records = ctx.records, None
         dev = dloss.device
         tok = ctx.token
-        defer = (HEADS_RECOMPUTE and _chain() and tok is not None and tok.kind == 'anchor' and
+        defer = (HEADS_RECOMPUTE and _chain() and tok is not None and tok.kind in ('anchor', 'truth') and
                  ctx.needs_input_grad[1] and ctx.needs_input_grad[2])
         dembed = None if defer else torch.empty(B, N, E, device=dev)
         dattr = torch.empty(B, C, E, device=dev)
@@ -1417,7 +1432,7 @@ class SeparatePitFn(torch.autograd.Function):
                                        ptr(phasor), None, ptr(records), 1.0,
                                        ptr(dl), ptr(dembed), ptr(dattr), ptr(w), wn))
         if defer:
-            # the anchor estimator's backward (next node) recomputes this kernel's dembed term
+            # the estimator's backward (next node) recomputes this kernel's dembed term
             # and returns the whole embedding gradient
             tok.recipe = (act, mode, mix_pwr, src, phasor, records, dl)
             return None, dattr, None, None, None, None, None, None

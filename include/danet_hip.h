@@ -369,6 +369,16 @@ int danet_attractor_truth_bwd(danet_stream_t stream, int mode, int B, int C,
                               int64_t N, int E, const float* dattr,
                               const float* src_pwr, const float* mix_pwr,
                               const float* denom, float eps, float* dembed);
+/* The same with the fused separator + loss backward's dembed term RECOMPUTED in the same pass
+ * (dembed is written, not accumulated; embed and attr = the forward's inputs / outputs): pair it
+ * with danet_separate_pit_bwd(dembed = NULL), which then produces dattr only.                  */
+int danet_attractor_truth_bwd_sep(danet_stream_t stream, int tmode, int B, int C, int64_t N, int E,
+                                  const float* dattr, const float* src_pwr, const float* mix_pwr,
+                                  const float* denom, float eps, const float* embed,
+                                  const float* attr, int act, int mode, const float* src_c64,
+                                  const float* phasor, const int32_t* perm_idx,
+                                  const float* records, float dloss, const float* dloss_dev,
+                                  float* dembed);
 
 /* ---------------------------------------------------------------- a11
  * Anchor estimator (app/modules.py:490-545, app/ops.py:273-292), fused: one

@@ -264,7 +264,9 @@ def test_bptt_with_only_the_recurrent_weight_gradient_fused(B, T, D, H, monkeypa
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (a.shape,)
 
 
-def test_estimator_backward_recomputes_the_separator_term(hp, monkeypatch):
+@pytest.mark.parametrize('est,sepn,C', [('anchor', 'dot-softmax-orig', 2), ('truth-weighted', 'dot-softmax-orig', 3),
+                                        ('truth', 'dot-sigmoid-orig', 2), ('truth-threshold', 'dot-softmax-orig', 2)])
+def test_estimator_backward_recomputes_the_separator_term(hp, monkeypatch, est, sepn, C):
     '''inside train_step with the anchor estimator the fused separator + loss backward only
     produces dattr and danet_attractor_anchor_bwd_embed_sep forms the whole embedding gradient
     in one pass (the separator's term is not written to HBM and read back): same additions in the
@@ -275,15 +277,15 @@ def test_estimator_backward_recomputes_the_separator_term(hp, monkeypatch):
     for recompute in (1, 0):
         monkeypatch.setattr(ops, 'HEADS_RECOMPUTE', recompute)
         hp.reset()
-        hp.load(dict(BATCH_SIZE=4, MAX_N_SIGNAL=2, FFT_SIZE=64, FFT_STRIDE=16, EMBED_SIZE=20,
+        hp.load(dict(BATCH_SIZE=4, MAX_N_SIGNAL=C, FFT_SIZE=64, FFT_STRIDE=16, EMBED_SIZE=20,
                      NUM_LSTM_LAYERS=2, LSTM_HDIM=16, NUM_ANCHOR=6, ENCODER_TYPE='bilstm-orig',
-                     TRAIN_ESTIMATOR_METHOD='anchor', INFER_ESTIMATOR_METHOD='anchor',
-                     SEPARATOR_TYPE='dot-softmax-orig'))
+                     TRAIN_ESTIMATOR_METHOD=est, INFER_ESTIMATOR_METHOD='anchor',
+                     SEPARATOR_TYPE=sepn))
         hp.digest()
         model = Model('rc', device='cuda', seed=3).build()
         model.keep_grads = True
         rng = np.random.RandomState(5)
-        src = torch.as_tensor(((rng.randn(4, 2, 70, 33) + 1j * rng.randn(4, 2, 70, 33)) * 5)
+        src = torch.as_tensor(((rng.randn(4, C, 70, 33) + 1j * rng.randn(4, C, 70, 33)) * 5)
                               .astype(np.complex64)).cuda()
         for _ in range(3):
             out = model.train_step(src)

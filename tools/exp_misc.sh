@@ -1,10 +1,10 @@
-B="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-parity-check"
-run() { tag=$1; shift; env "$@" $B 2>/dev/null | tail -1 | python -c "
+run() { tag=$1; cfg=$2; shift; shift; env "$@" python bench.py --config $cfg --steps 16 --warmup 4 --no-cpu-baseline --no-parity-check 2>/dev/null | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); k=d['kernels']
-print('$tag', d['ms_per_step'], 'bwd %.1f fwd %.1f group %.1f' % (k['lstm_bwd']['avg_us'], k['lstm_fwd']['avg_us'], k['gemm_f32_group']['avg_us']))" >> gpurun_out/exp11.log 2>&1; }
-rm -f gpurun_out/exp11.log
-run recompute A=1
-run two_pass DANET_HEADS_RECOMPUTE=0
-run recompute A=1
-run two_pass DANET_HEADS_RECOMPUTE=0
+d=json.loads(sys.stdin.read())
+print('$tag', '$cfg', d['ms_per_step'], d['value'])" >> gpurun_out/exp12.log 2>&1; }
+rm -f gpurun_out/exp12.log
+run recompute cfg4 A=1
+run two_pass cfg4 DANET_HEADS_RECOMPUTE=0
+run recompute cfg4 A=1
+run two_pass cfg4 DANET_HEADS_RECOMPUTE=0
+run recompute cfg4h600 A=1
