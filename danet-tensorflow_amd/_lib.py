@@ -75,6 +75,7 @@ PROTOTYPES = {
     'danet_lstm_bwd_db_supported': (c_int, [c_int, c_int, c_int, c_int]),
     'danet_lstm_bwd_db': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_int,
                                   c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_sz, c_p, c_int]),
+    'danet_lstm_bwd_db_reduce': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p, c_f32, c_p, c_sz]),
     'danet_lstm_bwd_fused_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'danet_lstm_bwd_fused_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     'danet_lstm_bwd_fused': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_int,

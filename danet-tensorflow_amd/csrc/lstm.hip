@@ -2297,6 +2297,29 @@ extern "C" int danet_lstm_bwd_db(danet_stream_t stream_, int T, int B, int H, in
                        cell_f, cell_b, da_f, da_b, ws, ws_bytes, status, db_f, db_b, beta, flags);
 }
 
+// The per-cluster bias-gradient partials a danet_lstm_bwd_db(..., DANET_LSTM_DB_DEFERRED) launch left
+// in its workspace, summed into db: 6 us the caller can put on any stream ordered behind that launch
+// instead of between the BPTT kernel and the dX product that waits for it.
+extern "C" int danet_lstm_bwd_db_reduce(danet_stream_t stream_, int T, int B, int H, int ndir,
+                                        float* db_f, float* db_b, float beta,
+                                        const void* ws, size_t ws_bytes) {
+  DANET_CHECK_ARG(db_f && (ndir == 1 || db_b), "lstm_bwd_db_reduce: null db pointer");
+  DANET_CHECK_ARG(beta == 0.f || beta == 1.f, "lstm_bwd_db_reduce: beta must be 0 or 1");
+  if (!danet_lstm_bwd_db_supported(T, B, H, ndir)) {
+    danet_set_error("lstm_bwd_db_reduce: B=%d H=%d outside the reduce-scatter geometry", B, H);
+    return DANET_ERR_UNSUPPORTED;
+  }
+  int rc = lstm_check_common(T, B, H, ndir, const_cast<void*>(ws), ws_bytes);
+  if (rc) return rc;
+  const RsPlan rs = choose_rs_plan(B, H, ndir);
+  const float* slab = (const float*)((const char*)ws + align_up(ring_offset(T) + rs.ring_bytes, 256));
+  dim3 grid((unsigned)cdiv(H, 256), ndir);
+  lstm_dw_reduce_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(nullptr, slab, nullptr, nullptr, db_f, db_b,
+                                                                rs.G, 0, 0, 0, 0, 4 * H, beta);
+  DANET_CHECK_LAUNCH();
+  return DANET_OK;
+}
+
 static int lstm_bwd_impl(danet_stream_t stream_, int T, int B, int H, int ndir,
                          const float* dy, int lddy,
                          const float* Wh_f, const float* Wh_b, int ldw,
@@ -2361,7 +2384,7 @@ static int lstm_bwd_impl(danet_stream_t stream_, int T, int B, int H, int ndir,
       default: LAUNCH_RS(UV, 5); break; }
     if (rs.U == 8) { LAUNCH_RS_U(8) } else if (rs.U == 16) { LAUNCH_RS_U(16) } else { LAUNCH_RS_U(32) }
     DANET_CHECK_LAUNCH();
-    if (db_f) {
+    if (db_f && !(flags & DANET_LSTM_DB_DEFERRED)) {
       dim3 grid((unsigned)cdiv(H, 256), ndir);
       lstm_dw_reduce_kernel<<<grid, 256, 0, stream>>>(nullptr, a.dbslab, nullptr, nullptr, db_f, db_b,
                                                       rs.G, 0, 0, 0, 0, 4 * H, beta);

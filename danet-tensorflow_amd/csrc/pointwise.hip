@@ -159,6 +159,41 @@ __global__ void center_apply_kernel(int B, int T, int D, const float* __restrict
   }
 }
 
+// Both phases in ONE launch, one workgroup of 16 waves per utterance (the second read comes out of
+// L2): for many small utterances (B >= 16, T*D <= 128 K elements) the two-launch form above is
+// two dependent ~6 us kernels on the critical path; a large utterance (cfg 5: 3 MB, B = 1) needs the
+// many workgroups of the two-launch form.  Same double-accumulated mean.
+__global__ __launch_bounds__(1024) void center_one_kernel(int B, int T, int D, const float* __restrict__ in,
+                                                          int in_layout, int ld_in, float* __restrict__ out,
+                                                          int out_layout, int ld_out,
+                                                          float* __restrict__ mean_out) {
+  __shared__ double redd[16];
+  __shared__ float mean_s;
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  double s = 0.0;
+  for (int t = wave; t < T; t += nw) {
+    const float* row = in + center_index(in_layout, B, T, ld_in, b, t);
+    for (int d = lane; d < D; d += 64) s += (double)row[d];
+  }
+  s = wave_sum_d(s);
+  if (lane == 0) redd[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int i = 0; i < nw; ++i) tot += redd[i];
+    const float m = (float)(tot / (double)((int64_t)T * D));
+    mean_s = m;
+    if (mean_out) mean_out[b] = m;
+  }
+  __syncthreads();
+  const float mean = mean_s;
+  for (int t = wave; t < T; t += nw) {
+    const float* src = in + center_index(in_layout, B, T, ld_in, b, t);
+    float* dst = out + center_index(out_layout, B, T, ld_out, b, t);
+    for (int d = lane; d < ld_out; d += 64) dst[d] = (d < D) ? src[d] - mean : 0.f;
+  }
+}
+
 // `mean` doubles as scratch: [B] means (padded to an even count) followed by
 // [B][CENTER_CHUNKS] DOUBLE partial sums (keeps the ABI allocation-free and re-entrant).
 extern "C" int danet_center_mean_elems(int B) { return ((B + 1) & ~1) + 2 * B * CENTER_CHUNKS; }
@@ -170,6 +205,12 @@ extern "C" int danet_center(danet_stream_t stream, int B, int T, int D, const fl
   DANET_CHECK_ARG(ld_in >= D && ld_out >= D, "center: ld < D");
   DANET_CHECK_ARG((in_layout | 1) == 1 && (out_layout | 1) == 1, "center: layout must be 0/1");
   DANET_CHECK_ARG(((uintptr_t)mean & 7) == 0, "center: mean scratch must be 8-byte aligned");
+  if (B >= 16 && (int64_t)T * D <= 131072) {
+    center_one_kernel<<<B, 1024, 0, (hipStream_t)stream>>>(B, T, D, in, in_layout, ld_in, out, out_layout,
+                                                          ld_out, mean);
+    DANET_CHECK_LAUNCH();
+    return DANET_OK;
+  }
   double* partial = reinterpret_cast<double*>(mean + ((B + 1) & ~1));
   dim3 g1(CENTER_CHUNKS, B);
   center_sum_kernel<<<g1, 256, 0, (hipStream_t)stream>>>(B, T, D, in, in_layout, ld_in, partial);

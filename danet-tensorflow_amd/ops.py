@@ -672,6 +672,7 @@ def _overlap_dw(H):
 DW_FORK_EARLY = __import__('os').environ.get('DANET_DW_FORK_EARLY', '0') == '1'
 # bias gradients summed inside the (unfused) BPTT kernel instead of by column-sum launches
 BWD_DB = __import__('os').environ.get('DANET_LSTM_BWD_DB', '1') == '1'
+DB_DEFER = __import__('os').environ.get('DANET_LSTM_DB_DEFER', '1') == '1'
 
 
 def bptt_fused(T, B, H, ndir, D, need_dx, is_top=False):
@@ -707,7 +708,7 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
              all(W.stride(0) == 4 * H and W.stride(1) == 1 and W.data_ptr() % 16 == 0 for W in c.Ws) and
              all(t.data_ptr() % 16 == 0 for t in dWs + dbs) and
              bptt_fused(T, B, H, ndir, D, need_dx, is_top))
-    db_in_kernel = False
+    db_in_kernel = db_deferred = False
     # 'h': only the recurrent weight gradient (dWh) and the bias gradient inside the BPTT kernel
     fused_h = (not fused and BWD_FUSED == 'h' and (all_direct or none_direct) and
                all(W.stride(0) == 4 * H and W.stride(1) == 1 and W.data_ptr() % 16 == 0 for W in c.Ws) and
@@ -749,6 +750,10 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
         db_in_kernel = (BWD_DB and (all(b_direct) or not any(b_direct)) and
                         all(t.data_ptr() % 16 == 0 for t in dbs) and
                         L.danet_lstm_bwd_db_supported(T, B, H, ndir) == 1)
+        # the 6-us sum of the kernel's per-cluster bias partials leaves the critical path (BPTT ->
+        # dX -> next BPTT) when a side chain is forked behind this launch anyway
+        db_deferred = (db_in_kernel and DB_DEFER and GROUPED_DW and SIDE_STREAMS > 0 and
+                       (not need_dx or _overlap_dw(H)))
         with _lib.timed('lstm_bwd'):
             if db_in_kernel:      # bias gradients summed inside the BPTT kernel: no colsum launches
                 check(L.danet_lstm_bwd_db(
@@ -756,7 +761,8 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
                     ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(c.gates[0]), ptr(c.gates[-1]),
                     ptr(c.cells[0]), ptr(c.cells[-1]), ptr(das[0]), ptr(das[-1]),
                     ptr(dbs[0]), ptr(dbs[-1]), 1.0 if all(b_direct) else 0.0, ptr(ws), wn,
-                    ptr(status_word(dev)), 1 if ws_prefilled is not None else 0))
+                    ptr(status_word(dev)),
+                    (1 if ws_prefilled is not None else 0) | (2 if db_deferred else 0)))
             else:
                 check(L.danet_lstm_bwd(
                     _lib.stream(), T, B, H, ndir, ptr(_f32(dy)), ndir * H,
@@ -800,6 +806,10 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
             bias_grads()
 
     def bias_grads():
+        if db_deferred:
+            check(L.danet_lstm_bwd_db_reduce(_lib.stream(), T, B, H, ndir, ptr(dbs[0]), ptr(dbs[-1]),
+                                             1.0 if direct[0][1] else 0.0, ptr(ws), wn))
+            return
         if db_in_kernel:
             return
         for d in range(ndir):
@@ -837,14 +847,14 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
         sides[0].wait_stream(main)
         with torch.cuda.stream(sides[0]):
             _fire_grad_ready(('rest',), list(c.Ws) + list(c.bs))
-    with _Fork(dev, ndir + 1, defer=True, keep=(das, c.x, c.ypad, dy)) as f:
+    with _Fork(dev, ndir + 1, defer=True, keep=(das, c.x, c.ypad, dy, ws)) as f:
         on_main = False
         if fused:
             on_main = True           # everything was issued on the main stream
         elif GROUPED_DW and not need_dx:
             # bottom layer: no BPTT kernel follows, so the group takes the whole GPU on
             # the main stream while the column sums (if any) run beside it
-            if not db_in_kernel:
+            if not db_in_kernel or db_deferred:
                 f.run(1, bias_grads)
             weight_grads_grouped(wgs=512, with_bias=False)
             on_main = True

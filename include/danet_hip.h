@@ -255,6 +255,10 @@ int danet_lstm_fwd(danet_stream_t stream, int T, int B, int H, int ndir,
  * (one fill launch for the buffers of ALL layers instead of one per call); 0 = the call prefills
  * its own buffers.                                                                          */
 #define DANET_LSTM_PREFILLED 1
+/* danet_lstm_bwd_db only: leave the per-cluster bias-gradient partials in the workspace and do NOT
+ * touch db; the caller finishes with danet_lstm_bwd_db_reduce on any stream ordered behind the
+ * launch (the workspace must stay untouched until then).                                     */
+#define DANET_LSTM_DB_DEFERRED 2
 int danet_lstm_fwd_prefill(danet_stream_t stream, int T, int B, int ldy, int n,
                            float* const* ypads, void* const* wss /* NULL or n workspaces */);
 int danet_lstm_bwd_prefill(danet_stream_t stream, int T, int B, int H, int ndir, int n,
@@ -309,6 +313,8 @@ int danet_lstm_bwd_db(danet_stream_t stream, int T, int B, int H, int ndir,
                       const float* cell_f, const float* cell_b,
                       float* da_f, float* da_b, float* db_f, float* db_b, float beta,
                       void* ws, size_t ws_bytes, int32_t* status, int flags);
+int danet_lstm_bwd_db_reduce(danet_stream_t stream, int T, int B, int H, int ndir,
+                             float* db_f, float* db_b, float beta, const void* ws, size_t ws_bytes);
 
 /* BPTT with the layer's weight and bias gradients FUSED: dW_d = [X | Hprev]^T da_d and
  * db_d = colsum(da_d) are accumulated inside the persistent kernel -- every workgroup owns

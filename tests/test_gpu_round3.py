@@ -11,6 +11,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def cu(x, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(x)).to('cuda', dtype)
+
+
 def test_two_host_threads_launch_concurrently():
     '''Two host threads, each on its own HIP stream with its own workspace, launch stream-K
     grouped GEMMs (the launches that number themselves from the process-wide atomic counter and
@@ -297,3 +301,101 @@ def test_estimator_backward_recomputes_the_separator_term(hp, monkeypatch, est, 
         assert np.abs(a - b).max() <= 1e-6 * (np.abs(b).max() + 1e-30), ('grad', k)
         a, b = res[0][1][k], res[1][1][k]
         assert np.abs(a - b).max() <= 1e-6 * (np.abs(b).max() + 1e-30), ('param', k)
+
+
+def test_deferred_bias_gradient_reduce_is_bit_identical(hp, monkeypatch):
+    '''danet_lstm_bwd_db(DANET_LSTM_DB_DEFERRED) + danet_lstm_bwd_db_reduce on the side chain: the
+    same partials summed by the same kernel, only later -> gradients and parameters bit-equal'''
+    from danet_amd.model import Model
+    from danet_amd import ops
+    res = []
+    for defer in (True, False):
+        monkeypatch.setattr(ops, 'DB_DEFER', defer)
+        hp.reset()
+        hp.load(dict(BATCH_SIZE=32, MAX_N_SIGNAL=2, FFT_SIZE=64, FFT_STRIDE=16, EMBED_SIZE=20,
+                     NUM_LSTM_LAYERS=3, LSTM_HDIM=64, NUM_ANCHOR=6, ENCODER_TYPE='bilstm-orig',
+                     TRAIN_ESTIMATOR_METHOD='anchor', INFER_ESTIMATOR_METHOD='anchor',
+                     SEPARATOR_TYPE='dot-softmax-orig'))
+        hp.digest()
+        model = Model('dbd', device='cuda', seed=3).build()
+        model.keep_grads = True
+        rng = np.random.RandomState(5)
+        src = torch.as_tensor(((rng.randn(32, 2, 40, 33) + 1j * rng.randn(32, 2, 40, 33)) * 5)
+                              .astype(np.complex64)).cuda()
+        for _ in range(3):
+            out = model.train_step(src)
+        torch.cuda.synchronize()
+        assert ops.lstm_status_ok()
+        res.append((float(out['loss']), model.param_dict(), model.grad_dict()))
+    assert res[0][0] == res[1][0]
+    nb = 0
+    for k in res[0][1]:
+        if k.endswith('/B'):
+            nb += 1
+            assert np.array_equal(res[0][2][k], res[1][2][k]), ('grad', k)
+            assert np.abs(res[0][2][k]).max() > 0
+    assert nb >= 3
+
+
+def test_lstm_bwd_db_reduce_entry_point():
+    '''the C entry points directly: deferred launch leaves db untouched, the reduce call then
+    produces exactly what the undeferred launch writes'''
+    from danet_amd import _lib
+    L = _lib.load()
+    T, B, H = 12, 32, 64
+    if L.danet_lstm_bwd_db_supported(T, B, H, 2) != 1:
+        pytest.skip('outside the reduce-scatter geometry')
+    g = torch.Generator(device='cuda').manual_seed(1)
+    rnd = lambda *s: torch.randn(*s, device='cuda', generator=g)
+    dy = rnd(T, B, 2 * H)
+    Wh = [rnd(H, 4 * H) * 0.1 for _ in range(2)]
+    gates = [torch.sigmoid(rnd(T * B, 4 * H)) for _ in range(2)]
+    cells = [rnd((T + 1) * B, H).tanh() for _ in range(2)]
+    wn = L.danet_lstm_workspace_bytes(T, B, H, 2)
+    outs = []
+    for flags in (0, 2):
+        ws = torch.zeros(wn, dtype=torch.uint8, device='cuda')
+        st = torch.zeros(1, dtype=torch.int32, device='cuda')
+        da = [torch.empty(T * B, 4 * H, device='cuda') for _ in range(2)]
+        db = [torch.full((4 * H,), 7.0, device='cuda') for _ in range(2)]
+        p = _lib.ptr
+        rc = L.danet_lstm_bwd_db(_lib.stream(), T, B, H, 2, p(dy), 2 * H, p(Wh[0]), p(Wh[1]), 4 * H,
+                                 p(gates[0]), p(gates[1]), p(cells[0]), p(cells[1]), p(da[0]), p(da[1]),
+                                 p(db[0]), p(db[1]), 0.0, p(ws), wn, p(st), flags)
+        assert rc == 0, L.danet_last_error()
+        if flags:
+            torch.cuda.synchronize()
+            assert all(bool((t == 7.0).all()) for t in db)
+            rc = L.danet_lstm_bwd_db_reduce(_lib.stream(), T, B, H, 2, p(db[0]), p(db[1]), 0.0, p(ws), wn)
+            assert rc == 0, L.danet_last_error()
+        torch.cuda.synchronize()
+        assert int(st) == 0
+        outs.append([t.cpu().numpy() for t in db + da])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    ref = outs[0][2].sum(axis=0)
+    assert np.abs(outs[0][0] - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('B,T,D', [(16, 128, 129), (32, 128, 600), (24, 100, 1300)])
+def test_center_single_launch_equals_two_launch(B, T, D):
+    '''B >= 16 utterances of <= 128 K elements take the one-launch centring kernel; the same
+    utterances in groups of 8 take the two-launch form: both means are the float32 rounding of a
+    double sum (app/modules.py:218-219 reduce_mean over (1, 2))'''
+    from danet_amd import ops
+    rng = np.random.RandomState(B + D)
+    x = (rng.randn(B, T, D) * 2 + rng.randn(B, 1, 1) * 5).astype(np.float32)
+    ldo = (D + 3) // 4 * 4
+    xd = cu(x)
+    out = torch.full((T, B, ldo), 9.0, device='cuda')
+    mean = ops.center(xd, B, T, D, 0, D, out, 1, ldo).cpu().numpy()
+    m64 = x.astype(np.float64).mean(axis=(1, 2))
+    assert np.abs(mean - m64).max() <= 1e-6 * np.abs(m64).max() + 1e-7
+    got = out.cpu().numpy()
+    assert np.all(got[:, :, D:] == 0.0)
+    for b0 in range(0, B, 8):
+        o2 = torch.full((T, 8, ldo), 9.0, device='cuda')
+        m2 = ops.center(xd[b0:b0 + 8].contiguous(), 8, T, D, 0, D, o2, 1, ldo).cpu().numpy()
+        ulp = np.spacing(np.abs(m2).astype(np.float32))
+        assert np.all(np.abs(m2 - mean[b0:b0 + 8]) <= ulp)
+        assert np.abs(o2.cpu().numpy() - got[:, b0:b0 + 8]).max() <= 2 * ulp.max()
