@@ -5,6 +5,7 @@
 // (main.py:359-363, app/ozers.py:15-18).  All are coalesced grid-stride streams;
 // the complex spectra are read as interleaved (re,im) float2.
 #include "common.h"
+#include "options.h"
 
 // ------------------------------------------------------------------ front-end
 __global__ void frontend_kernel(int B, int C, int64_t N, const float2* __restrict__ src,
@@ -160,9 +161,11 @@ __global__ void center_apply_kernel(int B, int T, int D, const float* __restrict
 }
 
 // Both phases in ONE launch, one workgroup of 16 waves per utterance (the second read comes out of
-// L2): for many small utterances (B >= 16, T*D <= 128 K elements) the two-launch form above is
-// two dependent ~6 us kernels on the critical path; a large utterance (cfg 5: 3 MB, B = 1) needs the
-// many workgroups of the two-launch form.  Same double-accumulated mean.
+// L2): for many small utterances (B >= 16, T*D <= 32 K elements: the step's input at 129 bins) the
+// two-launch form above is two dependent ~6 us kernels on the critical path (12.3 us -> 10.4 us
+// measured).  One workgroup cannot stream a larger utterance fast enough (T*D = 77 K elements: 26.8 us
+// against 12.6 us for the two-launch form), and cfg 5's single 3 MB utterance needs many workgroups.
+// Same double-accumulated mean.
 __global__ __launch_bounds__(1024) void center_one_kernel(int B, int T, int D, const float* __restrict__ in,
                                                           int in_layout, int ld_in, float* __restrict__ out,
                                                           int out_layout, int ld_out,
@@ -205,7 +208,7 @@ extern "C" int danet_center(danet_stream_t stream, int B, int T, int D, const fl
   DANET_CHECK_ARG(ld_in >= D && ld_out >= D, "center: ld < D");
   DANET_CHECK_ARG((in_layout | 1) == 1 && (out_layout | 1) == 1, "center: layout must be 0/1");
   DANET_CHECK_ARG(((uintptr_t)mean & 7) == 0, "center: mean scratch must be 8-byte aligned");
-  if (B >= 16 && (int64_t)T * D <= 131072) {
+  if (B >= 16 && (int64_t)T * D <= 32768 && danet_opt(OPT_CENTER_ONE) == 1) {
     center_one_kernel<<<B, 1024, 0, (hipStream_t)stream>>>(B, T, D, in, in_layout, ld_in, out, out_layout,
                                                           ld_out, mean);
     DANET_CHECK_LAUNCH();
