@@ -15,9 +15,17 @@
 #include "pit_common.h"
 #include <stdlib.h>
 
+#ifndef CHUNK_N
 #define CHUNK_N 2048       // bins per workgroup (reduction granularity; 512 / 1024 measured: the
                            // backward kernels gain 4 us, the chunk sums lose as much)
+#endif
 #define MAXA 8
+// threads per workgroup of the streaming separator / loss / estimator-backward kernels (512 measured
+// slower: sep_pit_fwd 13.6 -> 17.4 us, anchor_sep_bwd 40 -> 52 us at cfg 2)
+#ifndef SEP_NT
+#define SEP_NT 256
+#endif
+#define SEP_NW (SEP_NT / 64)
 #define MAXP 70            // C(8,4)
 
 __host__ __device__ static inline int n_chunks(int64_t N) { return (int)((N + CHUNK_N - 1) / CHUNK_N); }
@@ -66,8 +74,8 @@ __device__ __forceinline__ void store_row(float* __restrict__ p, int E, const fl
 }
 
 // block-reduce `cnt` per-thread values (static-indexed array) into dst[cnt]
-// (global), using LDS scratch red[4][cnt_max].  blockDim.x == 256.
-template <int CNT>
+// (global), using LDS scratch red[NW][CNT].  blockDim.x == 64 * NW; fixed summation order.
+template <int CNT, int NW = 4>
 __device__ __forceinline__ void block_reduce_store(float (&v)[CNT], int cnt, float* red,
                                                    float* __restrict__ dst) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -79,8 +87,12 @@ __device__ __forceinline__ void block_reduce_store(float (&v)[CNT], int cnt, flo
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < cnt; i += blockDim.x)
-    dst[i] = red[i] + red[CNT + i] + red[2 * CNT + i] + red[3 * CNT + i];
+  for (int i = threadIdx.x; i < cnt; i += 64 * NW) {
+    float t = red[i];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t += red[w * CNT + i];
+    dst[i] = t;
+  }
   __syncthreads();
 }
 
@@ -140,12 +152,12 @@ __global__ __launch_bounds__(256) void truth_fwd_kernel(
 // overhead at C = 3: 121 us at cfg 4).  A bin adds w * x to its own speaker's set and +0 to the
 // others, so every sum sees the same addends in the same order: bit-identical to the multi-pass form.
 template <int EP, int CP>
-__global__ __launch_bounds__(256) void truth_fwd1_kernel(
+__global__ __launch_bounds__(SEP_NT) void truth_fwd1_kernel(
     int mode, int64_t N, int E, const float* __restrict__ embed,
     const float* __restrict__ src_pwr, const float* __restrict__ mix_pwr,
     float* __restrict__ partial /* [B][chunks][C][EP+1] */) {
   constexpr int C = CP;
-  __shared__ float red[4 * (EP + 1)];
+  __shared__ float red[SEP_NW * (EP + 1)];
   const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
   const int64_t n0 = (int64_t)ch * CHUNK_N, n1 = min(N, n0 + CHUNK_N);
   const float* eb = embed + (int64_t)b * N * E;
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(256) void truth_fwd1_kernel(
   for (int c = 0; c < CP; ++c)
 #pragma unroll
     for (int e = 0; e <= EP; ++e) acc[c][e] = 0.f;
-  for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
+  for (int64_t n = n0 + threadIdx.x; n < n1; n += SEP_NT) {
     const int idx = argmax_src(sp, C, N, n);
     const float w = truth_weight(mode, mp[n]);
     float x[EP];
@@ -173,7 +185,7 @@ __global__ __launch_bounds__(256) void truth_fwd1_kernel(
     }
   }
 #pragma unroll
-  for (int c = 0; c < CP; ++c) block_reduce_store<EP + 1>(acc[c], EP + 1, red, out + c * (EP + 1));
+  for (int c = 0; c < CP; ++c) block_reduce_store<EP + 1, SEP_NW>(acc[c], EP + 1, red, out + c * (EP + 1));
 }
 
 __global__ void truth_final_kernel(int mode, int C, int E, int EP, int nch, float eps,
@@ -182,12 +194,10 @@ __global__ void truth_final_kernel(int mode, int C, int E, int EP, int nch, floa
   const int b = blockIdx.x;
   for (int i = threadIdx.x; i < C * E; i += blockDim.x) {
     const int c = i / E, e = i % E;
-    float s = 0.f, w = 0.f;
-    for (int ch = 0; ch < nch; ++ch) {
-      const float* p = partial + (((int64_t)b * nch + ch) * C + c) * (EP + 1);
-      s += p[e];
-      w += p[EP];
-    }
+    // (chunk loads in flight together, sums in ascending chunk order: pit_common.h)
+    const float* p = partial + ((int64_t)b * nch * C + c) * (EP + 1);
+    const float s = ordered_chunk_sum(p + e, nch, (int64_t)C * (EP + 1));
+    const float w = ordered_chunk_sum(p + EP, nch, (int64_t)C * (EP + 1));
     const float add = (mode == 0) ? 1.f : eps;     // modules.py:407 vs :447,:482
     attr[((int64_t)b * C + c) * E + e] = s / (w + add);
     if (e == 0) denom[b * C + c] = w;
@@ -445,16 +455,16 @@ __device__ __forceinline__ void sep_masks_lds(int act, const float (&x)[EP], con
 }
 
 template <int EP, int CP>
-__global__ __launch_bounds__(256) void sep_pit_fwd_kernel(
+__global__ __launch_bounds__(SEP_NT) void sep_pit_fwd_kernel(
     int act, int mode, int64_t N, int E, const float* __restrict__ mix_pwr,
     const float* __restrict__ attr, const float* __restrict__ embed,
     const float2* __restrict__ src, const float2* __restrict__ phasor,
     float* __restrict__ out /* optional [B][C][N] */, float* __restrict__ partial /* [B][nch][REC] */) {
   constexpr int C = CP;
   __shared__ float tab[CP * EP];
-  __shared__ float red[4 * REC];
+  __shared__ float red[SEP_NW * REC];
   const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
-  for (int i = threadIdx.x; i < C * EP; i += 256) {
+  for (int i = threadIdx.x; i < C * EP; i += SEP_NT) {
     const int c = i / EP, e = i % EP;
     tab[i] = (e < E) ? attr[((int64_t)b * C + c) * E + e] : 0.f;
   }
@@ -464,7 +474,7 @@ __global__ __launch_bounds__(256) void sep_pit_fwd_kernel(
   float acc[REC];
 #pragma unroll
   for (int i = 0; i < REC; ++i) acc[i] = 0.f;
-  for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
+  for (int64_t n = n0 + threadIdx.x; n < n1; n += SEP_NT) {
     float x[EP];
     load_row<EP>(eb + n * E, E, x);
     const float mp = mix_pwr[(int64_t)b * N + n];
@@ -489,8 +499,12 @@ __global__ __launch_bounds__(256) void sep_pit_fwd_kernel(
   }
   __syncthreads();
   float* po = partial + ((int64_t)b * nch + ch) * REC;
-  for (int i = threadIdx.x; i < REC; i += 256)
-    po[i] = red[i] + red[REC + i] + red[2 * REC + i] + red[3 * REC + i];
+  for (int i = threadIdx.x; i < REC; i += SEP_NT) {
+    float t = red[i];
+#pragma unroll
+    for (int w = 1; w < SEP_NW; ++w) t += red[w * REC + i];
+    po[i] = t;
+  }
 }
 
 // dL/dlogit_c of the fused separator + PIT loss for one bin (masks m, mixture magnitude mp,
@@ -532,12 +546,8 @@ __device__ __forceinline__ void sep_pit_perm(const float* __restrict__ records,
                                              int64_t N, float* rec_s, int* perm_s) {
   constexpr int C = CP;
   if (records != nullptr) {
-    if (threadIdx.x < REC) {
-      const float* pp = records + (int64_t)b * nch * REC + threadIdx.x;
-      float sacc = 0.f;
-      for (int c2 = 0; c2 < nch; ++c2) sacc += pp[(int64_t)c2 * REC];
-      rec_s[threadIdx.x] = sacc;
-    }
+    if (threadIdx.x < REC)
+      rec_s[threadIdx.x] = ordered_chunk_sum(records + (int64_t)b * nch * REC + threadIdx.x, nch, REC);
     __syncthreads();
     if (threadIdx.x == 0) {
       int nperm = 1;
@@ -560,7 +570,7 @@ __device__ __forceinline__ void sep_pit_perm(const float* __restrict__ records,
 }
 
 template <int EP, int CP>
-__global__ __launch_bounds__(256) void sep_pit_bwd_kernel(
+__global__ __launch_bounds__(SEP_NT) void sep_pit_bwd_kernel(
     int act, int mode, int B, int64_t N, int E, const float* __restrict__ mix_pwr,
     const float* __restrict__ attr, const float* __restrict__ embed,
     const float2* __restrict__ src, const float2* __restrict__ phasor,
@@ -569,12 +579,12 @@ __global__ __launch_bounds__(256) void sep_pit_bwd_kernel(
     float* __restrict__ dembed, float* __restrict__ partial /* [B][nch][C][EP] */) {
   constexpr int C = CP;
   __shared__ float tab[CP * EP];
-  __shared__ float red[4 * EP];
+  __shared__ float red[SEP_NW * EP];
   __shared__ float rec_s[REC + 1];
   __shared__ int perm_s;
   const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
   sep_pit_perm<CP>(records, perm_idx, b, nch, N, rec_s, &perm_s);
-  for (int i = threadIdx.x; i < C * EP; i += 256) {
+  for (int i = threadIdx.x; i < C * EP; i += SEP_NT) {
     const int c = i / EP, e = i % EP;
     tab[i] = (e < E) ? attr[((int64_t)b * C + c) * E + e] : 0.f;
   }
@@ -596,7 +606,7 @@ __global__ __launch_bounds__(256) void sep_pit_bwd_kernel(
   for (int c = 0; c < CP; ++c)
 #pragma unroll
     for (int e = 0; e < EP; ++e) accs[c][e] = 0.f;
-  for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
+  for (int64_t n = n0 + threadIdx.x; n < n1; n += SEP_NT) {
     float x[EP];
     load_row<EP>(eb + n * E, E, x);
     const float mp = mix_pwr[(int64_t)b * N + n];
@@ -630,14 +640,14 @@ __global__ __launch_bounds__(256) void sep_pit_bwd_kernel(
   }
   float* po = partial + ((int64_t)b * nch + ch) * C * EP;
 #pragma unroll
-  for (int c = 0; c < CP; ++c) block_reduce_store<EP>(accs[c], EP, red, po + c * EP);
+  for (int c = 0; c < CP; ++c) block_reduce_store<EP, SEP_NW>(accs[c], EP, red, po + c * EP);
 }
 
 // The truth-family estimator backward WITH the fused separator + loss backward's dembed term
 // recomputed in the same pass (see anchor_sep_bwd_kernel): dembed = dL/dembed|separator +
 // w(n) * dattr[idx(n)] / (denom + add), written once.
 template <int EP, int CP>
-__global__ __launch_bounds__(256) void truth_sep_bwd_kernel(
+__global__ __launch_bounds__(SEP_NT) void truth_sep_bwd_kernel(
     int tmode, int64_t N, int E, const float* __restrict__ dattr,
     const float* __restrict__ src_pwr, const float* __restrict__ mix_pwr,
     const float* __restrict__ denom, float eps,
@@ -652,7 +662,7 @@ __global__ __launch_bounds__(256) void truth_sep_bwd_kernel(
   __shared__ int perm_s;
   const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
   sep_pit_perm<CP>(records, perm_idx, b, nch, N, rec_s, &perm_s);
-  for (int i = threadIdx.x; i < C * EP; i += 256) {
+  for (int i = threadIdx.x; i < C * EP; i += SEP_NT) {
     const int c = i / EP, e = i % EP;
     const float add = (tmode == 0) ? 1.f : eps;
     dtab[i] = (e < E) ? dattr[((int64_t)b * C + c) * E + e] / (denom[b * C + c] + add) : 0.f;
@@ -667,7 +677,7 @@ __global__ __launch_bounds__(256) void truth_sep_bwd_kernel(
   const float* eb = embed + (int64_t)b * N * E;
   const float* sp = src_pwr + (int64_t)b * C * N;
   float* db = dembed + (int64_t)b * N * E;
-  for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
+  for (int64_t n = n0 + threadIdx.x; n < n1; n += SEP_NT) {
     float x[EP], dx[EP];
     load_row<EP>(eb + n * E, E, x);
     const float mp = mix_pwr[(int64_t)b * N + n];
@@ -1031,6 +1041,40 @@ __global__ void anchor_final_kernel(int C, int E, int EPA, int P, int nch,
   }
 }
 
+// Per-utterance tables of the anchor estimator's backward (chosen subset p*): anchors An, dL/dSnum
+// G = dattr / den, and the raw dattr / attractor / den values dL/dSden is formed from.  dL/dSden[c] =
+// -sum_e dattr[c][e] attr[c][e] / den[c] used to be a serial loop over E behind two dependent global
+// loads per term on one thread per c (~10 us at the head of a 40-us kernel); every thread now forms
+// it from the LDS tables (same terms, same order; the zero padding adds exact zeros).
+template <int EP, int CP>
+__device__ __forceinline__ void anchor_bwd_tables(int b, int E, const AnchorCombos& cb, int pstar,
+                                                  const float* __restrict__ dattr,
+                                                  const float* __restrict__ anchors,
+                                                  const float* __restrict__ attr,
+                                                  const float* __restrict__ asum,
+                                                  float* An, float* G, float* Dr, float* At, float* dn) {
+  constexpr int C = CP;
+  for (int i = threadIdx.x; i < C * EP; i += blockDim.x) {
+    const int c = i / EP, e = i % EP;
+    const int a = cb.idx[pstar][c];
+    const float den = asum[((int64_t)b * cb.P + pstar) * C + c];
+    const float d = (e < E) ? dattr[((int64_t)b * C + c) * E + e] : 0.f;
+    An[i] = (e < E) ? anchors[a * E + e] : 0.f;
+    G[i] = (e < E) ? d / den : 0.f;
+    Dr[i] = d;
+    At[i] = (e < E) ? attr[((int64_t)b * C + c) * E + e] : 0.f;
+    if (e == 0) dn[c] = den;
+  }
+}
+
+template <int EP>
+__device__ __forceinline__ float anchor_bwd_g0(const float* Dr, const float* At, const float* dn, int c) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < EP; ++e) s += Dr[c * EP + e] * At[c * EP + e];
+  return -s / dn[c];
+}
+
 // backward through the chosen subset only (argmin has no gradient)
 template <int EP, int CP>
 __global__ __launch_bounds__(256) void anchor_bwd_kernel(
@@ -1043,25 +1087,13 @@ __global__ __launch_bounds__(256) void anchor_bwd_kernel(
   (void)C_;
   __shared__ float An[MAXC * EP];   // chosen anchors
   __shared__ float G[MAXC * EP];    // dL/dSnum[c][e]
-  __shared__ float g0[MAXC];        // dL/dSden[c]
+  __shared__ float Dr[MAXC * EP];   // dattr
+  __shared__ float At[MAXC * EP];   // attractors
+  __shared__ float dn[MAXC];        // soft-assignment sums of the chosen subset
   __shared__ float red[4 * EP];
   const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
   const int pstar = choice[b];
-  for (int i = threadIdx.x; i < C * EP; i += 256) {
-    const int c = i / EP, e = i % EP;
-    const int a = cb.idx[pstar][c];
-    const float den = asum[((int64_t)b * cb.P + pstar) * C + c];
-    An[i] = (e < E) ? anchors[a * E + e] : 0.f;
-    G[i] = (e < E) ? dattr[((int64_t)b * C + c) * E + e] / den : 0.f;
-  }
-  if (threadIdx.x < C) {
-    const int c = threadIdx.x;
-    const float den = asum[((int64_t)b * cb.P + pstar) * C + c];
-    float s = 0.f;
-    for (int e = 0; e < E; ++e)
-      s += dattr[((int64_t)b * C + c) * E + e] * attr[((int64_t)b * C + c) * E + e];
-    g0[c] = -s / den;
-  }
+  anchor_bwd_tables<EP, CP>(b, E, cb, pstar, dattr, anchors, attr, asum, An, G, Dr, At, dn);
   __syncthreads();
   const int64_t n0 = (int64_t)ch * CHUNK_N, n1 = min(N, n0 + CHUNK_N);
   const float* eb = embed + (int64_t)b * N * E;
@@ -1071,7 +1103,7 @@ __global__ __launch_bounds__(256) void anchor_bwd_kernel(
   float sAn[CP][EP], sG[CP][EP], sg0[CP];
 #pragma unroll
   for (int c = 0; c < CP; ++c) {
-    sg0[c] = uniform(g0[c]);
+    sg0[c] = uniform(anchor_bwd_g0<EP>(Dr, At, dn, c));
 #pragma unroll
     for (int e = 0; e < EP; ++e) { sAn[c][e] = uniform(An[c * EP + e]); sG[c][e] = uniform(G[c * EP + e]); }
   }
@@ -1123,7 +1155,7 @@ __global__ __launch_bounds__(256) void anchor_bwd_kernel(
 // additions in the same order as sep_pit_bwd_kernel followed by anchor_bwd_kernel, without
 // writing the first term to HBM (42 MB at cfg 2) and reading it back.
 template <int EP, int CP>
-__global__ __launch_bounds__(256) void anchor_sep_bwd_kernel(
+__global__ __launch_bounds__(SEP_NT) void anchor_sep_bwd_kernel(
     int64_t N, int E, int A, AnchorCombos cb, const float* __restrict__ dattr,
     const float* __restrict__ embed, const float* __restrict__ anchors,
     const float* __restrict__ attr, const float* __restrict__ asum,
@@ -1136,30 +1168,16 @@ __global__ __launch_bounds__(256) void anchor_sep_bwd_kernel(
   constexpr int C = CP;
   __shared__ float An[MAXC * EP];   // chosen anchors
   __shared__ float G[MAXC * EP];    // dL/dSnum[c][e]
-  __shared__ float g0[MAXC];        // dL/dSden[c]
-  __shared__ float tab[CP * EP];    // attractors (the separator's table)
-  __shared__ float red[4 * EP];
+  __shared__ float Dr[MAXC * EP];   // dattr
+  __shared__ float tab[MAXC * EP];  // attractors (the separator's table)
+  __shared__ float dn[MAXC];        // soft-assignment sums of the chosen subset
+  __shared__ float red[SEP_NW * EP];
   __shared__ float rec_s[REC + 1];
   __shared__ int perm_s;
   const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  const int pstar = choice[b];      // (issued before the record sums: its latency hides behind them)
   sep_pit_perm<CP>(records, perm_idx, b, nch, N, rec_s, &perm_s);
-  const int pstar = choice[b];
-  for (int i = threadIdx.x; i < C * EP; i += 256) {
-    const int c = i / EP, e = i % EP;
-    const int a = cb.idx[pstar][c];
-    const float den = asum[((int64_t)b * cb.P + pstar) * C + c];
-    An[i] = (e < E) ? anchors[a * E + e] : 0.f;
-    G[i] = (e < E) ? dattr[((int64_t)b * C + c) * E + e] / den : 0.f;
-    tab[i] = (e < E) ? attr[((int64_t)b * C + c) * E + e] : 0.f;
-  }
-  if (threadIdx.x < C) {
-    const int c = threadIdx.x;
-    const float den = asum[((int64_t)b * cb.P + pstar) * C + c];
-    float sacc = 0.f;
-    for (int e = 0; e < E; ++e)
-      sacc += dattr[((int64_t)b * C + c) * E + e] * attr[((int64_t)b * C + c) * E + e];
-    g0[c] = -sacc / den;
-  }
+  anchor_bwd_tables<EP, CP>(b, E, cb, pstar, dattr, anchors, attr, asum, An, G, Dr, tab, dn);
   __syncthreads();
   int perm[MAXC], inv[MAXC];
   nth_perm(C, perm_s, perm);
@@ -1171,7 +1189,7 @@ __global__ __launch_bounds__(256) void anchor_sep_bwd_kernel(
   float sAn[CP][EP], sG[CP][EP], sg0[CP];
 #pragma unroll
   for (int c = 0; c < CP; ++c) {
-    sg0[c] = uniform(g0[c]);
+    sg0[c] = uniform(anchor_bwd_g0<EP>(Dr, tab, dn, c));
 #pragma unroll
     for (int e = 0; e < EP; ++e) { sAn[c][e] = uniform(An[c * EP + e]); sG[c][e] = uniform(G[c * EP + e]); }
   }
@@ -1180,7 +1198,7 @@ __global__ __launch_bounds__(256) void anchor_sep_bwd_kernel(
   for (int c = 0; c < CP; ++c)
 #pragma unroll
     for (int e = 0; e < EP; ++e) accs[c][e] = 0.f;
-  for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
+  for (int64_t n = n0 + threadIdx.x; n < n1; n += SEP_NT) {
     float x[EP], dx[EP];
     load_row<EP>(eb + n * E, E, x);
     // ---- the separator's term (sep_pit_bwd_kernel's arithmetic, attractor table from LDS)
@@ -1231,7 +1249,7 @@ __global__ __launch_bounds__(256) void anchor_sep_bwd_kernel(
   float* out = partial + ((int64_t)b * nch + ch) * C * EP;
 #pragma unroll
   for (int c = 0; c < CP; ++c)
-    if (c < C) block_reduce_store<EP>(accs[c], EP, red, out + c * EP);
+    if (c < C) block_reduce_store<EP, SEP_NW>(accs[c], EP, red, out + c * EP);
 }
 
 __global__ __launch_bounds__(256) void anchor_bwd_final_kernel(
@@ -1349,7 +1367,7 @@ extern "C" int danet_attractor_truth_fwd(danet_stream_t stream_, int mode, int B
   const int nch = n_chunks(N), EPV = pick_ep(E);
   dim3 grid(nch, B);
   if (C * (EPV + 1) <= 128) {
-    DISPATCH_EP(EPV, DISPATCH_CP(C, (truth_fwd1_kernel<EP, CP><<<grid, 256, 0, stream>>>(
+    DISPATCH_EP(EPV, DISPATCH_CP(C, (truth_fwd1_kernel<EP, CP><<<grid, SEP_NT, 0, stream>>>(
                          mode, N, E, embed, src_pwr, mix_pwr, (float*)ws))));
   } else {
     DISPATCH_EP(EPV, (truth_fwd_kernel<EP><<<grid, 256, 0, stream>>>(
@@ -1399,7 +1417,7 @@ extern "C" int danet_attractor_truth_bwd_sep(danet_stream_t stream_, int tmode, 
                   "attractor_truth_bwd_sep: mode");
   const int nch = n_chunks(N), EPV = pick_ep(E);
   dim3 grid(nch, B);
-  DISPATCH_EP(EPV, DISPATCH_CP(C, (truth_sep_bwd_kernel<EP, CP><<<grid, 256, 0, stream>>>(
+  DISPATCH_EP(EPV, DISPATCH_CP(C, (truth_sep_bwd_kernel<EP, CP><<<grid, SEP_NT, 0, stream>>>(
                        tmode, N, E, dattr, src_pwr, mix_pwr, denom, eps, embed, attr, act, mode, B,
                        (const float2*)src_c64, (const float2*)phasor, perm_idx, records, dloss,
                        dloss_dev, dembed))));
@@ -1478,7 +1496,7 @@ extern "C" int danet_separate_pit_fwd_records(danet_stream_t stream_, int act, i
                   "separate_pit_fwd: null pointer");
   const int nch = n_chunks(N), EPV = pick_ep(E);
   dim3 grid(nch, B);
-  DISPATCH_EP(EPV, DISPATCH_CP(C, (sep_pit_fwd_kernel<EP, CP><<<grid, 256, 0, stream>>>(
+  DISPATCH_EP(EPV, DISPATCH_CP(C, (sep_pit_fwd_kernel<EP, CP><<<grid, SEP_NT, 0, stream>>>(
                        act, mode, N, E, mix_pwr, attr, embed, (const float2*)src_c64,
                        (const float2*)phasor, sep_pwr_out, records))));
   DANET_CHECK_LAUNCH();
@@ -1535,7 +1553,7 @@ extern "C" int danet_separate_pit_bwd(danet_stream_t stream_, int act, int mode,
   }
   const int nch = n_chunks(N), EPV = pick_ep(E);
   dim3 grid(nch, B);
-  DISPATCH_EP(EPV, DISPATCH_CP(C, (sep_pit_bwd_kernel<EP, CP><<<grid, 256, 0, stream>>>(
+  DISPATCH_EP(EPV, DISPATCH_CP(C, (sep_pit_bwd_kernel<EP, CP><<<grid, SEP_NT, 0, stream>>>(
                        act, mode, B, N, E, mix_pwr, attr, embed, (const float2*)src_c64,
                        (const float2*)phasor, perm_idx, records, dloss, dloss_dev, dembed,
                        (float*)ws))));
@@ -1667,7 +1685,7 @@ extern "C" int danet_attractor_anchor_bwd_embed_sep(
   make_combos(A, C, cb);
   const int nch = n_chunks(N), EPV = pick_ep(E);
   dim3 grid(nch, B);
-  DISPATCH_EP(EPV, DISPATCH_CP(C, (anchor_sep_bwd_kernel<EP, CP><<<grid, 256, 0, stream>>>(
+  DISPATCH_EP(EPV, DISPATCH_CP(C, (anchor_sep_bwd_kernel<EP, CP><<<grid, SEP_NT, 0, stream>>>(
                        N, E, A, cb, dattr, embed, anchors, attr, asum, choice, act, mode, B, mix_pwr,
                        (const float2*)src_c64, (const float2*)phasor, perm_idx, records, dloss,
                        dloss_dev, dembed, (float*)ws))));

@@ -35,6 +35,23 @@ __device__ __forceinline__ void pit_accumulate(int mode, const float2 (&s)[C], c
   }
 }
 
+// sum_ch pp[ch * stride] in ascending order, the loads of 16 chunks in flight together: the same
+// additions in the same order (hence the same bits) as the plain serial loop, which waited one
+// memory latency per chunk (9 chunks at cfg 2: ~7 us at the head of every kernel that derives an
+// utterance's permutation from the forward's records).  Lanes past nch re-load the last chunk and
+// add +0 (exact: the running sum starts at +0 and can never be -0).
+__device__ __forceinline__ float ordered_chunk_sum(const float* __restrict__ pp, int nch, int64_t stride) {
+  float s = 0.f;
+  for (int c0 = 0; c0 < nch; c0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = pp[(int64_t)min(c0 + u, nch - 1) * stride];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += (c0 + u < nch) ? v[u] : 0.f;
+  }
+  return s;
+}
+
 __device__ __forceinline__ void nth_perm(int C, int p, int* out) {
   int avail[MAXC] = {0, 1, 2, 3};
   int fact = 1;
@@ -54,7 +71,8 @@ __device__ __forceinline__ void nth_perm(int C, int p, int* out) {
 // partials of an utterance are summed by ONE WAVE (lane i < REC owns record element i and walks
 // the chunks in ascending order -- the same order, hence the same bits, as a serial sum), 16
 // utterances at a time; the permutation search of those utterances is then one thread each.
-// (The serial form -- one thread per utterance, 9 x 33 dependent loads -- took 9.7 us at cfg 2.)
+// (The serial form -- one thread per utterance, 9 x 33 dependent loads -- took 9.7 us at cfg 2;
+// ordered_chunk_sum keeps the loads of a lane in flight together.)
 #define PIT_FINAL_THREADS 1024
 static __global__ __launch_bounds__(PIT_FINAL_THREADS) void pit_final_kernel(
     int B, int C, int64_t N, int nch, float eps, const float* __restrict__ partial,
@@ -69,10 +87,7 @@ static __global__ __launch_bounds__(PIT_FINAL_THREADS) void pit_final_kernel(
   for (int b0 = 0; b0 < B; b0 += NWV) {
     const int b = b0 + wave;
     if (b < B && lane < REC) {
-      const float* pp = partial + (int64_t)b * nch * REC + lane;
-      float s = 0.f;
-      for (int ch = 0; ch < nch; ++ch) s += pp[(int64_t)ch * REC];
-      recs[wave][lane] = s;
+      recs[wave][lane] = ordered_chunk_sum(partial + (int64_t)b * nch * REC + lane, nch, REC);
     }
     __syncthreads();
     if (threadIdx.x < NWV && b0 + (int)threadIdx.x < B) {
