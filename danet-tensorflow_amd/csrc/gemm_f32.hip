@@ -418,6 +418,179 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], float* sme
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The register-staged k-loop on v_mfma_f32_16x16x4_f32 (8 passes = 32 clocks per instruction
+// instead of the 64 of 32x32x2; same flops per clock, same LDS reads per flop): for the capped
+// weight-gradient groups that share every CU with a BPTT kernel.  That kernel's step is a chain of
+// 16 dependent MFMAs per wave, and each of them waits for the matrix pipe of its SIMD to finish
+// whatever the co-resident GEMM wave has in flight -- half as long with the short instruction.
+// The wave's 64x64 sub-tile is 4x4 accumulator tiles of 16x16 (64 VGPRs as before); fragments:
+// lane (fr = lane & 15, fq = lane >> 4) reads element (mn = 16 i + fr, k = 4 kk + fq).
+template <bool A_KCONTIG, bool B_KCONTIG>
+__device__ __forceinline__ void gemm_kloop16(const float* __restrict__ Ap, int lda,
+                                             const float* __restrict__ Bp, int ldb,
+                                             int M, int N, int m0, int n0, int kbeg, int kend,
+                                             float* smem, f32x4 (&acc)[4][4], int yield) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk <= 0) return;
+  float* const sA = smem;
+  float* const sB = smem + NSTAGE * STG;
+  const float* pa = Ap + (A_KCONTIG ? (size_t)m0 * lda + kbeg : (size_t)kbeg * lda + m0);
+  const float* pb = Bp + (B_KCONTIG ? (size_t)n0 * ldb + kbeg : (size_t)kbeg * ldb + n0);
+  const unsigned sta = (A_KCONTIG ? BK : BK * lda) * 4u;
+  const unsigned stb = (B_KCONTIG ? BK : BK * ldb) * 4u;
+  const int mrem = M - m0, nrem = N - n0;
+  const float* enda = Ap + (A_KCONTIG ? (size_t)(M - 1) * lda + kend : (size_t)(kend - 1) * lda + M);
+  const float* endb = Bp + (B_KCONTIG ? (size_t)(N - 1) * ldb + kend : (size_t)(kend - 1) * ldb + N);
+  const __amdgpu_buffer_rsrc_t rsa = tile_rsrc(pa, enda), rsb = tile_rsrc(pb, endb);
+  f32x4 ra[NLD], rb[NLD];
+  {
+    f32x4 ra1[NLD], rb1[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      ra[i] = load_piece<A_KCONTIG>(rsa, lda, mrem, kend - kbeg, tid, i, 0u);
+      rb[i] = load_piece<B_KCONTIG>(rsb, ldb, nrem, kend - kbeg, tid, i, 0u);
+    }
+    if (nk > 1) {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        ra1[i] = load_piece<A_KCONTIG>(rsa, lda, mrem, kend - kbeg - BK, tid, i, sta);
+        rb1[i] = load_piece<B_KCONTIG>(rsb, ldb, nrem, kend - kbeg - BK, tid, i, stb);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      store_piece<A_KCONTIG>(sA, tid, ra[i], i, mrem, kend - kbeg);
+      store_piece<B_KCONTIG>(sB, tid, rb[i], i, nrem, kend - kbeg);
+    }
+    if (nk > 1) {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        store_piece<A_KCONTIG>(sA + STG, tid, ra1[i], i, mrem, kend - kbeg - BK);
+        store_piece<B_KCONTIG>(sB + STG, tid, rb1[i], i, nrem, kend - kbeg - BK);
+      }
+    }
+  }
+  unsigned adva = 2 * sta, advb = 2 * stb;     // k-tile kt + 2
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int fa = wm * 64 + fr, fb = wn * 64 + fr;
+  int s_cur = 0, s_nxt = STG, s_fill = 2 * STG;
+  float a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = sA[fq * LDT + fa + 16 * i]; b[i] = sB[fq * LDT + fb + 16 * i]; }
+
+  for (int kt = 0; kt < nk; ++kt) {
+    float an[4], bn[4];
+    int k2rem;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      // fragments of the next k-group (of the next k-tile after the last group)
+      const int so = (kk + 1 < BK / 4) ? s_cur + ((kk + 1) * 4 + fq) * LDT : s_nxt + fq * LDT;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          __builtin_amdgcn_sched_barrier(0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          const int slot = i * 4 + j;       // side work in the MFMAs' shadows, one piece per slot
+          if (slot == 0 && kk == 0) {
+            k2rem = kend - kbeg - (kt + 2) * BK;
+            ra[0] = load_piece<A_KCONTIG>(rsa, lda, mrem, k2rem, tid, 0, adva);
+          }
+          if (slot == 1) { an[0] = sA[so + fa]; an[1] = sA[so + fa + 16]; }
+          if (slot == 2) { an[2] = sA[so + fa + 32]; an[3] = sA[so + fa + 48]; }
+          if (slot == 3) { bn[0] = sB[so + fb]; bn[1] = sB[so + fb + 16]; }
+          if (slot == 4) { bn[2] = sB[so + fb + 32]; bn[3] = sB[so + fb + 48]; }
+          if (slot == 5 && kk == 0) ra[1] = load_piece<A_KCONTIG>(rsa, lda, mrem, k2rem, tid, 1, adva);
+          if (slot == 6 && kk == 0) rb[0] = load_piece<B_KCONTIG>(rsb, ldb, nrem, k2rem, tid, 0, advb);
+          if (slot == 7 && kk == 0) rb[1] = load_piece<B_KCONTIG>(rsb, ldb, nrem, k2rem, tid, 1, advb);
+          if (slot == 8 && kk == BK / 4 - 2) store_piece<A_KCONTIG>(sA + s_fill, tid, ra[0], 0, mrem, k2rem);
+          if (slot == 10 && kk == BK / 4 - 2) store_piece<A_KCONTIG>(sA + s_fill, tid, ra[1], 1, mrem, k2rem);
+          if (slot == 8 && kk == BK / 4 - 1) store_piece<B_KCONTIG>(sB + s_fill, tid, rb[0], 0, nrem, k2rem);
+          if (slot == 10 && kk == BK / 4 - 1) store_piece<B_KCONTIG>(sB + s_fill, tid, rb[1], 1, nrem, k2rem);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = an[i]; b[i] = bn[i]; }
+    }
+    if (yield == 1) __builtin_amdgcn_s_sleep(1);
+    else if (yield == 2) __builtin_amdgcn_s_sleep(2);
+    else if (yield == 4) __builtin_amdgcn_s_sleep(4);
+    else for (int z = 0; z < (yield >> 3); ++z) __builtin_amdgcn_s_sleep(8);   // yield x 64 clocks
+    __syncthreads();
+    const int t = s_cur; s_cur = s_nxt; s_nxt = s_fill; s_fill = t;
+    adva += sta; advb += stb;
+  }
+}
+
+// store_tile for the 4x4 accumulator tiles of gemm_kloop16.
+// D layout (16x16): col = lane & 15, row = 4 * (lane >> 4) + r
+__device__ __forceinline__ void store_tile16(const f32x4 (&acc)[4][4], float* smem,
+                                             float* __restrict__ dst, int ldd, int m0, int n0,
+                                             int M, int N, const float* __restrict__ bias, float beta) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int col_l = lane & 15, row_l = 4 * (lane >> 4);
+  const bool vec = (ldd % 4 == 0) && (((uintptr_t)dst & 15) == 0) &&
+                   ((N - n0) >= BN || (N - n0) % 4 == 0);          // uniform
+  if (!vec) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int col = n0 + wn * 64 + nt * 16 + col_l;
+        if (col >= N) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wm * 64 + mt * 16 + row_l + r;
+          if (row >= M) continue;
+          float* c = dst + (size_t)row * ldd + col;
+          float v = acc[mt][nt][r] + bv;
+          if (beta != 0.f) v += *c;
+          *c = v;
+        }
+      }
+    return;
+  }
+  const int c4 = tid & 31, rr = tid >> 5;
+  const int col = n0 + c4 * 4;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias && col < N) { bv.x = bias[col]; bv.y = bias[col + 1]; bv.z = bias[col + 2]; bv.w = bias[col + 3]; }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            smem[(mt * 16 + row_l + r) * LDT + wn * 64 + nt * 16 + col_l] = acc[mt][nt][r];
+    }
+    __syncthreads();
+    if (col < N) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = m0 + half * 64 + rr + 8 * i;
+        if (row < M) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(&smem[(rr + 8 * i) * LDT + c4 * 4]);
+          float* c = dst + (size_t)row * ldd + col;
+          v += bv;
+          if (beta != 0.f) v += *reinterpret_cast<const f32x4*>(c);
+          *reinterpret_cast<f32x4*>(c) = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <bool A_KCONTIG, bool B_KCONTIG, bool DMA>
 __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // GEMM_SMEM_BYTES
@@ -688,8 +861,11 @@ struct SkArgs {
 
 #define SK_SPIN_LIMIT (1u << 22)
 
-template <bool A_KCONTIG, bool B_KCONTIG, bool DMA>
+// MF16: the 16x16x4 k-loop (register staging only; see gemm_kloop16) -- the accumulators are then
+// 4x4 tiles of f32x4; the slab holds a thread's 64 values either way.
+template <bool A_KCONTIG, bool B_KCONTIG, bool DMA, bool MF16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(SkArgs sk) {
+  static_assert(!(DMA && MF16), "the 16x16x4 k-loop has no DMA staging form");
   extern __shared__ __attribute__((aligned(16))) float smem[];   // GEMM_SMEM_BYTES
   // layout: see gemm_kloop
   const int tid = threadIdx.x;
@@ -745,24 +921,36 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(SkArgs sk) {
     const int m0 = tm * BM, n0 = tn * BN;
 
     f32x16 acc[2][2];
+    f32x4 acc16[4][4];
+    if constexpr (MF16) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
+        for (int jj = 0; jj < 4; ++jj) acc16[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+    }
 
     if (kb < sk.nk1) {       // the part of the segment inside the first operand pair
       const int ke1 = ke < sk.nk1 ? ke : sk.nk1;
-      if (DMA) gemm_kloop_dma<A_KCONTIG, B_KCONTIG>(g.A, g.lda, g.B, g.ldb, g.M, g.N, m0, n0,
-                                                    kb * BK, min(g.K, ke1 * BK), smem, acc, sk.yield);
+      if constexpr (MF16) gemm_kloop16<A_KCONTIG, B_KCONTIG>(g.A, g.lda, g.B, g.ldb, g.M, g.N, m0, n0,
+                                                             kb * BK, min(g.K, ke1 * BK), smem, acc16, sk.yield);
+      else if (DMA) gemm_kloop_dma<A_KCONTIG, B_KCONTIG>(g.A, g.lda, g.B, g.ldb, g.M, g.N, m0, n0,
+                                                         kb * BK, min(g.K, ke1 * BK), smem, acc, sk.yield);
       else gemm_kloop<A_KCONTIG, B_KCONTIG>(g.A, g.lda, g.B, g.ldb, g.M, g.N, m0, n0,
                                             kb * BK, min(g.K, ke1 * BK), smem, acc, sk.yield);
     }
     if (ke > sk.nk1) {       // ... and inside the second (same accumulators)
       const int kb2 = (kb > sk.nk1 ? kb : sk.nk1) - sk.nk1, ke2 = ke - sk.nk1;
-      if (DMA) gemm_kloop_dma<A_KCONTIG, B_KCONTIG>(pr.A2, pr.lda2, pr.B2, pr.ldb2, g.M, g.N, m0, n0,
-                                                    kb2 * BK, min(sk.K2, ke2 * BK), smem, acc, sk.yield);
+      if constexpr (MF16) gemm_kloop16<A_KCONTIG, B_KCONTIG>(pr.A2, pr.lda2, pr.B2, pr.ldb2, g.M, g.N, m0, n0,
+                                                             kb2 * BK, min(sk.K2, ke2 * BK), smem, acc16, sk.yield);
+      else if (DMA) gemm_kloop_dma<A_KCONTIG, B_KCONTIG>(pr.A2, pr.lda2, pr.B2, pr.ldb2, g.M, g.N, m0, n0,
+                                                         kb2 * BK, min(sk.K2, ke2 * BK), smem, acc, sk.yield);
       else gemm_kloop<A_KCONTIG, B_KCONTIG>(pr.A2, pr.lda2, pr.B2, pr.ldb2, g.M, g.N, m0, n0,
                                             kb2 * BK, min(sk.K2, ke2 * BK), smem, acc, sk.yield);
     }
@@ -772,10 +960,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(SkArgs sk) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         f32x4 v;
-        v.x = acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 0];
-        v.y = acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 1];
-        v.z = acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 2];
-        v.w = acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 3];
+        if constexpr (MF16) {
+          v = acc16[q >> 2][q & 3];
+        } else {
+          v.x = acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 0];
+          v.y = acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 1];
+          v.z = acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 2];
+          v.w = acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 3];
+        }
         __builtin_amdgcn_raw_buffer_store_b128(
             __builtin_bit_cast(v4u, v), sres,
             (unsigned)(((blockIdx.x * 16u + q) * 256u + tid) * 16u), 0, 16 /*sc1*/);
@@ -813,15 +1005,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(SkArgs sk) {
             for (int u = 0; u < 4; ++u) {
               const int q = q0 + u;
               const f32x4 v = __builtin_bit_cast(f32x4, raw[u]);
-              acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 0] += v.x;
-              acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 1] += v.y;
-              acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 2] += v.z;
-              acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 3] += v.w;
+              if constexpr (MF16) {
+                acc16[q >> 2][q & 3] += v;
+              } else {
+                acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 0] += v.x;
+                acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 1] += v.y;
+                acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 2] += v.z;
+                acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 3] += v.w;
+              }
             }
           }
         }
       }
-      store_tile(acc, smem, g.C, g.ldc, m0, n0, g.M, g.N, g.bias, g.beta);
+      if constexpr (MF16) store_tile16(acc16, smem, g.C, g.ldc, m0, n0, g.M, g.N, g.bias, g.beta);
+      else store_tile(acc, smem, g.C, g.ldc, m0, n0, g.M, g.N, g.bias, g.beta);
     }
     if (rem) it = tbase + kb;
   }
@@ -935,7 +1132,21 @@ static int sk_launch(danet_stream_t stream_, int transA, int transB, int K, int 
     else if (!ak && !bk) gemm_f32_sk_kernel<false, false, D_><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk); \
     else gemm_f32_sk_kernel<false, true, D_><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);                  \
   } while (0)
-  if (dma) SK_LAUNCH(true); else SK_LAUNCH(false);
+  // capped groups (they share every CU with a recurrent kernel): the short-instruction k-loop
+  const bool mf16 = !dma && sk.yield > 0 && danet_opt(OPT_GEMM_MFMA16) == 1;
+  if (mf16) {
+    static const bool lds16_ok = [] {
+      gemm_allow_lds((const void*)gemm_f32_sk_kernel<true, false, false, true>);
+      gemm_allow_lds((const void*)gemm_f32_sk_kernel<true, true, false, true>);
+      gemm_allow_lds((const void*)gemm_f32_sk_kernel<false, false, false, true>);
+      gemm_allow_lds((const void*)gemm_f32_sk_kernel<false, true, false, true>);
+      return true; }();
+    (void)lds16_ok;
+    if (ak && !bk) gemm_f32_sk_kernel<true, false, false, true><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);
+    else if (ak && bk) gemm_f32_sk_kernel<true, true, false, true><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);
+    else if (!ak && !bk) gemm_f32_sk_kernel<false, false, false, true><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);
+    else gemm_f32_sk_kernel<false, true, false, true><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);
+  } else if (dma) SK_LAUNCH(true); else SK_LAUNCH(false);
 #undef SK_LAUNCH
   DANET_CHECK_LAUNCH();
   return DANET_OK;

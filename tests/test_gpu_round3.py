@@ -15,6 +15,11 @@ def cu(x, dtype=torch.float32):
     return torch.as_tensor(np.asarray(x)).to('cuda', dtype)
 
 
+def relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
 def test_two_host_threads_launch_concurrently():
     '''Two host threads, each on its own HIP stream with its own workspace, launch stream-K
     grouped GEMMs (the launches that number themselves from the process-wide atomic counter and
@@ -399,3 +404,35 @@ def test_center_single_launch_equals_two_launch(B, T, D):
         ulp = np.spacing(np.abs(m2).astype(np.float32))
         assert np.all(np.abs(m2 - mean[b0:b0 + 8]) <= ulp)
         assert np.abs(o2.cpu().numpy() - got[:, b0:b0 + 8]).max() <= 2 * ulp.max()
+
+
+@pytest.mark.parametrize('K,shapes,ta,tb', [
+    (4096, [(600, 1200), (300, 1200), (600, 1200), (300, 1200)], 1, 0),   # a layer's dW group
+    (300, [(129, 70), (1, 5), (257, 300)], 0, 0), (90, [(64, 64), (130, 200)], 1, 1),
+    (1000, [(500, 40)], 0, 1)])
+def test_capped_group_on_the_short_mfma_instruction(K, shapes, ta, tb):
+    '''capped stream-K groups (the ones that run beside a BPTT kernel) take the 16x16x4 k-loop
+    (option gemm_mfma16): same products as the 32x32x2 loop to fp32 rounding, and against float64'''
+    from danet_amd import ops, _lib
+    rng = np.random.RandomState(K + len(shapes))
+    probs, refs, outs = [], [], []
+    for i, (M, N) in enumerate(shapes):
+        A = rng.randn(K, M) if ta else rng.randn(M, K)
+        Bm = rng.randn(N, K) if tb else rng.randn(K, N)
+        C0 = rng.randn(M, N)
+        beta = float(i % 2)
+        refs.append(((A.T if ta else A) @ (Bm.T if tb else Bm) + beta * C0, C0))
+        dA, dB, dC = cu(A), cu(Bm), cu(C0)
+        probs.append((dA, dA.shape[1], dB, dB.shape[1], dC, N, M, N, beta))
+        outs.append(dC)
+    res = {}
+    for mf in (1, 0):
+        _lib.set_option('gemm_mfma16', mf)
+        for (ref, C0), dC in zip(refs, outs):
+            dC.copy_(cu(C0))
+        ops.gemm_group(probs, K, transA=ta, transB=tb, max_workgroups=256)
+        torch.cuda.synchronize()
+        res[mf] = [dC.clone() for dC in outs]
+    for (ref, _), a, b in zip(refs, res[1], res[0]):
+        assert relerr(a.cpu().numpy(), ref) < 2e-5
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
