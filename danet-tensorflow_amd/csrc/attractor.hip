@@ -31,7 +31,9 @@
 __host__ __device__ static inline int n_chunks(int64_t N) { return (int)((N + CHUNK_N - 1) / CHUNK_N); }
 // the anchor forward kernel does much more work per bin than the others: smaller chunks =
 // 4x the workgroups hide its latencies (73 -> 51 us at cfg 2; its finalize 16 -> 22 us)
+#ifndef ANCH_CHUNK_N
 #define ANCH_CHUNK_N 512
+#endif
 __host__ __device__ static inline int n_chunks_anchor_fwd(int64_t N) { return (int)((N + ANCH_CHUNK_N - 1) / ANCH_CHUNK_N); }
 
 // a wave-uniform value as a scalar register
@@ -705,7 +707,19 @@ __global__ __launch_bounds__(SEP_NT) void truth_sep_bwd_kernel(
 // =========================================================================
 // anchor estimator (app/modules.py:501-545)
 // =========================================================================
-#define ANCH_TN 256   // bins per LDS tile (one per thread in phase 1)
+// threads per workgroup of the anchor forward kernel (a multiple of 64, >= ANCH_TN; 128 threads with
+// 128-bin tiles measured 41.9 us against 38.9 us for 256 at cfg 2)
+#ifndef ANCH_NT
+#define ANCH_NT 256
+#endif
+#define ANCH_NW (ANCH_NT / 64)
+#define ANCH_ITEMS (1024 / ANCH_NT)
+#ifndef ANCH_TN
+#define ANCH_TN 128   // bins per LDS tile (one per thread of the first two waves in phase 1; a multiple
+                      // of 8, <= 256).  128: 28 KB of LDS, five workgroups per CU overlap each other's load /
+                      // assignment / MFMA phases (256: 57 KB, two per CU; cfg 2 42.4 -> 38.6 us, E = 40 C = 3
+                      // 140 -> 109 us; fetching the next tile's rows ahead made both slower)
+#endif
 
 struct AnchorCombos { int P; int idx[MAXP][MAXC]; };
 
@@ -754,7 +768,7 @@ struct CombosCE {
 // T11: the contraction is ONE 32 x 32 MFMA tile (PC <= 32, EPA <= 32: cfg 2) known at compile time --
 // one accumulator tile instead of four behind run-time conditions
 template <int EP, int AT, int CTT, bool T11>
-__global__ __launch_bounds__(256) void anchor_fwd_kernel(
+__global__ __launch_bounds__(ANCH_NT) void anchor_fwd_kernel(
     int C, int64_t N, int E, int A, AnchorCombos cb, const float* __restrict__ embed,
     const float* __restrict__ anchors, float* __restrict__ partial /* [B][chunks][PC][EPA] */,
     int RT_, int CT_ /* MFMA tiling of the [PC][EPA] contraction; RT = 0: scalar path */) {
@@ -769,21 +783,21 @@ __global__ __launch_bounds__(256) void anchor_fwd_kernel(
   float* An = Ss + ANCH_TN * lds;       // [A][EP]
   const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
   const int tid = threadIdx.x;
-  for (int i = tid; i < A * EP; i += 256) {
+  for (int i = tid; i < A * EP; i += ANCH_NT) {
     const int a = i / EP, e = i % EP;
     An[i] = (e < E) ? anchors[a * E + e] : 0.f;
   }
   const int64_t n0 = (int64_t)ch * ANCH_CHUNK_N, n1 = min(N, n0 + ANCH_CHUNK_N);
   const float* eb = embed + (int64_t)b * N * E;
 
-  // work items: (pc, quad) -> 4 accumulators; up to 4 items per thread
+  // work items: (pc, quad) -> 4 accumulators; up to ANCH_ITEMS items per thread
   constexpr int EQ = EPA / 4;
   const int nitems = PC * EQ;
-  f32x4 acc[4];
+  f32x4 acc[ANCH_ITEMS];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < ANCH_ITEMS; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // MFMA path: out[pc][e] = sum_bins Ss[bin][pc] * Xs[bin][e] as RT x CT tiles of
-  // v_mfma_f32_32x32x2_f32, the tile's 256 bins split over the 4 waves.  Rows /
+  // v_mfma_f32_32x32x2_f32, the tile's bins split over the waves.  Rows /
   // columns past PC / EPA read whatever follows in LDS: they only ever reach
   // accumulator entries that are never stored.
   f32x16 macc[NM][NM];
@@ -902,8 +916,8 @@ __global__ __launch_bounds__(256) void anchor_fwd_kernel(
     if (RT > 0) {
       const int il = mlane & 31, kl = mlane >> 5;
 #pragma unroll 4
-      for (int ks = 0; ks < ANCH_TN / 8; ++ks) {
-        const int r = mwave * (ANCH_TN / 4) + ks * 2 + kl;
+      for (int ks = 0; ks < ANCH_TN / (2 * ANCH_NW); ++ks) {
+        const int r = mwave * (ANCH_TN / ANCH_NW) + ks * 2 + kl;
         float av[NM], bv[NM];
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
@@ -919,8 +933,8 @@ __global__ __launch_bounds__(256) void anchor_fwd_kernel(
       }
     } else
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int item = tid + it * 256;
+    for (int it = 0; it < ANCH_ITEMS; ++it) {
+      const int item = tid + it * ANCH_NT;
       if (item < nitems) {
         const int pc = item / EQ, q = item % EQ;
         f32x4 a4 = acc[it];
@@ -938,7 +952,7 @@ __global__ __launch_bounds__(256) void anchor_fwd_kernel(
   if (RT > 0) {
     // cross-wave reduction through LDS (tile buffers are dead now).
     // D layout 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* red = smem;   // [4 waves][RT*32][CT*32]
+    float* red = smem;   // [ANCH_NW waves][RT*32][CT*32]
     const int ldr = CT * 32;
 #pragma unroll
     for (int i = 0; i < NM; ++i)
@@ -952,18 +966,18 @@ __global__ __launch_bounds__(256) void anchor_fwd_kernel(
           }
         }
     __syncthreads();
-    for (int idx = tid; idx < PC * EPA; idx += 256) {
+    for (int idx = tid; idx < PC * EPA; idx += ANCH_NT) {
       const int pc = idx / EPA, e = idx % EPA;
       float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) v += red[(w * RT * 32 + pc) * ldr + e];
+      for (int w = 0; w < ANCH_NW; ++w) v += red[(w * RT * 32 + pc) * ldr + e];
       out[idx] = v;
     }
     return;
   }
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int item = tid + it * 256;
+  for (int it = 0; it < ANCH_ITEMS; ++it) {
+    const int item = tid + it * ANCH_NT;
     if (item < nitems) {
       const int pc = item / EQ, q = item % EQ;
       *reinterpret_cast<f32x4*>(&out[pc * EPA + q * 4]) = acc[it];
@@ -1611,14 +1625,14 @@ extern "C" int danet_attractor_anchor_fwd(danet_stream_t stream_, int B, int C, 
   int RT = 0, CT = 0;
   if (PC <= 64 && EPA <= 64 && danet_opt(OPT_ANCHOR_SCALAR) == 0) { RT = cdiv(PC, 32); CT = cdiv(EPA, 32); }
   size_t lds = ((size_t)ANCH_TN * EPA + (size_t)ANCH_TN * (PC + 1) + (size_t)A * EPV + 64) * sizeof(float);
-  const size_t lds_red = (size_t)4 * RT * 32 * CT * 32 * sizeof(float);
+  const size_t lds_red = (size_t)ANCH_NW * RT * 32 * CT * 32 * sizeof(float);
   if (lds_red > lds) lds = lds_red;
   dim3 grid(nch, B);
 #define LAUNCH_ANCHOR(AT_, CT_, T11_)                                                        \
   DISPATCH_EP(EPV, {                                                                         \
     DANET_CHECK_HIP(hipFuncSetAttribute((const void*)anchor_fwd_kernel<EP, AT_, CT_, T11_>,   \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                              \
-    anchor_fwd_kernel<EP, AT_, CT_, T11_><<<grid, 256, lds, stream>>>(C, N, E, A, cb, embed,  \
+    anchor_fwd_kernel<EP, AT_, CT_, T11_><<<grid, ANCH_NT, lds, stream>>>(C, N, E, A, cb, embed,  \
                                                                 anchors, (float*)ws, RT, CT); \
   })
   const bool t11 = (RT == 1 && CT == 1);
