@@ -30,7 +30,7 @@ enum DanetOpt {
   OPT_LSTM_BWD_FUSED_KERNEL, // 1 the dW-fusing BPTT kernel may be used | 0 never
   OPT_LSTM_BWD_TWIN_XCD,     // 1 (default): the twins of a BPTT group share an XCD (L2 hits on their re-reads) | 0
   OPT_LSTM_BWD_LDS_PAD,      // bytes of unused dynamic LDS of the BPTT kernel (CU exclusivity experiment)
-  OPT_CENTER_ONE,            // 1 (default): one-launch centring for B >= 16 utterances of <= 32 K elements | 0 always two launches
+  OPT_CENTER_ONE,            // 1: one-launch centring for B >= 16 utterances of <= 32 K elements | 0 (default): always two launches
   OPT_GEMM_MFMA16,           // 1: capped groups beside a recurrent kernel use the 16x16x4 k-loop | 0: 32x32x2
   OPT_COUNT
 };

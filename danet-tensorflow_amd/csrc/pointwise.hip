@@ -163,7 +163,8 @@ __global__ void center_apply_kernel(int B, int T, int D, const float* __restrict
 // Both phases in ONE launch, one workgroup of 16 waves per utterance (the second read comes out of
 // L2): for many small utterances (B >= 16, T*D <= 32 K elements: the step's input at 129 bins) the
 // two-launch form above is two dependent ~6 us kernels on the critical path (12.3 us -> 10.4 us
-// measured).  One workgroup cannot stream a larger utterance fast enough (T*D = 77 K elements: 26.8 us
+// in a loop of its own; inside the train step, behind the front-end, it measured 14.6 us against
+// 11.9 us, so it is an option -- center_one -- and off by default).  One workgroup cannot stream a larger utterance fast enough (T*D = 77 K elements: 26.8 us
 // against 12.6 us for the two-launch form), and cfg 5's single 3 MB utterance needs many workgroups.
 // Same double-accumulated mean.
 __global__ __launch_bounds__(1024) void center_one_kernel(int B, int T, int D, const float* __restrict__ in,

@@ -752,8 +752,10 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
                         L.danet_lstm_bwd_db_supported(T, B, H, ndir) == 1)
         # the 6-us sum of the kernel's per-cluster bias partials leaves the critical path (BPTT ->
         # dX -> next BPTT) when a side chain is forked behind this launch anyway
+        # (not for the bottom layer: its weight-gradient group takes every CU on the main stream
+        # and the side chain's reduce would sit behind it for the group's whole duration)
         db_deferred = (db_in_kernel and DB_DEFER and GROUPED_DW and SIDE_STREAMS > 0 and
-                       (not need_dx or _overlap_dw(H)))
+                       need_dx and _overlap_dw(H))
         with _lib.timed('lstm_bwd'):
             if db_in_kernel:      # bias gradients summed inside the BPTT kernel: no colsum launches
                 check(L.danet_lstm_bwd_db(
@@ -854,7 +856,7 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
         elif GROUPED_DW and not need_dx:
             # bottom layer: no BPTT kernel follows, so the group takes the whole GPU on
             # the main stream while the column sums (if any) run beside it
-            if not db_in_kernel or db_deferred:
+            if not db_in_kernel:
                 f.run(1, bias_grads)
             weight_grads_grouped(wgs=512, with_bias=False)
             on_main = True

@@ -387,7 +387,8 @@ def test_center_single_launch_equals_two_launch(B, T, D):
     '''B >= 16 utterances of <= 32 K elements take the one-launch centring kernel; the same
     utterances in groups of 8 take the two-launch form: both means are the float32 rounding of a
     double sum (app/modules.py:218-219 reduce_mean over (1, 2))'''
-    from danet_amd import ops
+    from danet_amd import ops, _lib
+    _lib.set_option('center_one', 1)
     rng = np.random.RandomState(B + D)
     x = (rng.randn(B, T, D) * 2 + rng.randn(B, 1, 1) * 5).astype(np.float32)
     ldo = (D + 3) // 4 * 4
