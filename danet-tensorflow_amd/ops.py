@@ -431,28 +431,39 @@ class _Fork(object):
     '''with _Fork(dev, n) as f:  f.run(i, fn)  -> fn runs on chain i
     (chain 0 = the current stream, chain i>0 = side stream i-1); join on exit.'''
 
-    def __init__(self, dev, nchains, defer=False, keep=()):
+    def __init__(self, dev, nchains, defer=False, keep=(), lazy=False):
         '''defer=True: do not join on exit -- the side chains keep running under
         whatever the main stream does next (e.g. weight-gradient GEMMs under the
         next layer's latency-bound BPTT kernel, which leaves most CUs idle);
         `join_deferred()` joins them.  `keep` = tensors the chains read that the
-        caller is about to drop (kept alive until the join).'''
+        caller is about to drop (kept alive until the join).
+        lazy=True: the fork event is recorded when the first side chain is issued instead of
+        on entry -- a fork that ends up with no side work then costs the main stream nothing
+        (an event record is a ~7 us bubble in front of the next kernel); only for forks whose
+        main-stream work comes AFTER their side chains.'''
         self.main = torch.cuda.current_stream(dev)
         n = min(nchains - 1, SIDE_STREAMS)
         self.sides = _side_streams(dev, n) if n > 0 else []
         self.used = set()
         self.defer, self.keep = defer, keep
+        self.lazy, self.forked = lazy, False
 
-    def __enter__(self):
-        if self.sides:
+    def _fork_now(self):
+        if self.sides and not self.forked:
             ev = self.main.record_event()
             for s in self.sides:
                 s.wait_event(ev)
+        self.forked = True
+
+    def __enter__(self):
+        if not self.lazy:
+            self._fork_now()
         return self
 
     def run(self, chain, fn):
         if not self.sides or chain == 0:
             return fn()
+        self._fork_now()
         s = self.sides[(chain - 1) % len(self.sides)]
         self.used.add(s)
         with torch.cuda.stream(s):
@@ -849,7 +860,7 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
         sides[0].wait_stream(main)
         with torch.cuda.stream(sides[0]):
             _fire_grad_ready(('rest',), list(c.Ws) + list(c.bs))
-    with _Fork(dev, ndir + 1, defer=True, keep=(das, c.x, c.ypad, dy, ws)) as f:
+    with _Fork(dev, ndir + 1, defer=True, keep=(das, c.x, c.ypad, dy, ws), lazy=True) as f:
         on_main = False
         if fused:
             on_main = True           # everything was issued on the main stream
@@ -961,7 +972,7 @@ class RnnEncoderFn(torch.autograd.Function):
         dWout, direct_out = _grad_target(ctx.Wout, (D, O), dev)
         dyc = torch.empty(B, T, D, device=dev)
         gemm(dembed, ctx.Wout, dyc, B * T, D, O, O, O, D, transB=True, streamk=(STREAMK & 1) != 0, tag='dYc')   # critical path first
-        with _Fork(dev, 2, defer=True, keep=(dembed, ctx.yc)) as f:
+        with _Fork(dev, 2, defer=True, keep=(dembed, ctx.yc), lazy=True) as f:
             if GROUPED_DW:    # alone on its stream under the top layer's BPTT kernel (or serial)
                 ov = _overlap_dw(H)
                 f.run(1 if ov else 0, lambda: gemm_group(
