@@ -119,11 +119,12 @@ __device__ __forceinline__ float truth_weight(int mode, float mix) {
 // =========================================================================
 // truth family forward (app/modules.py:390-487)
 // =========================================================================
-template <int EP>
+template <int EP, bool EF>
 __global__ __launch_bounds__(256) void truth_fwd_kernel(
-    int mode, int C, int64_t N, int E, const float* __restrict__ embed,
+    int mode, int C, int64_t N, int E_, const float* __restrict__ embed,
     const float* __restrict__ src_pwr, const float* __restrict__ mix_pwr,
     float* __restrict__ partial /* [B][chunks][C][EP+1] */) {
+  const int E = EF ? EP : E_;   // EF: E == EP known at compile time (guard-free 16-byte row accesses)
   __shared__ float red[4 * (EP + 1)];
   const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
   const int64_t n0 = (int64_t)ch * CHUNK_N, n1 = min(N, n0 + CHUNK_N);
@@ -153,11 +154,12 @@ __global__ __launch_bounds__(256) void truth_fwd_kernel(
 // the multi-pass kernel above walks the chunk once per speaker (3 x the src_pwr reads and the loop
 // overhead at C = 3: 121 us at cfg 4).  A bin adds w * x to its own speaker's set and +0 to the
 // others, so every sum sees the same addends in the same order: bit-identical to the multi-pass form.
-template <int EP, int CP>
+template <int EP, int CP, bool EF>
 __global__ __launch_bounds__(SEP_NT) void truth_fwd1_kernel(
-    int mode, int64_t N, int E, const float* __restrict__ embed,
+    int mode, int64_t N, int E_, const float* __restrict__ embed,
     const float* __restrict__ src_pwr, const float* __restrict__ mix_pwr,
     float* __restrict__ partial /* [B][chunks][C][EP+1] */) {
+  const int E = EF ? EP : E_;   // EF: E == EP known at compile time (guard-free 16-byte row accesses)
   constexpr int C = CP;
   __shared__ float red[SEP_NW * (EP + 1)];
   const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
@@ -237,11 +239,12 @@ __global__ __launch_bounds__(256) void truth_bwd_kernel(
 // =========================================================================
 // separators (app/modules.py:556-603)
 // =========================================================================
-template <int EP>
+template <int EP, bool EF>
 __global__ __launch_bounds__(256) void separate_fwd_kernel(
-    int act, int C, int64_t N, int E, const float* __restrict__ mix_pwr,
+    int act, int C, int64_t N, int E_, const float* __restrict__ mix_pwr,
     const float* __restrict__ attr, const float* __restrict__ embed,
     float* __restrict__ out, float* __restrict__ masks) {
+  const int E = EF ? EP : E_;   // EF: E == EP known at compile time (guard-free 16-byte row accesses)
   __shared__ float tab[MAXC * EP];
   const int b = blockIdx.y;
   for (int i = threadIdx.x; i < C * EP; i += 256) {
@@ -456,12 +459,13 @@ __device__ __forceinline__ void sep_masks_lds(int act, const float (&x)[EP], con
   }
 }
 
-template <int EP, int CP>
+template <int EP, int CP, bool EF>
 __global__ __launch_bounds__(SEP_NT) void sep_pit_fwd_kernel(
-    int act, int mode, int64_t N, int E, const float* __restrict__ mix_pwr,
+    int act, int mode, int64_t N, int E_, const float* __restrict__ mix_pwr,
     const float* __restrict__ attr, const float* __restrict__ embed,
     const float2* __restrict__ src, const float2* __restrict__ phasor,
     float* __restrict__ out /* optional [B][C][N] */, float* __restrict__ partial /* [B][nch][REC] */) {
+  const int E = EF ? EP : E_;   // EF: E == EP known at compile time (guard-free 16-byte row accesses)
   constexpr int C = CP;
   __shared__ float tab[CP * EP];
   __shared__ float red[SEP_NW * REC];
@@ -571,14 +575,15 @@ __device__ __forceinline__ void sep_pit_perm(const float* __restrict__ records,
   }
 }
 
-template <int EP, int CP>
+template <int EP, int CP, bool EF>
 __global__ __launch_bounds__(SEP_NT) void sep_pit_bwd_kernel(
-    int act, int mode, int B, int64_t N, int E, const float* __restrict__ mix_pwr,
+    int act, int mode, int B, int64_t N, int E_, const float* __restrict__ mix_pwr,
     const float* __restrict__ attr, const float* __restrict__ embed,
     const float2* __restrict__ src, const float2* __restrict__ phasor,
     const int32_t* __restrict__ perm_idx, const float* __restrict__ records,
     float dloss, const float* __restrict__ dloss_dev,
     float* __restrict__ dembed, float* __restrict__ partial /* [B][nch][C][EP] */) {
+  const int E = EF ? EP : E_;   // EF: E == EP known at compile time (guard-free 16-byte row accesses)
   constexpr int C = CP;
   __shared__ float tab[CP * EP];
   __shared__ float red[SEP_NW * EP];
@@ -648,15 +653,16 @@ __global__ __launch_bounds__(SEP_NT) void sep_pit_bwd_kernel(
 // The truth-family estimator backward WITH the fused separator + loss backward's dembed term
 // recomputed in the same pass (see anchor_sep_bwd_kernel): dembed = dL/dembed|separator +
 // w(n) * dattr[idx(n)] / (denom + add), written once.
-template <int EP, int CP>
+template <int EP, int CP, bool EF>
 __global__ __launch_bounds__(SEP_NT) void truth_sep_bwd_kernel(
-    int tmode, int64_t N, int E, const float* __restrict__ dattr,
+    int tmode, int64_t N, int E_, const float* __restrict__ dattr,
     const float* __restrict__ src_pwr, const float* __restrict__ mix_pwr,
     const float* __restrict__ denom, float eps,
     const float* __restrict__ embed, const float* __restrict__ attr,
     int act, int mode, int B, const float2* __restrict__ src, const float2* __restrict__ phasor,
     const int32_t* __restrict__ perm_idx, const float* __restrict__ records,
     float dloss, const float* __restrict__ dloss_dev, float* __restrict__ dembed) {
+  const int E = EF ? EP : E_;   // EF: E == EP known at compile time (guard-free 16-byte row accesses)
   constexpr int C = CP;
   __shared__ float dtab[CP * EP];   // dattr / (denom + add)
   __shared__ float tab[CP * EP];    // attractors (the separator's table)
@@ -767,11 +773,12 @@ struct CombosCE {
 // AT, CTT > 0: (A, C) specialisation; AT = 0: generic (run-time table in `cb`)
 // T11: the contraction is ONE 32 x 32 MFMA tile (PC <= 32, EPA <= 32: cfg 2) known at compile time --
 // one accumulator tile instead of four behind run-time conditions
-template <int EP, int AT, int CTT, bool T11>
+template <int EP, int AT, int CTT, bool T11, bool EF>
 __global__ __launch_bounds__(ANCH_NT) void anchor_fwd_kernel(
-    int C, int64_t N, int E, int A, AnchorCombos cb, const float* __restrict__ embed,
+    int C, int64_t N, int E_, int A, AnchorCombos cb, const float* __restrict__ embed,
     const float* __restrict__ anchors, float* __restrict__ partial /* [B][chunks][PC][EPA] */,
     int RT_, int CT_ /* MFMA tiling of the [PC][EPA] contraction; RT = 0: scalar path */) {
+  const int E = EF ? EP : E_;   // EF: E == EP known at compile time (guard-free 16-byte row accesses)
   constexpr int NM = T11 ? 1 : 2;
   const int RT = T11 ? 1 : RT_, CT = T11 ? 1 : CT_;
   constexpr int EPA = EP + 4;           // + ones column, padded to a float4
@@ -1168,9 +1175,9 @@ __global__ __launch_bounds__(256) void anchor_bwd_kernel(
 // this kernel forms dembed = dL/dembed|separator + dL/dembed|estimator in ONE pass -- the same
 // additions in the same order as sep_pit_bwd_kernel followed by anchor_bwd_kernel, without
 // writing the first term to HBM (42 MB at cfg 2) and reading it back.
-template <int EP, int CP>
+template <int EP, int CP, bool EF>
 __global__ __launch_bounds__(SEP_NT) void anchor_sep_bwd_kernel(
-    int64_t N, int E, int A, AnchorCombos cb, const float* __restrict__ dattr,
+    int64_t N, int E_, int A, AnchorCombos cb, const float* __restrict__ dattr,
     const float* __restrict__ embed, const float* __restrict__ anchors,
     const float* __restrict__ attr, const float* __restrict__ asum,
     const int32_t* __restrict__ choice,
@@ -1179,6 +1186,7 @@ __global__ __launch_bounds__(SEP_NT) void anchor_sep_bwd_kernel(
     const int32_t* __restrict__ perm_idx, const float* __restrict__ records,
     float dloss, const float* __restrict__ dloss_dev,
     float* __restrict__ dembed, float* __restrict__ partial /* [B][chunks][C][EP] */) {
+  const int E = EF ? EP : E_;   // EF: E == EP known at compile time (guard-free 16-byte row accesses)
   constexpr int C = CP;
   __shared__ float An[MAXC * EP];   // chosen anchors
   __shared__ float G[MAXC * EP];    // dL/dSnum[c][e]
@@ -1333,6 +1341,12 @@ static int pick_ep(int E) {
     default: break;                                \
   }
 
+// E == EP known at compile time (the usual case: E = 20 / 40): the kernels' row accesses lose their
+// per-vector guards (E = 40, C = 3: sep_pit_fwd 44 -> 28 us, sep_pit_bwd 63 -> 52, estimator backward
+// 163 -> 131; E = 20: 114 -> 111 us over the four head kernels)
+#define DISPATCH_EF(COND, ...)                     \
+  if (COND) { constexpr bool EF = true; __VA_ARGS__; } else { constexpr bool EF = false; __VA_ARGS__; }
+
 #define DISPATCH_CP(CV, ...)                      \
   switch (CV) {                                    \
     case 1: { constexpr int CP = 1; __VA_ARGS__; } break;   \
@@ -1381,10 +1395,10 @@ extern "C" int danet_attractor_truth_fwd(danet_stream_t stream_, int mode, int B
   const int nch = n_chunks(N), EPV = pick_ep(E);
   dim3 grid(nch, B);
   if (C * (EPV + 1) <= 128) {
-    DISPATCH_EP(EPV, DISPATCH_CP(C, (truth_fwd1_kernel<EP, CP><<<grid, SEP_NT, 0, stream>>>(
+    DISPATCH_EP(EPV, DISPATCH_CP(C, DISPATCH_EF(E == EPV, truth_fwd1_kernel<EP, CP, EF><<<grid, SEP_NT, 0, stream>>>(
                          mode, N, E, embed, src_pwr, mix_pwr, (float*)ws))));
   } else {
-    DISPATCH_EP(EPV, (truth_fwd_kernel<EP><<<grid, 256, 0, stream>>>(
+    DISPATCH_EP(EPV, DISPATCH_EF(E == EPV, truth_fwd_kernel<EP, EF><<<grid, 256, 0, stream>>>(
                          mode, C, N, E, embed, src_pwr, mix_pwr, (float*)ws)));
   }
   DANET_CHECK_LAUNCH();
@@ -1431,7 +1445,7 @@ extern "C" int danet_attractor_truth_bwd_sep(danet_stream_t stream_, int tmode, 
                   "attractor_truth_bwd_sep: mode");
   const int nch = n_chunks(N), EPV = pick_ep(E);
   dim3 grid(nch, B);
-  DISPATCH_EP(EPV, DISPATCH_CP(C, (truth_sep_bwd_kernel<EP, CP><<<grid, SEP_NT, 0, stream>>>(
+  DISPATCH_EP(EPV, DISPATCH_CP(C, DISPATCH_EF(E == EPV, truth_sep_bwd_kernel<EP, CP, EF><<<grid, SEP_NT, 0, stream>>>(
                        tmode, N, E, dattr, src_pwr, mix_pwr, denom, eps, embed, attr, act, mode, B,
                        (const float2*)src_c64, (const float2*)phasor, perm_idx, records, dloss,
                        dloss_dev, dembed))));
@@ -1449,7 +1463,7 @@ extern "C" int danet_separate_fwd(danet_stream_t stream_, int act, int B, int C,
   DANET_CHECK_ARG(mix_pwr && attr && embed && out, "separate_fwd: null pointer");
   const int EPV = pick_ep(E);
   dim3 grid((unsigned)min((int64_t)64, cdiv64(N, 256)), B);
-  DISPATCH_EP(EPV, (separate_fwd_kernel<EP><<<grid, 256, 0, stream>>>(
+  DISPATCH_EP(EPV, DISPATCH_EF(E == EPV, separate_fwd_kernel<EP, EF><<<grid, 256, 0, stream>>>(
                        act, C, N, E, mix_pwr, attr, embed, out, masks)));
   DANET_CHECK_LAUNCH();
   return DANET_OK;
@@ -1510,7 +1524,7 @@ extern "C" int danet_separate_pit_fwd_records(danet_stream_t stream_, int act, i
                   "separate_pit_fwd: null pointer");
   const int nch = n_chunks(N), EPV = pick_ep(E);
   dim3 grid(nch, B);
-  DISPATCH_EP(EPV, DISPATCH_CP(C, (sep_pit_fwd_kernel<EP, CP><<<grid, SEP_NT, 0, stream>>>(
+  DISPATCH_EP(EPV, DISPATCH_CP(C, DISPATCH_EF(E == EPV, sep_pit_fwd_kernel<EP, CP, EF><<<grid, SEP_NT, 0, stream>>>(
                        act, mode, N, E, mix_pwr, attr, embed, (const float2*)src_c64,
                        (const float2*)phasor, sep_pwr_out, records))));
   DANET_CHECK_LAUNCH();
@@ -1567,7 +1581,7 @@ extern "C" int danet_separate_pit_bwd(danet_stream_t stream_, int act, int mode,
   }
   const int nch = n_chunks(N), EPV = pick_ep(E);
   dim3 grid(nch, B);
-  DISPATCH_EP(EPV, DISPATCH_CP(C, (sep_pit_bwd_kernel<EP, CP><<<grid, SEP_NT, 0, stream>>>(
+  DISPATCH_EP(EPV, DISPATCH_CP(C, DISPATCH_EF(E == EPV, sep_pit_bwd_kernel<EP, CP, EF><<<grid, SEP_NT, 0, stream>>>(
                        act, mode, B, N, E, mix_pwr, attr, embed, (const float2*)src_c64,
                        (const float2*)phasor, perm_idx, records, dloss, dloss_dev, dembed,
                        (float*)ws))));
@@ -1629,12 +1643,12 @@ extern "C" int danet_attractor_anchor_fwd(danet_stream_t stream_, int B, int C, 
   if (lds_red > lds) lds = lds_red;
   dim3 grid(nch, B);
 #define LAUNCH_ANCHOR(AT_, CT_, T11_)                                                        \
-  DISPATCH_EP(EPV, {                                                                         \
-    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)anchor_fwd_kernel<EP, AT_, CT_, T11_>,   \
+  DISPATCH_EP(EPV, DISPATCH_EF(E == EPV, {                                                    \
+    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)anchor_fwd_kernel<EP, AT_, CT_, T11_, EF>, \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                              \
-    anchor_fwd_kernel<EP, AT_, CT_, T11_><<<grid, ANCH_NT, lds, stream>>>(C, N, E, A, cb, embed,  \
+    anchor_fwd_kernel<EP, AT_, CT_, T11_, EF><<<grid, ANCH_NT, lds, stream>>>(C, N, E, A, cb, embed, \
                                                                 anchors, (float*)ws, RT, CT); \
-  })
+  }))
   const bool t11 = (RT == 1 && CT == 1);
   if (A == 6 && C == 2) { if (t11) { LAUNCH_ANCHOR(6, 2, true); } else { LAUNCH_ANCHOR(6, 2, false); } }   // default.json: NUM_ANCHOR 6, 2 speakers
   else if (A == 6 && C == 3) { LAUNCH_ANCHOR(6, 3, false); }     // 3-speaker configs
@@ -1699,7 +1713,7 @@ extern "C" int danet_attractor_anchor_bwd_embed_sep(
   make_combos(A, C, cb);
   const int nch = n_chunks(N), EPV = pick_ep(E);
   dim3 grid(nch, B);
-  DISPATCH_EP(EPV, DISPATCH_CP(C, (anchor_sep_bwd_kernel<EP, CP><<<grid, SEP_NT, 0, stream>>>(
+  DISPATCH_EP(EPV, DISPATCH_CP(C, DISPATCH_EF(E == EPV, anchor_sep_bwd_kernel<EP, CP, EF><<<grid, SEP_NT, 0, stream>>>(
                        N, E, A, cb, dattr, embed, anchors, attr, asum, choice, act, mode, B, mix_pwr,
                        (const float2*)src_c64, (const float2*)phasor, perm_idx, records, dloss,
                        dloss_dev, dembed, (float*)ws))));

@@ -98,7 +98,8 @@ def test_status_word_lives_in_pinned_host_memory_and_kernels_can_write_it(hp):
 @pytest.mark.parametrize('act', [0, 1])
 @pytest.mark.parametrize('mode', [0, 1])
 @pytest.mark.parametrize('B,C,T,F,E', [(3, 2, 9, 33, 20), (2, 3, 17, 129, 40), (1, 1, 5, 7, 4),
-                                       (2, 2, 40, 129, 20)])
+                                       (2, 2, 40, 129, 20), (2, 2, 11, 33, 16), (2, 3, 9, 17, 7),
+                                       (1, 2, 300, 129, 33)])   # E != EP: the guarded row accesses
 def test_fused_separator_pit_matches_unfused_and_oracle(act, mode, B, C, T, F, E):
     '''danet_separate_pit_fwd / _bwd (separator + phase re-attach + PIT-MSE + SNR in one pass,
     app/modules.py:548-603 -> main.py:281-290 -> app/ops.py:374-431) against (i) the two-kernel
@@ -273,9 +274,10 @@ def test_bptt_with_only_the_recurrent_weight_gradient_fused(B, T, D, H, monkeypa
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (a.shape,)
 
 
+@pytest.mark.parametrize('E', [20, 6])      # 6: E != EP, the guarded row accesses
 @pytest.mark.parametrize('est,sepn,C', [('anchor', 'dot-softmax-orig', 2), ('truth-weighted', 'dot-softmax-orig', 3),
                                         ('truth', 'dot-sigmoid-orig', 2), ('truth-threshold', 'dot-softmax-orig', 2)])
-def test_estimator_backward_recomputes_the_separator_term(hp, monkeypatch, est, sepn, C):
+def test_estimator_backward_recomputes_the_separator_term(hp, monkeypatch, est, sepn, C, E):
     '''inside train_step with the anchor estimator the fused separator + loss backward only
     produces dattr and danet_attractor_anchor_bwd_embed_sep forms the whole embedding gradient
     in one pass (the separator's term is not written to HBM and read back): same additions in the
@@ -286,7 +288,7 @@ def test_estimator_backward_recomputes_the_separator_term(hp, monkeypatch, est, 
     for recompute in (1, 0):
         monkeypatch.setattr(ops, 'HEADS_RECOMPUTE', recompute)
         hp.reset()
-        hp.load(dict(BATCH_SIZE=4, MAX_N_SIGNAL=C, FFT_SIZE=64, FFT_STRIDE=16, EMBED_SIZE=20,
+        hp.load(dict(BATCH_SIZE=4, MAX_N_SIGNAL=C, FFT_SIZE=64, FFT_STRIDE=16, EMBED_SIZE=E,
                      NUM_LSTM_LAYERS=2, LSTM_HDIM=16, NUM_ANCHOR=6, ENCODER_TYPE='bilstm-orig',
                      TRAIN_ESTIMATOR_METHOD=est, INFER_ESTIMATOR_METHOD='anchor',
                      SEPARATOR_TYPE=sepn))
