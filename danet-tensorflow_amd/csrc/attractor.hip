@@ -783,7 +783,10 @@ __global__ __launch_bounds__(ANCH_NT) void anchor_fwd_kernel(
   const int RT = T11 ? 1 : RT_, CT = T11 ? 1 : CT_;
   constexpr int EPA = EP + 4;           // + ones column, padded to a float4
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int PC = cb.P * C;
+  // (A, C) specialisation: subset count, row stride and loop bounds are compile-time constants
+  constexpr int AMAX = AT > 0 ? AT : MAXA;
+  constexpr int PC_CE = AT > 0 ? CombosCE<(AT > 0 ? AT : 2), (AT > 0 ? CTT : 1)>().P * CTT : 0;
+  const int PC = AT > 0 ? PC_CE : cb.P * C;
   const int lds = PC + 1;               // odd-ish stride for the assignment tile
   float* Xs = smem;                     // [ANCH_TN][EPA]
   float* Ss = Xs + ANCH_TN * EPA;       // [ANCH_TN][lds]
@@ -832,7 +835,7 @@ __global__ __launch_bounds__(ANCH_NT) void anchor_fwd_kernel(
 #pragma unroll
         for (int a = 0; a < MAXA; ++a) {
           float s = 0.f;
-          if (a < A) {
+          if (a < AMAX && (AT > 0 || a < A)) {
 #pragma unroll
             for (int e = 0; e < EP; ++e) s += x[e] * An[a * EP + e];   // modules.py:513-515
           }
@@ -843,12 +846,12 @@ __global__ __launch_bounds__(ANCH_NT) void anchor_fwd_kernel(
         // subset (P*C = 30 -> A = 6 expf per bin at A=6, C=2)
         float dmax = d[0];
 #pragma unroll
-        for (int a = 1; a < MAXA; ++a) if (a < A) dmax = fmaxf(dmax, d[a]);
+        for (int a = 1; a < MAXA; ++a) if (a < AMAX && (AT > 0 || a < A)) dmax = fmaxf(dmax, d[a]);
         float ea[MAXA];
 #pragma unroll
         // (hardware exponential: arguments are <= 0 after the max subtraction; ~1e-7 relative in a
         // soft assignment, far inside the 1e-4 bar, and 6 x ~20 fewer vector instructions per bin)
-        for (int a = 0; a < MAXA; ++a) ea[a] = (a < A) ? __expf(d[a] - dmax) : 0.f;
+        for (int a = 0; a < MAXA; ++a) ea[a] = (a < AMAX && (AT > 0 || a < A)) ? __expf(d[a] - dmax) : 0.f;
         if constexpr (AT > 0) {
           constexpr CombosCE<AT, CTT> tb{};
           float* srow = Ss + tid * lds;
