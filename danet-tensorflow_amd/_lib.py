@@ -76,6 +76,10 @@ PROTOTYPES = {
     'danet_lstm_bwd_db': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_int,
                                   c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_sz, c_p, c_int]),
     'danet_lstm_bwd_db_reduce': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p, c_f32, c_p, c_sz]),
+    'danet_gemm_next_launch_stop_event': (c_int, [c_p]),
+    'danet_event_create': (c_int, [ctypes.POINTER(c_p)]),
+    'danet_event_destroy': (c_int, [c_p]),
+    'danet_stream_wait_event': (c_int, [c_p, c_p]),
     'danet_lstm_bwd_fused_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'danet_lstm_bwd_fused_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     'danet_lstm_bwd_fused': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_int,

@@ -11,6 +11,7 @@
 // itself between the MFMAs of consecutive k-tiles).  Small-output / long-K products (weight gradients) use a
 // deterministic split-K: per-slice slabs in `ws`, summed by a second kernel.
 #include "common.h"
+#include <hip/hip_ext.h>
 #include "options.h"
 #include <atomic>
 #include <stdlib.h>
@@ -1053,6 +1054,32 @@ extern "C" size_t danet_gemm_f32_streamk_workspace_bytes(int M, int N, int K) {
   return SK_HEADER + (size_t)SK_MAX_GRID * 65536;   // flags + one partial tile per workgroup
 }
 
+// Event plumbing for hosts that fork side streams behind a stream-K launch: the event given to
+// danet_gemm_next_launch_stop_event is attached to the NEXT stream-K launch of the calling host thread
+// (consumed by it); danet_event_* wrap the runtime's calls so that a ctypes host needs no second
+// library handle.
+static thread_local hipEvent_t g_stop_event = nullptr;
+extern "C" int danet_gemm_next_launch_stop_event(void* event) {
+  g_stop_event = (hipEvent_t)event;
+  return DANET_OK;
+}
+extern "C" int danet_event_create(void** event) {
+  DANET_CHECK_ARG(event != nullptr, "event_create: null pointer");
+  hipEvent_t e = nullptr;
+  DANET_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  *event = (void*)e;
+  return DANET_OK;
+}
+extern "C" int danet_event_destroy(void* event) {
+  if (event) DANET_CHECK_HIP(hipEventDestroy((hipEvent_t)event));
+  return DANET_OK;
+}
+extern "C" int danet_stream_wait_event(danet_stream_t stream, void* event) {
+  DANET_CHECK_ARG(event != nullptr, "stream_wait_event: null event");
+  DANET_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+  return DANET_OK;
+}
+
 // second: optional per-problem second operand pairs {A2, lda2, B2, ldb2} contracted over K2
 struct SkSecond { const float* A2; int lda2; const float* B2; int ldb2; };
 static int sk_launch(danet_stream_t stream_, int transA, int transB, int K, int K2, int nprob,
@@ -1125,12 +1152,22 @@ static int sk_launch(danet_stream_t stream_, int transA, int transB, int K, int 
       dma = dma && dma_operand_ok(second[i].A2, second[i].lda2, ak, K2) &&
             dma_operand_ok(second[i].B2, second[i].ldb2, bk, K2);
   }
+  // a caller-supplied event (danet_gemm_next_launch_stop_event) rides on this launch's own dispatch
+  // packet instead of a separate hipEventRecord behind it (tools/csrc/event_gap.hip: the record costs
+  // the stream 4.4 us before its next kernel, the attached event 1.1 us)
+  hipEvent_t stop = g_stop_event;
+  g_stop_event = nullptr;
+#define SK_GO(K_)                                                                                   \
+  do {                                                                                             \
+    if (stop) hipExtLaunchKernelGGL((K_), grid, block, GEMM_SMEM_BYTES, stream, nullptr, stop, 0, sk); \
+    else (K_)<<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);                                        \
+  } while (0)
 #define SK_LAUNCH(D_)                                                                              \
   do {                                                                                             \
-    if (ak && !bk) gemm_f32_sk_kernel<true, false, D_><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);        \
-    else if (ak && bk) gemm_f32_sk_kernel<true, true, D_><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);     \
-    else if (!ak && !bk) gemm_f32_sk_kernel<false, false, D_><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk); \
-    else gemm_f32_sk_kernel<false, true, D_><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);                  \
+    if (ak && !bk) SK_GO((gemm_f32_sk_kernel<true, false, D_>));                                    \
+    else if (ak && bk) SK_GO((gemm_f32_sk_kernel<true, true, D_>));                                 \
+    else if (!ak && !bk) SK_GO((gemm_f32_sk_kernel<false, false, D_>));                             \
+    else SK_GO((gemm_f32_sk_kernel<false, true, D_>));                                              \
   } while (0)
   // capped groups (they share every CU with a recurrent kernel): the short-instruction k-loop
   const bool mf16 = !dma && sk.yield > 0 && danet_opt(OPT_GEMM_MFMA16) == 1;
@@ -1142,12 +1179,13 @@ static int sk_launch(danet_stream_t stream_, int transA, int transB, int K, int 
       gemm_allow_lds((const void*)gemm_f32_sk_kernel<false, true, false, true>);
       return true; }();
     (void)lds16_ok;
-    if (ak && !bk) gemm_f32_sk_kernel<true, false, false, true><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);
-    else if (ak && bk) gemm_f32_sk_kernel<true, true, false, true><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);
-    else if (!ak && !bk) gemm_f32_sk_kernel<false, false, false, true><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);
-    else gemm_f32_sk_kernel<false, true, false, true><<<grid, block, GEMM_SMEM_BYTES, stream>>>(sk);
+    if (ak && !bk) SK_GO((gemm_f32_sk_kernel<true, false, false, true>));
+    else if (ak && bk) SK_GO((gemm_f32_sk_kernel<true, true, false, true>));
+    else if (!ak && !bk) SK_GO((gemm_f32_sk_kernel<false, false, false, true>));
+    else SK_GO((gemm_f32_sk_kernel<false, true, false, true>));
   } else if (dma) SK_LAUNCH(true); else SK_LAUNCH(false);
 #undef SK_LAUNCH
+#undef SK_GO
   DANET_CHECK_LAUNCH();
   return DANET_OK;
 }

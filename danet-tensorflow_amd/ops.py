@@ -45,7 +45,7 @@ STREAMK = int(__import__('os').environ.get('DANET_STREAMK', '5'))
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, beta=0.0,
-         max_workgroups=0, streamk=False, tag=None):
+         max_workgroups=0, streamk=False, tag=None, stop_event=None):
     '''C[M,N] = op(A) op(B) (+bias) (+beta*C) on the fp32 matrix cores.
     A, B, C are tensors whose data_ptr() is element (0,0); ld* in elements.
     max_workgroups > 0 caps the launch (persistent workgroups); streamk selects the
@@ -57,6 +57,8 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None,
         # hand-off flags, which must only ever contain earlier launch sequence numbers
         w = _lib.workspace(need, C.device, tag='gemm_sk')
         with _lib.timed('gemm_f32', tag):
+            if stop_event is not None:
+                stop_event.attach()
             check(L.danet_gemm_f32_streamk(_lib.stream(), int(transA), int(transB), M, N, K,
                                            ptr(_f32(A)), lda, ptr(_f32(B)), ldb, ptr(_f32(C)), ldc,
                                            ptr(bias), float(beta), ptr(w), w.numel()))
@@ -71,14 +73,18 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None,
 
 
 def gemm_kcat(A1, lda1, B1, ldb1, K1, A2, lda2, B2, ldb2, K2, C, M, N, ldc,
-              transA=False, transB=False, bias=None, beta=0.0, tag=None, streamk=False):
+              transA=False, transB=False, bias=None, beta=0.0, tag=None, streamk=False,
+              stop_event=None):
     '''C[M,N] = op(A1) op(B1) + op(A2) op(B2) (+bias) (+beta*C) in one launch.
-    streamk: the hybrid stream-K schedule (no slabs / reduce kernel; K1 % 16 == 0)'''
+    streamk: the hybrid stream-K schedule (no slabs / reduce kernel; K1 % 16 == 0)
+    stop_event: a ForkEvent that completes with this launch (stream-K path only)'''
     L = _L()
     if streamk and K1 % 16 == 0:
         w = _lib.workspace(L.danet_gemm_f32_streamk_workspace_bytes(M, N, K1 + K2), C.device,
                            tag='gemm_sk')
         with _lib.timed('gemm_f32', tag):
+            if stop_event is not None:
+                stop_event.attach()
             check(L.danet_gemm_f32_streamk_kcat(_lib.stream(), int(transA), int(transB), M, N,
                                                 K1, ptr(_f32(A1)), lda1, ptr(_f32(B1)), ldb1,
                                                 K2, ptr(_f32(A2)), lda2, ptr(_f32(B2)), ldb2,
@@ -427,11 +433,45 @@ def prepare_streams(dev):
     torch.cuda.synchronize(dev)
 
 
+# An event that rides on a stream-K launch's own dispatch packet (danet_gemm_next_launch_stop_event)
+# instead of a hipEventRecord behind it: the record costs the launching stream ~4.4 us before its
+# next kernel, the attached event ~1.1 us, and the side chain starts ~3.7 us earlier
+# (tools/csrc/event_gap.hip).  Raw events from a small rotating pool per device (a slot is reused
+# dozens of launches later; the host keeps at most MAX_STEPS_IN_FLIGHT steps queued).
+FORK_ATTACH = __import__('os').environ.get('DANET_FORK_ATTACH', '1') == '1'
+_fork_event_pool = {}
+
+
+class ForkEvent(object):
+    __slots__ = ('handle', 'attached')
+
+    def __init__(self, handle):
+        self.handle, self.attached = handle, False
+
+    def attach(self):
+        check(_L().danet_gemm_next_launch_stop_event(self.handle))
+        self.attached = True
+
+
+def fork_event(dev):
+    '''the next ForkEvent of the device's pool, or None when attaching is switched off'''
+    if not FORK_ATTACH or SIDE_STREAMS <= 0:
+        return None
+    pool = _fork_event_pool.setdefault(str(dev), {'i': 0, 'ev': []})
+    if len(pool['ev']) < 32:
+        h = _lib.c_p()
+        check(_L().danet_event_create(__import__('ctypes').byref(h)))
+        pool['ev'].append(h.value)
+        return ForkEvent(h.value)
+    pool['i'] = (pool['i'] + 1) % 32
+    return ForkEvent(pool['ev'][pool['i']])
+
+
 class _Fork(object):
     '''with _Fork(dev, n) as f:  f.run(i, fn)  -> fn runs on chain i
     (chain 0 = the current stream, chain i>0 = side stream i-1); join on exit.'''
 
-    def __init__(self, dev, nchains, defer=False, keep=(), lazy=False):
+    def __init__(self, dev, nchains, defer=False, keep=(), lazy=False, event=None):
         '''defer=True: do not join on exit -- the side chains keep running under
         whatever the main stream does next (e.g. weight-gradient GEMMs under the
         next layer's latency-bound BPTT kernel, which leaves most CUs idle);
@@ -440,19 +480,26 @@ class _Fork(object):
         lazy=True: the fork event is recorded when the first side chain is issued instead of
         on entry -- a fork that ends up with no side work then costs the main stream nothing
         (an event record is a ~7 us bubble in front of the next kernel); only for forks whose
-        main-stream work comes AFTER their side chains.'''
+        main-stream work comes AFTER their side chains.
+        event: a ForkEvent already attached to the last launch the side chains have to wait for
+        (then no event is recorded at all).'''
         self.main = torch.cuda.current_stream(dev)
         n = min(nchains - 1, SIDE_STREAMS)
         self.sides = _side_streams(dev, n) if n > 0 else []
         self.used = set()
         self.defer, self.keep = defer, keep
         self.lazy, self.forked = lazy, False
+        self.event = event if (event is not None and event.attached) else None
 
     def _fork_now(self):
         if self.sides and not self.forked:
-            ev = self.main.record_event()
-            for s in self.sides:
-                s.wait_event(ev)
+            if self.event is not None:
+                for s in self.sides:
+                    check(_L().danet_stream_wait_event(s.cuda_stream, self.event.handle))
+            else:
+                ev = self.main.record_event()
+                for s in self.sides:
+                    s.wait_event(ev)
         self.forked = True
 
     def __enter__(self):
@@ -828,11 +875,18 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
         for d in range(ndir):
             colsum(das[d], T * B, 4 * H, 4 * H, dbs[d], beta=1.0 if direct[d][1] else 0.0)
 
-    def input_grad():
+    fork_ev = [None]
+
+    def input_grad(attach=False):
         if ndir == 2:
-            # dX = da_f Wx_f^T + da_b Wx_b^T: one K-concatenated launch
+            # dX = da_f Wx_f^T + da_b Wx_b^T: one K-concatenated launch (the fork event of the
+            # weight-gradient chain rides on it: see ForkEvent)
+            sk = (STREAMK & 4) != 0 and (4 * H) % 16 == 0
+            if attach and sk:
+                fork_ev[0] = fork_event(dev)
             gemm_kcat(das[0], 4 * H, c.Ws[0], 4 * H, 4 * H, das[1], 4 * H, c.Ws[1], 4 * H, 4 * H,
-                      dx, T * B, D, D, transB=True, tag='dX', streamk=(STREAMK & 4) != 0)
+                      dx, T * B, D, D, transB=True, tag='dX', streamk=(STREAMK & 4) != 0,
+                      stop_event=fork_ev[0])
             return
         for d in range(ndir):
             # dX += da Wx^T
@@ -846,7 +900,7 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
     # (`join_deferred`).
     fork_early = DW_FORK_EARLY and need_dx and GROUPED_DW and not fused
     if need_dx and not fork_early:
-        input_grad()
+        input_grad(attach=GROUPED_DW and not fused and _overlap_dw(H))
     hooks = bool(GRAD_READY_HOOKS) and _fast() and layer_tag is not None and \
         all(a and b for a, b in direct)
     if hooks and not need_dx:
@@ -860,7 +914,8 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
         sides[0].wait_stream(main)
         with torch.cuda.stream(sides[0]):
             _fire_grad_ready(('rest',), list(c.Ws) + list(c.bs))
-    with _Fork(dev, ndir + 1, defer=True, keep=(das, c.x, c.ypad, dy, ws), lazy=True) as f:
+    with _Fork(dev, ndir + 1, defer=True, keep=(das, c.x, c.ypad, dy, ws), lazy=True,
+               event=fork_ev[0]) as f:
         on_main = False
         if fused:
             on_main = True           # everything was issued on the main stream
@@ -971,8 +1026,10 @@ class RnnEncoderFn(torch.autograd.Function):
         dev = dembed.device
         dWout, direct_out = _grad_target(ctx.Wout, (D, O), dev)
         dyc = torch.empty(B, T, D, device=dev)
-        gemm(dembed, ctx.Wout, dyc, B * T, D, O, O, O, D, transB=True, streamk=(STREAMK & 1) != 0, tag='dYc')   # critical path first
-        with _Fork(dev, 2, defer=True, keep=(dembed, ctx.yc), lazy=True) as f:
+        ev = fork_event(dev) if (STREAMK & 1) != 0 else None
+        gemm(dembed, ctx.Wout, dyc, B * T, D, O, O, O, D, transB=True, streamk=(STREAMK & 1) != 0, tag='dYc',
+             stop_event=ev)                                   # critical path first
+        with _Fork(dev, 2, defer=True, keep=(dembed, ctx.yc), lazy=True, event=ev) as f:
             if GROUPED_DW:    # alone on its stream under the top layer's BPTT kernel (or serial)
                 ov = _overlap_dw(H)
                 f.run(1 if ov else 0, lambda: gemm_group(

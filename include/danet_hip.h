@@ -204,6 +204,16 @@ int danet_gemm_f32_streamk_kcat(danet_stream_t stream, int transA, int transB, i
                                 float* C, int ldc, const float* bias, float beta,
                                 void* ws, size_t ws_bytes);
 
+/* Fork without a separate event record: `event` (danet_event_create, or any hipEvent_t) is attached
+ * to the NEXT stream-K launch issued by the calling host thread (danet_gemm_f32_streamk*, consumed by
+ * it) and completes with that kernel; another stream then waits with danet_stream_wait_event.  A
+ * hipEventRecord behind the launch costs the launching stream ~4 us before its next kernel, the
+ * attached event ~1 us (tools/csrc/event_gap.hip).                                             */
+int danet_gemm_next_launch_stop_event(void* event);
+int danet_event_create(void** event);
+int danet_event_destroy(void* event);
+int danet_stream_wait_event(danet_stream_t stream, void* event);
+
 /* out[N] = sum_m A[m][n] (+ beta*out): bias gradients.                     */
 int danet_colsum_f32(danet_stream_t stream, int M, int N, const float* A,
                      int lda, float* out, float beta, void* ws,
