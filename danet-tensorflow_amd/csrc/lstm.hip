@@ -1081,8 +1081,14 @@ struct LstmBwdRsArgs {
   float* dbslab;   // optional [ndir*G][4H]: per-cluster bias-gradient partials (colsum of da)
 };
 
+// cache-policy bits of the reduce-scatter's publish stores: 16 = sc1 (agent scope, write-through);
+// build variants -DRS_STORE_AUX=17 (sc0 sc1: system scope) / 18 (sc1 nt) exist for the PMC comparison
+// in profiles/EXPERIMENTS.md -- WRITE_SIZE is the same for all three, the step is not
+#ifndef RS_STORE_AUX
+#define RS_STORE_AUX 16
+#endif
 __device__ __forceinline__ void store_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned off, v4u v) {
-  __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16 /*sc1*/);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, RS_STORE_AUX);
 }
 
 #define RS_NI_MAX 6
