@@ -106,6 +106,41 @@ def make_batches(hp, rank, n_batches, device):
     return out
 
 
+def make_host_batches(hp, rank, n_batches, device, extra_frames=32):
+    '''what a dataset iterator yields (app/datasets/*.py): host numpy complex64 [B*C, T+extra, F]
+    single-speaker spectra, longer than MAX_TRAIN_LEN so that the loop's random crop
+    (main.py:422-426) is exercised'''
+    from danet_amd import datasets, utils
+    B, C, T = hp.BATCH_SIZE, hp.MAX_N_SIGNAL, hp.MAX_TRAIN_LEN + extra_frames
+    out = []
+    for i in range(n_batches):
+        waves = datasets.synth_waves(7331 + rank + 1000 * i, B * C, T)
+        out.append(utils.stft(torch.as_tensor(waves).to(device)).cpu().numpy())
+    return out
+
+
+def run_e2e(args, hp, model, device, rank, use_dist, barrier, sync_feed=False):
+    '''the drop-in train loop (cli.train_epoch = main.py:413-436) over HOST-resident batches:
+    staging, crop, upload and the metric reads are inside the timed region'''
+    import io
+    import random
+    from danet_amd import cli
+    host = make_host_batches(hp, rank, 4, device)
+    random.seed(1337 + rank)
+
+    def epoch(n):
+        for i in range(n):
+            yield (host[i % len(host)],)
+    cli.train_epoch(model, epoch(max(args.warmup, 4)), io.StringIO(), sync_feed=sync_feed)
+    barrier()
+    t0 = time.perf_counter()
+    rep, n = cli.train_epoch(model, epoch(args.steps), io.StringIO(), sync_feed=sync_feed)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, device, use_dist)
+    assert n == args.steps and np.isfinite(rep['loss']), (n, rep)
+    return dt, host[0].nbytes, rep
+
+
 def host_info():
     return dict(os_cpu_count=os.cpu_count(),
                 sched_affinity=len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None)
@@ -306,6 +341,8 @@ def main():
     ap.add_argument('--step-times', action='store_true',
                     help='diagnostic: one HIP event per timed step, per-step GPU times to stderr')
     ap.add_argument('--cpu-sample', type=int)
+    ap.add_argument('--no-e2e', action='store_true',
+                    help='skip the second timed region (the train loop over host-resident batches)')
     ap.add_argument('--allreduce-schedule', choices=['0', 'tail', '1'], default=None,
                     help="gradient reduction schedule under data parallelism (Model.grad_schedule; "
                          "default '0' = ONE all-reduce per step)")
@@ -473,6 +510,27 @@ def run_train(args, cfg, hp, device, rank, world, use_dist):
 
     mix_s_per_step = hp.BATCH_SIZE * hp.MAX_TRAIN_LEN * hp.FFT_STRIDE / hp.SMPRATE
     value = world * mix_s_per_step * args.steps / dt
+    # second timed region (not `value`): the same K steps through the drop-in train loop with
+    # batches that start in HOST memory (every rank runs it: the steps contain the all-reduce)
+    e2e = None
+    if not args.no_e2e:
+        dt_e, nbytes, rep_e = run_e2e(args, hp, model, device, rank, use_dist, barrier)
+        dt_s, _, _ = run_e2e(args, hp, model, device, rank, use_dist, barrier, sync_feed=True)
+        assert ops.lstm_status_ok()
+        e2e = dict(loop='cli.train_epoch (main.py:413-436): host numpy batches [B*C, T+32, F] -> crop '
+                        '-> pinned staging -> async upload one batch ahead -> train_step; metrics '
+                        'read once per epoch',
+                   ms_per_step=round(1e3 * dt_e / args.steps, 3),
+                   value=round(world * mix_s_per_step * args.steps / dt_e, 2),
+                   frac_of_resident=round(dt / dt_e, 4),
+                   host_batch_bytes=int(nbytes),
+                   uploaded_bytes_per_step=int(nbytes * hp.MAX_TRAIN_LEN // (hp.MAX_TRAIN_LEN + 32)),
+                   sync_feed_ms_per_step=round(1e3 * dt_s / args.steps, 3),
+                   sync_feed_note='the reference\'s literal loop: blocking upload from pageable '
+                                  'memory + float() of loss / SNR every step',
+                   epoch_mean_loss=rep_e['loss'])
+        log('e2e train loop: %.3f ms/step (resident %.3f, sync feed %.3f)'
+            % (e2e['ms_per_step'], 1e3 * dt / args.steps, e2e['sync_feed_ms_per_step']))
     if rank != 0:
         return None
 
@@ -559,6 +617,8 @@ def run_train(args, cfg, hp, device, rank, world, use_dist):
                rccl_ranks=(torch.distributed.get_world_size() if use_dist else 0),
                allreduce_ms_standalone=(round(allreduce_ms, 4) if allreduce_ms is not None else None),
                roofline=roofline, kernels=kernels_table(prof_all, nb), host=host_info())
+    if e2e is not None:
+        res['e2e'] = e2e
     if world == 1:
         torch.set_num_threads(min(os.cpu_count() or 1, 16))
         rep, mse = (None, None) if args.no_parity_check else parity_vs_oracle(hp, model, batches[0], 4)

@@ -17,7 +17,6 @@ import os
 import sys
 from collections import OrderedDict
 from math import isnan
-from random import randint
 
 import numpy as np
 import torch
@@ -25,30 +24,40 @@ import torch
 from .hparams import hparams
 from . import datasets  # noqa: F401  (registers datasets)
 from . import dist
+from . import feed
 from . import utils
 from .model import Model
 
 
-def _dict_add(dst, src):
-    for k, v in src.items():
-        dst[k] = dst.get(k, 0.) + float(v)
-
-
-def _dict_mul(di, coeff):
-    for k in di:
-        di[k] = di[k] * coeff
+# DANET_SYNC_FEED=1: the reference's literal loop (blocking upload, a host read of every metric
+# every step) instead of the one-batch-ahead feed
+SYNC_FEED = os.environ.get('DANET_SYNC_FEED', '0') == '1'
 
 
 def _dict_format(di):
     return ' '.join('='.join((k, str(v))) for k, v in di.items())
 
 
-def _to_batch(data_pt, device):
-    '''dataset batch [B*C, T, F] (real or complex) -> complex64 [B, C, T, F] on the GPU
-    (main.py:417-421)'''
-    a = np.asarray(data_pt[0])
-    a = a.reshape(hparams.BATCH_SIZE, hparams.MAX_N_SIGNAL, -1, hparams.FEATURE_SIZE)
-    return torch.as_tensor(a.astype(np.complex64)).to(device)
+def train_epoch(model, batches, out=sys.stdout, sync_feed=None):
+    '''the batch loop of Model.train (main.py:413-436) over host batches [B*C, T, F]: crop to
+    MAX_TRAIN_LEN (main.py:422-426), one train step per batch, a ':' per step, epoch means of the
+    fetched metrics.  The host never waits for the device inside the loop: batches are staged,
+    cropped and uploaded one step ahead (feed.BatchFeed), the per-step metrics stay on the device
+    until the epoch mean is read (feed.StepReport).  sync_feed=True is the reference's literal
+    form -- blocking upload, `float()` of every metric every step -- kept for the equality test
+    and `bench.py --e2e --sync-feed`.  Returns (OrderedDict of epoch means, number of batches).'''
+    if sync_feed is None:
+        sync_feed = SYNC_FEED
+    src = feed.BatchFeed(batches, model.device, hparams.MAX_TRAIN_LEN,
+                         threaded=False if sync_feed else None)
+    report = feed.StepReport(flush_every=1 if sync_feed else 1024)
+    for spectra in src:
+        step_fetch = model.train_step(spectra)
+        model.reset_state()
+        out.write(':')
+        out.flush()
+        report.add(step_fetch)
+    return report.mean(), report.n
 
 
 def train(model, n_epoch, dataset, args, out=sys.stdout):
@@ -58,20 +67,9 @@ def train(model, n_epoch, dataset, args, out=sys.stdout):
     out.write('Set learning rate to %f\n' % hparams.LR)
     i_epoch = 0
     while i_epoch < n_epoch:
-        cli_report = OrderedDict()
-        i_batch = 0
-        for i_batch, data_pt in enumerate(dataset.epoch(
-                'train', hparams.BATCH_SIZE * hparams.MAX_N_SIGNAL, shuffle=True)):
-            spectra = _to_batch(data_pt, model.device)
-            if hparams.MAX_TRAIN_LEN is not None and spectra.shape[2] > hparams.MAX_TRAIN_LEN:
-                beg = randint(0, spectra.shape[2] - hparams.MAX_TRAIN_LEN - 1)   # main.py:424-425
-                spectra = spectra[:, :, beg:beg + hparams.MAX_TRAIN_LEN].contiguous()
-            step_fetch = model.train_step(spectra)
-            model.reset_state()
-            out.write(':')
-            out.flush()
-            _dict_add(cli_report, step_fetch)
-        _dict_mul(cli_report, 1. / (i_batch + 1))
+        cli_report, _n = train_epoch(model, dataset.epoch(
+            'train', hparams.BATCH_SIZE * hparams.MAX_N_SIGNAL, shuffle=True), out,
+            sync_feed=getattr(args, 'sync_feed', None))
         model.check_status()       # hand-off timeouts of the persistent kernels surface here at the latest
         # data parallel: every rank must take the SAME learning-rate and NaN decisions, so
         # they are taken on the rank-mean of the epoch metrics (NaN anywhere -> NaN everywhere)
@@ -99,7 +97,7 @@ def train(model, n_epoch, dataset, args, out=sys.stdout):
         i_epoch += 1
         if args.no_valid_on_epoch:
             continue
-        rep = evaluate(model, dataset, 'valid', out)
+        rep = evaluate(model, dataset, 'valid', out, sync_feed=getattr(args, 'sync_feed', None))
         out.write('\nValid  %d/%d %s\n' % (i_epoch, n_epoch, _dict_format(rep)))
         out.flush()
 
@@ -135,17 +133,21 @@ def restore_checkpoint(model, filename):
     dist.broadcast_params_(model._flat)
 
 
-def evaluate(model, dataset, subset, out=sys.stdout):
-    '''validation / test sweep with valid_fetches (main.py:486-510, :512-532)'''
-    rep = OrderedDict()
-    i_batch = 0
-    for i_batch, data_pt in enumerate(dataset.epoch(
-            subset, hparams.BATCH_SIZE * hparams.MAX_N_SIGNAL, shuffle=False)):
-        _dict_add(rep, model.valid_step(_to_batch(data_pt, model.device)))
+def evaluate(model, dataset, subset, out=sys.stdout, sync_feed=None):
+    '''validation / test sweep with valid_fetches (main.py:486-510, :512-532); fed like
+    train_epoch (no crop: main.py:497-498)'''
+    if sync_feed is None:
+        sync_feed = SYNC_FEED
+    src = feed.BatchFeed(dataset.epoch(subset, hparams.BATCH_SIZE * hparams.MAX_N_SIGNAL,
+                                       shuffle=False), model.device, None,
+                         threaded=False if sync_feed else None)
+    report = feed.StepReport(flush_every=1 if sync_feed else 1024)
+    for spectra in src:
+        report.add(model.valid_step(spectra))
         model.reset_state()
         out.write('.')
         out.flush()
-    _dict_mul(rep, 1. / (i_batch + 1))
+    rep = report.mean()
     # a hand-off timeout in any step of the sweep invalidates its metrics: surface it here
     # (blocking; collective under data parallelism -- every rank reaches this line)
     model.check_status()
@@ -219,6 +221,8 @@ def build_parser():
     p.add_argument('-bs', '--batch-size', type=int, help='overrides hparams.BATCH_SIZE')
     p.add_argument('--no-save-on-epoch', action='store_true')
     p.add_argument('--no-valid-on-epoch', action='store_true')
+    p.add_argument('--sync-feed', action='store_true', default=None,
+                   help='(not in the reference) blocking uploads + per-step metric reads')
     return p
 
 

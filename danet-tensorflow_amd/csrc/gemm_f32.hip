@@ -1090,6 +1090,12 @@ static int sk_launch(danet_stream_t stream_, int transA, int transB, int K, int 
   static std::atomic<unsigned> launch_seq{0x5eed0000u};
   static const bool lds_ok = [] { GEMM_FOR_ALL_VARIANTS(gemm_f32_sk_kernel, gemm_allow_lds); return true; }();
   (void)lds_ok;
+  // a caller-supplied event (danet_gemm_next_launch_stop_event) rides on this launch's own dispatch
+  // packet instead of a separate hipEventRecord behind it (tools/csrc/event_gap.hip: the record costs
+  // the stream 4.4 us before its next kernel, the attached event 1.1 us).  Consumed HERE, before
+  // any check can return: a rejected call must not leave it armed for an unrelated later launch.
+  hipEvent_t stop = g_stop_event;
+  g_stop_event = nullptr;
   hipStream_t stream = (hipStream_t)stream_;
   DANET_CHECK_ARG(probs && nprob >= 1 && nprob <= SK_MAX_PROBLEMS, "gemm group: 1..%d problems",
                   SK_MAX_PROBLEMS);
@@ -1152,11 +1158,6 @@ static int sk_launch(danet_stream_t stream_, int transA, int transB, int K, int 
       dma = dma && dma_operand_ok(second[i].A2, second[i].lda2, ak, K2) &&
             dma_operand_ok(second[i].B2, second[i].ldb2, bk, K2);
   }
-  // a caller-supplied event (danet_gemm_next_launch_stop_event) rides on this launch's own dispatch
-  // packet instead of a separate hipEventRecord behind it (tools/csrc/event_gap.hip: the record costs
-  // the stream 4.4 us before its next kernel, the attached event 1.1 us)
-  hipEvent_t stop = g_stop_event;
-  g_stop_event = nullptr;
 #define SK_GO(K_)                                                                                   \
   do {                                                                                             \
     if (stop) hipExtLaunchKernelGGL((K_), grid, block, GEMM_SMEM_BYTES, stream, nullptr, stop, 0, sk); \
@@ -1205,6 +1206,7 @@ extern "C" int danet_gemm_f32_streamk_kcat(danet_stream_t stream_, int transA, i
                                            int K2, const float* A2, int lda2, const float* B2, int ldb2,
                                            float* C, int ldc, const float* bias, float beta,
                                            void* ws, size_t ws_bytes) {
+  if (K2 <= 0) g_stop_event = nullptr;       // (an armed event dies with the rejected call)
   DANET_CHECK_ARG(K2 > 0, "gemm_streamk_kcat: K2 must be positive");
   danet_gemm_problem_t q;
   q.A = A1; q.lda = lda1; q.B = B1; q.ldb = ldb1; q.C = C; q.ldc = ldc; q.M = M; q.N = N;

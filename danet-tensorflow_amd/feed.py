@@ -1,0 +1,200 @@
+'''
+Host -> HBM feed of the train / valid loops: what `feed_dict={s_src_signals: ...}` does in the
+reference (main.py:417-431, :497-500), one batch AHEAD of the step that consumes it.
+
+The reference builds every batch on the host (dataset iterator -> reshape -> random crop to
+MAX_TRAIN_LEN, main.py:417-426) and hands it to `g_sess.run`, which copies it to the device
+synchronously.  Here a feeder thread does, for batch i+1 while step i is being enqueued and run:
+
+    next(dataset iterator)                      (the iterator's own numpy / GPU work)
+    draw the crop offset  randint(0, T-L-1)     (same `random` stream, same order as main.py:424-425)
+    cast / crop / reshape into a PINNED staging slot   (one pass over the data; only the cropped
+                                                        frames ever cross PCIe)
+    hipMemcpyAsync on a copy stream + event
+
+and the consumer only makes the compute stream wait for that event.  No arithmetic happens here:
+the cast real -> complex64 (toy data, main.py:418-421) is a numpy copy into the staging slot.
+
+On a CPU "device" (the host-logic tests' stub model) the feed degenerates to the synchronous
+conversion, in the caller's thread.
+'''
+import queue
+import threading
+from random import randint
+
+import numpy as np
+import torch
+
+from .hparams import hparams
+
+
+def to_batch_host(data_pt, crop_len=None):
+    '''dataset batch [B*C, T, F] (real or complex) -> numpy view [B, C, T', F] + the crop applied
+    (main.py:417-426).  Draws from python's `random` exactly when the reference does.'''
+    a = np.asarray(data_pt[0])
+    a = a.reshape(hparams.BATCH_SIZE, hparams.MAX_N_SIGNAL, -1, hparams.FEATURE_SIZE)
+    if crop_len is not None and a.shape[2] > crop_len:
+        beg = randint(0, a.shape[2] - crop_len - 1)                       # main.py:424-425
+        a = a[:, :, beg:beg + crop_len]
+    return a
+
+
+class _Slot(object):
+    '''one pinned staging buffer (grow-only) + the event of the last copy that read it'''
+    __slots__ = ('buf', 'event')
+
+    def __init__(self):
+        self.buf, self.event = None, None
+
+    def stage(self, a, pin=True):
+        n = int(np.prod(a.shape))
+        if self.event is not None:
+            self.event.synchronize()           # the previous H2D copy out of this slot is done
+        if self.buf is None or self.buf.numel() < n:
+            self.buf = torch.empty(max(n, 1), dtype=torch.complex64)
+            if pin:
+                self.buf = self.buf.pin_memory()
+        t = self.buf[:n].view(*a.shape)
+        np.copyto(t.numpy(), a, casting='same_kind')      # cast + crop + gather in one pass
+        return t
+
+
+class BatchFeed(object):
+    '''for spectra in BatchFeed(dataset.epoch(...), device, crop_len): model.train_step(spectra)
+
+    Yields complex64 [B, C, T', F] tensors on `device`, already ordered behind their upload on
+    the stream that is current in the consumer.  depth = staging slots (batches in flight on the
+    host side).'''
+
+    def __init__(self, source, device, crop_len=None, depth=3, threaded=None):
+        self.source = source
+        self.device = torch.device(device)
+        self.crop_len = crop_len
+        self.async_ = self.device.type == 'cuda' if threaded is None else bool(threaded)
+        self.depth = max(2, depth)
+        self.n = 0
+        self._thread = None
+        self.cuda = self.device.type == 'cuda'
+        if self.async_:
+            self.copy_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+            self.slots = [_Slot() for _ in range(self.depth)]
+            self.q = queue.Queue(maxsize=self.depth - 1)
+            self._stop = False
+            self._thread = threading.Thread(target=self._produce, name='danet-feed', daemon=True)
+            self._thread.start()
+
+    # ------------------------------------------------------------- producer
+    def _produce(self):
+        import contextlib
+        try:
+            if self.cuda:
+                torch.cuda.set_device(self.device)
+            k = 0
+            # the iterator's own device work (e.g. a dataset that runs danet_stft) goes to the
+            # copy stream: it must not queue behind the training steps on the compute stream
+            with (torch.cuda.stream(self.copy_stream) if self.cuda else contextlib.nullcontext()):
+                it = iter(self.source)
+                while not self._stop:
+                    try:
+                        data_pt = next(it)
+                    except StopIteration:
+                        break
+                    a = to_batch_host(data_pt, self.crop_len)
+                    slot = self.slots[k % self.depth]
+                    t = slot.stage(a, pin=self.cuda)
+                    ev = None
+                    if self.cuda:
+                        d = t.to(self.device, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(self.copy_stream)
+                        slot.event = ev
+                    else:                   # (host-logic tests: the "upload" is a copy)
+                        d = t.clone()
+                    k += 1
+                    self._put((d, ev))
+            self._put(None)
+        except BaseException as e:           # surfaces in the consumer
+            self._put(e)
+
+    def _put(self, item):
+        while not self._stop:
+            try:
+                self.q.put(item, timeout=0.1)
+                return
+            except queue.Full:
+                continue
+
+    # ------------------------------------------------------------- consumer
+    def __iter__(self):
+        if not self.async_:
+            for data_pt in self.source:
+                a = to_batch_host(data_pt, self.crop_len)
+                self.n += 1
+                yield torch.as_tensor(np.ascontiguousarray(a).astype(np.complex64)).to(self.device)
+            return
+        try:
+            while True:
+                item = self.q.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                d, ev = item
+                if ev is not None:
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_event(ev)
+                    d.record_stream(cur)      # allocated on the copy stream, used on this one
+                self.n += 1
+                yield d
+        finally:
+            self.close()
+
+    def close(self):
+        if self._thread is not None:
+            self._stop = True
+            try:
+                while True:
+                    self.q.get_nowait()
+            except queue.Empty:
+                pass
+            self._thread.join(timeout=5.0)
+            self._thread = None
+
+
+class StepReport(object):
+    '''cli_report of main.py:413-436 without a host synchronisation per step: the fetched
+    metrics are kept as they come (device scalars stay on the device) and summed on the host, in
+    step order, when the epoch mean is read -- ONE device read per `flush_every` steps.  The
+    result equals the reference's running `dst[k] += float(v)` sum bit for bit (same values, same
+    order of double additions).'''
+
+    def __init__(self, flush_every=1024):
+        self.sums, self.pending, self.n = {}, {}, 0
+        self.keys = []
+        self.flush_every = flush_every
+
+    def add(self, fetch):
+        for k, v in fetch.items():
+            if k not in self.pending:
+                self.pending[k] = []
+                self.keys.append(k)
+            self.pending[k].append(v)
+        self.n += 1
+        if self.n % self.flush_every == 0:
+            self.flush()
+
+    def flush(self):
+        for k, li in self.pending.items():
+            tens = [v.detach().reshape(()) for v in li if torch.is_tensor(v)]
+            vals = iter(torch.stack(tens).cpu().tolist()) if tens else iter(())
+            s = self.sums.get(k, 0.)
+            for v in li:
+                s = s + (next(vals) if torch.is_tensor(v) else float(v))
+            self.sums[k] = s
+            li[:] = []
+
+    def mean(self):
+        '''OrderedDict-like list of (key, epoch mean) in first-seen key order'''
+        from collections import OrderedDict
+        self.flush()
+        return OrderedDict((k, self.sums[k] * (1. / max(self.n, 1))) for k in self.keys)

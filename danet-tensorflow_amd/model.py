@@ -290,6 +290,7 @@ class Model(object):
             out = self.forward(s_src_signals, fuse_heads=self.fuse_heads)
         except BaseException:
             chain.__exit__(None, None, None)
+            ops.drop_lazy(self.device)     # this step's queued finalizers must not run in the next
             raise
         self._early, self._in_step = None, True
         # from here until the final optimiser piece has been issued the bucket holds partial

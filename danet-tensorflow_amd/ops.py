@@ -58,10 +58,12 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None,
         w = _lib.workspace(need, C.device, tag='gemm_sk')
         with _lib.timed('gemm_f32', tag):
             if stop_event is not None:
-                stop_event.attach()
+                stop_event.arm()
             check(L.danet_gemm_f32_streamk(_lib.stream(), int(transA), int(transB), M, N, K,
                                            ptr(_f32(A)), lda, ptr(_f32(B)), ldb, ptr(_f32(C)), ldc,
                                            ptr(bias), float(beta), ptr(w), w.numel()))
+            if stop_event is not None:
+                stop_event.attached = True
         return C
     need = L.danet_gemm_f32_workspace_bytes(M, N, K)
     w, wn = _ws(need, C.device)
@@ -84,12 +86,14 @@ def gemm_kcat(A1, lda1, B1, ldb1, K1, A2, lda2, B2, ldb2, K2, C, M, N, ldc,
                            tag='gemm_sk')
         with _lib.timed('gemm_f32', tag):
             if stop_event is not None:
-                stop_event.attach()
+                stop_event.arm()
             check(L.danet_gemm_f32_streamk_kcat(_lib.stream(), int(transA), int(transB), M, N,
                                                 K1, ptr(_f32(A1)), lda1, ptr(_f32(B1)), ldb1,
                                                 K2, ptr(_f32(A2)), lda2, ptr(_f32(B2)), ldb2,
                                                 ptr(_f32(C)), ldc, ptr(bias), float(beta),
                                                 ptr(w), w.numel()))
+            if stop_event is not None:
+                stop_event.attached = True
         return C
     w, wn = _ws(L.danet_gemm_f32_kcat_workspace_bytes(M, N, K1, K2), C.device)
     with _lib.timed('gemm_f32', tag):
@@ -339,15 +343,34 @@ def _retire(st, block):
     return True
 
 
+def _collective():
+    return torch.distributed.is_available() and torch.distributed.is_initialized()
+
+
 def poll_status(dev):
     '''admission of a new step (called first by Model.train_step / valid_step / infer):
     retire every completed step, wait until fewer than MAX_STEPS_IN_FLIGHT are in flight;
-    raises DanetHipError when a retired step recorded a hand-off timeout'''
+    raises DanetHipError when a retired step recorded a hand-off timeout.
+
+    Under torch.distributed the retirement is DETERMINISTIC: at the admission of step n a rank
+    retires exactly step n - MAX_STEPS_IN_FLIGHT (blocking on its event) and nothing else -- no
+    opportunistic `query()` path, whose outcome depends on how far each rank's GPU happens to
+    be.  Every rank issues the same sequence of steps and the flag of step k is the same on
+    every rank (it rides in that step's gradient all-reduce), so all ranks raise at the
+    admission of the SAME step, with the same collectives enqueued behind it
+    (test_handoff_timeout_raises_at_the_same_step_on_every_rank_gloo_world2).'''
     st = _dev_status(dev)
-    while st.queue and _retire(st, block=False):
-        pass
+    if not _collective():
+        while st.queue and _retire(st, block=False):
+            pass
     while len(st.queue) >= max(MAX_STEPS_IN_FLIGHT, 1):
         _retire(st, block=True)
+
+
+def _record_event():
+    ev = torch.cuda.Event()
+    ev.record()
+    return ev
 
 
 def step_done(dev, collective_consistent=True):
@@ -362,9 +385,7 @@ def step_done(dev, collective_consistent=True):
         slot = st.n % st.slots.shape[0]
         st.slots[slot].copy_(st.word, non_blocking=True)
     st.n += 1
-    ev = torch.cuda.Event()
-    ev.record()
-    st.queue.append((ev, slot, collective_consistent))
+    st.queue.append((_record_event(), slot, collective_consistent))
 
 
 def check_status(dev=None):
@@ -448,9 +469,11 @@ class ForkEvent(object):
     def __init__(self, handle):
         self.handle, self.attached = handle, False
 
-    def attach(self):
+    def arm(self):
+        '''the NEXT stream-K launch of this host thread completes the event; `attached` is set
+        by the caller once that launch has been accepted (a rejected launch consumes the armed
+        event inside the library and nothing may wait for it)'''
         check(_L().danet_gemm_next_launch_stop_event(self.handle))
-        self.attached = True
 
 
 def fork_event(dev):
@@ -514,9 +537,10 @@ class _Fork(object):
         s = self.sides[(chain - 1) % len(self.sides)]
         self.used.add(s)
         with torch.cuda.stream(s):
-            if _lazy:
-                self.keep = tuple(self.keep) + tuple(k for _f, k in _lazy)
-                _flush_lazy()          # queued small kernels ride on this fork's event
+            q = _lazy.get(_dev_key(s.device))
+            if q:
+                self.keep = tuple(self.keep) + tuple(k for _f, k in q)
+                _flush_lazy(s.device)  # queued small kernels ride on this fork's event
             return fn()
 
     def after_all(self, fn, wait_main=False):
@@ -1176,7 +1200,11 @@ def _chain():
     return _chain_depth[0] > 0 and SIDE_STREAMS > 0
 
 
-_lazy = []
+_lazy = {}          # device index -> [(fn, keep)]
+
+
+def _dev_key(dev):
+    return dev.index if (dev is not None and dev.index is not None) else torch.cuda.current_device()
 
 
 def _on_side(dev, fn, keep=()):
@@ -1186,13 +1214,28 @@ def _on_side(dev, fn, keep=()):
     an event on the main stream costs it ~8 us (the following kernel cannot overlap the
     previous one's tail), more than the small kernels moved here take.  Without any fork before
     the join, fn() runs in stream order at the join.'''
-    _lazy.append((fn, keep))
+    _lazy.setdefault(_dev_key(dev), []).append((fn, keep))
 
 
-def _flush_lazy():
-    while _lazy:
-        fn, _keep = _lazy.pop(0)
-        fn()
+def _flush_lazy(dev=None):
+    '''run the queued closures of `dev` (default: the current device) on the current stream; a
+    closure that raises leaves nothing queued behind it'''
+    q = _lazy.get(_dev_key(dev))
+    try:
+        while q:
+            fn, _keep = q.pop(0)
+            fn()
+    finally:
+        if q:
+            del q[:]
+
+
+def drop_lazy(dev=None):
+    '''forget the queued side-stream closures of `dev` (Model.train_step: forward raised, the
+    finalizers of that step must not run inside the next step's first fork)'''
+    q = _lazy.get(_dev_key(dev))
+    if q:
+        del q[:]
 
 
 class _DembedToken(object):
@@ -1201,12 +1244,23 @@ class _DembedToken(object):
     (`attr._danet_dembed_token`; lost -- and the fusion with it -- if the caller
     transforms the attractors in between), picked up by SeparateFn.forward.  No global
     state, so several models / re-entrant backward passes cannot alias each other.'''
-    __slots__ = ('dembed', 'kind', 'recipe')
+    __slots__ = ('dembed', 'kind', 'recipe', 'inputs')
 
     def __init__(self):
         self.dembed = None
         self.kind = None          # 'anchor': the estimator's backward can recompute the separator's term
         self.recipe = None        # set by SeparatePitFn.backward when it left that term to the estimator
+        self.inputs = None        # (embed ptr, numel, mix_pwr ptr or None) the estimator saw
+
+    def same_inputs(self, embed_flat, mix_pwr):
+        '''the recompute kernels form the separator's term from the ESTIMATOR's saved embedding
+        (and, for the truth family, are handed the separator's mix_pwr where the estimator's own
+        is expected): only valid when both modules were given the same tensors'''
+        if self.inputs is None:
+            return False
+        e_ptr, e_n, m_ptr = self.inputs
+        return (embed_flat.data_ptr() == e_ptr and embed_flat.numel() == e_n and
+                (m_ptr is None or mix_pwr.data_ptr() == m_ptr))
 
 
 def _new_token(attr):
@@ -1250,6 +1304,7 @@ class TruthAttractorFn(torch.autograd.Function):
         ctx.token = _new_token(attr)
         if ctx.token is not None:
             ctx.token.kind = 'truth'
+            ctx.token.inputs = (embed.data_ptr(), embed.numel(), mix_pwr.data_ptr())
         return attr
 
     @staticmethod
@@ -1307,6 +1362,7 @@ class AnchorAttractorFn(torch.autograd.Function):
         ctx.token = _new_token(attr)
         if ctx.token is not None:
             ctx.token.kind = 'anchor'
+            ctx.token.inputs = (embed.data_ptr(), embed.numel(), None)
         return attr, asets, choice
 
     @staticmethod
@@ -1500,7 +1556,8 @@ class SeparatePitFn(torch.autograd.Function):
         dev = dloss.device
         tok = ctx.token
         defer = (HEADS_RECOMPUTE and _chain() and tok is not None and tok.kind in ('anchor', 'truth') and
-                 ctx.needs_input_grad[1] and ctx.needs_input_grad[2])
+                 ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and
+                 tok.same_inputs(embed_flat, mix_pwr))
         dembed = None if defer else torch.empty(B, N, E, device=dev)
         dattr = torch.empty(B, C, E, device=dev)
         dl = _f32(dloss.contiguous())

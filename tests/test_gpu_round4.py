@@ -1,0 +1,169 @@
+'''
+Round 4 (run with -m gpu): the oracle next to the EXACT kernel path bench.py times, at full size.
+
+`Model.train_step` at BASELINE cfg 2 / cfg 4 with B = 32, T = 128 takes: the fused-input
+persistent forward (B >= 24, H <= 384) or the hoisted GEMM + persistent forward (H = 600), the
+reduce-scatter BPTT with twins and in-kernel bias sums, the stream-K / K-concatenated / grouped
+GEMMs, the fused separator + PIT kernels with the separator-term recompute, `fast_backward`
+accumulation into the flat bucket and the side-stream finalizers.  Every parameter gradient, the
+loss, the SNR and the permutation indices of ONE such step are compared with the float64 torch-CPU
+restatement (oracle/torch_ref.py) of main.py:208-337 + :354-358 (`compute_gradients` over all
+trainables) on the same 32 mixtures.
+
+Tolerance: gradients 2e-4 relative to the tensor's max (fp32 path vs float64 authority), loss and
+SNR 1e-4 relative, permutation indices exact.
+'''
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as R
+from test_gpu_fullsize import _setup, _synth, _cfg, relerr
+
+pytestmark = pytest.mark.gpu
+GTOL = 2e-4
+
+
+@pytest.fixture(autouse=True)
+def _lstm_status():
+    yield
+    from danet_amd import ops
+    torch.cuda.synchronize()
+    assert ops.lstm_status_ok(), 'persistent LSTM kernel reported a hand-off timeout'
+
+
+def _oracle_step(src, params, cfg):
+    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params.items()}
+    r = R.model_forward(src.cpu().to(torch.complex128), tp, cfg)
+    r['loss'].backward()
+    return r, tp
+
+
+def _train_step_vs_oracle(hp, model, src, min_checked):
+    from danet_amd import ops
+    model.keep_grads = True                  # the optimiser leaves the bucket readable
+    assert model.fuse_heads                  # the path bench.py times
+    params = model.param_dict()              # BEFORE the step (Adam moves them)
+    out = model.train_step(src)
+    torch.cuda.synchronize()
+    assert ops.lstm_status_ok()
+    t0 = time.time()
+    ref, tp = _oracle_step(src, params, _cfg(hp))
+    print('float64 oracle forward+backward: %.1f s' % (time.time() - t0))
+    assert relerr(float(out['loss']), float(ref['loss'])) < 1e-4
+    assert relerr(float(out['SNR']), float(ref['SNR'])) < 1e-4
+    g = model.grad_dict()
+    worst, checked = {}, 0
+    for k in tp:
+        if tp[k].grad is None:               # e.g. the inference estimator's anchors (main.py:362)
+            assert not np.any(g[k]), k
+            continue
+        worst[k] = relerr(g[k], tp[k].grad.numpy())
+        checked += 1
+    bad = {k: v for k, v in worst.items() if not v < GTOL}
+    print('worst gradient error: %s' % max(worst.items(), key=lambda kv: kv[1]).__repr__())
+    assert not bad, bad
+    assert checked >= min_checked, checked
+    return out, ref
+
+
+def test_cfg2_b32_train_step_gradients_vs_oracle(hp):
+    '''BASELINE configs[1] exactly as bench.py runs it: B = 32, T = 128, 3 x 300, anchor
+    estimator, dot-softmax.  13 BiLSTM tensors + W_out + anchors.'''
+    from danet_amd import _lib
+    model = _setup(hp, BATCH_SIZE=32)
+    L = _lib.load()
+    # the kernels the timed step takes at this shape
+    assert L.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 132) == 1
+    assert L.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 600) == 1
+    assert L.danet_lstm_bwd_db_supported(128, 32, 300, 2) == 1
+    src = _synth(hp, 32, 128, 1337)
+    out, ref = _train_step_vs_oracle(hp, model, src, min_checked=14)
+    # (the fused path returns the permutation through the side-stream finalizer)
+    with torch.no_grad():
+        o2 = model.forward(src, fuse_heads=True)        # parameters have moved: only a smoke check
+    assert int(o2['perm_idx'].min()) >= 0 and int(o2['perm_idx'].max()) <= 1
+
+
+def test_cfg2_b32_perm_idx_and_trajectory_vs_oracle(hp):
+    '''permutation indices of the fused path at B = 32 (read before the optimiser moves anything:
+    forward only), then THREE train steps against three float64 TF1-Adam steps of the oracle
+    (main.py:359-363): the loss trajectory must agree'''
+    model = _setup(hp, BATCH_SIZE=32)
+    src = _synth(hp, 32, 128, 2024)
+    params = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True)
+              for k, v in model.param_dict().items()}
+    with torch.no_grad():
+        o = model.forward(src, fuse_heads=True)
+        r0 = R.model_forward(src.cpu().to(torch.complex128), params, _cfg(hp))
+    assert np.array_equal(o['perm_idx'].cpu().numpy(), r0['perm_idx'].numpy())
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v = {k: torch.zeros_like(p) for k, p in params.items()}
+    for t in range(1, 4):
+        got = float(model.train_step(src)['loss'])
+        for p in params.values():
+            p.grad = None
+        r = R.model_forward(src.cpu().to(torch.complex128), params, _cfg(hp))
+        r['loss'].backward()
+        assert relerr(got, float(r['loss'])) < 2e-4, (t, got, float(r['loss']))
+        R.tf_adam_step_(params, {k: p.grad for k, p in params.items()}, m, v, t, float(hp.LR),
+                        clip=float(hp.GRAD_CLIP_THRES))
+
+
+def test_cfg4_b32_train_step_gradients_vs_oracle(hp):
+    '''BASELINE configs[3] at H = 300: C = 3, E = 40, L = 4, truth-weighted training estimator
+    (6 permutations; the separator-term recompute runs inside danet_attractor_truth_bwd_sep)'''
+    model = _setup(hp, BATCH_SIZE=32, MAX_N_SIGNAL=3, EMBED_SIZE=40, NUM_LSTM_LAYERS=4,
+                   TRAIN_ESTIMATOR_METHOD='truth-weighted')
+    src = _synth(hp, 32, 128, 4)
+    out, ref = _train_step_vs_oracle(hp, model, src, min_checked=17)
+
+
+def test_cfg4_h600_b32_train_step_gradients_vs_oracle(hp):
+    '''BASELINE configs[3] as written (4 x 600): hoisted input GEMM + persistent forward, BPTT at
+    H = 600, weight-gradient groups serial on the main stream.  Every layer's gradients (bottom
+    and top included) against the oracle.'''
+    model = _setup(hp, BATCH_SIZE=32, MAX_N_SIGNAL=3, EMBED_SIZE=40, NUM_LSTM_LAYERS=4,
+                   LSTM_HDIM=600, TRAIN_ESTIMATOR_METHOD='truth-weighted')
+    src = _synth(hp, 32, 128, 6)
+    out, ref = _train_step_vs_oracle(hp, model, src, min_checked=17)
+
+
+def test_train_loop_async_feed_equals_synchronous_loop_bit_for_bit(hp):
+    '''cli.train_epoch (main.py:413-436): the one-batch-ahead pinned feed + deferred metric reads
+    produce EXACTLY the epoch metrics and parameters of the reference's literal loop (blocking
+    upload, float() of every metric every step) on the same batches and `random` stream'''
+    import io
+    import random
+    from danet_amd import cli
+    from danet_amd.model import Model
+
+    def run(sync):
+        hp.reset()
+        hp.load(dict(BATCH_SIZE=8, MAX_N_SIGNAL=2, FFT_SIZE=256, FFT_STRIDE=64, EMBED_SIZE=20,
+                     NUM_LSTM_LAYERS=2, LSTM_HDIM=300, NUM_ANCHOR=6, MAX_TRAIN_LEN=64,
+                     ENCODER_TYPE='bilstm-orig', TRAIN_ESTIMATOR_METHOD='anchor',
+                     INFER_ESTIMATOR_METHOD='anchor', SEPARATOR_TYPE='dot-softmax-orig'))
+        hp.digest()
+        model = Model('loop', device='cuda', seed=5).build()
+        rng = np.random.RandomState(0)
+        host = []
+        for i in range(12):                      # ragged lengths: some cropped, some not
+            T = [96, 64, 80, 50][i % 4]
+            a = (rng.randn(16, T, hp.FEATURE_SIZE) + 1j * rng.randn(16, T, hp.FEATURE_SIZE))
+            host.append(((30 * a).astype(np.complex64),))
+        random.seed(9)
+        out = io.StringIO()
+        rep, n = cli.train_epoch(model, iter(host), out, sync_feed=sync)
+        model.check_status()
+        return rep, n, out.getvalue(), model._flat.detach().cpu().numpy().copy()
+
+    rep_s, n_s, ticks_s, p_s = run(True)
+    rep_a, n_a, ticks_a, p_a = run(False)
+    assert n_s == n_a == 12 and ticks_s == ticks_a == ':' * 12
+    assert list(rep_s) == list(rep_a) == ['loss', 'SNR', 'LR']
+    for k in rep_s:
+        assert rep_s[k] == rep_a[k], (k, rep_s[k], rep_a[k])       # bit for bit
+    assert np.array_equal(p_s, p_a)

@@ -260,3 +260,158 @@ def test_bench_cli_surface():
     finally:
         os.environ.clear()
         os.environ.update(env)
+
+
+# ------------------------------------------------------------------ round 4: the feed
+def _varlen_batches(hp, n, seed=3):
+    '''host batches [B*C, T_i, F] of different lengths, some real some complex (toy data is
+    real, main.py:418-421)'''
+    rng = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        T = int(rng.randint(10, 40))
+        a = rng.rand(hp.BATCH_SIZE * hp.MAX_N_SIGNAL, T, hp.FEATURE_SIZE).astype(np.float32)
+        if i % 2:
+            a = (a + 1j * rng.rand(*a.shape)).astype(np.complex64)
+        out.append((a,))
+    return out
+
+
+def test_batch_feed_threaded_equals_synchronous_loop(hp):
+    '''feed.BatchFeed: the one-batch-ahead feeder thread yields exactly the tensors of the
+    reference's synchronous loop (reshape, cast to complex64, random crop to MAX_TRAIN_LEN with
+    the SAME draws from python's `random`, main.py:417-426)'''
+    from danet_amd import feed
+    _toy_dataset(hp)
+    batches = _varlen_batches(hp, 9)
+    random.seed(11)
+    sync = [t.clone() for t in feed.BatchFeed(iter(batches), 'cpu', hp.MAX_TRAIN_LEN, threaded=False)]
+    random.seed(11)
+    thr = [t.clone() for t in feed.BatchFeed(iter(batches), 'cpu', hp.MAX_TRAIN_LEN, threaded=True)]
+    assert len(sync) == len(thr) == 9
+    for a, b, (raw,) in zip(sync, thr, batches):
+        assert a.dtype == b.dtype == torch.complex64 and torch.equal(a, b)
+        assert a.shape == (hp.BATCH_SIZE, hp.MAX_N_SIGNAL, min(raw.shape[1], hp.MAX_TRAIN_LEN),
+                           hp.FEATURE_SIZE)
+    # the reference's crop by hand (main.py:422-426) on the same random stream
+    random.seed(11)
+    for a, (raw,) in zip(sync, batches):
+        x = raw.reshape(hp.BATCH_SIZE, hp.MAX_N_SIGNAL, -1, hp.FEATURE_SIZE)
+        if x.shape[2] > hp.MAX_TRAIN_LEN:
+            beg = random.randint(0, x.shape[2] - hp.MAX_TRAIN_LEN - 1)
+            x = x[:, :, beg:beg + hp.MAX_TRAIN_LEN]
+        assert np.array_equal(a.numpy(), x.astype(np.complex64))
+
+
+def test_batch_feed_propagates_dataset_errors_and_stops(hp):
+    from danet_amd import feed
+    _toy_dataset(hp)
+
+    def bad():
+        yield _varlen_batches(hp, 1)[0]
+        raise RuntimeError('corpus file missing')
+    f = feed.BatchFeed(bad(), 'cpu', None, threaded=True)
+    it = iter(f)
+    next(it)
+    with pytest.raises(RuntimeError, match='corpus file missing'):
+        next(it)
+    assert f._thread is None                        # joined
+    # a consumer that stops early (exception in the train step) leaves no thread behind
+    f = feed.BatchFeed(iter(_varlen_batches(hp, 50)), 'cpu', None, threaded=True)
+    for i, _ in enumerate(f):
+        if i == 2:
+            break
+    f.close()
+    assert f._thread is None
+
+
+def test_step_report_equals_running_float_sum():
+    '''feed.StepReport == the reference's `dst[k] += float(v)` / `* 1/(n)` (main.py:433-436)
+    bit for bit, for device-style scalars and python floats, across a flush boundary'''
+    from danet_amd import feed
+    rng = np.random.RandomState(0)
+    vals = rng.randn(2500).astype(np.float32) * 1e3
+    rep = feed.StepReport(flush_every=1024)
+    ref = {}
+    for i, v in enumerate(vals):
+        fetch = dict(loss=torch.tensor(v), SNR=torch.tensor(np.float32(v * 0.5)), LR=3e-4)
+        rep.add(fetch)
+        for k, x in fetch.items():
+            ref[k] = ref.get(k, 0.) + float(x)
+    got = rep.mean()
+    assert list(got) == ['loss', 'SNR', 'LR']
+    for k in ref:
+        assert got[k] == ref[k] * (1. / len(vals)), k
+    nan = feed.StepReport()
+    nan.add(dict(loss=torch.tensor(float('nan'))))
+    assert nan.mean()['loss'] != nan.mean()['loss']
+
+
+_DP_FAULT_WORKER = r'''
+import collections, datetime, os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+import __graft_entry__ as g; g.load_package()
+from danet_amd import ops, _lib
+torch.distributed.init_process_group('gloo', timeout=datetime.timedelta(seconds=60))
+rank = torch.distributed.get_rank()
+assert torch.distributed.get_world_size() == 2
+# a CPU stand-in for the device's status record (ops._DeviceStatus needs pinned memory): the word
+# is the 4-float tail of a gradient bucket, as Model sets it up under data parallelism
+n = 10
+grad_store = torch.zeros(n + 4)
+st = object.__new__(ops._DeviceStatus)
+st.dev, st.own = torch.device('cuda', 0), torch.zeros(4, dtype=torch.int32)
+st.word, st.host_mapped = grad_store[n:].view(torch.int32), False
+st.slots = torch.zeros(ops.MAX_STEPS_IN_FLIGHT + 2, 4, dtype=torch.int32)
+st.queue, st.n, st.retired = collections.deque(), 0, 0
+ops._status[0] = st
+torch.cuda.synchronize = lambda *a, **k: None
+rng = np.random.RandomState(100 + rank)       # how far "this rank's GPU" happens to be: differs per rank
+
+class FakeEvent(object):
+    def query(self):
+        return bool(rng.rand() < 0.5)
+    def synchronize(self):
+        pass
+ops._record_event = lambda: FakeEvent()
+FAULT_STEP = 6
+raised_at, steps_enqueued = None, 0
+for step in range(20):
+    try:
+        ops.poll_status(st.dev)                # admission (Model.train_step's first line)
+    except _lib.DanetHipError:
+        raised_at = step
+        break
+    grad_store[:n] = float(step)               # "backward"
+    if rank == 1 and step == FAULT_STEP:
+        grad_store[n] = 1.0                    # the persistent kernel's DANET_STATUS_TIMEOUT store
+    torch.distributed.all_reduce(grad_store)   # the step's ONE gradient all-reduce carries the word
+    ops.step_done(st.dev)
+    steps_enqueued += 1
+open(os.path.join(os.environ['DP_OUT'], 'fault%%d.txt' %% rank), 'w').write(
+    '%%s %%d' %% (raised_at, steps_enqueued))
+'''
+
+
+def test_handoff_timeout_raises_at_the_same_step_on_every_rank_gloo_world2(tmp_path):
+    '''ADVICE r3 (ops.poll_status): a hand-off timeout on ONE rank is seen by all ranks through
+    the gradient all-reduce, and every rank raises DanetHipError at the admission of the SAME
+    step (fault step + MAX_STEPS_IN_FLIGHT) with the same number of collectives enqueued --
+    whatever the completion state of each rank's events'''
+    from danet_amd import ops
+    script = tmp_path / 'fault_worker.py'
+    script.write_text(_DP_FAULT_WORKER % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', DP_OUT=str(tmp_path))
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    out = subprocess.run(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+         '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
+        capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    res = [(tmp_path / ('fault%d.txt' % r)).read_text() for r in range(2)]
+    expect = '%d %d' % (6 + ops.MAX_STEPS_IN_FLIGHT, 6 + ops.MAX_STEPS_IN_FLIGHT)
+    assert res == [expect, expect], res
