@@ -136,6 +136,46 @@ def est_anchor(embed, anchors, C, return_all=False):
     return attr
 
 
+def est_kmeans(embed, anchors, C, mix_pwr=None, iters=10, eps=1e-7):
+    '''k-means attractor estimation (BASELINE cfg 5).  NOT in the reference (README.md:216) --
+    this restates what the product's extension documents, from the reference's own pieces:
+    start at the anchor estimator's attractors (app/modules.py:501-545), then `iters` Lloyd
+    iterations: assign every bin to the attractor with the largest dot product (the
+    separator's similarity, app/modules.py:587-589; ties -> lowest index like tf.argmax) and
+    recompute each attractor as the |mix|-weighted mean of its bins (the truth-weighted
+    formula, app/modules.py:476-482, with estimated assignments).'''
+    B, T, F, E = embed.shape
+    attr = est_anchor(embed, anchors, C)
+    w = torch.ones_like(embed[..., 0]) if mix_pwr is None else mix_pwr
+    ef = embed.reshape(B, -1, E)
+    for _ in range(int(iters)):
+        idx = (ef @ attr.transpose(1, 2)).argmax(dim=-1)            # [B, N]
+        onehot = torch.nn.functional.one_hot(idx, C).to(embed.dtype) * w.reshape(B, -1, 1)
+        attr = torch.einsum('bnc,bne->bce', onehot, ef) / (onehot.sum(dim=1)[..., None] + eps)
+    return attr
+
+
+def infer_forward(mix, params, cfg):
+    '''the inference fetches (main.py:384-385, :333-335, :685-690): complex mixture [B,T,F] ->
+    dict(embed, attrs, masks, sep_pwr, sep) with the inference estimator and the mixture
+    phase.  cfg['infer_est'] in ('anchor', 'kmeans' (extension)).'''
+    fe = frontend(mix[:, None])
+    H, L, E, C = cfg['H'], cfg['L'], cfg['E'], cfg['C']
+    embed = bilstm_encoder(fe['mix_log'], params, H, L, E)
+    B = embed.shape[0]
+    anchors = params['global/infer_estimator/anchors']
+    if cfg['infer_est'] == 'kmeans':
+        attrs = est_kmeans(embed, anchors, C, fe['mix_pwr'], cfg.get('kmeans_iters', 10),
+                           cfg.get('eps', 1e-7))
+    else:
+        attrs = est_anchor(embed, anchors, C)
+    act = {'dot-softmax-orig': 'softmax', 'dot-sigmoid-orig': 'sigmoid'}[cfg['separator']]
+    sep_pwr, masks = sep_dot(fe['mix_pwr'], attrs, embed.reshape(B, -1, E), act)
+    ph = fe['phase'][:, None]
+    sep = torch.complex(torch.cos(ph) * sep_pwr, torch.sin(ph) * sep_pwr)
+    return dict(embed=embed, attrs=attrs, masks=masks, sep_pwr=sep_pwr, sep=sep)
+
+
 def sep_dot(mix_pwr, attr, embed_flat, act):
     '''app/modules.py:556-603'''
     B, T, F = mix_pwr.shape

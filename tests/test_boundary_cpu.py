@@ -179,6 +179,40 @@ def test_toy_dataset_matches_reference_shape(hp):
     assert abs(np.sqrt(np.mean(waves[0] ** 2)) - 1000.0) < 1.0
 
 
+def test_toy_dataset_stream_against_reference_golden(hp):
+    '''the `toy` generator's STREAM (not just its shape) against arrays produced by the
+    reference's own app/datasets/dataset.py:43-63 under np.random.seed(1337)
+    (tests/golden/make_golden_toy.py -> toy_ref.npz): bit-exact, float32, 10 batches per
+    epoch, the next epoch continues the same numpy stream, unloaded -> RuntimeError'''
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'toy_ref.npz'))
+    hp.load(dict(DATASET_TYPE='toy', FFT_SIZE=8, FFT_STRIDE=2))
+    hp.digest()
+    assert hp.FEATURE_SIZE == 5
+    ds = hp.get_dataset()()
+    assert int(gold['unloaded_raises']) == 1
+    with pytest.raises(RuntimeError):
+        next(ds.epoch('train', 4))
+    ds.install_and_load()
+    np.random.seed(1337)
+    ep = np.stack([b for (b,) in ds.epoch('train', 4, shuffle=True)])
+    assert ep.dtype == np.float32 and np.array_equal(ep, gold['toy_f5_seed1337'])
+    nxt, = next(ds.epoch('valid', 4))
+    assert np.array_equal(nxt, gold['toy_f5_seed1337_second_epoch_first'])
+    # BASELINE cfg 1's shape (F = 129, B*C = 8)
+    hp.reset()
+    hp.load(dict(DATASET_TYPE='toy'))
+    hp.digest()
+    ds = hp.get_dataset()()
+    ds.install_and_load()
+    np.random.seed(1337)
+    ep = [b for (b,) in ds.epoch('train', 8)]
+    assert len(ep) == int(gold['toy_f129_n_batches'])
+    assert tuple(ep[0].shape) == tuple(gold['toy_f129_shape']) and str(ep[0].dtype) == str(gold['toy_f129_dtype'])
+    assert np.array_equal(np.array([b.astype(np.float64).sum() for b in ep]), gold['toy_f129_sums'])
+    assert np.array_equal(ep[0][:, 0, :], gold['toy_f129_first_rows'])
+    assert np.array_equal(ep[-1][:, -1, :], gold['toy_f129_last_rows'])
+
+
 # -------------------------------------------------- data parallel (gloo, N=2)
 _DP_WORKER = r'''
 import os, sys

@@ -453,7 +453,8 @@ def test_cfg4_as_written_4x600_model_level(hp):
 def test_cfg5_kmeans_at_full_length(hp):
     '''cfg 5 with the k-means estimator at T = 1251 (16 kHz, FFT 512/128, B = 1).  The
     estimator is an extension (README.md:216: not in the reference), so it is checked
-    against a literal numpy statement of what modules.KMeansEstimator documents: start from
+    against the oracle's float64 restatement (oracle/torch_ref.py est_kmeans) of what
+    modules.KMeansEstimator documents: start from
     the anchor estimator's attractors, KMEANS_ITERS times assign every bin to the attractor
     with the largest dot product and recompute |mix|-weighted means.  On an embedding with
     two well-separated clusters that ends at the weighted cluster means whenever both
@@ -475,13 +476,13 @@ def test_cfg5_kmeans_at_full_length(hp):
     got = model.valid_estimator(cu(emb), s_mix_pwr=cu(w)).cpu().numpy()[0]      # [2, E]
     anchors = model.vars['global/infer_estimator/anchors']
     a_attr, _, _ = ops.AnchorAttractorFn.apply(cu(emb), anchors.detach(), 2)
-    attr = a_attr.cpu().numpy()[0].astype(np.float64)
+    # the oracle's float64 restatement of the extension (oracle/torch_ref.py est_kmeans)
+    from oracle import torch_ref as R
+    attr = R.est_kmeans(torch.tensor(emb, dtype=torch.float64),
+                        anchors.detach().cpu().double(), 2, torch.tensor(w, dtype=torch.float64),
+                        int(hp.KMEANS_ITERS), float(hp.EPS))[0].numpy()
     ef, wf = emb.reshape(-1, E).astype(np.float64), w.reshape(-1).astype(np.float64)
-    for _ in range(int(hp.KMEANS_ITERS)):
-        idx = np.argmax(ef @ attr.T, axis=1)
-        attr = np.stack([(ef[idx == c] * wf[idx == c][:, None]).sum(0) / (wf[idx == c].sum() + hp.EPS)
-                         for c in range(2)])
-    assert relerr(got, attr) < 1e-3
+    assert relerr(got, attr) < 1e-4
     truth = np.stack([(ef[assign.reshape(-1) == c] * wf[assign.reshape(-1) == c][:, None]).sum(0)
                       / (wf[assign.reshape(-1) == c].sum() + hp.EPS) for c in range(2)])
     if len(set(np.argmax(truth @ a_attr.cpu().numpy()[0].T.astype(np.float64), axis=1))) == 2:
