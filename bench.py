@@ -548,8 +548,7 @@ def run_train(args, cfg, hp, device, rank, world, use_dist):
     L_ = _lib.load()
     Ds = [F if l == 0 else 2 * H for l in range(L)]
     fwd_fused = [L_.danet_lstm_fwd_fused_supported(T, B, H, 2, D) == 1 for D in Ds]
-    bwd_fused = [ops.bptt_fused(T, B, H, 2, D, need_dx=(l > 0), is_top=(l == L - 1))
-                 for l, D in enumerate(Ds)]
+    bwd_fused = [False] * L          # (weight gradients are never fused into BPTT: EXPERIMENTS.md)
     rec = 2.0 * 2 * B * T * H * 4 * H
     flops = dict(
         lstm_fwd=sum(rec + (2.0 * 2 * B * T * D * 4 * H if f else 0.0) for D, f in zip(Ds, fwd_fused)) / L,
@@ -561,9 +560,7 @@ def run_train(args, cfg, hp, device, rank, world, use_dist):
     achieved = flops[dom] / (ms / n * 1e-3) / 1e12
     # kernel symbol behind the label (csrc/lstm.hip)
     ksym = {'lstm_fwd': 'lstm_fwd_fx_kernel' if any(fwd_fused) else 'lstm_fwd_kernel',
-            'lstm_bwd': 'lstm_bwd_rsw_kernel' if any(bwd_fused) else
-                        ('lstm_bwd_kernel' if _lib.get_option('lstm_bwd_rs') == 0
-                         else 'lstm_bwd_rs_kernel')}[dom]
+            'lstm_bwd': 'lstm_bwd_rs_kernel'}[dom]
     traffic, tsrc = pmc_traffic(ksym)
     if tsrc is not None and tsrc.get('workload', 'cfg2') != args.config:
         traffic, tsrc = None, None

@@ -33,24 +33,15 @@ PROTOTYPES = {
     'danet_reset_options': (None, []),
     'danet_option_count': (c_int, []),
     'danet_option_name': (ctypes.c_char_p, [c_int]),
+    'danet_workspace_bytes': (c_sz, [c_int, ctypes.POINTER(c_i64), c_int]),
     'danet_stft_num_frames': (c_int, [c_i64, c_int, c_int]),
     'danet_stft': (c_int, [c_p, c_int, c_i64, c_int, c_int, c_p, c_p, c_p]),
-    'danet_istft_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int]),
     'danet_istft': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_sz]),
     'danet_frontend_fwd': (c_int, [c_p, c_int, c_int, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'danet_reattach_phase': (c_int, [c_p, c_int, c_int, c_i64, c_p, c_p, c_p, c_p]),
-    'danet_center_mean_elems': (c_int, [c_int]),
     'danet_center': (c_int, [c_p, c_int, c_int, c_int, c_p, c_int, c_int, c_p, c_int, c_int, c_p]),
-    'danet_gemm_f32_workspace_bytes': (c_sz, [c_int, c_int, c_int]),
     'danet_gemm_f32': (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_int,
-                               c_p, c_int, c_p, c_f32, c_p, c_sz]),
-    'danet_gemm_f32_ex': (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_int,
-                                  c_p, c_int, c_p, c_f32, c_p, c_sz, c_int]),
-    'danet_gemm_f32_kcat_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int]),
-    'danet_gemm_f32_kcat': (c_int, [c_p, c_int, c_int, c_int, c_int,
-                                    c_int, c_p, c_int, c_p, c_int, c_int, c_p, c_int, c_p, c_int,
-                                    c_p, c_int, c_p, c_f32, c_p, c_sz]),
-    'danet_gemm_f32_streamk_workspace_bytes': (c_sz, [c_int, c_int, c_int]),
+                               c_p, c_int, c_p, c_f32, c_p, c_sz, c_int]),
     'danet_gemm_f32_streamk': (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_int,
                                        c_p, c_int, c_p, c_f32, c_p, c_sz]),
     'danet_gemm_f32_streamk_grouped': (c_int, [c_p, c_int, c_int, c_int, c_int,
@@ -58,39 +49,25 @@ PROTOTYPES = {
     'danet_gemm_f32_streamk_kcat': (c_int, [c_p, c_int, c_int, c_int, c_int,
                                             c_int, c_p, c_int, c_p, c_int, c_int, c_p, c_int, c_p, c_int,
                                             c_p, c_int, c_p, c_f32, c_p, c_sz]),
-    'danet_colsum_f32_workspace_bytes': (c_sz, [c_int, c_int]),
     'danet_colsum_f32': (c_int, [c_p, c_int, c_int, c_p, c_int, c_p, c_f32, c_p, c_sz]),
-    'danet_lstm_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int]),
     'danet_lstm_fwd': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_int,
                                c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_sz, c_p, c_int]),
     'danet_lstm_fwd_prefill': (c_int, [c_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_p),
                                        ctypes.POINTER(c_p)]),
     'danet_lstm_bwd_prefill': (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_p)]),
     'danet_lstm_fwd_fused_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    'danet_lstm_fwd_fused_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'danet_lstm_fwd_fused': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_int, c_p, c_p,
                                      c_int, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_sz, c_p,
                                      c_int]),
     'danet_lstm_bwd': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_int,
-                               c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+                               c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_sz, c_p, c_int]),
     'danet_lstm_bwd_db_supported': (c_int, [c_int, c_int, c_int, c_int]),
-    'danet_lstm_bwd_db': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_int,
-                                  c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_sz, c_p, c_int]),
     'danet_lstm_bwd_db_reduce': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p, c_f32, c_p, c_sz]),
     'danet_gemm_next_launch_stop_event': (c_int, [c_p]),
     'danet_event_create': (c_int, [ctypes.POINTER(c_p)]),
     'danet_event_destroy': (c_int, [c_p]),
     'danet_stream_wait_event': (c_int, [c_p, c_p]),
-    'danet_lstm_bwd_fused_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
-    'danet_lstm_bwd_fused_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int, c_int]),
-    'danet_lstm_bwd_fused': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_int,
-                                     c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_p, c_int, c_p, c_p,
-                                     c_p, c_p, c_p, c_p, c_f32, c_p, c_sz, c_p]),
-    'danet_lstm_bwd_fused_h_supported': (c_int, [c_int, c_int, c_int, c_int]),
-    'danet_lstm_bwd_fused_h_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int]),
-    'danet_lstm_bwd_fused_h': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_p, c_p, c_int,
-                                       c_p, c_p, c_p, c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_p,
-                                       c_f32, c_p, c_sz, c_p]),
-    'danet_attractor_truth_workspace_bytes': (c_sz, [c_int, c_int, c_i64, c_int]),
     'danet_attractor_truth_fwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p,
                                           c_f32, c_p, c_p, c_p, c_sz]),
     'danet_attractor_truth_bwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p,
@@ -98,21 +75,15 @@ PROTOTYPES = {
     'danet_attractor_truth_bwd_sep': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p, c_p,
                                               c_f32, c_p, c_p, c_int, c_int, c_p, c_p, c_p, c_p, c_f32,
                                               c_p, c_p]),
-    'danet_attractor_anchor_workspace_bytes': (c_sz, [c_int, c_int, c_i64, c_int, c_int]),
     'danet_attractor_anchor_fwd': (c_int, [c_p, c_int, c_int, c_i64, c_int, c_int, c_p, c_p, c_p,
                                            c_p, c_p, c_p, c_p, c_sz]),
-    'danet_attractor_anchor_bwd': (c_int, [c_p, c_int, c_int, c_i64, c_int, c_int, c_p, c_p, c_p,
-                                           c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_f32]),
     'danet_separate_fwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p, c_p, c_p]),
-    'danet_separate_bwd_workspace_bytes': (c_sz, [c_int, c_int, c_i64, c_int]),
     'danet_separate_bwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p, c_p,
                                    c_p, c_p, c_p, c_sz]),
-    'danet_separate_pit_workspace_bytes': (c_sz, [c_int, c_int, c_i64, c_int]),
-    'danet_separate_pit_fwd': (c_int, [c_p, c_int, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p,
-                                       c_p, c_p, c_f32, c_p, c_p, c_p, c_p, c_p, c_sz]),
     'danet_separate_pit_bwd': (c_int, [c_p, c_int, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p,
                                        c_p, c_p, c_p, c_p, c_f32, c_p, c_p, c_p, c_p, c_sz]),
-    'danet_separate_pit_records_bytes': (c_sz, [c_int, c_i64]),
+    'danet_separate_pit_bwd': (c_int, [c_p, c_int, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p,
+                                       c_p, c_p, c_p, c_p, c_f32, c_p, c_p, c_p, c_p, c_sz]),
     'danet_separate_pit_fwd_records': (c_int, [c_p, c_int, c_int, c_int, c_int, c_i64, c_int, c_p, c_p,
                                                c_p, c_p, c_p, c_p, c_p]),
     'danet_separate_pit_final': (c_int, [c_p, c_int, c_int, c_i64, c_f32, c_p, c_p, c_p, c_p]),
@@ -123,7 +94,6 @@ PROTOTYPES = {
                                                      c_f32, c_p, c_p, c_p, c_sz]),
     'danet_attractor_anchor_bwd_anchors': (c_int, [c_p, c_int, c_int, c_i64, c_int, c_int, c_p, c_p,
                                                    c_p, c_sz, c_f32]),
-    'danet_pit_mse_workspace_bytes': (c_sz, [c_int, c_int, c_i64]),
     'danet_pit_mse_fwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_p, c_p, c_p, c_f32, c_p,
                                   c_p, c_p, c_p, c_sz]),
     'danet_pit_mse_bwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_p, c_p, c_p, c_p, c_f32, c_p, c_p]),
@@ -160,7 +130,7 @@ def load():
             fn = getattr(lib, name)      # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.danet_abi_version() != 3:
+        if lib.danet_abi_version() != 4:
             raise DanetHipError('libdanet_hip.so ABI version mismatch')
         _lib = lib
         apply_env_options()
@@ -201,6 +171,20 @@ def check(rc):
         msg = load().danet_last_error()
         raise DanetHipError('libdanet_hip error %d: %s' % (
             rc, msg.decode() if msg else '?'))
+
+
+# DANET_WS_* (include/danet_hip.h)
+(WS_ISTFT, WS_GEMM, WS_GEMM_STREAMK, WS_COLSUM, WS_LSTM, WS_ATTRACTOR_TRUTH, WS_ATTRACTOR_ANCHOR,
+ WS_SEPARATE_BWD, WS_SEPARATE_PIT, WS_SEPARATE_PIT_RECORDS, WS_PIT_MSE, WS_CENTER_MEAN) = range(12)
+
+
+def ws_bytes(op, *dims):
+    '''danet_workspace_bytes(op, dims): scratch bytes of the entry point behind DANET_WS_<op>'''
+    arr = (c_i64 * len(dims))(*[int(d) for d in dims])
+    n = load().danet_workspace_bytes(op, arr, len(dims))
+    if n == ctypes.c_size_t(-1).value:
+        check(-1)
+    return n
 
 
 def ptr(t):

@@ -1375,7 +1375,7 @@ static int check_common(const char* who, int B, int C, int64_t N, int E) {
   return DANET_OK;
 }
 
-extern "C" size_t danet_attractor_truth_workspace_bytes(int B, int C, int64_t N, int E) {
+size_t dn_ws_attractor_truth(int B, int C, int64_t N, int E) {
   const int EP = pick_ep(E);
   return (size_t)B * n_chunks(N) * C * (EP + 1) * sizeof(float);
 }
@@ -1390,7 +1390,7 @@ extern "C" int danet_attractor_truth_fwd(danet_stream_t stream_, int mode, int B
   DANET_CHECK_ARG(mode >= 0 && mode <= 2, "attractor_truth_fwd: mode");
   DANET_CHECK_ARG(embed && src_pwr && attr && denom && (mode == 0 || mix_pwr),
                   "attractor_truth_fwd: null pointer");
-  if (!ws || ws_bytes < danet_attractor_truth_workspace_bytes(B, C, N, E)) {
+  if (!ws || ws_bytes < dn_ws_attractor_truth(B, C, N, E)) {
     danet_set_error("attractor_truth_fwd: workspace too small");
     return DANET_ERR_WORKSPACE;
   }
@@ -1472,7 +1472,7 @@ extern "C" int danet_separate_fwd(danet_stream_t stream_, int act, int B, int C,
   return DANET_OK;
 }
 
-extern "C" size_t danet_separate_bwd_workspace_bytes(int B, int C, int64_t N, int E) {
+size_t dn_ws_separate_bwd(int B, int C, int64_t N, int E) {
   return (size_t)B * n_chunks(N) * C * pick_ep(E) * sizeof(float);
 }
 
@@ -1485,7 +1485,7 @@ extern "C" int danet_separate_bwd(danet_stream_t stream_, int act, int B, int C,
   if (rc) return rc;
   DANET_CHECK_ARG(act == 0 || act == 1, "separate_bwd: act");
   DANET_CHECK_ARG(mix_pwr && attr && embed && dout && dembed && dattr, "separate_bwd: null pointer");
-  if (!ws || ws_bytes < danet_separate_bwd_workspace_bytes(B, C, N, E)) {
+  if (!ws || ws_bytes < dn_ws_separate_bwd(B, C, N, E)) {
     danet_set_error("separate_bwd: workspace too small");
     return DANET_ERR_WORKSPACE;
   }
@@ -1499,18 +1499,18 @@ extern "C" int danet_separate_bwd(danet_stream_t stream_, int act, int B, int C,
   return DANET_OK;
 }
 
-extern "C" size_t danet_separate_pit_workspace_bytes(int B, int C, int64_t N, int E) {
+size_t dn_ws_separate_pit(int B, int C, int64_t N, int E) {
   const size_t fwd = (size_t)B * n_chunks(N) * REC * sizeof(float);
   const size_t bwd = (size_t)B * n_chunks(N) * C * pick_ep(E) * sizeof(float);
   return fwd > bwd ? fwd : bwd;
 }
 
 // The forward in two stream-ordered parts: part 1 writes the per-chunk cross-error records
-// (`records`, danet_separate_pit_records_bytes, caller-owned: the backward reads them again),
+// (`records`, dn_ws_separate_pit_records, caller-owned: the backward reads them again),
 // part 2 turns them into loss / SNR / permutation index.  The backward derives each utterance's
 // permutation from the records itself (same sums, same order), so part 2 is not on the
 // critical path between forward and backward: a host may issue it on another stream.
-extern "C" size_t danet_separate_pit_records_bytes(int B, int64_t N) {
+size_t dn_ws_separate_pit_records(int B, int64_t N) {
   return (size_t)B * n_chunks(N) * REC * sizeof(float);
 }
 
@@ -1546,23 +1546,6 @@ extern "C" int danet_separate_pit_final(danet_stream_t stream_, int B, int C, in
   return DANET_OK;
 }
 
-extern "C" int danet_separate_pit_fwd(danet_stream_t stream_, int act, int mode, int B, int C,
-                                      int64_t N, int E, const float* mix_pwr, const float* attr,
-                                      const float* embed, const float* src_c64,
-                                      const float* phasor, float eps, float* sep_pwr_out,
-                                      float* loss, float* snr, int32_t* perm_idx, void* ws,
-                                      size_t ws_bytes) {
-  DANET_CHECK_ARG(loss && perm_idx, "separate_pit_fwd: null pointer");
-  if (!ws || ws_bytes < danet_separate_pit_workspace_bytes(B, C, N, E)) {
-    danet_set_error("separate_pit_fwd: workspace too small");
-    return DANET_ERR_WORKSPACE;
-  }
-  int rc = danet_separate_pit_fwd_records(stream_, act, mode, B, C, N, E, mix_pwr, attr, embed,
-                                          src_c64, phasor, sep_pwr_out, (float*)ws);
-  if (rc) return rc;
-  return danet_separate_pit_final(stream_, B, C, N, eps, (const float*)ws, loss, snr, perm_idx);
-}
-
 extern "C" int danet_separate_pit_bwd(danet_stream_t stream_, int act, int mode, int B, int C,
                                       int64_t N, int E, const float* mix_pwr, const float* attr,
                                       const float* embed, const float* src_c64,
@@ -1578,7 +1561,7 @@ extern "C" int danet_separate_pit_bwd(danet_stream_t stream_, int act, int mode,
   // separator's contribution to dembed: danet_attractor_anchor_bwd_embed_sep)
   DANET_CHECK_ARG(mix_pwr && attr && embed && src_c64 && phasor && (perm_idx || records) && dattr,
                   "separate_pit_bwd: null pointer (one of perm_idx / records is required)");
-  if (!ws || ws_bytes < danet_separate_pit_workspace_bytes(B, C, N, E)) {
+  if (!ws || ws_bytes < dn_ws_separate_pit(B, C, N, E)) {
     danet_set_error("separate_pit_bwd: workspace too small");
     return DANET_ERR_WORKSPACE;
   }
@@ -1610,7 +1593,7 @@ static int n_combos(int A, int C) {
   return (int)r;
 }
 
-extern "C" size_t danet_attractor_anchor_workspace_bytes(int B, int C, int64_t N, int E, int A) {
+size_t dn_ws_attractor_anchor(int B, int C, int64_t N, int E, int A) {
   const int EP = pick_ep(E), P = n_combos(A, C);
   const size_t fwd = (size_t)B * n_chunks_anchor_fwd(N) * P * C * (EP + 4) * sizeof(float);
   const size_t bwd = (size_t)B * n_chunks(N) * C * EP * sizeof(float);
@@ -1626,7 +1609,7 @@ extern "C" int danet_attractor_anchor_fwd(danet_stream_t stream_, int B, int C, 
   if (rc) return rc;
   DANET_CHECK_ARG(embed && anchors && attr && asets && asum && choice,
                   "attractor_anchor_fwd: null pointer");
-  if (!ws || ws_bytes < danet_attractor_anchor_workspace_bytes(B, C, N, E, A)) {
+  if (!ws || ws_bytes < dn_ws_attractor_anchor(B, C, N, E, A)) {
     danet_set_error("attractor_anchor_fwd: workspace too small");
     return DANET_ERR_WORKSPACE;
   }
@@ -1640,7 +1623,7 @@ extern "C" int danet_attractor_anchor_fwd(danet_stream_t stream_, int B, int C, 
   const int nch = n_chunks_anchor_fwd(N);
   // the [PC][EPA] contraction runs on the matrix cores when it fits 2 x 2 tiles of 32 x 32
   int RT = 0, CT = 0;
-  if (PC <= 64 && EPA <= 64 && danet_opt(OPT_ANCHOR_SCALAR) == 0) { RT = cdiv(PC, 32); CT = cdiv(EPA, 32); }
+  if (PC <= 64 && EPA <= 64) { RT = cdiv(PC, 32); CT = cdiv(EPA, 32); }
   size_t lds = ((size_t)ANCH_TN * EPA + (size_t)ANCH_TN * (PC + 1) + (size_t)A * EPV + 64) * sizeof(float);
   const size_t lds_red = (size_t)ANCH_NW * RT * 32 * CT * 32 * sizeof(float);
   if (lds_red > lds) lds = lds_red;
@@ -1678,7 +1661,7 @@ extern "C" int danet_attractor_anchor_bwd_embed(danet_stream_t stream_, int B, i
   if (rc) return rc;
   DANET_CHECK_ARG(dattr && embed && anchors && attr && asum && choice && dembed,
                   "attractor_anchor_bwd: null pointer");
-  if (!ws || ws_bytes < danet_attractor_anchor_workspace_bytes(B, C, N, E, A)) {
+  if (!ws || ws_bytes < dn_ws_attractor_anchor(B, C, N, E, A)) {
     danet_set_error("attractor_anchor_bwd: workspace too small");
     return DANET_ERR_WORKSPACE;
   }
@@ -1708,7 +1691,7 @@ extern "C" int danet_attractor_anchor_bwd_embed_sep(
   DANET_CHECK_ARG(dattr && embed && anchors && attr && asum && choice && dembed && mix_pwr && src_c64 &&
                   phasor && (perm_idx || records), "attractor_anchor_bwd_embed_sep: null pointer");
   DANET_CHECK_ARG((act == 0 || act == 1) && (mode == 0 || mode == 1), "attractor_anchor_bwd_embed_sep: act / mode");
-  if (!ws || ws_bytes < danet_attractor_anchor_workspace_bytes(B, C, N, E, A)) {
+  if (!ws || ws_bytes < dn_ws_attractor_anchor(B, C, N, E, A)) {
     danet_set_error("attractor_anchor_bwd: workspace too small");
     return DANET_ERR_WORKSPACE;
   }
@@ -1733,7 +1716,7 @@ extern "C" int danet_attractor_anchor_bwd_anchors(danet_stream_t stream_, int B,
   if (rc) return rc;
   DANET_CHECK_ARG(choice && danchors, "attractor_anchor_bwd: null pointer");
   DANET_CHECK_ARG(danchors_beta == 0.f || danchors_beta == 1.f, "attractor_anchor_bwd: beta must be 0 or 1");
-  if (!ws || ws_bytes < danet_attractor_anchor_workspace_bytes(B, C, N, E, A)) {
+  if (!ws || ws_bytes < dn_ws_attractor_anchor(B, C, N, E, A)) {
     danet_set_error("attractor_anchor_bwd: workspace too small");
     return DANET_ERR_WORKSPACE;
   }
@@ -1744,18 +1727,4 @@ extern "C" int danet_attractor_anchor_bwd_anchors(danet_stream_t stream_, int B,
                                                  choice, danchors, danchors_beta);
   DANET_CHECK_LAUNCH();
   return DANET_OK;
-}
-
-extern "C" int danet_attractor_anchor_bwd(danet_stream_t stream_, int B, int C, int64_t N, int E,
-                                          int A, const float* dattr, const float* embed,
-                                          const float* anchors, const float* attr,
-                                          const float* asum, const int32_t* choice,
-                                          float* dembed, float* danchors, void* ws,
-                                          size_t ws_bytes, float danchors_beta) {
-  DANET_CHECK_ARG(danchors, "attractor_anchor_bwd: null pointer");
-  int rc = danet_attractor_anchor_bwd_embed(stream_, B, C, N, E, A, dattr, embed, anchors, attr, asum,
-                                            choice, dembed, ws, ws_bytes);
-  if (rc) return rc;
-  return danet_attractor_anchor_bwd_anchors(stream_, B, C, N, E, A, choice, danchors, ws, ws_bytes,
-                                            danchors_beta);
 }

@@ -692,24 +692,9 @@ static int choose_splitk(int M, int N, int K) {
   return s < 1 ? 1 : s;
 }
 
-extern "C" size_t danet_gemm_f32_workspace_bytes(int M, int N, int K) {
+size_t dn_ws_gemm(int M, int N, int K) {
   const int s = choose_splitk(M, N, K);
   return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
-}
-
-extern "C" int danet_gemm_f32_ex(danet_stream_t stream_, int transA, int transB,
-                                 int M, int N, int K, const float* A, int lda,
-                                 const float* B, int ldb, float* C, int ldc,
-                                 const float* bias, float beta, void* ws,
-                                 size_t ws_bytes, int max_workgroups);
-
-extern "C" int danet_gemm_f32(danet_stream_t stream_, int transA, int transB,
-                              int M, int N, int K, const float* A, int lda,
-                              const float* B, int ldb, float* C, int ldc,
-                              const float* bias, float beta, void* ws,
-                              size_t ws_bytes) {
-  return danet_gemm_f32_ex(stream_, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, beta,
-                           ws, ws_bytes, 0);
 }
 
 // the kernels address an operand through one 32-bit buffer view per tile
@@ -788,29 +773,13 @@ static int gemm_launch(hipStream_t stream, int transA, int transB, int M, int N,
   return DANET_OK;
 }
 
-extern "C" int danet_gemm_f32_ex(danet_stream_t stream_, int transA, int transB,
-                                 int M, int N, int K, const float* A, int lda,
-                                 const float* B, int ldb, float* C, int ldc,
-                                 const float* bias, float beta, void* ws,
-                                 size_t ws_bytes, int max_workgroups) {
+extern "C" int danet_gemm_f32(danet_stream_t stream_, int transA, int transB,
+                              int M, int N, int K, const float* A, int lda,
+                              const float* B, int ldb, float* C, int ldc,
+                              const float* bias, float beta, void* ws,
+                              size_t ws_bytes, int max_workgroups) {
   return gemm_launch((hipStream_t)stream_, transA, transB, M, N, K, A, lda, B, ldb,
                      0, nullptr, 0, nullptr, 0, C, ldc, bias, beta, ws, ws_bytes, max_workgroups);
-}
-
-extern "C" size_t danet_gemm_f32_kcat_workspace_bytes(int M, int N, int K1, int K2) {
-  int s = choose_splitk(M, N, K1 + K2);
-  if (s < 2) s = 2;
-  return (size_t)(s + 2) * M * N * sizeof(float);   // chunk rounding can add a slice per pair
-}
-
-extern "C" int danet_gemm_f32_kcat(danet_stream_t stream_, int transA, int transB, int M, int N,
-                                   int K1, const float* A1, int lda1, const float* B1, int ldb1,
-                                   int K2, const float* A2, int lda2, const float* B2, int ldb2,
-                                   float* C, int ldc, const float* bias, float beta,
-                                   void* ws, size_t ws_bytes) {
-  DANET_CHECK_ARG(K2 > 0, "gemm_kcat: K2 must be positive");
-  return gemm_launch((hipStream_t)stream_, transA, transB, M, N, K1, A1, lda1, B1, ldb1,
-                     K2, A2, lda2, B2, ldb2, C, ldc, bias, beta, ws, ws_bytes, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -1049,7 +1018,7 @@ static int sk_grid(int tiles, int nk, int max_workgroups) {
 #define SK_MAX_GRID 1024
 #define SK_HEADER (SK_MAX_GRID * sizeof(unsigned))
 
-extern "C" size_t danet_gemm_f32_streamk_workspace_bytes(int M, int N, int K) {
+size_t dn_ws_gemm_streamk(int M, int N, int K) {
   (void)M; (void)N; (void)K;
   return SK_HEADER + (size_t)SK_MAX_GRID * 65536;   // flags + one partial tile per workgroup
 }
@@ -1200,7 +1169,7 @@ extern "C" int danet_gemm_f32_streamk_grouped(danet_stream_t stream_, int transA
 // C = op(A1) op(B1) + op(A2) op(B2) (+bias) (+beta C) on the hybrid stream-K schedule: the two
 // operand pairs are one K-concatenated contraction (k-iterations of pair 1, then of pair 2,
 // continuing the same accumulators), so there are no per-pair slabs and no reduce kernel.
-// K1 must be a multiple of 16.  Workspace: danet_gemm_f32_streamk_workspace_bytes.
+// K1 must be a multiple of 16.  Workspace: dn_ws_gemm_streamk.
 extern "C" int danet_gemm_f32_streamk_kcat(danet_stream_t stream_, int transA, int transB, int M, int N,
                                            int K1, const float* A1, int lda1, const float* B1, int ldb1,
                                            int K2, const float* A2, int lda2, const float* B2, int ldb2,

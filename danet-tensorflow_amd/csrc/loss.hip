@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void pit_bwd_kernel(
   }
 }
 
-extern "C" size_t danet_pit_mse_workspace_bytes(int B, int C, int64_t N) {
+size_t dn_ws_pit_mse(int B, int C, int64_t N) {
   (void)C;
   return (size_t)B * loss_chunks(N) * REC * sizeof(float);
 }
@@ -105,7 +105,7 @@ extern "C" int danet_pit_mse_fwd(danet_stream_t stream_, int mode, int B, int C,
   DANET_CHECK_ARG(B > 0 && B <= 65535 && C > 0 && C <= MAXC && N > 0, "pit_mse_fwd: bad shape");
   DANET_CHECK_ARG(mode == 0 || mode == 1, "pit_mse_fwd: mode");
   DANET_CHECK_ARG(src_c64 && sep_pwr && phasor && loss && perm_idx, "pit_mse_fwd: null pointer");
-  if (!ws || ws_bytes < danet_pit_mse_workspace_bytes(B, C, N)) {
+  if (!ws || ws_bytes < dn_ws_pit_mse(B, C, N)) {
     danet_set_error("pit_mse_fwd: workspace too small");
     return DANET_ERR_WORKSPACE;
   }

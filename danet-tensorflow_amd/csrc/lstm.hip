@@ -38,10 +38,8 @@
 #include <stdlib.h>
 
 #define LSTM_UNITS_FWD 8    // hidden units per workgroup (x4 gates = 32 columns)
-#define LSTM_UNITS_BWD 16   // hidden units per workgroup in BPTT
 #define SPIN_LIMIT (1u << 20)
 #define FWD_CH 5            // k-groups (16 k each) per wave whose loads fly together
-#define BWD_CH 19
 #define SENTINEL 0xFFFFFFFFu
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -71,19 +69,6 @@ struct LstmFwdArgs {
   int xmap;   // consecutive block ids cycle over the clusters (placement, see kernel)
   unsigned spin_limit;   // bound of every inter-workgroup wait (validation passes)
   int fault;             // test hook: workgroup 0 exits without publishing (forces a timeout)
-};
-
-struct LstmBwdArgs {
-  const float* dy;
-  const float* Wh[2];
-  const float* gates[2];
-  const float* cell[2];
-  float* da[2];
-  int* status;
-  int T, B, H, ndir, lddy, ldw, P, G, R;   // R = batch rows per cluster (<= 16*MT)
-  int xmap;
-  unsigned spin_limit;
-  int fault;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
@@ -524,7 +509,6 @@ struct LstmFwdFxArgs {
   int xmap;
   unsigned spin_limit;
   int fault;
-  int mode;
 };
 
 #ifndef FX_CHA_NUM
@@ -852,193 +836,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// backward (BPTT)
-// ---------------------------------------------------------------------------
-// NW waves per workgroup split K: 4 (one per SIMD) or 8 -- the MFMA pipe is per
-// SIMD so 8 waves do not speed the MFMA phase up, but each wave then issues half
-// the exchange loads, and sc1 reads of remotely written lines are bound per wave.
-template <int MT, int NW>
-__global__ __launch_bounds__(64 * NW) void lstm_bwd_kernel(LstmBwdArgs a) {
-  constexpr int CH = (BWD_CH * 4 + NW - 1) / NW;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  // smem: weights^T [4H/4][16][4] | red [NW waves][16*MT][17]
-  const int H = a.H, B = a.B, T = a.T, H4 = 4 * a.H;
-  float* Wl = smem;
-  float* red = smem + (size_t)H4 * 16;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bid = blockIdx.x;
-  if (a.fault && bid == 0) return;   // test hook
-  const int ncl = a.ndir * a.G;
-  const int cl = a.xmap ? bid % ncl : bid / a.P;
-  const int dir = cl / a.G, grp = cl % a.G;
-  const int p = a.xmap ? bid / ncl : bid % a.P;
-  const int u0 = p * LSTM_UNITS_BWD;
-  const int b0 = grp * a.R;
-
-  // stationary Wh^T slice: element (n, j) = Wh[u0+j][n] at ((n/4)*16 + j)*4 + n%4
-  {
-    const float* W = a.Wh[dir];
-    for (int idx = tid; idx < H4 * 16; idx += 64 * NW) {
-      const int j = idx / H4, n = idx % H4;   // n fastest -> coalesced row reads
-      float v = 0.f;
-      if (u0 + j < H) v = W[(size_t)(u0 + j) * a.ldw + n];
-      Wl[((n >> 2) * 16 + j) * 4 + (n & 3)] = v;
-    }
-  }
-  __syncthreads();
-
-  const unsigned dbytes = (unsigned)((size_t)T * B * H4 * sizeof(float));
-  const __amdgpu_buffer_rsrc_t dres = make_rsrc(a.da[dir], dbytes);
-
-  // ownership: thread -> pairs (bl = tid/16 + 16*i, unit j = tid%16), i < MT
-  const int jl = tid & 15, unit = u0 + jl;
-  float dc_state[MT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) dc_state[i] = 0.f;
-
-  const int fr = lane & 15, fq = lane >> 4;
-  const int NG = H4 / 16;
-
-  // stationary Wh^T fragments of the wave's first CH k-groups in registers
-  // (see forward kernel); later chunks (H > 304) read LDS
-  f32x4 wreg[CH];
-#pragma unroll
-  for (int g = 0; g < CH; ++g) {
-    const int kg = g * NW + wave;
-    wreg[g] = *reinterpret_cast<const f32x4*>(&Wl[(((kg < NG ? kg : 0) * 4 + fq) * 16 + fr) * 4]);
-  }
-
-  for (int s = 0; s < T; ++s) {
-    const int t = dir ? s : (T - 1 - s);          // BPTT order per direction
-    const int t_done = dir ? (t - 1) : (t + 1);   // step processed just before
-    const int t_cprev = dir ? (t + 1) : (t - 1);  // time of c_{prev} in scan order
-
-    TRACE(0);
-    // prefetch everything that does not depend on the exchange
-    float gv[MT][4], cv[MT], cpv[MT], dyv[MT];
-    bool own[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int bl = (tid >> 4) + 16 * i, bg = b0 + bl;
-      own[i] = (bl < a.R) && (bg < B) && (unit < H);
-      cv[i] = cpv[i] = dyv[i] = 0.f;
-      gv[i][0] = gv[i][1] = gv[i][2] = gv[i][3] = 0.f;
-      if (own[i]) {
-        const float* gp = a.gates[dir] + ((size_t)t * B + bg) * H4 + unit;
-        gv[i][0] = gp[0]; gv[i][1] = gp[H]; gv[i][2] = gp[2 * H]; gv[i][3] = gp[3 * H];
-        cv[i] = a.cell[dir][((size_t)t * B + bg) * H + unit];
-        if (t_cprev >= 0 && t_cprev < T)
-          cpv[i] = a.cell[dir][((size_t)t_cprev * B + bg) * H + unit];
-        dyv[i] = a.dy[((size_t)t * B + bg) * a.lddy + dir * H + unit];
-      }
-    }
-
-    f32x4 acc[MT][2];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      acc[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acc[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-
-    if (s > 0) {
-      for (int g0 = 0; g0 * NW + wave < NG; g0 += CH) {
-        v4u av[CH][MT];
-        unsigned spins = 0;
-        for (;;) {
-          bool ok = true;
-#pragma unroll
-          for (int g = 0; g < CH; ++g) {
-            const int kg = (g0 + g) * NW + wave;
-            const int n = kg * 16 + fq * 4;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              const int row = b0 + mt * 16 + fr;
-              unsigned off = dbytes;  // == num_records: out of range -> 0 (valid)
-              if (row < B && kg < NG && mt * 16 + fr < a.R) off = (unsigned)((((size_t)t_done * B + row) * H4 + n) * 4);
-              av[g][mt] = load_sc1_b128(dres, off);
-            }
-          }
-#pragma unroll
-          for (int g = 0; g < CH; ++g)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) ok &= !has_sentinel(av[g][mt]);
-          if (__all(ok)) break;
-          if (spin_fail(spins, a.status, lane, a.spin_limit)) break;
-        }
-        TRACE(1); TRACE_VAL(6, spins);
-        f32x4 wq[CH];     // straight-line MFMA chain (see forward kernel)
-        if (g0 == 0) {
-#pragma unroll
-          for (int g = 0; g < CH; ++g) wq[g] = wreg[g];
-        } else {
-#pragma unroll
-          for (int g = 0; g < CH; ++g) {
-            const int kg = (g0 + g) * NW + wave;
-            wq[g] = *reinterpret_cast<const f32x4*>(&Wl[(((kg < NG ? kg : 0) * 4 + fq) * 16 + fr) * 4]);
-          }
-        }
-#pragma unroll
-        for (int g = 0; g < CH; ++g) {
-          {
-            const f32x4 w = wq[g];
-            f32x4 af[MT];   // whole-vector bit_cast (see forward kernel)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) af[mt] = __builtin_bit_cast(f32x4, av[g][mt]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt)
-                acc[mt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                    af[mt][j], w[j], acc[mt][j & 1], 0, 0, 0);
-          }
-        }
-      }
-    }
-
-    TRACE(2);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        red[(wave * 16 * MT + mt * 16 + 4 * fq + r) * 17 + fr] = acc[mt][0][r] + acc[mt][1][r];
-    __syncthreads();
-    TRACE(3);
-
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      if (!own[i]) continue;
-      const int bl = (tid >> 4) + 16 * i, bg = b0 + bl;
-      float dh = dyv[i];
-#pragma unroll
-      for (int w = 0; w < NW; ++w) dh += red[(w * 16 * MT + bl) * 17 + jl];
-      const float g = gv[i][0], ig = gv[i][1], fg = gv[i][2], og = gv[i][3];
-      const float tc = tanh_hw(cv[i]);
-      const float dc = dc_state[i] + dh * og * (1.f - tc * tc);
-      const float da_g = dc * ig;
-      const float da_i = dc * g * ig * (1.f - ig);
-      const float da_f = dc * cpv[i] * fg * (1.f - fg);
-      const float da_o = dh * tc * og * (1.f - og);
-      dc_state[i] = dc * fg;
-      // publish da_t (also the kernel's output): write-through 4-byte stores
-      float* dp = a.da[dir] + ((size_t)t * B + bg) * H4 + unit;
-      __hip_atomic_store(dp, da_g, RLX_AGENT);
-      __hip_atomic_store(dp + H, da_i, RLX_AGENT);
-      __hip_atomic_store(dp + 2 * H, da_f, RLX_AGENT);
-      __hip_atomic_store(dp + 3 * H, da_o, RLX_AGENT);
-    }
-    TRACE(4);
-    __syncthreads();   // `red` reuse (see forward kernel)
-    TRACE(5);
-  }
-}
-
-// ---------------------------------------------------------------------------
 // backward (BPTT), reduce-scatter form
 // ---------------------------------------------------------------------------
-// The all-gather kernel above makes every workgroup read its cluster's whole
-// da_t (R x 4H floats) each step.  Here the product dh_{prev} = da_t Wh^T is split
-// along K instead.  A cluster = 16 batch rows of one direction.  Producer group p
+// An all-gather formulation (every workgroup reads its cluster's whole da_t, 16 x 4H
+// floats, each step: rounds 1-2) costs 441 us per cfg-2 launch against 303 us for this one.
+// Here the product dh_{prev} = da_t Wh^T is split along K instead.  A cluster = 16 batch rows of one direction.  Producer group p
 // owns U units, i.e. the 4U columns {gate*H + u0 + j} of da_t, keeps the matching
 // Wh columns stationary IN REGISTERS and publishes its partial dh for all units
 //     part_p[r][i] = sum_{n in own 4U columns} da_t[r][n] * Wh[i][n]
@@ -1322,371 +1124,6 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
   }
 }
 
-// ---------------------------------------------------------------------------
-// backward (BPTT), reduce-scatter form, WEIGHT GRADIENTS FUSED
-// ---------------------------------------------------------------------------
-// dW = [X | Hprev]^T da and db = colsum(da) of a layer are 3x the flops of its recurrence
-// (17.7 vs 5.9 GFLOP at cfg 2).  As separate GEMMs they ran on a side stream UNDER the next
-// layer's BPTT kernel and cost it 1.0 us per step (fabric contention on the exchange hops),
-// and the bottom layer's group sat on the critical path.  But the BPTT workgroup that owns
-// 4U columns of da_t already has them in LDS every step, its matrix cores idle during the
-// ~1.2 us exchange wait, and dW[:, own columns] += A_t^T da_t is a rank-16 update that needs
-// no other workgroup's data.  So: the S twins of a group split the D+H feature rows, every
-// wave keeps NFT feature tiles x 4U/16 column tiles of fp32 accumulators in registers
-// (<= 48 VGPRs), and the update of step s-1 runs at the TOP of step s -- a quarter of it
-// before the exchange loads are issued (so the first-attempt loads are not issued ahead of
-// slower producers: a miss would only be noticed after the MFMA block), the rest while the
-// loads fly.  The A operand (16 batch rows x 16 features of x_t / h_prev) is prefetched one
-// step ahead with coalesced dword loads straight into MFMA operand layout; the B operand
-// is the da_t tile the gate phase left in LDS.  At the end each workgroup writes its
-// [features x 4U] block of its cluster's partial dW (and twin 0 the partial db) to a slab;
-// a small kernel adds the ceil(B/16) cluster partials into dW / db (fixed order:
-// deterministic).  No weight-gradient GEMM, no column-sum kernel, nothing on a side stream.
-struct LstmBwdRswArgs {
-  LstmBwdRsArgs r;
-  const float* x;      // [T][B][ldx] layer input (time-major)
-  const float* ypad;   // [T+2][B][ldy] layer output: h_prev(t) = block t (fwd) / t+2 (bwd)
-  float* dwslab;       // [ndir*G][NFP][4H]
-  float* dbslab;       // [ndir*G][4H]
-  // feature space of the slab: [0, Dp) = x columns (Dp = Din padded to 16), [Dp, Dp+Hp) =
-  // h_prev units, so that a 16-feature tile never mixes the two sources (its base pointer
-  // and strides stay scalar).  NFt = feature rows per twin (multiple of 16), NFP = S*NFt.
-  int ldx, ldy, Din, Dp, NFt, NFP;
-};
-
-#define RSW_NI_MAX 3
-
-template <int U, int NTW, int NFT>
-__global__ __launch_bounds__(512) void lstm_bwd_rsw_kernel(LstmBwdRswArgs aa) {
-  const LstmBwdRsArgs& a = aa.r;
-  constexpr int NW = 8;
-  constexpr int KG = U / 4;
-  constexpr int OWN = 16 * U;
-  constexpr int CPP = 4 * U;
-  constexpr int PPR = 512 / CPP;
-  constexpr int LDA = 4 * U + 4;
-  constexpr int NCT = U / 4;         // 16-wide column tiles of the own 4U columns
-  __shared__ __attribute__((aligned(16))) float psum[PPR * OWN];
-  __shared__ __attribute__((aligned(16))) float atile[16 * LDA];
-
-  const int H = a.H, B = a.B, T = a.T, P = a.P, S = a.S;
-  const int tid = threadIdx.x, lane = tid & 63;
-  // wave-uniform by construction: keep what derives from it (tile base pointers, strides) scalar
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int bid = blockIdx.x;
-  if (a.fault && bid == 0) return;   // test hook
-  const int ncl = a.ndir * a.G;
-  const int cl = a.xmap ? bid % ncl : bid / (P * S);
-  const int m = a.xmap ? bid / ncl : bid % (P * S);
-  const int p = m / S, tw = m % S;
-  const int dir = cl / a.G, grp = cl % a.G;
-  const int u0 = p * U, b0 = grp * 16;
-  const int fr = lane & 15, fq = lane >> 4;
-
-  f32x4 wreg[NTW][KG];
-  {
-    const float* W = a.Wh[dir];
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-      const int tl = tw + S * (wave + NW * i);
-      const int unit_i = tl * 16 + fr;
-#pragma unroll
-      for (int kg = 0; kg < KG; ++kg) {
-        const int k0 = kg * 16 + fq * 4;
-        const int gate = k0 / U, j0 = k0 % U;
-        f32x4 w = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (tl < a.NT && unit_i < H && u0 + j0 < H)
-          w = *reinterpret_cast<const f32x4*>(&W[(size_t)unit_i * a.ldw + gate * H + u0 + j0]);
-        wreg[i][kg] = w;
-      }
-    }
-  }
-
-  const size_t slot_floats = (size_t)ncl * P * a.NT * 256;
-  const unsigned rbytes = (unsigned)(slot_floats * a.D * sizeof(float));
-  const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.ring, rbytes);
-
-  const int qq = tid / CPP, within = tid % CPP;
-  const int xr = within / (U / 4), xunit = u0 + (within % (U / 4)) * 4;
-  const unsigned xoff = (unsigned)((((xunit >> 4) * 16 + xr) * 16 + (xunit & 15)) * 4);
-
-  const bool othr = tid < OWN;
-  const int orow = tid / U, oj = tid % U;
-  const int bg = b0 + orow, unit = u0 + oj;
-  const bool owner = othr && bg < B && unit < H;
-  float dc_state = 0.f;
-  float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
-
-  // Feature tiles go to waves by RANK, not by wave id: the last slot is partly filled (19
-  // tiles over 8 waves at cfg 2) and its tiles must land on different SIMDs whether the
-  // hardware deals waves to SIMDs round-robin (w % 4) or in pairs (w / 2): ranks 0,1,2,3 =
-  // waves 0,3,5,6.  (Waves 0,1,2 holding the three extra tiles put 6 tiles on one SIMD if
-  // waves 0,1 share it: 96 instead of 80 MFMAs per step on the busiest SIMD.)
-  const int wrank = (0x73261540u >> (4 * wave)) & 7;
-  // ---- weight-gradient accumulators and their A-operand addressing -------------------
-  // feature tile i of this wave: slab rows tw*NFt + (wave + 8 i)*16 + [0,16); MFMA kk pairs
-  // batch rows 4 kk + fq.  Tile-uniform source: x_t (slab rows < Dp) or h_prev(t).
-  f32x4 wacc[NFT][NCT];
-  const float* abase[NFT];   // (wave-uniform) element (row b0, first feature of the tile), t = 0
-  int ald[NFT], atstride[NFT], avalid[NFT];   // avalid: number of real features in the tile
-#pragma unroll
-  for (int i = 0; i < NFT; ++i) {
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) wacc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int ftile = wrank + NW * i;
-    const int fb = tw * aa.NFt + ftile * 16;          // first slab row of the tile
-    abase[i] = aa.x; ald[i] = 0; atstride[i] = 0; avalid[i] = 0;
-    if (ftile * 16 < aa.NFt) {
-      if (fb < aa.Dp) {
-        abase[i] = aa.x + (size_t)b0 * aa.ldx + fb;
-        ald[i] = aa.ldx; atstride[i] = B * aa.ldx; avalid[i] = aa.Din - fb;
-      } else {
-        const int hf = fb - aa.Dp;
-        abase[i] = aa.ypad + (size_t)((dir ? 2 : 0) * B + b0) * aa.ldy + dir * H + hf;
-        ald[i] = aa.ldy; atstride[i] = B * aa.ldy; avalid[i] = H - hf;
-      }
-    }
-  }
-  // does this wave's LAST tile slot hold a tile?  (wave-uniform)
-  const bool full_tiles = (NFT == 1) || ((wrank + NW * (NFT - 1)) * 16 < aa.NFt);
-  float af[NFT][4];
-#pragma unroll
-  for (int i = 0; i < NFT; ++i)
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) af[i][kk] = 0.f;
-  // step 0 runs the update on zeros (no branch around the MFMA chains: a branch makes the
-  // compiler move the accumulators around it)
-  for (int i = tid; i < 16 * LDA; i += 512) atile[i] = 0.f;
-  __syncthreads();
-
-  for (int s = 0; s <= T; ++s) {
-    const int t = dir ? s : (T - 1 - s);
-    const int t_cprev = dir ? (t + 1) : (t - 1);
-
-    // ---- weight-gradient update of step s-1: first quarter
-    // (two straight-line copies: waves whose last tile slot is empty -- 19 tiles over 8 waves
-    // at cfg 2 -- skip its MFMAs; a branch INSIDE a chain would make the compiler shuffle
-    // the accumulators)
-    // B operand (da of step s-1, all four row groups) in one batch of LDS reads: MFMA chains
-    // that wait on an LDS read per group ran at 22 ns per MFMA and SIMD instead of 15
-    float bfv[4][NCT];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) bfv[kk][ct] = atile[(4 * kk + fq) * LDA + ct * 16 + fr];
-#define DW_UPDATE_N(kk, NT_)                                                                  \
-    do {                                                                                      \
-      _Pragma("unroll") for (int i = 0; i < (NT_); ++i)                                       \
-        _Pragma("unroll") for (int ct = 0; ct < NCT; ++ct)                                    \
-          wacc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][kk], bfv[kk][ct],          \
-                                                             wacc[i][ct], 0, 0, 0);           \
-    } while (0)
-#define DW_UPDATE(kk)                                                                         \
-    do { if (full_tiles) DW_UPDATE_N(kk, NFT); else DW_UPDATE_N(kk, NFT - 1); } while (0)
-    TRACE(0);
-    DW_UPDATE(0);
-    TRACE(1);
-    if (s == T) {
-      // last update: no further step
-      DW_UPDATE(1); DW_UPDATE(2); DW_UPDATE(3);
-      break;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- rest of the weight-gradient update of step s-1, under the exchange wait
-    if (full_tiles) { DW_UPDATE_N(1, NFT); DW_UPDATE_N(2, NFT); DW_UPDATE_N(3, NFT); }
-    else { DW_UPDATE_N(1, NFT - 1); DW_UPDATE_N(2, NFT - 1); DW_UPDATE_N(3, NFT - 1); }
-#undef DW_UPDATE
-#undef DW_UPDATE_N
-    __builtin_amdgcn_sched_barrier(0);
-    TRACE(2);
-    // ---- exchange loads of the partial dh of step s-1, issued only NOW: the previous step's
-    // write-through stores block the wave's next vector-memory instruction until they are
-    // acknowledged (~0.8 us); behind the MFMA block that wait is free, in front of it the
-    // matrix cores idle for it.  (They are also late enough never to race a producer.)
-    // Branch-free: producers that do not exist (and everything at step 0) are out-of-range
-    // offsets, which return 0 without a memory access and count as valid.  (Conditional
-    // loads into a partly defined array made the compiler copy the first result right
-    // after issuing it -- an s_waitcnt vmcnt(0) that exposed the whole exchange latency.)
-    unsigned off[RSW_NI_MAX];
-    v4u av[RSW_NI_MAX];
-    const int sm1 = s > 0 ? s - 1 : 0;
-    const unsigned par = (unsigned)((sm1 / a.D) & 1);
-    {
-      const int slot = sm1 % a.D;
-#pragma unroll
-      for (int i = 0; i < RSW_NI_MAX; ++i) {
-        const int q = qq + PPR * i;
-        off[i] = (s > 0 && q < P)
-                     ? (unsigned)((((size_t)slot * ncl + cl) * P + q) * a.NT * 1024) + xoff : rbytes;
-      }
-#pragma unroll
-      for (int i = 0; i < RSW_NI_MAX; ++i) av[i] = load_sc1_b128(rres, off[i]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- everything of step s that does not depend on the exchange
-    float gv[4] = {0.f, 0.f, 0.f, 0.f}, cv = 0.f, cpv = 0.f, dyv = 0.f;
-    if (owner) {
-      const float* gp = a.gates[dir] + ((size_t)t * B + bg) * (4 * H) + unit;
-      gv[0] = gp[0]; gv[1] = gp[H]; gv[2] = gp[2 * H]; gv[3] = gp[3 * H];
-      cv = a.cell[dir][((size_t)t * B + bg) * H + unit];
-      if (t_cprev >= 0 && t_cprev < T) cpv = a.cell[dir][((size_t)t_cprev * B + bg) * H + unit];
-      dyv = a.dy[((size_t)t * B + bg) * a.lddy + dir * H + unit];
-    }
-
-    {
-      unsigned spins = 0;
-      for (;;) {
-        bool ok = true;
-#pragma unroll
-        for (int i = 0; i < RSW_NI_MAX; ++i) {
-          const unsigned mm = par ? ~(av[i][0] & av[i][1] & av[i][2] & av[i][3])
-                                  : (av[i][0] | av[i][1] | av[i][2] | av[i][3]);
-          ok &= (off[i] == rbytes) || !(mm & 1u);
-        }
-        if (__all(ok)) break;
-        if (spin_fail(spins, a.status, lane, a.spin_limit)) break;
-#pragma unroll
-        for (int i = 0; i < RSW_NI_MAX; ++i) av[i] = load_sc1_b128(rres, off[i]);
-      }
-      TRACE(3); TRACE_VAL(6, spins);
-      f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < RSW_NI_MAX; ++i) {
-        v4u w = av[i];
-        if (off[i] == rbytes) w = (v4u){0u, 0u, 0u, 0u};
-        w[0] &= ~1u; w[1] &= ~1u; w[2] &= ~1u; w[3] &= ~1u;
-        sum += __builtin_bit_cast(f32x4, w);
-      }
-      *reinterpret_cast<f32x4*>(&psum[qq * OWN + within * 4]) = sum;
-    }
-    // A operand of THIS step's update (consumed at the top of the next step).  Issued only now:
-    // guarded loads in flight make the compiler wait for ALL outstanding loads (vmcnt(0)) at
-    // the validation above, i.e. the exchange would also wait for this prefetch.
-#pragma unroll
-    for (int i = 0; i < NFT; ++i)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        float v = 0.f;
-        if (fr < avalid[i] && b0 + 4 * kk + fq < B)
-          v = abase[i][(size_t)t * atstride[i] + (size_t)(4 * kk + fq) * ald[i] + fr];
-        af[i][kk] = v;
-      }
-
-    __syncthreads();   // also: every wave is done reading atile (da of step s-1)
-    TRACE(4);
-
-    float dav[4] = {0.f, 0.f, 0.f, 0.f};
-    if (othr) {
-      float dh = dyv;
-#pragma unroll
-      for (int k = 0; k < PPR; ++k) dh += psum[k * OWN + tid];   // zeros at step 0
-      if (owner) {
-        const float g = gv[0], ig = gv[1], fg = gv[2], og = gv[3];
-        const float tc = tanh_hw(cv);
-        const float dc = dc_state + dh * og * (1.f - tc * tc);
-        dav[0] = dc * ig;
-        dav[1] = dc * g * ig * (1.f - ig);
-        dav[2] = dc * cpv * fg * (1.f - fg);
-        dav[3] = dh * tc * og * (1.f - og);
-        dc_state = dc * fg;
-        dbacc[0] += dav[0]; dbacc[1] += dav[1]; dbacc[2] += dav[2]; dbacc[3] += dav[3];
-      }
-      float* ap = &atile[orow * LDA + oj];
-      ap[0] = dav[0]; ap[U] = dav[1]; ap[2 * U] = dav[2]; ap[3 * U] = dav[3];
-    }
-    __syncthreads();
-    TRACE(5);
-    // The prefetched A operand is loop-carried: without this, the compiler waits for it at the
-    // loop latch with s_waitcnt vmcnt(0) -- which on gfx9 also waits for the write-through
-    // publish stores issued just before (0.5 us per step).  Consuming the values HERE puts the
-    // wait where only loads are outstanding (they were issued two phases ago).
-#pragma unroll
-    for (int i = 0; i < NFT; ++i)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) asm volatile("" : "+v"(af[i][kk]));
-
-    if (s + 1 < T) {
-      f32x4 bq[KG];
-#pragma unroll
-      for (int kg = 0; kg < KG; ++kg)
-        bq[kg] = *reinterpret_cast<const f32x4*>(&atile[fr * LDA + kg * 16 + fq * 4]);
-      constexpr int NACC = 2;
-      f32x4 acc2[NTW][NACC];
-#pragma unroll
-      for (int i = 0; i < NTW; ++i)
-#pragma unroll
-        for (int c = 0; c < NACC; ++c) acc2[i][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kg = 0; kg < KG; ++kg)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int i = 0; i < NTW; ++i)
-            acc2[i][j % NACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                wreg[i][kg][j], bq[kg][j], acc2[i][j % NACC], 0, 0, 0);
-      const int slot = s % a.D;
-      const unsigned ppub = (unsigned)((s / a.D) & 1);
-#pragma unroll
-      for (int i = 0; i < NTW; ++i) {
-        const f32x4 accs = acc2[i][0] + acc2[i][1];
-        const int tl = tw + S * (wave + NW * i);
-        unsigned o = rbytes;
-        if (tl < a.NT)
-          o = (unsigned)(((((size_t)slot * ncl + cl) * P + p) * a.NT + tl) * 1024) +
-              (unsigned)((fr * 16 + fq * 4) * 4);
-        v4u w = __builtin_bit_cast(v4u, accs);
-        w[0] = (w[0] & ~1u) | ppub; w[1] = (w[1] & ~1u) | ppub;
-        w[2] = (w[2] & ~1u) | ppub; w[3] = (w[3] & ~1u) | ppub;
-        store_sc1_b128(rres, o, w);
-      }
-    }
-    if (owner && tw == 0) {
-      float* dp = a.da[dir] + ((size_t)t * B + bg) * (4 * H) + unit;
-      dp[0] = dav[0]; dp[H] = dav[1]; dp[2 * H] = dav[2]; dp[3 * H] = dav[3];
-    }
-    TRACE(7);
-  }
-
-  // ---- this workgroup's block of the cluster's partial dW: D layout row = 4 fq + r, col = fr
-  {
-    float* slab = aa.dwslab + (size_t)cl * aa.NFP * (4 * H);
-#pragma unroll
-    for (int i = 0; i < NFT; ++i) {
-      const int ftile = wrank + NW * i;
-      if (ftile * 16 >= aa.NFt) continue;
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) {
-        const int acol = ct * 16 + fr;
-        const int gate = acol / U, j = acol % U;
-        if (u0 + j >= H) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int f = tw * aa.NFt + ftile * 16 + 4 * fq + r;     // slab row (padded space)
-          slab[(size_t)f * (4 * H) + gate * H + u0 + j] = wacc[i][ct][r];
-        }
-      }
-    }
-  }
-  // ---- partial db of the cluster: sum of the own da columns over the 16 rows (twin 0)
-  __syncthreads();
-  if (tw == 0) {
-    if (othr) {
-      float* ap = &atile[orow * LDA + oj];
-      ap[0] = dbacc[0]; ap[U] = dbacc[1]; ap[2 * U] = dbacc[2]; ap[3 * U] = dbacc[3];
-    }
-    __syncthreads();
-    if (tid < 4 * U) {
-      float v = 0.f;
-#pragma unroll
-      for (int rr = 0; rr < 16; ++rr) v += atile[rr * LDA + tid];
-      const int gate = tid / U, j = tid % U;
-      if (u0 + j < H) aa.dbslab[(size_t)cl * (4 * H) + gate * H + u0 + j] = v;
-    }
-  }
-}
-
 // dW_d[f][c] (+)= sum over the G clusters of direction d of their partial; same for db
 __global__ __launch_bounds__(256) void lstm_dw_reduce_kernel(
     const float* __restrict__ dwslab, const float* __restrict__ dbslab, float* dW0, float* dW1,
@@ -1783,39 +1220,27 @@ static int num_cus() {
 
 // MT=1 (16-row clusters) halves the per-step MFMA time and the payload per
 // workgroup at the price of twice the workgroups; it is used whenever one
-// workgroup per CU still fits.  DANET_LSTM_FWD_MT / DANET_LSTM_BWD_MT = 1|2
-// override the choice (A/B experiments).
-static LstmPlan make_plan(int B, int H, int ndir, bool bwd) {
+// workgroup per CU still fits.
+static LstmPlan make_plan(int B, int H, int ndir) {
   LstmPlan pl;
-  pl.UN = bwd ? LSTM_UNITS_BWD : LSTM_UNITS_FWD;
+  pl.UN = LSTM_UNITS_FWD;
   pl.P = cdiv(H, pl.UN);
   pl.KP = cdiv(H, 16) * 16;
   pl.MT = (ndir * cdiv(B, 16) * pl.P > num_cus()) ? 2 : 1;
-  const int force = danet_opt(bwd ? OPT_LSTM_BWD_MT : OPT_LSTM_FWD_MT);
-  if (force == 1 || force == 2) pl.MT = force;
-  // forward, wide layers: 12 units per workgroup keep 16-row clusters on the GPU where 8 units
+  // wide layers: 12 units per workgroup keep 16-row clusters on the GPU where 8 units
   // would need 32-row clusters (cfg 4 as written, H = 600: 200 workgroups of 16 rows instead of
   // 150 of 32: 5.8 -> 4.6 us per timestep, 12.15 -> 11.55 ms per cfg-4h600 step).
-  // DANET_LSTM_FWD_UN=8|12 overrides.
-  if (!bwd && B > 4) {
+  // option lstm_fwd_un = 8|12 overrides.
+  if (B > 4) {
     const int want = danet_opt(OPT_LSTM_FWD_UN);
     const bool fits12 = ndir * cdiv(B, 16) * cdiv(H, 12) <= num_cus();
-    if ((want == 12 || (want != 8 && pl.MT == 2 && force != 2)) && fits12) {
+    if ((want == 12 || (want != 8 && pl.MT == 2)) && fits12) {
       pl.UN = 12; pl.P = cdiv(H, 12); pl.MT = 1;
     }
   }
   pl.G = cdiv(B, 16 * pl.MT);
-  // waves per workgroup: more waves = shorter per-wave exchange-load chains
-  pl.NW = bwd ? 8 : 4;
-  const int fnw = danet_opt(bwd ? OPT_LSTM_BWD_NW : OPT_LSTM_FWD_NW);
-  if (fnw == 4 || fnw == 8 || fnw == 16) pl.NW = fnw;
-  if ((pl.MT == 2 || pl.UN == 12) && pl.NW > 4) pl.NW = 4;   // ownership map: 256 threads
-  for (;;) {
-    pl.lds = bwd ? ((size_t)4 * H * 16 + (size_t)pl.NW * 16 * pl.MT * 17) * sizeof(float)
-                 : ((size_t)pl.KP * 4 * pl.UN + (size_t)pl.NW * 16 * pl.MT * (4 * pl.UN + 1)) * sizeof(float);
-    if (pl.lds <= 160 * 1024 || pl.NW == 4) break;
-    pl.NW /= 2;
-  }
+  pl.NW = 4;             // one wave per SIMD
+  pl.lds = ((size_t)pl.KP * 4 * pl.UN + (size_t)pl.NW * 16 * pl.MT * (4 * pl.UN + 1)) * sizeof(float);
   return pl;
 }
 
@@ -1842,10 +1267,9 @@ static RsPlan make_rs_plan(int B, int H, int ndir, int U) {
          r.ring_bytes < 0xFFFFFFF0ull;
   return r;
 }
-// DANET_LSTM_BWD_RS=0 selects the all-gather kernel; DANET_LSTM_BWD_U=8|16|32 pins U
+// option lstm_bwd_u = 8|16|32 pins U
 static RsPlan choose_rs_plan(int B, int H, int ndir) {
   RsPlan none; none.ok = false; none.ring_bytes = 0;
-  if (danet_opt(OPT_LSTM_BWD_RS) == 0) return none;
   const int pin = danet_opt(OPT_LSTM_BWD_U);
   // fewest MFMAs per SIMD and step (tiles of a workgroup spread over 4 SIMDs, 4U/4
   // k-steps each); ties go to the smaller U (shorter dependent chains).  Measured at
@@ -1874,7 +1298,7 @@ static unsigned spin_limit_env() {
 }
 static int fault_env() { return danet_opt(OPT_LSTM_FAULT_INJECT) == 1; }
 
-extern "C" size_t danet_lstm_workspace_bytes(int T, int B, int H, int ndir) {
+size_t dn_ws_lstm(int T, int B, int H, int ndir) {
   // status word (+ padding) (+ trace records) + partial-dh ring of the BPTT kernel
   size_t ring = 0;
   for (int U = 8; U <= 32; U *= 2) {
@@ -1892,7 +1316,7 @@ static int lstm_check_common(int T, int B, int H, int ndir, void* ws, size_t ws_
     danet_set_error("lstm: H=%d must be a multiple of 4", H);
     return DANET_ERR_UNSUPPORTED;
   }
-  if (!ws || ((uintptr_t)ws & 15) != 0 || ws_bytes < danet_lstm_workspace_bytes(T, B, H, ndir)) {
+  if (!ws || ((uintptr_t)ws & 15) != 0 || ws_bytes < dn_ws_lstm(T, B, H, ndir)) {
     danet_set_error("lstm: workspace too small or not 16-B aligned");
     return DANET_ERR_WORKSPACE;
   }
@@ -1957,7 +1381,7 @@ extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int n
   DANET_CHECK_ARG(ldy >= ndir * H && ldy % 4 == 0 && ldw >= 4 * H, "lstm_fwd: bad ld");
   DANET_CHECK_ARG(((uintptr_t)ypad & 15) == 0, "lstm_fwd: ypad must be 16-B aligned");
   DANET_CHECK_ARG((size_t)(T + 2) * B * ldy * 4 < 0xFFFFFFF0ull, "lstm_fwd: ypad > 4 GiB");
-  LstmPlan pl = make_plan(B, H, ndir, false);
+  LstmPlan pl = make_plan(B, H, ndir);
   if (pl.lds > 160 * 1024) {
     danet_set_error("lstm_fwd: H=%d needs %zu B LDS", H, pl.lds);
     return DANET_ERR_UNSUPPORTED;
@@ -2007,8 +1431,6 @@ extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int n
   }
   if (pl.UN == 12) LAUNCH_FWD(1, 4, 12);
   else if (pl.MT == 2) LAUNCH_FWD(2, 4, 8);
-  else if (pl.NW == 16) LAUNCH_FWD(1, 16, 8);
-  else if (pl.NW == 8) LAUNCH_FWD(1, 8, 8);
   else LAUNCH_FWD(1, 4, 8);
   DANET_CHECK_LAUNCH();
   return DANET_OK;
@@ -2066,7 +1488,6 @@ extern "C" int danet_lstm_fwd_fused(danet_stream_t stream_, int T, int B, int H,
   a.gates[0] = gates_f; a.gates[1] = gates_b; a.cell[0] = cell_f; a.cell[1] = cell_b;
   a.ypad = ypad; a.status = status ? (int*)status : (int*)ws; a.status_ws = ws;
   a.spin_limit = spin_limit_env(); a.fault = fault_env();
-  a.mode = danet_opt(OPT_LSTM_FX_MODE);
   a.T = T; a.B = B; a.H = H; a.D = D; a.ndir = ndir; a.ldx = ldx; a.ldy = ldy; a.ldw = ldw;
   a.P = cdiv(H, LSTM_UNITS_FWD); a.G = cdiv(B, 16); a.KP = cdiv(H, 16) * 16;
   a.DP = cdiv(D, 16) * 16;
@@ -2100,210 +1521,12 @@ extern "C" int danet_lstm_fwd_fused(danet_stream_t stream_, int T, int B, int H,
   return DANET_OK;
 }
 
-// ---- BPTT with fused weight gradients: geometry and entry points ---------------------
-struct RswPlan { bool ok; RsPlan rs; int NFt, NFP, NFT; size_t dw_bytes, db_bytes; };
-static RswPlan make_rsw_plan(int B, int H, int ndir, int D, bool h_only = false) {
-  RswPlan w; w.ok = false; w.NFt = w.NFP = w.NFT = 0; w.dw_bytes = w.db_bytes = 0;
-  w.rs = choose_rs_plan(B, H, ndir);
-  // Envelope only; WHERE it is used is the caller's policy.  Measured (profiles/
-  // r02_d_fused_bwd_trace.txt): at parity with the separate GEMMs for a layer whose weight-
-  // gradient group can hide under the next layer's BPTT kernel (cfg 2: 3.615 vs 3.602 ms per
-  // step with all layers fused) -- the 80 weight-gradient MFMAs per SIMD and step run at 22 ns
-  // instead of the 15 ns the pipe can do and make the step MFMA-bound at 3.6 us.  Fusing only
-  // the bottom layer (whose group has nothing to hide under) LOSES: the layer-1 group then runs
-  // beside an MFMA-heavy kernel (3.82 ms).  option lstm_bwd_fused_kernel = 0 turns the kernel off.
-  if (danet_opt(OPT_LSTM_BWD_FUSED_KERNEL) == 0) return w;
-  if (!w.rs.ok || (h_only ? D != 0 : D <= 0)) return w;
-  if (w.rs.U != 8 && w.rs.U != 16) return w;
-  if (w.rs.NTW > 2 || w.rs.NI > RSW_NI_MAX) return w;
-  const int Dp = cdiv(D, 16) * 16, Hp = cdiv(H, 16) * 16;
-  w.NFt = cdiv((Dp + Hp) / 16, w.rs.S) * 16;
-  w.NFP = w.rs.S * w.NFt;
-  w.NFT = cdiv(w.NFt / 16, 8);
-  if (w.NFT > 3 || (w.rs.U == 16 && w.rs.NTW == 2 && w.NFT == 3)) return w;   // register budget
-  const size_t ncl = (size_t)ndir * w.rs.G;
-  w.dw_bytes = align_up(ncl * w.NFP * 4 * H * sizeof(float), 256);
-  w.db_bytes = align_up(ncl * 4 * H * sizeof(float), 256);
-  w.ok = true;
-  return w;
-}
-
-extern "C" int danet_lstm_bwd_fused_supported(int T, int B, int H, int ndir, int D) {
-  if (T <= 0 || B <= 0 || H <= 0 || H % 4 != 0 || (ndir != 1 && ndir != 2)) return 0;
-  return make_rsw_plan(B, H, ndir, D).ok ? 1 : 0;
-}
-
-extern "C" size_t danet_lstm_bwd_fused_workspace_bytes(int T, int B, int H, int ndir, int D) {
-  const RswPlan w = make_rsw_plan(B, H, ndir, D);
-  if (!w.ok) return 0;
-  return align_up(ring_offset(T) + w.rs.ring_bytes, 256) + w.dw_bytes + w.db_bytes;
-}
-
-// h_only: only the RECURRENT rows of the weight gradient (dWh = Hprev^T da, K = H per step, 16
-// update MFMAs per wave and step at cfg 2) are accumulated in the kernel; W_f / W_b / dW_f / dW_b
-// then point at the recurrent rows and x is not read (D = 0).
-static int lstm_bwd_fused_impl(danet_stream_t stream_, int T, int B, int H, int ndir,
-                               const float* dy, int lddy,
-                               const float* W_f, const float* W_b, int ldw,
-                               const float* gates_f, const float* gates_b,
-                               const float* cell_f, const float* cell_b,
-                               const float* x, int ldx, int D,
-                               const float* ypad, int ldy,
-                               float* da_f, float* da_b,
-                               float* dW_f, float* dW_b, float* db_f, float* db_b,
-                               float beta, void* ws, size_t ws_bytes, int32_t* status, bool h_only) {
-  hipStream_t stream = (hipStream_t)stream_;
-  DANET_CHECK_ARG(T > 0 && B > 0 && H > 0 && (h_only ? D == 0 : D > 0), "lstm_bwd_fused: non-positive shape");
-  DANET_CHECK_ARG(ndir == 1 || ndir == 2, "lstm_bwd_fused: ndir must be 1 or 2");
-  if (H % 4 != 0) {
-    danet_set_error("lstm: H=%d must be a multiple of 4", H);
-    return DANET_ERR_UNSUPPORTED;
-  }
-  const RswPlan w = make_rsw_plan(B, H, ndir, D, h_only);
-  if (!w.ok) {
-    danet_set_error("lstm_bwd_fused: T=%d B=%d H=%d D=%d outside the fused envelope", T, B, H, D);
-    return DANET_ERR_UNSUPPORTED;
-  }
-  const size_t need = align_up(ring_offset(T) + w.rs.ring_bytes, 256) + w.dw_bytes + w.db_bytes;
-  if (!ws || ((uintptr_t)ws & 15) != 0 || ws_bytes < need) {
-    danet_set_error("lstm_bwd_fused: workspace too small or not 16-B aligned");
-    return DANET_ERR_WORKSPACE;
-  }
-  DANET_CHECK_ARG(dy && W_f && gates_f && cell_f && da_f && (x || h_only) && ypad && dW_f && db_f,
-                  "lstm_bwd_fused: null pointer");
-  DANET_CHECK_ARG(ndir == 1 || (W_b && gates_b && cell_b && da_b && dW_b && db_b),
-                  "lstm_bwd_fused: null bwd pointer");
-  DANET_CHECK_ARG(lddy >= ndir * H && ldw >= 4 * H && ldw % 4 == 0 && ldx >= D && ldy >= ndir * H,
-                  "lstm_bwd_fused: bad ld");
-  DANET_CHECK_ARG(beta == 0.f || beta == 1.f, "lstm_bwd_fused: beta must be 0 or 1");
-  DANET_CHECK_ARG((((uintptr_t)da_f | (uintptr_t)da_b | (uintptr_t)dW_f | (uintptr_t)dW_b |
-                    (uintptr_t)db_f | (uintptr_t)db_b | (uintptr_t)W_f | (uintptr_t)W_b) & 15) == 0,
-                  "lstm_bwd_fused: W, da, dW, db must be 16-B aligned");
-  DANET_CHECK_ARG((size_t)T * B * 4 * H * 4 < 0xFFFFFFF0ull, "lstm_bwd_fused: da > 4 GiB");
-  const RsPlan& rs = w.rs;
-  LstmBwdRswArgs aa;
-  LstmBwdRsArgs& a = aa.r;
-  a.dy = dy; a.lddy = lddy;
-  a.Wh[0] = W_f + (size_t)D * ldw; a.Wh[1] = W_b ? W_b + (size_t)D * ldw : nullptr; a.ldw = ldw;
-  a.gates[0] = gates_f; a.gates[1] = gates_b; a.cell[0] = cell_f; a.cell[1] = cell_b;
-  a.da[0] = da_f; a.da[1] = da_b; a.status = status ? (int*)status : (int*)ws;
-  a.spin_limit = spin_limit_env(); a.fault = fault_env();
-  a.ring = (float*)((char*)ws + ring_offset(T));
-  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.P = rs.P; a.G = rs.G; a.S = rs.S;
-  a.NT = rs.NT; a.NI = rs.NI; a.D = rs.D;
-  a.xmap = (danet_opt(OPT_LSTM_XMAP) >= 0 ? danet_opt(OPT_LSTM_XMAP) : 1);
-  a.dbslab = nullptr;
-  aa.x = x; aa.ypad = ypad; aa.ldx = ldx; aa.ldy = ldy; aa.Din = D; aa.Dp = cdiv(D, 16) * 16;
-  aa.NFt = w.NFt; aa.NFP = w.NFP;
-  aa.dwslab = (float*)((char*)ws + align_up(ring_offset(T) + rs.ring_bytes, 256));
-  aa.dbslab = (float*)((char*)aa.dwslab + w.dw_bytes);
-  {
-    FillList fl;
-    fl.add(ws, 64 + TRACE_BYTES(T), 0u);
-    fl.add(a.ring, rs.ring_bytes, 1u);   // phase 1 in bit 0 of every word
-    DANET_CHECK_HIP(fl.launch(stream));
-  }
-  const int nblk = ndir * rs.G * rs.P * rs.S;
-#define LAUNCH_RSW(UV, NTWV, NFTV) lstm_bwd_rsw_kernel<UV, NTWV, NFTV><<<nblk, 512, 0, stream>>>(aa)
-#define LAUNCH_RSW_F(UV, NTWV)                                            \
-    switch (w.NFT) {                                                      \
-      case 1: LAUNCH_RSW(UV, NTWV, 1); break; case 2: LAUNCH_RSW(UV, NTWV, 2); break; \
-      default: LAUNCH_RSW(UV, NTWV, 3); break; }
-  if (rs.U == 8) { if (rs.NTW == 1) { LAUNCH_RSW_F(8, 1) } else { LAUNCH_RSW_F(8, 2) } }
-  else { if (rs.NTW == 1) { LAUNCH_RSW_F(16, 1) } else { LAUNCH_RSW_F(16, 2) } }
-  DANET_CHECK_LAUNCH();
-  const int NF = D + H;
-  const int64_t items = (int64_t)NF * H + H;
-  dim3 grid((unsigned)(cdiv64(items, 256) < 1024 ? cdiv64(items, 256) : 1024), ndir);
-  lstm_dw_reduce_kernel<<<grid, 256, 0, stream>>>(aa.dwslab, aa.dbslab, dW_f, dW_b, db_f, db_b,
-                                                  rs.G, D, aa.Dp, NF, w.NFP, 4 * H, beta);
-  DANET_CHECK_LAUNCH();
-  return DANET_OK;
-}
-
-extern "C" int danet_lstm_bwd_fused(danet_stream_t stream_, int T, int B, int H, int ndir,
-                                    const float* dy, int lddy,
-                                    const float* W_f, const float* W_b, int ldw,
-                                    const float* gates_f, const float* gates_b,
-                                    const float* cell_f, const float* cell_b,
-                                    const float* x, int ldx, int D,
-                                    const float* ypad, int ldy,
-                                    float* da_f, float* da_b,
-                                    float* dW_f, float* dW_b, float* db_f, float* db_b,
-                                    float beta, void* ws, size_t ws_bytes, int32_t* status) {
-  return lstm_bwd_fused_impl(stream_, T, B, H, ndir, dy, lddy, W_f, W_b, ldw, gates_f, gates_b, cell_f,
-                             cell_b, x, ldx, D, ypad, ldy, da_f, da_b, dW_f, dW_b, db_f, db_b, beta,
-                             ws, ws_bytes, status, false);
-}
-
-// BPTT with ONLY the recurrent weight gradient (and the bias gradient) fused: dWh_d[H][4H] +=
-// Hprev^T da_d inside the kernel (Wh_d / dWh_d = rows D.. of the layer's W / dW); dWx stays a GEMM.
-extern "C" int danet_lstm_bwd_fused_h_supported(int T, int B, int H, int ndir) {
-  if (T <= 0 || B <= 0 || H <= 0 || H % 4 != 0 || (ndir != 1 && ndir != 2)) return 0;
-  return make_rsw_plan(B, H, ndir, 0, true).ok ? 1 : 0;
-}
-extern "C" size_t danet_lstm_bwd_fused_h_workspace_bytes(int T, int B, int H, int ndir) {
-  const RswPlan w = make_rsw_plan(B, H, ndir, 0, true);
-  if (!w.ok) return 0;
-  return align_up(ring_offset(T) + w.rs.ring_bytes, 256) + w.dw_bytes + w.db_bytes;
-}
-extern "C" int danet_lstm_bwd_fused_h(danet_stream_t stream_, int T, int B, int H, int ndir,
-                                      const float* dy, int lddy,
-                                      const float* Wh_f, const float* Wh_b, int ldw,
-                                      const float* gates_f, const float* gates_b,
-                                      const float* cell_f, const float* cell_b,
-                                      const float* ypad, int ldy,
-                                      float* da_f, float* da_b,
-                                      float* dWh_f, float* dWh_b, float* db_f, float* db_b,
-                                      float beta, void* ws, size_t ws_bytes, int32_t* status) {
-  return lstm_bwd_fused_impl(stream_, T, B, H, ndir, dy, lddy, Wh_f, Wh_b, ldw, gates_f, gates_b, cell_f,
-                             cell_b, nullptr, 4, 0, ypad, ldy, da_f, da_b, dWh_f, dWh_b, db_f, db_b, beta,
-                             ws, ws_bytes, status, true);
-}
-
-static int lstm_bwd_impl(danet_stream_t stream_, int T, int B, int H, int ndir,
-                         const float* dy, int lddy,
-                         const float* Wh_f, const float* Wh_b, int ldw,
-                         const float* gates_f, const float* gates_b,
-                         const float* cell_f, const float* cell_b,
-                         float* da_f, float* da_b, void* ws, size_t ws_bytes,
-                         int32_t* status, float* db_f, float* db_b, float beta, int flags);
-
-extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int ndir,
-                              const float* dy, int lddy,
-                              const float* Wh_f, const float* Wh_b, int ldw,
-                              const float* gates_f, const float* gates_b,
-                              const float* cell_f, const float* cell_b,
-                              float* da_f, float* da_b, void* ws, size_t ws_bytes,
-                              int32_t* status) {
-  return lstm_bwd_impl(stream_, T, B, H, ndir, dy, lddy, Wh_f, Wh_b, ldw, gates_f, gates_b,
-                       cell_f, cell_b, da_f, da_b, ws, ws_bytes, status, nullptr, nullptr, 0.f, 0);
-}
-
 extern "C" int danet_lstm_bwd_db_supported(int T, int B, int H, int ndir) {
   if (T <= 0 || B <= 0 || H <= 0 || H % 4 != 0 || (ndir != 1 && ndir != 2)) return 0;
   return choose_rs_plan(B, H, ndir).ok ? 1 : 0;
 }
 
-extern "C" int danet_lstm_bwd_db(danet_stream_t stream_, int T, int B, int H, int ndir,
-                                 const float* dy, int lddy,
-                                 const float* Wh_f, const float* Wh_b, int ldw,
-                                 const float* gates_f, const float* gates_b,
-                                 const float* cell_f, const float* cell_b,
-                                 float* da_f, float* da_b, float* db_f, float* db_b, float beta,
-                                 void* ws, size_t ws_bytes, int32_t* status, int flags) {
-  DANET_CHECK_ARG(db_f && (ndir == 1 || db_b), "lstm_bwd_db: null db pointer");
-  DANET_CHECK_ARG((((uintptr_t)db_f | (uintptr_t)db_b) & 15) == 0, "lstm_bwd_db: db must be 16-B aligned");
-  DANET_CHECK_ARG(beta == 0.f || beta == 1.f, "lstm_bwd_db: beta must be 0 or 1");
-  if (!danet_lstm_bwd_db_supported(T, B, H, ndir)) {
-    danet_set_error("lstm_bwd_db: B=%d H=%d outside the reduce-scatter geometry", B, H);
-    return DANET_ERR_UNSUPPORTED;
-  }
-  return lstm_bwd_impl(stream_, T, B, H, ndir, dy, lddy, Wh_f, Wh_b, ldw, gates_f, gates_b,
-                       cell_f, cell_b, da_f, da_b, ws, ws_bytes, status, db_f, db_b, beta, flags);
-}
-
-// The per-cluster bias-gradient partials a danet_lstm_bwd_db(..., DANET_LSTM_DB_DEFERRED) launch left
+// The per-cluster bias-gradient partials a danet_lstm_bwd(..., DANET_LSTM_DB_DEFERRED) launch left
 // in its workspace, summed into db: 6 us the caller can put on any stream ordered behind that launch
 // instead of between the BPTT kernel and the dX product that waits for it.
 extern "C" int danet_lstm_bwd_db_reduce(danet_stream_t stream_, int T, int B, int H, int ndir,
@@ -2326,13 +1549,24 @@ extern "C" int danet_lstm_bwd_db_reduce(danet_stream_t stream_, int T, int B, in
   return DANET_OK;
 }
 
-static int lstm_bwd_impl(danet_stream_t stream_, int T, int B, int H, int ndir,
-                         const float* dy, int lddy,
-                         const float* Wh_f, const float* Wh_b, int ldw,
-                         const float* gates_f, const float* gates_b,
-                         const float* cell_f, const float* cell_b,
-                         float* da_f, float* da_b, void* ws, size_t ws_bytes,
-                         int32_t* status, float* db_f, float* db_b, float beta, int flags) {
+extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int ndir,
+                              const float* dy, int lddy,
+                              const float* Wh_f, const float* Wh_b, int ldw,
+                              const float* gates_f, const float* gates_b,
+                              const float* cell_f, const float* cell_b,
+                              float* da_f, float* da_b, float* db_f, float* db_b, float beta,
+                              void* ws, size_t ws_bytes, int32_t* status, int flags) {
+  if (db_f) {
+    DANET_CHECK_ARG(ndir == 1 || db_b, "lstm_bwd: null db pointer");
+    DANET_CHECK_ARG((((uintptr_t)db_f | (uintptr_t)db_b) & 15) == 0, "lstm_bwd: db must be 16-B aligned");
+    DANET_CHECK_ARG(beta == 0.f || beta == 1.f, "lstm_bwd: beta must be 0 or 1");
+    if (!danet_lstm_bwd_db_supported(T, B, H, ndir)) {
+      danet_set_error("lstm_bwd: db requested, but B=%d H=%d is outside the reduce-scatter geometry", B, H);
+      return DANET_ERR_UNSUPPORTED;
+    }
+  } else {
+    DANET_CHECK_ARG((flags & DANET_LSTM_DB_DEFERRED) == 0, "lstm_bwd: DB_DEFERRED without db");
+  }
   hipStream_t stream = (hipStream_t)stream_;
   int rc = lstm_check_common(T, B, H, ndir, ws, ws_bytes);
   if (rc) return rc;
@@ -2372,17 +1606,7 @@ static int lstm_bwd_impl(danet_stream_t stream_, int T, int B, int H, int ndir,
         if (g2 <= num_cus()) { a.xmap = 2; nblk = g2; }
       }
     }
-    // lstm_bwd_lds_pad (bytes, experiment): extra dynamic LDS the kernel never touches -- with
-    // ~100 KB a GEMM workgroup (50 KB of LDS) cannot become co-resident on a CU that carries a
-    // BPTT workgroup, so an overlapped weight-gradient group only lands on the CUs BPTT leaves free
-    const int pad = danet_opt(OPT_LSTM_BWD_LDS_PAD);
-#define LAUNCH_RS(UV, NTWV)                                                                     \
-    do {                                                                                        \
-      if (pad > 0)                                                                              \
-        DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_bwd_rs_kernel<UV, NTWV>,          \
-            hipFuncAttributeMaxDynamicSharedMemorySize, pad));                                  \
-      lstm_bwd_rs_kernel<UV, NTWV><<<nblk, 512, pad > 0 ? pad : 0, stream>>>(a);                \
-    } while (0)
+#define LAUNCH_RS(UV, NTWV) lstm_bwd_rs_kernel<UV, NTWV><<<nblk, 512, 0, stream>>>(a)
 #define LAUNCH_RS_U(UV)                                          \
     switch (rs.NTW) {                                            \
       case 1: LAUNCH_RS(UV, 1); break; case 2: LAUNCH_RS(UV, 2); break; \
@@ -2398,48 +1622,7 @@ static int lstm_bwd_impl(danet_stream_t stream_, int T, int B, int H, int ndir,
     }
     return DANET_OK;
   }
-  LstmPlan pl = make_plan(B, H, ndir, true);
-  if (pl.lds > 160 * 1024) {
-    danet_set_error("lstm_bwd: H=%d needs %zu B LDS", H, pl.lds);
-    return DANET_ERR_UNSUPPORTED;
-  }
-  // rows per cluster: 8-row clusters halve the all-gather payload per workgroup
-  // (measured -7% on the BPTT launch at cfg 2) while the MFMA tile stays 16 rows;
-  // used whenever one workgroup per CU still fits.  DANET_LSTM_BWD_ROWS=16 overrides.
-  int R = 16 * pl.MT;
-  if (pl.MT == 1 && ndir * cdiv(B, 8) * pl.P <= num_cus()) R = 8;
-  if (pl.MT == 1 && danet_opt(OPT_LSTM_BWD_ROWS) == 16) R = 16;
-  const int G = cdiv(B, R);
-  const int nblk = ndir * G * pl.P;
-  if (nblk > num_cus()) {
-    danet_set_error("lstm_bwd: %d workgroups exceed the %d CUs", nblk, num_cus());
-    return DANET_ERR_UNSUPPORTED;
-  }
-  LstmBwdArgs a;
-  a.dy = dy; a.lddy = lddy; a.Wh[0] = Wh_f; a.Wh[1] = Wh_b; a.ldw = ldw;
-  a.gates[0] = gates_f; a.gates[1] = gates_b; a.cell[0] = cell_f; a.cell[1] = cell_b;
-  a.da[0] = da_f; a.da[1] = da_b; a.status = status ? (int*)status : (int*)ws;
-  a.spin_limit = spin_limit_env(); a.fault = fault_env();
-  a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.P = pl.P; a.G = G; a.R = R;
-  a.xmap = (danet_opt(OPT_LSTM_XMAP) >= 0 ? danet_opt(OPT_LSTM_XMAP) : 0);
-  const size_t dbytes = (size_t)T * B * 4 * H * sizeof(float);
-  {
-    FillList fl;
-    fl.add(ws, 64 + TRACE_BYTES(T), 0u);
-    fl.add(da_f, dbytes, SENTINEL);
-    if (ndir == 2) fl.add(da_b, dbytes, SENTINEL);
-    DANET_CHECK_HIP(fl.launch(stream));
-  }
-#define LAUNCH_BWD(MTV, NWV)                                                         \
-  do {                                                                               \
-    DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_bwd_kernel<MTV, NWV>,       \
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));                   \
-    lstm_bwd_kernel<MTV, NWV><<<nblk, 64 * NWV, pl.lds, stream>>>(a);                \
-  } while (0)
-  if (pl.MT == 2) LAUNCH_BWD(2, 4);
-  else if (pl.NW == 16) LAUNCH_BWD(1, 16);
-  else if (pl.NW == 8) LAUNCH_BWD(1, 8);
-  else LAUNCH_BWD(1, 4);
-  DANET_CHECK_LAUNCH();
-  return DANET_OK;
+  danet_set_error("lstm_bwd: B=%d H=%d ndir=%d outside the reduce-scatter geometry (one workgroup per CU)",
+                  B, H, ndir);
+  return DANET_ERR_UNSUPPORTED;
 }

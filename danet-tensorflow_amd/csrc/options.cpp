@@ -10,12 +10,9 @@ namespace {
 struct OptDef { const char* name; int dflt; };
 const OptDef kDefs[OPT_COUNT] = {
   {"gemm_dma", 3}, {"splitk_target", 512}, {"gemm_wgs", 512}, {"gemm_maxsplit", 8},
-  {"gemm_yield", 16}, {"anchor_scalar", 0}, {"lstm_fwd_mt", 0}, {"lstm_bwd_mt", 0},
-  {"lstm_fwd_un", 0}, {"lstm_fwd_nw", 0}, {"lstm_bwd_nw", 0}, {"lstm_bwd_s", 0},
-  {"lstm_bwd_rs", 1}, {"lstm_bwd_u", 0}, {"lstm_bwd_rows", 0}, {"lstm_spin_limit", 0},
-  {"lstm_fault_inject", 0}, {"lstm_xmap", -1}, {"lstm_fwd_small", 1}, {"lstm_fwd_fused", -1},
-  {"lstm_fx_mode", 0}, {"lstm_bwd_fused_kernel", 1}, {"lstm_bwd_twin_xcd", 1}, {"lstm_bwd_lds_pad", 0},
-  {"center_one", 0}, {"gemm_mfma16", 1},
+  {"gemm_yield", 16}, {"lstm_fwd_un", 0}, {"lstm_bwd_s", 0},
+  {"lstm_bwd_u", 0}, {"lstm_spin_limit", 0}, {"lstm_fault_inject", 0}, {"lstm_xmap", -1},
+  {"lstm_fwd_small", 1}, {"lstm_fwd_fused", -1}, {"lstm_bwd_twin_xcd", 1}, {"gemm_mfma16", 1},
 };
 std::atomic<int> g_val[OPT_COUNT];
 std::atomic<bool> g_init{false};

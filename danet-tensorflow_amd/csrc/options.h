@@ -11,26 +11,15 @@ enum DanetOpt {
   OPT_GEMM_WGS,              // persistent workgroups of a stream-K launch (multiple of 8, <= 1024)
   OPT_GEMM_MAXSPLIT,         // workgroups that may share one stream-K tile
   OPT_GEMM_YIELD,            // capped groups sleep n*64 clocks per k-tile
-  OPT_ANCHOR_SCALAR,         // 1: anchor estimator contraction on the vector ALU
-  OPT_LSTM_FWD_MT,           // 0 auto | 1 | 2 : 16-row tiles per forward cluster
-  OPT_LSTM_BWD_MT,
   OPT_LSTM_FWD_UN,           // 0 auto | 8 | 12 units per forward workgroup
-  OPT_LSTM_FWD_NW,           // 0 auto | 4 | 8 | 16 waves
-  OPT_LSTM_BWD_NW,
   OPT_LSTM_BWD_S,            // 0 auto | twins per BPTT group
-  OPT_LSTM_BWD_RS,           // 1 reduce-scatter BPTT kernel | 0 all-gather kernel
   OPT_LSTM_BWD_U,            // 0 auto | 8 | 16 | 32 units per BPTT producer group
-  OPT_LSTM_BWD_ROWS,         // 0 auto | 16 rows per all-gather cluster
   OPT_LSTM_SPIN_LIMIT,       // 0 default bound | >= 256 polls
   OPT_LSTM_FAULT_INJECT,     // 1: workgroup 0 of every launch exits without publishing (tests)
   OPT_LSTM_XMAP,             // -1 per-kernel default | 0 | 1 XCD-aware workgroup order
   OPT_LSTM_FWD_SMALL,        // 1 GEMV kernel for B <= 4 | 0 MFMA kernel
   OPT_LSTM_FWD_FUSED,        // -1 auto (B >= 24) | 0 off | 1 whenever supported
-  OPT_LSTM_FX_MODE,          // diagnostic modes of the fused forward kernel
-  OPT_LSTM_BWD_FUSED_KERNEL, // 1 the dW-fusing BPTT kernel may be used | 0 never
   OPT_LSTM_BWD_TWIN_XCD,     // 1 (default): the twins of a BPTT group share an XCD (L2 hits on their re-reads) | 0
-  OPT_LSTM_BWD_LDS_PAD,      // bytes of unused dynamic LDS of the BPTT kernel (CU exclusivity experiment)
-  OPT_CENTER_ONE,            // 1: one-launch centring for B >= 16 utterances of <= 32 K elements | 0 (default): always two launches
   OPT_GEMM_MFMA16,           // 1: capped groups beside a recurrent kernel use the 16x16x4 k-loop | 0: 32x32x2
   OPT_COUNT
 };

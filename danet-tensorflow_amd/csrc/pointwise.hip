@@ -160,47 +160,9 @@ __global__ void center_apply_kernel(int B, int T, int D, const float* __restrict
   }
 }
 
-// Both phases in ONE launch, one workgroup of 16 waves per utterance (the second read comes out of
-// L2): for many small utterances (B >= 16, T*D <= 32 K elements: the step's input at 129 bins) the
-// two-launch form above is two dependent ~6 us kernels on the critical path (12.3 us -> 10.4 us
-// in a loop of its own; inside the train step, behind the front-end, it measured 14.6 us against
-// 11.9 us, so it is an option -- center_one -- and off by default).  One workgroup cannot stream a larger utterance fast enough (T*D = 77 K elements: 26.8 us
-// against 12.6 us for the two-launch form), and cfg 5's single 3 MB utterance needs many workgroups.
-// Same double-accumulated mean.
-__global__ __launch_bounds__(1024) void center_one_kernel(int B, int T, int D, const float* __restrict__ in,
-                                                          int in_layout, int ld_in, float* __restrict__ out,
-                                                          int out_layout, int ld_out,
-                                                          float* __restrict__ mean_out) {
-  __shared__ double redd[16];
-  __shared__ float mean_s;
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  double s = 0.0;
-  for (int t = wave; t < T; t += nw) {
-    const float* row = in + center_index(in_layout, B, T, ld_in, b, t);
-    for (int d = lane; d < D; d += 64) s += (double)row[d];
-  }
-  s = wave_sum_d(s);
-  if (lane == 0) redd[wave] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double tot = 0.0;
-    for (int i = 0; i < nw; ++i) tot += redd[i];
-    const float m = (float)(tot / (double)((int64_t)T * D));
-    mean_s = m;
-    if (mean_out) mean_out[b] = m;
-  }
-  __syncthreads();
-  const float mean = mean_s;
-  for (int t = wave; t < T; t += nw) {
-    const float* src = in + center_index(in_layout, B, T, ld_in, b, t);
-    float* dst = out + center_index(out_layout, B, T, ld_out, b, t);
-    for (int d = lane; d < ld_out; d += 64) dst[d] = (d < D) ? src[d] - mean : 0.f;
-  }
-}
-
 // `mean` doubles as scratch: [B] means (padded to an even count) followed by
 // [B][CENTER_CHUNKS] DOUBLE partial sums (keeps the ABI allocation-free and re-entrant).
-extern "C" int danet_center_mean_elems(int B) { return ((B + 1) & ~1) + 2 * B * CENTER_CHUNKS; }
+int dn_center_mean_elems(int B) { return ((B + 1) & ~1) + 2 * B * CENTER_CHUNKS; }
 
 extern "C" int danet_center(danet_stream_t stream, int B, int T, int D, const float* in,
                             int in_layout, int ld_in, float* out, int out_layout,
@@ -209,12 +171,6 @@ extern "C" int danet_center(danet_stream_t stream, int B, int T, int D, const fl
   DANET_CHECK_ARG(ld_in >= D && ld_out >= D, "center: ld < D");
   DANET_CHECK_ARG((in_layout | 1) == 1 && (out_layout | 1) == 1, "center: layout must be 0/1");
   DANET_CHECK_ARG(((uintptr_t)mean & 7) == 0, "center: mean scratch must be 8-byte aligned");
-  if (B >= 16 && (int64_t)T * D <= 32768 && danet_opt(OPT_CENTER_ONE) == 1) {
-    center_one_kernel<<<B, 1024, 0, (hipStream_t)stream>>>(B, T, D, in, in_layout, ld_in, out, out_layout,
-                                                          ld_out, mean);
-    DANET_CHECK_LAUNCH();
-    return DANET_OK;
-  }
   double* partial = reinterpret_cast<double*>(mean + ((B + 1) & ~1));
   dim3 g1(CENTER_CHUNKS, B);
   center_sum_kernel<<<g1, 256, 0, (hipStream_t)stream>>>(B, T, D, in, in_layout, ld_in, partial);
@@ -264,14 +220,14 @@ __global__ void colsum_final_kernel(int nparts, int N, const float* __restrict__
   out[col] = (beta != 0.f) ? out[col] + s : s;
 }
 
-extern "C" size_t danet_colsum_f32_workspace_bytes(int M, int N) {
+size_t dn_ws_colsum(int M, int N) {
   return (size_t)cdiv(M, COLSUM_ROWS) * N * sizeof(float);
 }
 
 extern "C" int danet_colsum_f32(danet_stream_t stream, int M, int N, const float* A, int lda,
                                 float* out, float beta, void* ws, size_t ws_bytes) {
   DANET_CHECK_ARG(M > 0 && N > 0 && A && out && lda >= N, "colsum: bad args");
-  if (!ws || ws_bytes < danet_colsum_f32_workspace_bytes(M, N)) {
+  if (!ws || ws_bytes < dn_ws_colsum(M, N)) {
     danet_set_error("colsum: workspace too small");
     return DANET_ERR_WORKSPACE;
   }

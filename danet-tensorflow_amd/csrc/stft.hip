@@ -194,7 +194,7 @@ static int istft_used_frames(int T, int N, int S) {
   return (int)((stop + S - 1) / S);
 }
 
-extern "C" size_t danet_istft_workspace_bytes(int n_sig, int T, int N, int S) {
+size_t dn_ws_istft(int n_sig, int T, int N, int S) {
   const int used = istft_used_frames(T, N, S);
   return (size_t)n_sig * (used > 0 ? used : 1) * N * sizeof(double);
 }
@@ -208,7 +208,7 @@ extern "C" int danet_istft(danet_stream_t stream_, int n_sig, int T, int N, int 
   DANET_CHECK_ARG(logN >= 6 && logN <= 11, "istft: N must be a power of two in [64, 2048]");
   DANET_CHECK_ARG(S > 0 && S <= N, "istft: stride");
   DANET_CHECK_ARG(X_c64 && window && out, "istft: null pointer");
-  if (!ws || ws_bytes < danet_istft_workspace_bytes(n_sig, T, N, S)) {
+  if (!ws || ws_bytes < dn_ws_istft(n_sig, T, N, S)) {
     danet_set_error("istft: workspace too small");
     return DANET_ERR_WORKSPACE;
   }

@@ -63,25 +63,72 @@ class BatchFeed(object):
     '''for spectra in BatchFeed(dataset.epoch(...), device, crop_len): model.train_step(spectra)
 
     Yields complex64 [B, C, T', F] tensors on `device`, already ordered behind their upload on
-    the stream that is current in the consumer.  depth = staging slots (batches in flight on the
-    host side).'''
+    the stream that is current in the consumer.  depth = pinned staging slots.
 
-    def __init__(self, source, device, crop_len=None, depth=3, threaded=None):
+    mode (default: env DANET_FEED_MODE or 'inline' on a GPU, 'sync' on a CPU device):
+      'sync'    the reference's literal form: convert, blocking upload, in the caller's thread
+      'inline'  no thread: once step i has been enqueued, batch i+1 is staged into pinned
+                memory and its upload is issued on the copy stream -- the host does that work
+                while the device runs the steps it has queued (the host enqueues a step in
+                about a third of the time the device needs for it)
+      'thread'  a feeder thread runs the dataset iterator, stages AND issues the uploads
+      'thread-stage'  the feeder thread only runs the iterator and stages; the uploads are
+                issued by the consumer (no HIP call ever comes from a second thread)'''
+
+    def __init__(self, source, device, crop_len=None, depth=3, threaded=None, mode=None):
+        import os
         self.source = source
         self.device = torch.device(device)
+        if self.device.type == 'cuda' and self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        self.cuda = self.device.type == 'cuda'
         self.crop_len = crop_len
-        self.async_ = self.device.type == 'cuda' if threaded is None else bool(threaded)
+        if mode is None:
+            if threaded is not None:            # (round-4 tests: True = thread, False = sync)
+                mode = 'thread' if threaded else 'sync'
+            else:
+                mode = os.environ.get('DANET_FEED_MODE', 'inline') if self.cuda else 'sync'
+        assert mode in ('sync', 'inline', 'thread', 'thread-stage'), mode
+        self.mode = mode
         self.depth = max(2, depth)
         self.n = 0
         self._thread = None
-        self.cuda = self.device.type == 'cuda'
-        if self.async_:
+        self._stop = False
+        if mode != 'sync':
             self.copy_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
             self.slots = [_Slot() for _ in range(self.depth)]
+            self._k = 0
+        if mode in ('thread', 'thread-stage'):
             self.q = queue.Queue(maxsize=self.depth - 1)
-            self._stop = False
             self._thread = threading.Thread(target=self._produce, name='danet-feed', daemon=True)
             self._thread.start()
+
+    # ---------------------------------------------------------- shared pieces
+    def _stage(self, data_pt):
+        '''host batch -> (pinned staging tensor, its slot); draws the crop offset'''
+        a = to_batch_host(data_pt, self.crop_len)
+        slot = self.slots[self._k % self.depth]
+        self._k += 1
+        return slot.stage(a, pin=self.cuda), slot
+
+    def _upload(self, t, slot):
+        '''issue the H2D copy of a staged batch on the copy stream -> (device tensor, event)'''
+        if not self.cuda:                       # (host-logic tests: the "upload" is a copy)
+            return t.clone(), None
+        with torch.cuda.stream(self.copy_stream):
+            d = t.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        slot.event = ev
+        return d, ev
+
+    def _hand_out(self, d, ev):
+        if ev is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            d.record_stream(cur)                # allocated on the copy stream, used on this one
+        self.n += 1
+        return d
 
     # ------------------------------------------------------------- producer
     def _produce(self):
@@ -89,7 +136,6 @@ class BatchFeed(object):
         try:
             if self.cuda:
                 torch.cuda.set_device(self.device)
-            k = 0
             # the iterator's own device work (e.g. a dataset that runs danet_stft) goes to the
             # copy stream: it must not queue behind the training steps on the compute stream
             with (torch.cuda.stream(self.copy_stream) if self.cuda else contextlib.nullcontext()):
@@ -99,19 +145,8 @@ class BatchFeed(object):
                         data_pt = next(it)
                     except StopIteration:
                         break
-                    a = to_batch_host(data_pt, self.crop_len)
-                    slot = self.slots[k % self.depth]
-                    t = slot.stage(a, pin=self.cuda)
-                    ev = None
-                    if self.cuda:
-                        d = t.to(self.device, non_blocking=True)
-                        ev = torch.cuda.Event()
-                        ev.record(self.copy_stream)
-                        slot.event = ev
-                    else:                   # (host-logic tests: the "upload" is a copy)
-                        d = t.clone()
-                    k += 1
-                    self._put((d, ev))
+                    t, slot = self._stage(data_pt)
+                    self._put(self._upload(t, slot) if self.mode == 'thread' else (t, slot))
             self._put(None)
         except BaseException as e:           # surfaces in the consumer
             self._put(e)
@@ -124,28 +159,44 @@ class BatchFeed(object):
             except queue.Full:
                 continue
 
+    def _take(self):
+        item = self.q.get()
+        if isinstance(item, BaseException):
+            raise item
+        return item
+
     # ------------------------------------------------------------- consumer
     def __iter__(self):
-        if not self.async_:
+        if self.mode == 'sync':
             for data_pt in self.source:
                 a = to_batch_host(data_pt, self.crop_len)
                 self.n += 1
                 yield torch.as_tensor(np.ascontiguousarray(a).astype(np.complex64)).to(self.device)
             return
         try:
-            while True:
-                item = self.q.get()
-                if item is None:
-                    return
-                if isinstance(item, BaseException):
-                    raise item
-                d, ev = item
-                if ev is not None:
-                    cur = torch.cuda.current_stream(self.device)
-                    cur.wait_event(ev)
-                    d.record_stream(cur)      # allocated on the copy stream, used on this one
-                self.n += 1
-                yield d
+            if self.mode == 'thread':
+                while True:
+                    item = self._take()
+                    if item is None:
+                        return
+                    yield self._hand_out(*item)
+            # one batch ahead, uploads issued here: `nxt` is the batch whose upload is in flight
+            if self.mode == 'inline':
+                it = iter(self.source)
+
+                def fetch():
+                    try:
+                        return self._stage(next(it))
+                    except StopIteration:
+                        return None
+            else:
+                fetch = self._take
+            staged = fetch()
+            nxt = self._upload(*staged) if staged is not None else None
+            while nxt is not None:
+                yield self._hand_out(*nxt)        # the consumer enqueues step i ...
+                staged = fetch()                  # ... then batch i+1 is staged / taken from the
+                nxt = self._upload(*staged) if staged is not None else None   # thread and uploaded
         finally:
             self.close()
 

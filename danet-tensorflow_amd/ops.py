@@ -52,7 +52,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None,
     stream-K schedule (for a product that has the GPU to itself).'''
     L = _L()
     if streamk:
-        need = L.danet_gemm_f32_streamk_workspace_bytes(M, N, K)
+        need = _lib.ws_bytes(_lib.WS_GEMM_STREAMK, M, N, K)
         # dedicated (zero-initialised, never shared) scratch: it holds the stream-K
         # hand-off flags, which must only ever contain earlier launch sequence numbers
         w = _lib.workspace(need, C.device, tag='gemm_sk')
@@ -65,10 +65,10 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None,
             if stop_event is not None:
                 stop_event.attached = True
         return C
-    need = L.danet_gemm_f32_workspace_bytes(M, N, K)
+    need = _lib.ws_bytes(_lib.WS_GEMM, M, N, K)
     w, wn = _ws(need, C.device)
     with _lib.timed('gemm_f32', tag):
-        check(L.danet_gemm_f32_ex(_lib.stream(), int(transA), int(transB), M, N, K,
+        check(L.danet_gemm_f32(_lib.stream(), int(transA), int(transB), M, N, K,
                                   ptr(_f32(A)), lda, ptr(_f32(B)), ldb, ptr(_f32(C)), ldc,
                                   ptr(bias), float(beta), ptr(w), wn, int(max_workgroups)))
     return C
@@ -82,7 +82,7 @@ def gemm_kcat(A1, lda1, B1, ldb1, K1, A2, lda2, B2, ldb2, K2, C, M, N, ldc,
     stop_event: a ForkEvent that completes with this launch (stream-K path only)'''
     L = _L()
     if streamk and K1 % 16 == 0:
-        w = _lib.workspace(L.danet_gemm_f32_streamk_workspace_bytes(M, N, K1 + K2), C.device,
+        w = _lib.workspace(_lib.ws_bytes(_lib.WS_GEMM_STREAMK, M, N, K1 + K2), C.device,
                            tag='gemm_sk')
         with _lib.timed('gemm_f32', tag):
             if stop_event is not None:
@@ -95,12 +95,10 @@ def gemm_kcat(A1, lda1, B1, ldb1, K1, A2, lda2, B2, ldb2, K2, C, M, N, ldc,
             if stop_event is not None:
                 stop_event.attached = True
         return C
-    w, wn = _ws(L.danet_gemm_f32_kcat_workspace_bytes(M, N, K1, K2), C.device)
-    with _lib.timed('gemm_f32', tag):
-        check(L.danet_gemm_f32_kcat(_lib.stream(), int(transA), int(transB), M, N,
-                                    K1, ptr(_f32(A1)), lda1, ptr(_f32(B1)), ldb1,
-                                    K2, ptr(_f32(A2)), lda2, ptr(_f32(B2)), ldb2,
-                                    ptr(_f32(C)), ldc, ptr(bias), float(beta), ptr(w), wn))
+    # (no stream-K: two accumulating products on the tile kernel)
+    gemm(A1, B1, C, M, N, K1, lda1, ldb1, ldc, transA=transA, transB=transB, bias=bias, beta=beta,
+         tag=tag)
+    gemm(A2, B2, C, M, N, K2, lda2, ldb2, ldc, transA=transA, transB=transB, beta=1.0, tag=tag)
     return C
 
 
@@ -120,7 +118,7 @@ def gemm_group(problems, K, transA=False, transB=False, max_workgroups=0):
         arr[i].C, arr[i].ldc, arr[i].M, arr[i].N = ptr(C), ldc, M, N
         arr[i].bias, arr[i].beta = ptr(bias), float(beta)
     dev = problems[0][4].device
-    w = _lib.workspace(L.danet_gemm_f32_streamk_workspace_bytes(0, 0, K), dev, tag='gemm_sk')
+    w = _lib.workspace(_lib.ws_bytes(_lib.WS_GEMM_STREAMK, 0, 0, K), dev, tag='gemm_sk')
     with _lib.timed('gemm_f32_group'):
         check(L.danet_gemm_f32_streamk_grouped(_lib.stream(), int(transA), int(transB), K,
                                                len(problems), arr, int(max_workgroups),
@@ -136,7 +134,7 @@ GROUPED_GX = int(__import__('os').environ.get('DANET_GROUPED_GX', '512'))   # gr
 
 def colsum(A, M, N, lda, out, beta=0.0):
     L = _L()
-    w, wn = _ws(L.danet_colsum_f32_workspace_bytes(M, N), out.device)
+    w, wn = _ws(_lib.ws_bytes(_lib.WS_COLSUM, M, N), out.device)
     check(L.danet_colsum_f32(_lib.stream(), M, N, ptr(_f32(A)), lda, ptr(out), float(beta),
                              ptr(w), wn))
     return out
@@ -145,7 +143,7 @@ def colsum(A, M, N, lda, out, beta=0.0):
 def center(x, B, T, D, in_layout, ld_in, out, out_layout, ld_out):
     '''out[b] = x[b] - mean(x[b]) with an optional layout switch; returns means [B]'''
     L = _L()
-    scratch = torch.empty(L.danet_center_mean_elems(B), dtype=torch.float32, device=x.device)
+    scratch = torch.empty(_lib.ws_bytes(_lib.WS_CENTER_MEAN, B) // 4, dtype=torch.float32, device=x.device)
     check(L.danet_center(_lib.stream(), B, T, D, ptr(_f32(x)), in_layout, ld_in,
                          ptr(out), out_layout, ld_out, ptr(scratch)))
     return scratch[:B]
@@ -227,7 +225,7 @@ def istft(X, stride, window):
     N = (F - 1) * 2
     L = _L()
     out = torch.empty(n_sig, T * stride, dtype=torch.float64, device=X.device)
-    w, wn = _ws(L.danet_istft_workspace_bytes(n_sig, T, N, stride), X.device)
+    w, wn = _ws(_lib.ws_bytes(_lib.WS_ISTFT, n_sig, T, N, stride), X.device)
     check(L.danet_istft(_lib.stream(), n_sig, T, N, stride, ptr(torch.view_as_real(X)),
                         ptr(_f32(window)), ptr(out), ptr(w), wn))
     return out[0] if squeeze else out
@@ -418,7 +416,7 @@ def lstm_status_ok():
 
 
 def _lstm_ws(T, B, H, ndir, dev):
-    n = _L().danet_lstm_workspace_bytes(T, B, H, ndir)
+    n = _lib.ws_bytes(_lib.WS_LSTM, T, B, H, ndir)
     return torch.empty(n, dtype=torch.uint8, device=dev), n
 
 
@@ -724,17 +722,6 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs, x_pad_zero=False, ypad=None, ws=N
     return c
 
 
-# (Python-side POLICY; the library's own kill-switch for that kernel is the separate option
-# `lstm_bwd_fused_kernel`, env DANET_LSTM_BWD_FUSED_KERNEL.)
-# Where BPTT accumulates dW / db inside the persistent kernel (danet_lstm_bwd_fused): '0'
-# (default) = nowhere; '1' = every layer inside the kernel's envelope; 'bottom' = only the
-# layer whose input needs no gradient; 'h' = only dWh (and db) inside the kernel, dWx by the group
-# (round 3: 3.35 vs 3.13 ms per step, profiles/EXPERIMENTS.md).  Measured at cfg 2 / cfg 4 (ms per step): '0' 3.60 /
-# 5.12, '1' 3.61 / 5.27, 'bottom' 3.82 / 5.30 -- the fused kernel runs at 3.4 us per step alone
-# (MFMA block first, all loads behind it) but ~3.9 in the step, what the GEMM path reaches with
-# its contention; a fused bottom layer slows the layer-1 weight-gradient group that runs beside
-# it.  Kept as a tested opt-in.
-BWD_FUSED = __import__('os').environ.get('DANET_LSTM_BWD_FUSED', '0')
 # Do the weight-gradient groups run UNDER the next BPTT kernel (side stream) or serially on the
 # main stream?  Under: the group is hidden but the BPTT kernel beside it slows down for as long as
 # the overlap lasts.  Measured: H = 300 (cfg 2 / cfg 4) 3.61 / 5.13 ms per step overlapped vs
@@ -757,17 +744,6 @@ BWD_DB = __import__('os').environ.get('DANET_LSTM_BWD_DB', '1') == '1'
 DB_DEFER = __import__('os').environ.get('DANET_LSTM_DB_DEFER', '1') == '1'
 
 
-def bptt_fused(T, B, H, ndir, D, need_dx, is_top=False):
-    '''policy + envelope: does lstm_layer_bwd take the fused kernel for this layer?'''
-    if BWD_FUSED == '1':
-        use = True
-    elif BWD_FUSED == 'bottom':
-        use = not need_dx
-    else:
-        use = False
-    return use and _L().danet_lstm_bwd_fused_supported(T, B, H, ndir, D) == 1
-
-
 def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=None):
     '''dy: [T, B, ndir*H] contiguous.  Returns (dx [T*B, D] or None, dWs, dbs).
     ws_prefilled: a workspace whose ring the caller prefilled (lstm_prefill_bwd)'''
@@ -784,75 +760,32 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
         gb, okb = _grad_target(c.bs[d], (4 * H,), dev)
         dWs.append(gW); dbs.append(gb); direct.append((okW, okb))
     dx = torch.empty(T * B, D, device=dev) if need_dx else None
-    all_direct = all(a and b for a, b in direct)
-    none_direct = not any(a or b for a, b in direct)
-    fused = ((all_direct or none_direct) and
-             all(W.stride(0) == 4 * H and W.stride(1) == 1 and W.data_ptr() % 16 == 0 for W in c.Ws) and
-             all(t.data_ptr() % 16 == 0 for t in dWs + dbs) and
-             bptt_fused(T, B, H, ndir, D, need_dx, is_top))
-    db_in_kernel = db_deferred = False
-    # 'h': only the recurrent weight gradient (dWh) and the bias gradient inside the BPTT kernel
-    fused_h = (not fused and BWD_FUSED == 'h' and (all_direct or none_direct) and
-               all(W.stride(0) == 4 * H and W.stride(1) == 1 and W.data_ptr() % 16 == 0 for W in c.Ws) and
-               all(t.data_ptr() % 16 == 0 for t in dbs) and (D * 4 * H) % 4 == 0 and
-               all(dW[D:].data_ptr() % 16 == 0 for dW in dWs) and
-               L.danet_lstm_bwd_fused_h_supported(T, B, H, ndir) == 1)
-    if fused_h:
-        wn = L.danet_lstm_bwd_fused_h_workspace_bytes(T, B, H, ndir)
-        ws = torch.empty(wn, dtype=torch.uint8, device=dev)
-        Whs = [W[D:] for W in c.Ws]
-        dWhs = [dW[D:] for dW in dWs]
-        with _lib.timed('lstm_bwd'):
-            check(L.danet_lstm_bwd_fused_h(
-                _lib.stream(), T, B, H, ndir, ptr(_f32(dy)), ndir * H,
-                ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(c.gates[0]), ptr(c.gates[-1]),
-                ptr(c.cells[0]), ptr(c.cells[-1]), ptr(c.ypad), ldy,
-                ptr(das[0]), ptr(das[-1]), ptr(dWhs[0]), ptr(dWhs[-1]), ptr(dbs[0]), ptr(dbs[-1]),
-                1.0 if all_direct else 0.0, ptr(ws), wn, ptr(status_word(dev))))
-        db_in_kernel = True
-    elif fused:
-        # BPTT with dW / db accumulated inside the persistent kernel (csrc/lstm.hip): no
-        # weight-gradient GEMMs, no column sums, nothing on a side stream
-        wn = L.danet_lstm_bwd_fused_workspace_bytes(T, B, H, ndir, D)
-        ws = torch.empty(wn, dtype=torch.uint8, device=dev)
-        with _lib.timed('lstm_bwd'):
-            check(L.danet_lstm_bwd_fused(
-                _lib.stream(), T, B, H, ndir, ptr(_f32(dy)), ndir * H,
-                ptr(c.Ws[0]), ptr(c.Ws[-1]), 4 * H, ptr(c.gates[0]), ptr(c.gates[-1]),
-                ptr(c.cells[0]), ptr(c.cells[-1]), ptr(c.x), c.ldx, D, ptr(c.ypad), ldy,
-                ptr(das[0]), ptr(das[-1]), ptr(dWs[0]), ptr(dWs[-1]), ptr(dbs[0]), ptr(dbs[-1]),
-                1.0 if all_direct else 0.0, ptr(ws), wn, ptr(status_word(dev))))
+    if ws_prefilled is not None:
+        ws, wn = ws_prefilled, ws_prefilled.numel()
     else:
-        if ws_prefilled is not None:
-            ws, wn = ws_prefilled, ws_prefilled.numel()
-        else:
-            ws, wn = _lstm_ws(T, B, H, ndir, dev)
-        Whs = [W[D:] for W in c.Ws]
-        b_direct = [okb for _, okb in direct]
-        db_in_kernel = (BWD_DB and (all(b_direct) or not any(b_direct)) and
-                        all(t.data_ptr() % 16 == 0 for t in dbs) and
-                        L.danet_lstm_bwd_db_supported(T, B, H, ndir) == 1)
-        # the 6-us sum of the kernel's per-cluster bias partials leaves the critical path (BPTT ->
-        # dX -> next BPTT) when a side chain is forked behind this launch anyway
-        # (not for the bottom layer: its weight-gradient group takes every CU on the main stream
-        # and the side chain's reduce would sit behind it for the group's whole duration)
-        db_deferred = (db_in_kernel and DB_DEFER and GROUPED_DW and SIDE_STREAMS > 0 and
-                       need_dx and _overlap_dw(H))
-        with _lib.timed('lstm_bwd'):
-            if db_in_kernel:      # bias gradients summed inside the BPTT kernel: no colsum launches
-                check(L.danet_lstm_bwd_db(
-                    _lib.stream(), T, B, H, ndir, ptr(_f32(dy)), ndir * H,
-                    ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(c.gates[0]), ptr(c.gates[-1]),
-                    ptr(c.cells[0]), ptr(c.cells[-1]), ptr(das[0]), ptr(das[-1]),
-                    ptr(dbs[0]), ptr(dbs[-1]), 1.0 if all(b_direct) else 0.0, ptr(ws), wn,
-                    ptr(status_word(dev)),
-                    (1 if ws_prefilled is not None else 0) | (2 if db_deferred else 0)))
-            else:
-                check(L.danet_lstm_bwd(
-                    _lib.stream(), T, B, H, ndir, ptr(_f32(dy)), ndir * H,
-                    ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(c.gates[0]), ptr(c.gates[-1]),
-                    ptr(c.cells[0]), ptr(c.cells[-1]), ptr(das[0]), ptr(das[-1]), ptr(ws), wn,
-                    ptr(status_word(dev))))
+        ws, wn = _lstm_ws(T, B, H, ndir, dev)
+    Whs = [W[D:] for W in c.Ws]
+    b_direct = [okb for _, okb in direct]
+    # bias gradients summed inside the BPTT kernel (no column-sum launches) where the
+    # reduce-scatter kernel covers the shape
+    db_in_kernel = (BWD_DB and (all(b_direct) or not any(b_direct)) and
+                    all(t.data_ptr() % 16 == 0 for t in dbs) and
+                    L.danet_lstm_bwd_db_supported(T, B, H, ndir) == 1)
+    # the 6-us sum of the kernel's per-cluster bias partials leaves the critical path (BPTT ->
+    # dX -> next BPTT) when a side chain is forked behind this launch anyway
+    # (not for the bottom layer: its weight-gradient group takes every CU on the main stream
+    # and the side chain's reduce would sit behind it for the group's whole duration)
+    db_deferred = (db_in_kernel and DB_DEFER and GROUPED_DW and SIDE_STREAMS > 0 and
+                   need_dx and _overlap_dw(H))
+    with _lib.timed('lstm_bwd'):
+        check(L.danet_lstm_bwd(
+            _lib.stream(), T, B, H, ndir, ptr(_f32(dy)), ndir * H,
+            ptr(Whs[0]), ptr(Whs[-1]), 4 * H, ptr(c.gates[0]), ptr(c.gates[-1]),
+            ptr(c.cells[0]), ptr(c.cells[-1]), ptr(das[0]), ptr(das[-1]),
+            ptr(dbs[0]) if db_in_kernel else None, ptr(dbs[-1]) if db_in_kernel else None,
+            1.0 if all(b_direct) else 0.0, ptr(ws), wn, ptr(status_word(dev)),
+            ((1 if ws_prefilled is not None else 0) | (2 if db_deferred else 0))
+            if db_in_kernel else 0))
 
     # the weight-gradient products overlap the NEXT layer's BPTT kernel (152 of
     # 256 CUs at cfg 2): cap each chain so both together stay on the idle CUs
@@ -865,9 +798,8 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
              max_workgroups=cap)
         # dWh = Hprev^T da; Hprev(t) = ypad block t (fwd) / block t+2 (bwd)
         hprev = c.ypad.view(-1)[(0 if d == 0 else 2 * B * ldy + H):]
-        if not fused_h:
-            gemm(hprev, das[d], dWs[d][D:], H, 4 * H, T * B, ldy, 4 * H, 4 * H, transA=True, beta=bW,
-                 max_workgroups=cap)
+        gemm(hprev, das[d], dWs[d][D:], H, 4 * H, T * B, ldy, 4 * H, 4 * H, transA=True, beta=bW,
+             max_workgroups=cap)
         if not db_in_kernel:
             colsum(das[d], T * B, 4 * H, 4 * H, dbs[d], beta=bb)
 
@@ -881,8 +813,7 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
         for d in range(ndir):
             bW = 1.0 if direct[d][0] else 0.0
             probs.append((c.x, c.ldx, das[d], 4 * H, dWs[d], 4 * H, D, 4 * H, bW))
-            if not fused_h:          # ('h': dWh came out of the BPTT kernel)
-                probs.append((hprev_of(d), ldy, das[d], 4 * H, dWs[d][D:], 4 * H, H, 4 * H, bW))
+            probs.append((hprev_of(d), ldy, das[d], 4 * H, dWs[d][D:], 4 * H, H, 4 * H, bW))
         gemm_group(probs, T * B, transA=True, max_workgroups=wgs)
         # (the bias gradients as M = 1 members of the group were measured slower than
         # the two column-sum kernels: +25 us on the group for 128-row tiles with one row)
@@ -922,9 +853,9 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
     # is recorded behind dX), so they do not compete with dX for CUs but overlap
     # the next layer's latency-bound BPTT kernel instead; the caller joins them
     # (`join_deferred`).
-    fork_early = DW_FORK_EARLY and need_dx and GROUPED_DW and not fused
+    fork_early = DW_FORK_EARLY and need_dx and GROUPED_DW
     if need_dx and not fork_early:
-        input_grad(attach=GROUPED_DW and not fused and _overlap_dw(H))
+        input_grad(attach=GROUPED_DW and _overlap_dw(H))
     hooks = bool(GRAD_READY_HOOKS) and _fast() and layer_tag is not None and \
         all(a and b for a, b in direct)
     if hooks and not need_dx:
@@ -941,9 +872,7 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
     with _Fork(dev, ndir + 1, defer=True, keep=(das, c.x, c.ypad, dy, ws), lazy=True,
                event=fork_ev[0]) as f:
         on_main = False
-        if fused:
-            on_main = True           # everything was issued on the main stream
-        elif GROUPED_DW and not need_dx:
+        if GROUPED_DW and not need_dx:
             # bottom layer: no BPTT kernel follows, so the group takes the whole GPU on
             # the main stream while the column sums (if any) run beside it
             if not db_in_kernel:
@@ -1068,11 +997,9 @@ class RnnEncoderFn(torch.autograd.Function):
         dy = torch.empty(T, B, D, device=dev)
         center(dyc, B, T, D, 0, D, dy, 1, D)                 # centre is self-adjoint
         grads = [None] * (2 * L * ndir)
-        # partial-dh rings of all layers' BPTT launches, prefilled by one fill launch (layers
-        # that take the dW-fusing kernel allocate and prefill their own, larger workspace)
+        # partial-dh rings of all layers' BPTT launches, prefilled by one fill launch
         bwss = [None] * L
-        plain = [] if BWD_FUSED == 'h' else \
-            [l for l in range(L) if not bptt_fused(T, B, H, ndir, ctx.ctxs[l].D, l > 0, l == L - 1)]
+        plain = list(range(L))
         if plain and BWD_DB and _L().danet_lstm_bwd_db_supported(T, B, H, ndir) == 1:
             cand = [_lstm_ws(T, B, H, ndir, dev)[0] for _ in plain]
             if lstm_prefill_bwd(T, B, H, ndir, cand):
@@ -1295,7 +1222,7 @@ class TruthAttractorFn(torch.autograd.Function):
         attr = torch.empty(B, C, E, device=dev)
         denom = torch.empty(B, C, device=dev)
         L = _L()
-        w, wn = _ws(L.danet_attractor_truth_workspace_bytes(B, C, N, E), dev)
+        w, wn = _ws(_lib.ws_bytes(_lib.WS_ATTRACTOR_TRUTH, B, C, N, E), dev)
         check(L.danet_attractor_truth_fwd(_lib.stream(), mode, B, C, N, E, ptr(embed),
                                           ptr(src_pwr), ptr(mix_pwr), eps, ptr(attr),
                                           ptr(denom), ptr(w), wn))
@@ -1350,7 +1277,7 @@ class AnchorAttractorFn(torch.autograd.Function):
         asum = torch.empty(B, P, C, device=dev)
         choice = torch.empty(B, dtype=torch.int32, device=dev)
         L = _L()
-        w, wn = _ws(L.danet_attractor_anchor_workspace_bytes(B, C, N, E, A), dev)
+        w, wn = _ws(_lib.ws_bytes(_lib.WS_ATTRACTOR_ANCHOR, B, C, N, E, A), dev)
         check(L.danet_attractor_anchor_fwd(_lib.stream(), B, C, N, E, A, ptr(embed),
                                            ptr(anchors), ptr(attr), ptr(asets), ptr(asum),
                                            ptr(choice), ptr(w), wn))
@@ -1383,7 +1310,7 @@ class AnchorAttractorFn(torch.autograd.Function):
         # fast backward: add straight into the parameter's .grad (no autograd accumulate kernel)
         danchors, direct = _grad_target(ctx.anchors_param, (A, E), dev)
         L = _L()
-        nbytes = L.danet_attractor_anchor_workspace_bytes(B, C, N, E, A)
+        nbytes = _lib.ws_bytes(_lib.WS_ATTRACTOR_ANCHOR, B, C, N, E, A)
         dattr = _f32(dattr.contiguous())
         if recipe is not None:
             # the separator's embedding-gradient term is recomputed here (one pass, one store)
@@ -1408,10 +1335,12 @@ class AnchorAttractorFn(torch.autograd.Function):
                 1.0 if direct else 0.0)), keep=(w, choice, danchors))
         else:
             w, wn = _ws(nbytes, dev)
-            check(L.danet_attractor_anchor_bwd(
-                _lib.stream(), B, C, N, E, A, ptr(dattr), ptr(embed),
-                ptr(anchors), ptr(attr), ptr(asum), ptr(choice), ptr(dembed), ptr(danchors),
-                ptr(w), wn, 1.0 if direct else 0.0))
+            check(L.danet_attractor_anchor_bwd_embed(
+                _lib.stream(), B, C, N, E, A, ptr(dattr), ptr(embed), ptr(anchors), ptr(attr),
+                ptr(asum), ptr(choice), ptr(dembed), ptr(w), wn))
+            check(L.danet_attractor_anchor_bwd_anchors(
+                _lib.stream(), B, C, N, E, A, ptr(choice), ptr(danchors), ptr(w), wn,
+                1.0 if direct else 0.0))
         return (None if shared is not None else dembed), (None if direct else danchors), None
 
 
@@ -1451,7 +1380,7 @@ class SeparateFn(torch.autograd.Function):
         dembed = torch.empty(B, N, E, device=dev)
         dattr = torch.empty(B, C, E, device=dev)
         L = _L()
-        w, wn = _ws(L.danet_separate_bwd_workspace_bytes(B, C, N, E), dev)
+        w, wn = _ws(_lib.ws_bytes(_lib.WS_SEPARATE_BWD, B, C, N, E), dev)
         check(L.danet_separate_bwd(_lib.stream(), act, B, C, N, E, ptr(mix_pwr), ptr(attr),
                                    ptr(embed_flat), ptr(_f32(dout.contiguous())), ptr(dembed),
                                    ptr(dattr), ptr(w), wn))
@@ -1479,7 +1408,7 @@ class PitMseFn(torch.autograd.Function):
         loss, snr = torch.empty((), device=dev), torch.empty((), device=dev)
         perm_idx = torch.empty(B, dtype=torch.int32, device=dev)
         L = _L()
-        w, wn = _ws(L.danet_pit_mse_workspace_bytes(B, C, N), dev)
+        w, wn = _ws(_lib.ws_bytes(_lib.WS_PIT_MSE, B, C, N), dev)
         check(L.danet_pit_mse_fwd(_lib.stream(), mode, B, C, N, ptr(torch.view_as_real(src)),
                                   ptr(sep_pwr), ptr(phasor), eps, ptr(loss), ptr(snr),
                                   ptr(perm_idx), ptr(w), wn))
@@ -1505,7 +1434,7 @@ class PitMseFn(torch.autograd.Function):
 
 class SeparatePitFn(torch.autograd.Function):
     '''Separator + phase re-attach + PIT-MSE + SNR in ONE pass over the embedding and ONE
-    pass back (danet_separate_pit_fwd / _bwd): the training path of app/modules.py:548-603 ->
+    pass back (danet_separate_pit_fwd_records + _final / _bwd): the training path of app/modules.py:548-603 ->
     main.py:281-290, 308-309 -> app/ops.py:374-431.  Same arithmetic as SeparateFn followed by
     PitMseFn; the masks, the separated magnitudes and dL/dsep never touch HBM.
     (mix_pwr [B,T,F], attr [B,C,E], embed_flat [B,N,E], src complex64 [B,C,T,F],
@@ -1526,7 +1455,7 @@ class SeparatePitFn(torch.autograd.Function):
         loss, snr = torch.empty((), device=dev), torch.empty((), device=dev)
         perm_idx = torch.empty(B, dtype=torch.int32, device=dev)
         L = _L()
-        records = torch.empty(L.danet_separate_pit_records_bytes(B, N) // 4, device=dev)
+        records = torch.empty(_lib.ws_bytes(_lib.WS_SEPARATE_PIT_RECORDS, B, N) // 4, device=dev)
         check(L.danet_separate_pit_fwd_records(
             _lib.stream(), act, mode, B, C, N, E, ptr(mix_pwr), ptr(attr_c), ptr(embed_flat),
             ptr(torch.view_as_real(src)), ptr(phasor), None, ptr(records)))
@@ -1562,7 +1491,7 @@ class SeparatePitFn(torch.autograd.Function):
         dattr = torch.empty(B, C, E, device=dev)
         dl = _f32(dloss.contiguous())
         L = _L()
-        w, wn = _ws(L.danet_separate_pit_workspace_bytes(B, C, N, E), dev)
+        w, wn = _ws(_lib.ws_bytes(_lib.WS_SEPARATE_PIT, B, C, N, E), dev)
         # dloss is a device scalar: the kernel reads it (no host sync, no extra pass)
         check(L.danet_separate_pit_bwd(_lib.stream(), act, mode, B, C, N, E, ptr(mix_pwr),
                                        ptr(attr), ptr(embed_flat), ptr(torch.view_as_real(src)),

@@ -14,7 +14,8 @@
  *    allocates or frees), dense row-major, fp32 unless the name says
  *    otherwise; `stream` is a hipStream_t passed as void*.
  *  - `ws` is caller-provided device scratch of at least
- *    `*_workspace_bytes(...)` bytes; contents are clobbered.
+ *    `danet_workspace_bytes(DANET_WS_<op>, dims, n)` bytes (below); contents
+ *    are clobbered.
  *  - return value: 0 = DANET_OK, negative = error (no exceptions cross the
  *    ABI); `danet_last_error()` returns a thread-local message.
  *  - all launches are asynchronous on `stream`; calls are re-entrant per stream
@@ -45,22 +46,20 @@ extern "C" {
 #define DANET_ERR_UNSUPPORTED (-3)  /* shape outside the compiled envelope     */
 #define DANET_ERR_WORKSPACE (-4)    /* ws too small                            */
 
-#define DANET_ABI_VERSION 3
+#define DANET_ABI_VERSION 4
 
 typedef void* danet_stream_t;
 
 int danet_abi_version(void);
 const char* danet_last_error(void);
 
-/* Options: kernel-variant selection and diagnostics that round 2 read from
- * DANET_* environment variables inside the library.  Every launch reads the
- * current value; defaults are the shipped configuration.  Names (value meaning
- * in csrc/options.h): gemm_dma, splitk_target, gemm_wgs, gemm_maxsplit,
- * gemm_yield, anchor_scalar, lstm_fwd_mt, lstm_bwd_mt, lstm_fwd_un,
- * lstm_fwd_nw, lstm_bwd_nw, lstm_bwd_s, lstm_bwd_rs, lstm_bwd_u,
- * lstm_bwd_rows, lstm_spin_limit, lstm_fault_inject, lstm_xmap,
- * lstm_fwd_small, lstm_fwd_fused, lstm_fx_mode, lstm_bwd_fused_kernel,
- * lstm_bwd_twin_xcd, lstm_bwd_lds_pad.
+/* Options: the kernel-schedule switches a caller may legitimately need (a
+ * different GPU partition, a co-scheduled workload, fault-injection tests).
+ * Every launch reads the current value; defaults are the shipped configuration.
+ * Names (value meaning in csrc/options.h): gemm_dma, splitk_target, gemm_wgs,
+ * gemm_maxsplit, gemm_yield, gemm_mfma16, lstm_fwd_un, lstm_fwd_small,
+ * lstm_fwd_fused, lstm_bwd_u, lstm_bwd_s, lstm_bwd_twin_xcd,
+ * lstm_xmap, lstm_spin_limit, lstm_fault_inject.
  * danet_set_option / danet_get_option return DANET_ERR_ARG for an unknown
  * name; danet_option_name(i), 0 <= i < danet_option_count(), enumerates.   */
 int danet_set_option(const char* name, int value);
@@ -68,6 +67,27 @@ int danet_get_option(const char* name, int* value);
 void danet_reset_options(void);
 int danet_option_count(void);
 const char* danet_option_name(int index);
+
+/* Scratch sizes: ONE query for every entry point that takes `ws`.  `dims` are
+ * the shape arguments of that entry point in the order listed; returns the
+ * bytes needed, or (size_t)-1 for a bad op / dim count (danet_last_error says
+ * which).                                                                    */
+enum {
+  DANET_WS_ISTFT = 0,            /* n_sig, T, N, S          danet_istft                       */
+  DANET_WS_GEMM,                 /* M, N, K                 danet_gemm_f32 (split-K slabs; may be 0) */
+  DANET_WS_GEMM_STREAMK,         /* M, N, K                 danet_gemm_f32_streamk* (dims ignored)   */
+  DANET_WS_COLSUM,               /* M, N                    danet_colsum_f32                  */
+  DANET_WS_LSTM,                 /* T, B, H, ndir           danet_lstm_fwd* / danet_lstm_bwd  */
+  DANET_WS_ATTRACTOR_TRUTH,      /* B, C, N, E              danet_attractor_truth_fwd         */
+  DANET_WS_ATTRACTOR_ANCHOR,     /* B, C, N, E, A           danet_attractor_anchor_*          */
+  DANET_WS_SEPARATE_BWD,         /* B, C, N, E              danet_separate_bwd                */
+  DANET_WS_SEPARATE_PIT,         /* B, C, N, E              danet_separate_pit_bwd            */
+  DANET_WS_SEPARATE_PIT_RECORDS, /* B, N                    `records` of danet_separate_pit_* */
+  DANET_WS_PIT_MSE,              /* B, C, N                 danet_pit_mse_fwd                 */
+  DANET_WS_CENTER_MEAN,          /* B                       `mean` of danet_center            */
+  DANET_WS_COUNT
+};
+size_t danet_workspace_bytes(int op, const int64_t* dims, int n_dims);
 
 /* ---------------------------------------------------------------- a1 / a2
  * STFT: replaces scipy.signal.stft(x, window=FFT_WND, nperseg=N,
@@ -86,7 +106,6 @@ int danet_stft(danet_stream_t stream, int n_sig, int64_t Ls, int N, int S,
  * overlap-added w^2 where non-zero; float64 accumulators and output
  * [n_sig][T*S]; does NOT undo the 1/sum(w) STFT scaling (neither does the
  * reference).                                                              */
-size_t danet_istft_workspace_bytes(int n_sig, int T, int N, int S);
 int danet_istft(danet_stream_t stream, int n_sig, int T, int N, int S,
                 const float* X_c64, const float* window, double* out,
                 void* ws, size_t ws_bytes);
@@ -114,13 +133,12 @@ int danet_reattach_phase(danet_stream_t stream, int B, int C, int64_t N,
  * 1 = time-major [T][B][ld]; in/out layouts are independent (this is where
  * the encoder switches between the API's batch-major tensors and the LSTM
  * stack's time-major ones).  Columns D..ld_out-1 of `out` are zero-filled.
- * `mean` is REQUIRED scratch+output of danet_center_mean_elems(B) floats,
+ * `mean` is REQUIRED scratch+output of DANET_WS_CENTER_MEAN bytes,
  * 8-byte aligned: the first B hold the per-utterance means, the rest per-chunk
  * partial sums.  The sum is accumulated in double and the mean is its correctly
  * rounded float32 value (the mean's error is a common-mode error of every
  * element; a float32 tree sum is off by more than any single element's rounding).
  * The same call is its own backward.                                        */
-int danet_center_mean_elems(int B);
 int danet_center(danet_stream_t stream, int B, int T, int D,
                  const float* in, int in_layout, int ld_in,
                  float* out, int out_layout, int ld_out, float* mean);
@@ -138,32 +156,14 @@ int danet_center(danet_stream_t stream, int B, int T, int D,
  * leading dimension are accepted -- 16-byte aligned operands with ld % 4 == 0 (and
  * K % 4 == 0 for an operand stored contiguous along K) take the faster DMA staging
  * path, with bit-identical results.                                            */
-size_t danet_gemm_f32_workspace_bytes(int M, int N, int K);
+/* `max_workgroups` > 0 caps the launch at that many persistent workgroups
+ * (0 = one per tile): lets a product that is overlapped with a latency-bound
+ * kernel on another stream stay off the CUs that kernel occupies.             */
 int danet_gemm_f32(danet_stream_t stream, int transA, int transB,
                    int M, int N, int K,
                    const float* A, int lda, const float* B, int ldb,
                    float* C, int ldc, const float* bias, float beta,
-                   void* ws, size_t ws_bytes);
-/* Same, with the launch capped at `max_workgroups` persistent workgroups
- * (0 = one per tile): lets a product that is overlapped with a latency-bound
- * kernel on another stream (weight gradients under the BPTT kernel) stay off the
- * CUs that kernel occupies.                                                  */
-int danet_gemm_f32_ex(danet_stream_t stream, int transA, int transB,
-                      int M, int N, int K,
-                      const float* A, int lda, const float* B, int ldb,
-                      float* C, int ldc, const float* bias, float beta,
-                      void* ws, size_t ws_bytes, int max_workgroups);
-
-/* K-concatenated product  C = op(A1) op(B1) + op(A2) op(B2) (+bias) (+beta*C)  as one
- * launch (the K slices of the two pairs share the deterministic split-K reduction):
- * dX = da_fwd Wx_fwd^T + da_bwd Wx_bwd^T of a BiLSTM layer without a second GEMM and a
- * second read-modify-write of dX.                                              */
-size_t danet_gemm_f32_kcat_workspace_bytes(int M, int N, int K1, int K2);
-int danet_gemm_f32_kcat(danet_stream_t stream, int transA, int transB, int M, int N,
-                        int K1, const float* A1, int lda1, const float* B1, int ldb1,
-                        int K2, const float* A2, int lda2, const float* B2, int ldb2,
-                        float* C, int ldc, const float* bias, float beta,
-                        void* ws, size_t ws_bytes);
+                   void* ws, size_t ws_bytes, int max_workgroups);
 
 /* Same product, stream-K schedule: G persistent workgroups each take an equal
  * share of the (tile, k-iteration) space of their XCD band; cut tiles are finished
@@ -171,8 +171,8 @@ int danet_gemm_f32_kcat(danet_stream_t stream, int transA, int transB, int M, in
  * danet_gemm_f32 for a product that has the GPU to itself (critical-path dX / dYc),
  * slower when several products share the CUs.  `ws` (>= the _workspace_bytes value,
  * 16-B aligned) must be zero-initialised once and then only ever be used by this
- * function: it keeps the hand-off flags of earlier launches.                  */
-size_t danet_gemm_f32_streamk_workspace_bytes(int M, int N, int K);
+ * function: it keeps the hand-off flags of earlier launches.  `ws` >=
+ * DANET_WS_GEMM_STREAMK bytes.                                                 */
 int danet_gemm_f32_streamk(danet_stream_t stream, int transA, int transB,
                            int M, int N, int K,
                            const float* A, int lda, const float* B, int ldb,
@@ -195,9 +195,10 @@ typedef struct {
 int danet_gemm_f32_streamk_grouped(danet_stream_t stream, int transA, int transB,
                                    int K, int nprob, const danet_gemm_problem_t* probs,
                                    int max_workgroups, void* ws, size_t ws_bytes);
-/* K-concatenated product C = op(A1) op(B1) + op(A2) op(B2) on the stream-K schedule (one
- * launch, no slabs, no reduce kernel; K1 % 16 == 0).  Same result as danet_gemm_f32_kcat up to
- * summation order.  Workspace: danet_gemm_f32_streamk_workspace_bytes.                    */
+/* K-concatenated product C = op(A1) op(B1) + op(A2) op(B2) (+bias) (+beta*C) on the stream-K
+ * schedule (one launch, no slabs, no reduce kernel; K1 % 16 == 0): dX = da_fwd Wx_fwd^T +
+ * da_bwd Wx_bwd^T of a BiLSTM layer without a second GEMM and a second read-modify-write of
+ * dX.  Workspace: DANET_WS_GEMM_STREAMK.                                                 */
 int danet_gemm_f32_streamk_kcat(danet_stream_t stream, int transA, int transB, int M, int N,
                                 int K1, const float* A1, int lda1, const float* B1, int ldb1,
                                 int K2, const float* A2, int lda2, const float* B2, int ldb2,
@@ -218,7 +219,6 @@ int danet_stream_wait_event(danet_stream_t stream, void* event);
 int danet_colsum_f32(danet_stream_t stream, int M, int N, const float* A,
                      int lda, float* out, float beta, void* ws,
                      size_t ws_bytes);
-size_t danet_colsum_f32_workspace_bytes(int M, int N);
 
 /* ---------------------------------------------------------------- a5-a7
  * Recurrent half of Model.lyr_lstm / _lyr_bilstm (main.py:76-132,
@@ -251,7 +251,6 @@ size_t danet_colsum_f32_workspace_bytes(int M, int N);
  * any rank from the collective it issues anyway).  The word may also be pinned,
  * device-mapped HOST memory: the kernels touch it only on the timeout path.   */
 #define DANET_STATUS_TIMEOUT 0x3F800000
-size_t danet_lstm_workspace_bytes(int T, int B, int H, int ndir);
 int danet_lstm_fwd(danet_stream_t stream, int T, int B, int H, int ndir,
                    const float* gx_f, const float* gx_b,
                    const float* Wh_f, const float* Wh_b, int ldw,
@@ -260,12 +259,12 @@ int danet_lstm_fwd(danet_stream_t stream, int T, int B, int H, int ndir,
                    float* cell_f, float* cell_b,
                    void* ws, size_t ws_bytes, int32_t* status, int flags);
 
-/* `flags` of danet_lstm_fwd / danet_lstm_fwd_fused / danet_lstm_bwd_db: DANET_LSTM_PREFILLED = the
+/* `flags` of danet_lstm_fwd / danet_lstm_fwd_fused / danet_lstm_bwd: DANET_LSTM_PREFILLED = the
  * caller has prefilled this launch's buffers with danet_lstm_fwd_prefill / danet_lstm_bwd_prefill
  * (one fill launch for the buffers of ALL layers instead of one per call); 0 = the call prefills
  * its own buffers.                                                                          */
 #define DANET_LSTM_PREFILLED 1
-/* danet_lstm_bwd_db only: leave the per-cluster bias-gradient partials in the workspace and do NOT
+/* danet_lstm_bwd with db only: leave the per-cluster bias-gradient partials in the workspace and do NOT
  * touch db; the caller finishes with danet_lstm_bwd_db_reduce on any stream ordered behind the
  * launch (the workspace must stay untouched until then).                                     */
 #define DANET_LSTM_DB_DEFERRED 2
@@ -298,75 +297,28 @@ int danet_lstm_fwd_fused(danet_stream_t stream, int T, int B, int H, int ndir,
                          void* ws, size_t ws_bytes, int32_t* status, int flags);
 
 /* BPTT of the above.  dy [T][B][lddy] (dir d uses columns [d*H,(d+1)*H)).
- * Outputs da_d [T][B][4H] = dL/d(pre-activation) (16-byte aligned; pre-filled
- * with the 0xFFFFFFFF sentinel by the call); the caller finishes with GEMMs:
- * dWx = X^T da, dWh = Hprev^T da, db = colsum(da), dX = da Wx^T.  Same status
- * convention as danet_lstm_fwd.                                             */
+ * Outputs da_d [T][B][4H] = dL/d(pre-activation) (16-byte aligned); the caller
+ * finishes with GEMMs: dWx = X^T da, dWh = Hprev^T da, dX = da Wx^T.  Same status
+ * convention as danet_lstm_fwd.
+ * db_d [4H] (optional, NULL = not wanted; 16-byte aligned): the bias gradients
+ * sum_{t,b} da_d, overwritten for beta = 0, accumulated into for beta = 1 -- the
+ * owner threads of the reduce-scatter kernel add their da to a register per step, so
+ * no column-sum launches are needed (NULL: the caller may use danet_colsum_f32 on da).
+ * Envelope = the reduce-scatter geometry (one workgroup per CU: at H = 300 up to B = 200,
+ * at H = 600 up to B = 96, both directions); danet_lstm_bwd_db_supported() == 1 inside
+ * it, DANET_ERR_UNSUPPORTED outside.  With DANET_LSTM_DB_DEFERRED in
+ * `flags` db is not touched by this call: danet_lstm_bwd_db_reduce finishes it on any
+ * stream ordered behind the launch.                                             */
+int danet_lstm_bwd_db_supported(int T, int B, int H, int ndir);
 int danet_lstm_bwd(danet_stream_t stream, int T, int B, int H, int ndir,
                    const float* dy, int lddy,
                    const float* Wh_f, const float* Wh_b, int ldw,
                    const float* gates_f, const float* gates_b,
                    const float* cell_f, const float* cell_b,
-                   float* da_f, float* da_b,
-                   void* ws, size_t ws_bytes, int32_t* status);
-
-/* danet_lstm_bwd that also returns the bias gradients db_d[4H] = sum_{t,b} da_d (overwritten
- * for beta = 0, accumulated into for beta = 1; 16-byte aligned): the owner threads of the
- * reduce-scatter kernel add their da to a register per step, so no column-sum launches are
- * needed.  Only for shapes the reduce-scatter kernel covers (danet_lstm_bwd_db_supported);
- * workspace as danet_lstm_bwd.                                                 */
-int danet_lstm_bwd_db_supported(int T, int B, int H, int ndir);
-int danet_lstm_bwd_db(danet_stream_t stream, int T, int B, int H, int ndir,
-                      const float* dy, int lddy,
-                      const float* Wh_f, const float* Wh_b, int ldw,
-                      const float* gates_f, const float* gates_b,
-                      const float* cell_f, const float* cell_b,
-                      float* da_f, float* da_b, float* db_f, float* db_b, float beta,
-                      void* ws, size_t ws_bytes, int32_t* status, int flags);
+                   float* da_f, float* da_b, float* db_f, float* db_b, float beta,
+                   void* ws, size_t ws_bytes, int32_t* status, int flags);
 int danet_lstm_bwd_db_reduce(danet_stream_t stream, int T, int B, int H, int ndir,
                              float* db_f, float* db_b, float beta, const void* ws, size_t ws_bytes);
-
-/* BPTT with the layer's weight and bias gradients FUSED: dW_d = [X | Hprev]^T da_d and
- * db_d = colsum(da_d) are accumulated inside the persistent kernel -- every workgroup owns
- * a block of da_t columns, has them in LDS each step, and runs the rank-16 update of its
- * dW columns on the matrix cores while it waits for the other workgroups' partial dh --
- * instead of in separate GEMM / column-sum launches.  x [T][B][ldx] and ypad [T+2][B][ldy]
- * are the layer's forward input and output (h_prev(t) = ypad block t for the forward scan,
- * block t+2 for the reversed one); W_d is the full [D+H][ldw] matrix (recurrent rows at D);
- * dW_d [D+H][4H] and db_d [4H] (16-byte aligned, dense) are overwritten (beta = 0) or
- * accumulated into (beta = 1).  da_d as in danet_lstm_bwd (the caller still computes
- * dX = da Wx^T).  Envelope: the reduce-scatter BPTT geometry with U <= 16 units per group
- * and H <= 384 (danet_lstm_bwd_fused_supported; DANET_LSTM_BWD_FUSED=0 turns it off).
- * Measured at parity with separate GEMMs that hide under another layer's BPTT kernel, not
- * ahead of them: callers choose per layer (the Python mirror keeps it opt-in).            */
-int danet_lstm_bwd_fused_supported(int T, int B, int H, int ndir, int D);
-size_t danet_lstm_bwd_fused_workspace_bytes(int T, int B, int H, int ndir, int D);
-int danet_lstm_bwd_fused(danet_stream_t stream, int T, int B, int H, int ndir,
-                         const float* dy, int lddy,
-                         const float* W_f, const float* W_b, int ldw,
-                         const float* gates_f, const float* gates_b,
-                         const float* cell_f, const float* cell_b,
-                         const float* x, int ldx, int D,
-                         const float* ypad, int ldy,
-                         float* da_f, float* da_b,
-                         float* dW_f, float* dW_b, float* db_f, float* db_b,
-                         float beta, void* ws, size_t ws_bytes, int32_t* status);
-
-/* The same with ONLY the recurrent rows of the weight gradient fused: dWh_d [H][4H] (+)= Hprev^T
- * da_d and db_d inside the persistent kernel (16 update MFMAs per wave and step at cfg 2, issued in
- * the exchange wait); Wh_d / dWh_d point at rows D.. of the layer's W / dW, x is not read and
- * dWx_d = X^T da_d stays a GEMM of the caller.                                              */
-int danet_lstm_bwd_fused_h_supported(int T, int B, int H, int ndir);
-size_t danet_lstm_bwd_fused_h_workspace_bytes(int T, int B, int H, int ndir);
-int danet_lstm_bwd_fused_h(danet_stream_t stream, int T, int B, int H, int ndir,
-                           const float* dy, int lddy,
-                           const float* Wh_f, const float* Wh_b, int ldw,
-                           const float* gates_f, const float* gates_b,
-                           const float* cell_f, const float* cell_b,
-                           const float* ypad, int ldy,
-                           float* da_f, float* da_b,
-                           float* dWh_f, float* dWh_b, float* db_f, float* db_b,
-                           float beta, void* ws, size_t ws_bytes, int32_t* status);
 
 /* ---------------------------------------------------------------- a8-a10
  * Truth-family attractor estimators (app/modules.py:382-487).
@@ -374,7 +326,6 @@ int danet_lstm_bwd_fused_h(danet_stream_t stream, int T, int B, int H, int ndir,
  * denom +eps), 2 'truth-weighted' (w=|mix|, denom +eps).
  * embed [B][N][E], src_pwr [B][C][N], mix_pwr [B][N] -> attr [B][C][E],
  * denom [B][C] (sum of weights, before the +1 / +eps; saved for bwd).      */
-size_t danet_attractor_truth_workspace_bytes(int B, int C, int64_t N, int E);
 int danet_attractor_truth_fwd(danet_stream_t stream, int mode, int B, int C,
                               int64_t N, int E, const float* embed,
                               const float* src_pwr, const float* mix_pwr,
@@ -401,25 +352,15 @@ int danet_attractor_truth_bwd_sep(danet_stream_t stream, int tmode, int B, int C
  * read of the embedding instead of the reference's [B][P][T][F][C] tensors.
  * anchors [A][E]; outputs attr [B][C][E], asets [B][P][C][E] (attractor per
  * subset), asum [B][P][C] (sum of soft assignments), choice int32 [B].     */
-size_t danet_attractor_anchor_workspace_bytes(int B, int C, int64_t N, int E,
-                                              int A);
 int danet_attractor_anchor_fwd(danet_stream_t stream, int B, int C, int64_t N,
                                int E, int A, const float* embed,
                                const float* anchors, float* attr,
                                float* asets, float* asum, int32_t* choice,
                                void* ws, size_t ws_bytes);
-/* dembed [B][N][E] += ..., danchors [A][E] = ... (through the chosen subset);
- * danchors_beta = 1 accumulates into danchors instead of overwriting it              */
-int danet_attractor_anchor_bwd(danet_stream_t stream, int B, int C, int64_t N,
-                               int E, int A, const float* dattr,
-                               const float* embed, const float* anchors,
-                               const float* attr, const float* asum,
-                               const int32_t* choice, float* dembed,
-                               float* danchors, void* ws, size_t ws_bytes,
-                               float danchors_beta);
-/* The same backward in two stream-ordered parts: `_embed` does everything the rest of backward
- * waits for (dembed += ..., per-chunk anchor-gradient partials into ws), `_anchors` reduces the
- * partials in ws to danchors (only the optimiser needs it; ws must stay untouched in between). */
+/* Backward (through the chosen subset) in two stream-ordered parts: `_embed` does everything the
+ * rest of backward waits for (dembed [B][N][E] += ..., per-chunk anchor-gradient partials into ws),
+ * `_anchors` reduces the partials in ws to danchors [A][E] (only the optimiser needs it; ws must
+ * stay untouched in between; danchors_beta = 1 accumulates instead of overwriting).             */
 int danet_attractor_anchor_bwd_embed(danet_stream_t stream, int B, int C, int64_t N, int E, int A,
                                      const float* dattr, const float* embed, const float* anchors,
                                      const float* attr, const float* asum, const int32_t* choice,
@@ -446,7 +387,6 @@ int danet_separate_fwd(danet_stream_t stream, int act, int B, int C,
                        int64_t N, int E, const float* mix_pwr,
                        const float* attr, const float* embed, float* out,
                        float* masks);
-size_t danet_separate_bwd_workspace_bytes(int B, int C, int64_t N, int E);
 /* dembed [B][N][E] = (overwritten), dattr [B][C][E] = (overwritten)        */
 int danet_separate_bwd(danet_stream_t stream, int act, int B, int C,
                        int64_t N, int E, const float* mix_pwr,
@@ -464,19 +404,12 @@ int danet_separate_bwd(danet_stream_t stream, int act, int B, int C,
  * The backward recomputes the masks and returns the gradient w.r.t. the
  * embedding (dembed [B][N][E], overwritten) and the attractors (dattr [B][C][E]):
  * danet_pit_mse_bwd + danet_separate_bwd without the dsep round trip.        */
-size_t danet_separate_pit_workspace_bytes(int B, int C, int64_t N, int E);
-int danet_separate_pit_fwd(danet_stream_t stream, int act, int mode, int B, int C, int64_t N,
-                           int E, const float* mix_pwr, const float* attr, const float* embed,
-                           const float* src_c64, const float* phasor, float eps,
-                           float* sep_pwr_out, float* loss, float* snr, int32_t* perm_idx,
-                           void* ws, size_t ws_bytes);
-/* The forward in two stream-ordered parts.  Part 1 writes the per-chunk cross-error `records`
- * (danet_separate_pit_records_bytes, caller-owned); part 2 reduces them to loss / SNR /
+/* The forward is two stream-ordered parts.  Part 1 writes the per-chunk cross-error `records`
+ * (DANET_WS_SEPARATE_PIT_RECORDS bytes, caller-owned); part 2 reduces them to loss / SNR /
  * permutation index.  danet_separate_pit_bwd accepts `records` INSTEAD of perm_idx (pass
  * perm_idx = NULL) and derives each utterance's permutation from them itself -- the same sums
  * in the same order, hence the same index -- so part 2 is off the forward -> backward critical
  * path and a host may issue it on another stream.                                          */
-size_t danet_separate_pit_records_bytes(int B, int64_t N);
 int danet_separate_pit_fwd_records(danet_stream_t stream, int act, int mode, int B, int C,
                                    int64_t N, int E, const float* mix_pwr, const float* attr,
                                    const float* embed, const float* src_c64, const float* phasor,
@@ -497,7 +430,6 @@ int danet_separate_pit_bwd(danet_stream_t stream, int act, int mode, int B, int 
  * Outputs: loss[1]; perm_idx[B] (index into itertools.permutations(range(C)),
  * first on ties); snr[1] (optional) = mean batch_snr of src vs the complex
  * estimate permuted by perm_idx (main.py:308-309, :336-337).  C <= 4.       */
-size_t danet_pit_mse_workspace_bytes(int B, int C, int64_t N);
 int danet_pit_mse_fwd(danet_stream_t stream, int mode, int B, int C,
                       int64_t N, const float* src_c64, const float* sep_pwr,
                       const float* phasor, float eps, float* loss,

@@ -33,14 +33,32 @@ def test_library_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), 'missing export: ' + s
     assert set(_lib.PROTOTYPES) == set(syms), set(_lib.PROTOTYPES) ^ set(syms)
-    assert lib.danet_abi_version() == 3
+    assert lib.danet_abi_version() == 4
+    assert len(syms) <= 50                  # round 4: the ABI is what ships, not every experiment
     # pure host-side helpers are callable without a GPU
     assert lib.danet_stft_num_frames(8000, 256, 64) == 126
     assert lib.danet_stft_num_frames(160000, 512, 128) == 1251
     assert lib.danet_stft_num_frames(255, 256, 64) < 0
-    assert lib.danet_center_mean_elems(4) >= 4
-    assert lib.danet_gemm_f32_workspace_bytes(300, 1200, 4096) > 0
-    assert lib.danet_gemm_f32_workspace_bytes(4096, 1200, 600) == 0
+    # the ONE scratch-size query (danet_workspace_bytes): every DANET_WS_* op answers, a wrong
+    # op / dim count is an error value, not a crash
+    assert _lib.ws_bytes(_lib.WS_CENTER_MEAN, 4) >= 16
+    assert _lib.ws_bytes(_lib.WS_GEMM, 300, 1200, 4096) > 0
+    assert _lib.ws_bytes(_lib.WS_GEMM, 4096, 1200, 600) == 0
+    dims = {_lib.WS_ISTFT: (2, 128, 256, 64), _lib.WS_GEMM_STREAMK: (128, 128, 128),
+            _lib.WS_COLSUM: (4096, 1200), _lib.WS_LSTM: (128, 32, 300, 2),
+            _lib.WS_ATTRACTOR_TRUTH: (32, 2, 16512, 20), _lib.WS_ATTRACTOR_ANCHOR: (32, 2, 16512, 20, 6),
+            _lib.WS_SEPARATE_BWD: (32, 2, 16512, 20), _lib.WS_SEPARATE_PIT: (32, 2, 16512, 20),
+            _lib.WS_SEPARATE_PIT_RECORDS: (32, 16512), _lib.WS_PIT_MSE: (32, 2, 16512)}
+    for op, d in dims.items():
+        assert 0 < _lib.ws_bytes(op, *d) < (1 << 32), op
+    txt = open(os.path.join(ROOT, 'include', 'danet_hip.h')).read()
+    assert re.search(r'DANET_WS_CENTER_MEAN,[^\n]*\n\s*DANET_WS_COUNT', txt)       # enum order == _lib's
+    assert _lib.WS_CENTER_MEAN == 11
+    arr = (ctypes.c_int64 * 3)(1, 2, 3)
+    assert lib.danet_workspace_bytes(_lib.WS_LSTM, arr, 3) == ctypes.c_size_t(-1).value
+    assert lib.danet_workspace_bytes(99, arr, 3) == ctypes.c_size_t(-1).value
+    with pytest.raises(_lib.DanetHipError):
+        _lib.ws_bytes(_lib.WS_LSTM, 1, 2, 3)
 
 
 def test_abi_has_no_torch_types():
@@ -54,7 +72,7 @@ def test_abi_has_no_torch_types():
 def test_bad_arguments_return_error_codes_not_crashes():
     from danet_amd import _lib
     lib = _lib.load()
-    rc = lib.danet_gemm_f32(None, 0, 0, 0, 4, 4, None, 4, None, 4, None, 4, None, 0.0, None, 0)
+    rc = lib.danet_gemm_f32(None, 0, 0, 0, 4, 4, None, 4, None, 4, None, 4, None, 0.0, None, 0, 0)
     assert rc == -1 and b'gemm' in lib.danet_last_error()
     rc = lib.danet_lstm_fwd(None, 4, 2, 6, 2, None, None, None, None, 24, None, 12,
                             None, None, None, None, ctypes.c_void_p(8), 64, None, 0)
@@ -354,8 +372,8 @@ def test_library_never_reads_the_environment_and_options_abi(monkeypatch):
     blob = open(_lib.LIB_PATH, 'rb').read()
     assert b'getenv' not in blob                # no import of getenv / secure_getenv at all
     names = _lib.option_names()
-    assert len(names) == lib.danet_option_count() >= 20 and len(set(names)) == len(names)
-    for must in ('gemm_dma', 'lstm_fwd_fused', 'lstm_bwd_rs', 'lstm_spin_limit', 'gemm_yield'):
+    assert len(names) == lib.danet_option_count() <= 16 and len(set(names)) == len(names)
+    for must in ('gemm_dma', 'lstm_fwd_fused', 'lstm_bwd_u', 'lstm_spin_limit', 'gemm_yield'):
         assert must in names
     assert lib.danet_option_name(lib.danet_option_count()) is None
     lib.danet_reset_options()

@@ -149,7 +149,8 @@ def test_gemm_streamk_grouped(K, shapes, ta, tb):
 @pytest.mark.parametrize('M,N,K1,K2,ta,tb', [(4096, 600, 1200, 1200, 0, 1), (130, 70, 33, 500, 0, 0),
                                              (64, 300, 16, 17, 1, 0), (257, 129, 700, 90, 1, 1)])
 def test_gemm_kcat(M, N, K1, K2, ta, tb):
-    '''danet_gemm_f32_kcat: C = A1 B1 + A2 B2 (+bias)(+beta C) in one launch'''
+    '''ops.gemm_kcat without stream-K (two accumulating tile-kernel products): C = A1 B1 + A2 B2
+    (+bias)(+beta C); the stream-K one-launch form is tested in test_gpu_round3'''
     from danet_amd import ops
     rng = np.random.RandomState(M + N + K1 + K2)
     mk = lambda K: (rng.randn(K, M) if ta else rng.randn(M, K), rng.randn(N, K) if tb else rng.randn(K, N))
@@ -256,7 +257,7 @@ def test_gemm_rejects_operands_of_2gib():
     L = _lib.load()
     t = torch.zeros(16, device='cuda')
     rc = L.danet_gemm_f32(_lib.stream(), 0, 0, 128, 128, 128, _lib.ptr(t), 1 << 23,
-                          _lib.ptr(t), 128, _lib.ptr(t), 128, None, 0.0, None, 0)
+                          _lib.ptr(t), 128, _lib.ptr(t), 128, None, 0.0, None, 0, 0)
     assert rc == -1 and b'2 GiB' in L.danet_last_error()
 
 
@@ -845,8 +846,9 @@ def test_lstm_unsupported_shapes_fail_loudly():
 def test_lstm_bwd_handoff_under_uneven_load(B, T, H):
     '''the BPTT kernel's inter-workgroup hand-off (phase-tagged partial-dh ring,
     csrc/lstm.hip) repeated under an UNEVEN concurrent load (a GEMM stream that comes
-    and goes on another HIP stream), every output word compared with the independent
-    all-gather kernel (DANET_LSTM_BWD_RS=0) and the hand-off status word checked'''
+    and goes on another HIP stream), every output word compared with an undisturbed launch
+    (the kernel vs the float64 oracle: test_lstm_layer_fwd_bwd, test_bptt_vs_oracle_long_sequence)
+    and the hand-off status word checked'''
     from danet_amd import _lib
     L = _lib.load()
     ptr = _lib.ptr
@@ -856,7 +858,7 @@ def test_lstm_bwd_handoff_under_uneven_load(B, T, H):
     gx = [rnd(T * B, 4 * H) * 0.5 for _ in range(2)]
     Wh = [rnd(H, 4 * H) * (0.75 / H ** 0.5) for _ in range(2)]
     dy = rnd(T, B, 2 * H)
-    n = L.danet_lstm_workspace_bytes(T, B, H, 2)
+    n = _lib.ws_bytes(_lib.WS_LSTM, T, B, H, 2)
     st = torch.cuda.current_stream().cuda_stream
     ypad = torch.empty(T + 2, B, 2 * H, device=dev)
     gates = [x.clone() for x in gx]
@@ -873,16 +875,12 @@ def test_lstm_bwd_handoff_under_uneven_load(B, T, H):
         w = torch.zeros(n, dtype=torch.uint8, device=dev)
         _lib.check(L.danet_lstm_bwd(st, T, B, H, 2, ptr(dy), 2 * H, ptr(Wh[0]), ptr(Wh[1]), 4 * H,
                                     ptr(gates[0]), ptr(gates[1]), ptr(cells[0]), ptr(cells[1]),
-                                    ptr(das[0]), ptr(das[1]), ptr(w), n, None))
+                                    ptr(das[0]), ptr(das[1]), None, None, 0.0, ptr(w), n, None, 0))
         return das, w
 
-    _lib.set_option('lstm_bwd_rs', 0)              # the all-gather kernel as the reference
-    try:
-        ref, w = bwd()
-        torch.cuda.synchronize()
-        assert int(w[:4].view(torch.int32)[0]) == 0
-    finally:
-        _lib.set_option('lstm_bwd_rs', 1)
+    ref, w = bwd()                                 # an undisturbed launch as the reference
+    torch.cuda.synchronize()
+    assert int(w[:4].view(torch.int32)[0]) == 0
     scale = max(float(r.abs().max()) for r in ref)
     side = torch.cuda.Stream()
     a = torch.randn(2048, 2048, device=dev)

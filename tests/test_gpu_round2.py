@@ -624,18 +624,11 @@ def _lstm_ref(x, Ws, bs, H, dy):
 @pytest.mark.parametrize('fused', ['1', '0'])
 def test_lstm_forward_fused_input_projection(B, T, D, H, ndir, fused, monkeypatch):
     '''danet_lstm_fwd_fused (x_t*Wx computed inside the persistent scan, in the exchange
-    wait) + danet_lstm_bwd_fused (dW / db accumulated inside the BPTT kernel) on one side, the
-    hoisted-GEMM / separate-GEMM paths on the other: both give the oracle's outputs and
-    gradients; the envelope queries decide which one runs'''
+    wait) on one side, the hoisted-GEMM path on the other: both give the oracle's outputs and
+    gradients; the envelope query decides which one runs'''
     from danet_amd import ops, _lib
     _lib.set_option('lstm_fwd_fused', int(fused))
-    _lib.set_option('lstm_bwd_fused_kernel', int(fused))   # BPTT with fused dW / db alongside
-    monkeypatch.setattr(ops, 'BWD_FUSED', fused)
     assert _lib.load().danet_lstm_fwd_fused_supported(T, B, H, ndir, D) == int(fused)
-    bwd_fused = _lib.load().danet_lstm_bwd_fused_supported(T, B, H, ndir, D)
-    assert bwd_fused in (0, int(fused))        # (48, ...) and tiny shapes fall outside its envelope
-    if (B, H, D) in ((32, 300, 600), (32, 300, 132)):
-        assert bwd_fused == int(fused)
     rng = np.random.RandomState(B * 100 + T * 10 + H + D)
     r = 0.75 / np.sqrt(H)
     x = rng.randn(B, T, D) * 0.7
@@ -663,17 +656,8 @@ def test_lstm_fused_envelope_query(monkeypatch):
     L.danet_reset_options()
     assert L.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 600) == 1      # default: B >= 24
     assert L.danet_lstm_fwd_fused_supported(1251, 1, 300, 2, 600) == 0      # B = 1: hoisted GEMM
-    assert L.danet_lstm_bwd_fused_supported(128, 32, 300, 2, 600) == 1      # envelope
-    from danet_amd import ops
-    monkeypatch.setattr(ops, 'BWD_FUSED', '0')                              # the default policy
-    assert ops.bptt_fused(128, 32, 300, 2, 129, need_dx=False) is False
-    monkeypatch.setattr(ops, 'BWD_FUSED', 'bottom')
-    assert ops.bptt_fused(128, 32, 300, 2, 129, need_dx=False) is True
-    assert ops.bptt_fused(128, 32, 300, 2, 600, need_dx=True) is False
-    _lib.set_option('lstm_bwd_fused_kernel', 0)
-    assert L.danet_lstm_bwd_fused_supported(128, 32, 300, 2, 600) == 0
-    _lib.set_option('lstm_bwd_fused_kernel', 1)
-    assert L.danet_lstm_bwd_fused_supported(128, 32, 600, 2, 1200) == 0     # U = 32 geometry
+    assert L.danet_lstm_bwd_db_supported(128, 32, 300, 2) == 1              # reduce-scatter BPTT
+    assert L.danet_lstm_bwd_db_supported(128, 32, 302, 2) == 0              # H % 4 != 0: all-gather kernel
     _lib.set_option('lstm_fwd_fused', 1)
     assert L.danet_lstm_fwd_fused_supported(1251, 1, 300, 2, 600) == 1
     assert L.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 129) == 1

@@ -241,39 +241,6 @@ def test_gemm_hybrid_streamk_many_tiles(M, N, K):
     assert np.abs(C.cpu().numpy() - ref).max() / np.abs(ref).max() < 2e-5
 
 
-@pytest.mark.parametrize('B,T,D,H', [(32, 40, 600, 300), (32, 24, 132, 300), (16, 12, 64, 64), (20, 9, 36, 40)])
-def test_bptt_with_only_the_recurrent_weight_gradient_fused(B, T, D, H, monkeypatch):
-    '''danet_lstm_bwd_fused_h: dWh = Hprev^T da and db accumulated inside the persistent BPTT
-    kernel, dWx left to the GEMM group -- every gradient equals the unfused path's to
-    summation-order rounding (tf.gradients through main.py:130-131, app/ops.py:139-147)'''
-    from danet_amd import ops, _lib
-    if _lib.load().danet_lstm_bwd_fused_h_supported(T, B, H, 2) != 1:
-        pytest.skip('outside the envelope')
-    rng = np.random.RandomState(B + T + D + H)
-    r = 0.75 / np.sqrt(H)
-    x = torch.as_tensor((rng.randn(B, T, D) * 0.7).astype(np.float32)).cuda()
-    Ws = [torch.as_tensor((rng.uniform(-r, r, size=(D + H, 4 * H)) * 2).astype(np.float32)).cuda() for _ in range(2)]
-    bs = [torch.as_tensor((rng.randn(4 * H) * 0.1).astype(np.float32)).cuda() for _ in range(2)]
-    dy = torch.as_tensor(rng.randn(B, T, 2 * H).astype(np.float32)).cuda()
-
-    def run(policy):
-        monkeypatch.setattr(ops, 'BWD_FUSED', policy)
-        xi = x.clone().requires_grad_(True)
-        ps = []
-        for W, b in zip(Ws, bs):
-            ps += [W.clone().requires_grad_(True), b.clone().requires_grad_(True)]
-        y = ops.LstmLayerFn.apply(xi, H, *ps)
-        y.backward(dy)
-        torch.cuda.synchronize()
-        return [xi.grad] + [p.grad for p in ps]
-
-    ref = run('0')
-    got = run('h')
-    assert ops.lstm_status_ok()
-    for a, b in zip(got, ref):
-        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (a.shape,)
-
-
 @pytest.mark.parametrize('E', [20, 6])      # 6: E != EP, the guarded row accesses
 @pytest.mark.parametrize('est,sepn,C', [('anchor', 'dot-softmax-orig', 2), ('truth-weighted', 'dot-softmax-orig', 3),
                                         ('truth', 'dot-sigmoid-orig', 2), ('truth-threshold', 'dot-softmax-orig', 2)])
@@ -311,7 +278,7 @@ def test_estimator_backward_recomputes_the_separator_term(hp, monkeypatch, est, 
 
 
 def test_deferred_bias_gradient_reduce_is_bit_identical(hp, monkeypatch):
-    '''danet_lstm_bwd_db(DANET_LSTM_DB_DEFERRED) + danet_lstm_bwd_db_reduce on the side chain: the
+    '''danet_lstm_bwd(db, DANET_LSTM_DB_DEFERRED) + danet_lstm_bwd_db_reduce on the side chain: the
     same partials summed by the same kernel, only later -> gradients and parameters bit-equal'''
     from danet_amd.model import Model
     from danet_amd import ops
@@ -358,7 +325,7 @@ def test_lstm_bwd_db_reduce_entry_point():
     Wh = [rnd(H, 4 * H) * 0.1 for _ in range(2)]
     gates = [torch.sigmoid(rnd(T * B, 4 * H)) for _ in range(2)]
     cells = [rnd((T + 1) * B, H).tanh() for _ in range(2)]
-    wn = L.danet_lstm_workspace_bytes(T, B, H, 2)
+    wn = _lib.ws_bytes(_lib.WS_LSTM, T, B, H, 2)
     outs = []
     for flags in (0, 2):
         ws = torch.zeros(wn, dtype=torch.uint8, device='cuda')
@@ -366,9 +333,9 @@ def test_lstm_bwd_db_reduce_entry_point():
         da = [torch.empty(T * B, 4 * H, device='cuda') for _ in range(2)]
         db = [torch.full((4 * H,), 7.0, device='cuda') for _ in range(2)]
         p = _lib.ptr
-        rc = L.danet_lstm_bwd_db(_lib.stream(), T, B, H, 2, p(dy), 2 * H, p(Wh[0]), p(Wh[1]), 4 * H,
-                                 p(gates[0]), p(gates[1]), p(cells[0]), p(cells[1]), p(da[0]), p(da[1]),
-                                 p(db[0]), p(db[1]), 0.0, p(ws), wn, p(st), flags)
+        rc = L.danet_lstm_bwd(_lib.stream(), T, B, H, 2, p(dy), 2 * H, p(Wh[0]), p(Wh[1]), 4 * H,
+                              p(gates[0]), p(gates[1]), p(cells[0]), p(cells[1]), p(da[0]), p(da[1]),
+                              p(db[0]), p(db[1]), 0.0, p(ws), wn, p(st), flags)
         assert rc == 0, L.danet_last_error()
         if flags:
             torch.cuda.synchronize()
@@ -382,31 +349,6 @@ def test_lstm_bwd_db_reduce_entry_point():
         assert np.array_equal(a, b)
     ref = outs[0][2].sum(axis=0)
     assert np.abs(outs[0][0] - ref).max() <= 1e-4 * np.abs(ref).max()
-
-
-@pytest.mark.parametrize('B,T,D', [(16, 128, 129), (32, 100, 300), (24, 7, 1300), (32, 128, 600)])
-def test_center_single_launch_equals_two_launch(B, T, D):
-    '''B >= 16 utterances of <= 32 K elements take the one-launch centring kernel; the same
-    utterances in groups of 8 take the two-launch form: both means are the float32 rounding of a
-    double sum (app/modules.py:218-219 reduce_mean over (1, 2))'''
-    from danet_amd import ops, _lib
-    _lib.set_option('center_one', 1)
-    rng = np.random.RandomState(B + D)
-    x = (rng.randn(B, T, D) * 2 + rng.randn(B, 1, 1) * 5).astype(np.float32)
-    ldo = (D + 3) // 4 * 4
-    xd = cu(x)
-    out = torch.full((T, B, ldo), 9.0, device='cuda')
-    mean = ops.center(xd, B, T, D, 0, D, out, 1, ldo).cpu().numpy()
-    m64 = x.astype(np.float64).mean(axis=(1, 2))
-    assert np.abs(mean - m64).max() <= 1e-6 * np.abs(m64).max() + 1e-7
-    got = out.cpu().numpy()
-    assert np.all(got[:, :, D:] == 0.0)
-    for b0 in range(0, B, 8):
-        o2 = torch.full((T, 8, ldo), 9.0, device='cuda')
-        m2 = ops.center(xd[b0:b0 + 8].contiguous(), 8, T, D, 0, D, o2, 1, ldo).cpu().numpy()
-        ulp = np.spacing(np.abs(m2).astype(np.float32))
-        assert np.all(np.abs(m2 - mean[b0:b0 + 8]) <= ulp)
-        assert np.abs(o2.cpu().numpy() - got[:, b0:b0 + 8]).max() <= 2 * ulp.max()
 
 
 @pytest.mark.parametrize('K,shapes,ta,tb', [

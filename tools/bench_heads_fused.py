@@ -48,10 +48,10 @@ def main():
     asets = torch.empty(B, P, C, E, device=dev)
     asum = torch.empty(B, P, C, device=dev)
     choice = torch.empty(B, dtype=torch.int32, device=dev)
-    wn = L.danet_attractor_anchor_workspace_bytes(B, C, N, E, A)
+    wn = _lib.ws_bytes(_lib.WS_ATTRACTOR_ANCHOR, B, C, N, E, A)
     ws = torch.empty(wn, dtype=torch.uint8, device=dev)
-    rec = torch.empty(L.danet_separate_pit_records_bytes(B, N), dtype=torch.uint8, device=dev)
-    wn2 = L.danet_separate_pit_workspace_bytes(B, C, N, E)
+    rec = torch.empty(_lib.ws_bytes(_lib.WS_SEPARATE_PIT_RECORDS, B, N), dtype=torch.uint8, device=dev)
+    wn2 = _lib.ws_bytes(_lib.WS_SEPARATE_PIT, B, C, N, E)
     ws2 = torch.empty(wn2, dtype=torch.uint8, device=dev)
     dattr = torch.empty(B, C, E, device=dev)
     dembed = torch.empty(B, N, E, device=dev)

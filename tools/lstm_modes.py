@@ -30,7 +30,7 @@ def main():
     gx = [torch.randn(T * B, 4 * H, device=dev) * 0.5 for _ in range(2)]
     Wh = [torch.randn(H, 4 * H, device=dev) * (0.75 / H ** 0.5) for _ in range(2)]
     dy = torch.randn(T, B, 2 * H, device=dev)
-    n = L.danet_lstm_workspace_bytes(T, B, H, 2)
+    n = _lib.ws_bytes(_lib.WS_LSTM, T, B, H, 2)
     ws = torch.zeros(n, dtype=torch.uint8, device=dev)
 
     def fwd():
@@ -53,19 +53,18 @@ def main():
         e0.record()
         _lib.check(L.danet_lstm_bwd(st, T, B, H, 2, ptr(dy), 2 * H, ptr(Wh[0]), ptr(Wh[1]), 4 * H,
                                     ptr(gates[0]), ptr(gates[1]), ptr(cells[0]), ptr(cells[1]),
-                                    ptr(das[0]), ptr(das[1]), ptr(ws), n, None))
+                                    ptr(das[0]), ptr(das[1]), None, None, 0.0, ptr(ws), n, None, 0))
         e1.record()
         torch.cuda.synchronize()
         assert int(ws[:4].view(torch.int32)[0]) == 0, 'status'
         return e0.elapsed_time(e1) * 1e3, das
 
     ref = None
-    modes = [dict(DANET_LSTM_BWD_RS='0')]
+    modes = [dict()]
     for u, ss in (('32', ('4', '5', '6')), ('16', ('2', '3')), ('8', ('1',))):
         for sv in ss:
             modes.append(dict(DANET_LSTM_BWD_U=u, DANET_LSTM_BWD_S=sv))
     modes.append(dict(DANET_LSTM_BWD_U='32', DANET_LSTM_BWD_S='5', DANET_LSTM_XMAP='0'))
-    modes.append(dict(DANET_LSTM_BWD_RS='0'))
     for m in modes:
         _lib.apply_env_options()          # defaults (+ process environment), then this mode
         for k, v in m.items():

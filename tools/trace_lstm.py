@@ -71,7 +71,7 @@ def fused(B, T, H, D):
     ypad = torch.empty(T + 2, B, 2 * H, device=dev)
     gates = [torch.empty(T * B, 4 * H, device=dev) for _ in range(2)]
     cells = [torch.empty(T * B, H, device=dev) for _ in range(2)]
-    n = L.danet_lstm_workspace_bytes(T, B, H, ndir)
+    n = _lib.ws_bytes(_lib.WS_LSTM, T, B, H, ndir)
     for it in range(3):
         ws = torch.zeros(n, dtype=torch.uint8, device=dev)
         _lib.check(L.danet_lstm_fwd_fused(st, T, B, H, ndir, ptr(x), D, D, ptr(W[0]), ptr(W[1]), 4 * H,
@@ -82,60 +82,11 @@ def fused(B, T, H, D):
     report_fused('lstm_fwd_fused D=%d' % D, ws, T)
 
 
-def report_bwd_fused(name, ws, T):
-    '''lstm_bwd_rsw_kernel: 0 top | 1 first quarter of the dW update issued | 2 rest issued,
-    A operand prefetched | 3 exchange valid (6 retries) | 4 barrier after partial sums |
-    5 gate math + barrier | 7 partial dh published'''
-    tr = ws[64:64 + T * 64].view(torch.int64).view(T, 8).cpu().numpy().astype(np.float64)
-    tr = tr[2:-1]
-    us = lambda a: a / 100.0
-    step = us(np.diff(tr[:, 0]))
-    ph = dict(top_to_quarter=us(tr[:, 1] - tr[:, 0]), quarter_to_rest_issued=us(tr[:, 2] - tr[:, 1]),
-              rest_to_valid=us(tr[:, 3] - tr[:, 2]), valid_to_barrier=us(tr[:, 4] - tr[:, 3]),
-              gate_barrier=us(tr[:, 5] - tr[:, 4]), mfma_publish=us(tr[:, 7] - tr[:, 5]),
-              publish_to_next_top=us(tr[1:, 0] - tr[:-1, 7]))
-    print('%s: step %.2f us (median %.2f)  retries/step %.2f' % (
-        name, step.mean(), np.median(step), tr[:, 6].mean()))
-    for k, v in ph.items():
-        print('   %-24s mean %.2f  median %.2f  p90 %.2f' % (k, v.mean(), np.median(v), np.percentile(v, 90)))
-
-
-def bwd_fused(B, T, H, D):
-    dev = torch.device('cuda')
-    st = torch.cuda.current_stream().cuda_stream
-    ndir = 2
-    if L.danet_lstm_bwd_fused_supported(T, B, H, ndir, D) != 1:
-        print('fused BPTT: shape outside the envelope')
-        return
-    x = torch.randn(T, B, D, device=dev) * 0.5
-    W = [torch.randn(D + H, 4 * H, device=dev) * (0.75 / H ** 0.5) for _ in range(2)]
-    ypad = torch.randn(T + 2, B, 2 * H, device=dev) * 0.3
-    gates = [torch.rand(T * B, 4 * H, device=dev) for _ in range(2)]
-    cells = [torch.randn(T * B, H, device=dev) * 0.5 for _ in range(2)]
-    dy = torch.randn(T, B, 2 * H, device=dev)
-    das = [torch.empty(T * B, 4 * H, device=dev) for _ in range(2)]
-    dW = [torch.empty(D + H, 4 * H, device=dev) for _ in range(2)]
-    db = [torch.empty(4 * H, device=dev) for _ in range(2)]
-    n = L.danet_lstm_bwd_fused_workspace_bytes(T, B, H, ndir, D)
-    for it in range(3):
-        ws = torch.zeros(n, dtype=torch.uint8, device=dev)
-        _lib.check(L.danet_lstm_bwd_fused(st, T, B, H, ndir, ptr(dy), 2 * H, ptr(W[0]), ptr(W[1]), 4 * H,
-                                          ptr(gates[0]), ptr(gates[1]), ptr(cells[0]), ptr(cells[1]),
-                                          ptr(x), D, D, ptr(ypad), 2 * H, ptr(das[0]), ptr(das[1]),
-                                          ptr(dW[0]), ptr(dW[1]), ptr(db[0]), ptr(db[1]), 0.0,
-                                          ptr(ws), n, None))
-        torch.cuda.synchronize()
-    assert int(ws[:4].view(torch.int32)[0]) == 0
-    report_bwd_fused('lstm_bwd_fused D=%d' % D, ws, T)
-
-
 def main():
     B, T, H = (int(x) for x in sys.argv[1:4]) if len(sys.argv) >= 4 else (32, 128, 300)
     if _lib.get_option('lstm_fwd_fused') == 1:
         fused(B, T, H, 2 * H)
         fused(B, T, H, 132)
-    bwd_fused(B, T, H, 2 * H)
-    bwd_fused(B, T, H, 132)
     dev = torch.device('cuda')
     st = torch.cuda.current_stream().cuda_stream
     ndir = 2
@@ -143,7 +94,7 @@ def main():
     Wh = [torch.randn(H, 4 * H, device=dev) * (0.75 / H ** 0.5) for _ in range(2)]
     ypad = torch.empty(T + 2, B, 2 * H, device=dev)
     cells = [torch.empty(T * B, H, device=dev) for _ in range(2)]
-    n = L.danet_lstm_workspace_bytes(T, B, H, ndir)
+    n = _lib.ws_bytes(_lib.WS_LSTM, T, B, H, ndir)
     for it in range(3):
         ws = torch.zeros(n, dtype=torch.uint8, device=dev)
         gates = [x.clone() for x in gx]
@@ -159,7 +110,7 @@ def main():
         ws = torch.zeros(n, dtype=torch.uint8, device=dev)
         _lib.check(L.danet_lstm_bwd(st, T, B, H, ndir, ptr(dy), 2 * H, ptr(Wh[0]), ptr(Wh[1]), 4 * H,
                                     ptr(gates[0]), ptr(gates[1]), ptr(cells[0]), ptr(cells[1]),
-                                    ptr(das[0]), ptr(das[1]), ptr(ws), n, None))
+                                    ptr(das[0]), ptr(das[1]), None, None, 0.0, ptr(ws), n, None, 0))
         torch.cuda.synchronize()
     assert int(ws[:4].view(torch.int32)[0]) == 0
     report('lstm_bwd', ws, T)
@@ -188,7 +139,7 @@ def main():
                 group()
             _lib.check(L.danet_lstm_bwd(st, T, B, H, ndir, ptr(dy), 2 * H, ptr(Wh[0]), ptr(Wh[1]), 4 * H,
                                         ptr(gates[0]), ptr(gates[1]), ptr(cells[0]), ptr(cells[1]),
-                                        ptr(das[0]), ptr(das[1]), ptr(ws), n, None))
+                                        ptr(das[0]), ptr(das[1]), None, None, 0.0, ptr(ws), n, None, 0))
             torch.cuda.synchronize()
         assert int(ws[:4].view(torch.int32)[0]) == 0
         report('lstm_bwd ' + variant, ws, T)
