@@ -40,11 +40,17 @@ def to_batch_host(data_pt, crop_len=None):
 
 
 class _Slot(object):
-    '''one pinned staging buffer (grow-only) + the event of the last copy that read it'''
-    __slots__ = ('buf', 'event')
+    '''one pinned staging buffer + one device buffer (both grow-only), the event of the last
+    upload out of / into them, and the event behind the last step that consumed the device
+    buffer.  No caching-allocator traffic per batch: a tensor allocated on the copy stream and
+    handed to the compute stream (`record_stream`) makes the allocator re-allocate and poll
+    events every step (measured: 4.1 instead of 3.1 ms per cfg-2 step).'''
+    __slots__ = ('buf', 'dev', 'event', 'consumed', 'free')
 
     def __init__(self):
-        self.buf, self.event = None, None
+        self.buf, self.dev, self.event, self.consumed = None, None, None, None
+        self.free = threading.Event()          # the consumer is done enqueuing readers of `dev`
+        self.free.set()
 
     def stage(self, a, pin=True):
         n = int(np.prod(a.shape))
@@ -63,7 +69,9 @@ class BatchFeed(object):
     '''for spectra in BatchFeed(dataset.epoch(...), device, crop_len): model.train_step(spectra)
 
     Yields complex64 [B, C, T', F] tensors on `device`, already ordered behind their upload on
-    the stream that is current in the consumer.  depth = pinned staging slots.
+    the stream that is current in the consumer.  A yielded tensor is a view of one of `depth`
+    fixed device buffers: it stays valid until the consumer asks for the next batch but `depth - 1`
+    (copy it to keep it longer).  depth = pinned staging slots = device buffers.
 
     mode (default: env DANET_FEED_MODE or 'inline' on a GPU, 'sync' on a CPU device):
       'sync'    the reference's literal form: convert, blocking upload, in the caller's thread
@@ -94,6 +102,7 @@ class BatchFeed(object):
         self.n = 0
         self._thread = None
         self._stop = False
+        self._out = None
         if mode != 'sync':
             self.copy_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
             self.slots = [_Slot() for _ in range(self.depth)]
@@ -112,23 +121,41 @@ class BatchFeed(object):
         return slot.stage(a, pin=self.cuda), slot
 
     def _upload(self, t, slot):
-        '''issue the H2D copy of a staged batch on the copy stream -> (device tensor, event)'''
+        '''issue the H2D copy of a staged batch on the copy stream -> (device tensor, slot)'''
         if not self.cuda:                       # (host-logic tests: the "upload" is a copy)
-            return t.clone(), None
+            return t.clone(), slot
+        n = t.numel()
+        while not slot.free.wait(0.1):          # (feeder thread: the consumer still holds this buffer)
+            if self._stop:
+                return None, slot
+        slot.free.clear()
+        if slot.dev is None or slot.dev.numel() < n:
+            slot.dev = torch.empty(n, dtype=torch.complex64, device=self.device)
+            torch.cuda.current_stream(self.device).synchronize()     # (growth only)
+        d = slot.dev[:n].view(t.shape)
         with torch.cuda.stream(self.copy_stream):
-            d = t.to(self.device, non_blocking=True)
+            if slot.consumed is not None:       # the step that read this buffer last has finished
+                self.copy_stream.wait_event(slot.consumed)
+            d.copy_(t, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
         slot.event = ev
-        return d, ev
+        return d, slot
 
-    def _hand_out(self, d, ev):
-        if ev is not None:
-            cur = torch.cuda.current_stream(self.device)
-            cur.wait_event(ev)
-            d.record_stream(cur)                # allocated on the copy stream, used on this one
+    def _hand_out(self, d, slot):
+        if self.cuda:
+            torch.cuda.current_stream(self.device).wait_event(slot.event)
+        self._out = slot
         self.n += 1
         return d
+
+    def _consumed(self):
+        '''the consumer is back: everything it enqueued that reads the last batch is on its
+        stream now -- mark the point after which that batch's device buffer may be rewritten'''
+        slot, self._out = self._out, None
+        if slot is not None and self.cuda:
+            slot.consumed = torch.cuda.current_stream(self.device).record_event()
+            slot.free.set()
 
     # ------------------------------------------------------------- producer
     def _produce(self):
@@ -180,6 +207,7 @@ class BatchFeed(object):
                     if item is None:
                         return
                     yield self._hand_out(*item)
+                    self._consumed()
             # one batch ahead, uploads issued here: `nxt` is the batch whose upload is in flight
             if self.mode == 'inline':
                 it = iter(self.source)
@@ -195,14 +223,15 @@ class BatchFeed(object):
             nxt = self._upload(*staged) if staged is not None else None
             while nxt is not None:
                 yield self._hand_out(*nxt)        # the consumer enqueues step i ...
+                self._consumed()
                 staged = fetch()                  # ... then batch i+1 is staged / taken from the
                 nxt = self._upload(*staged) if staged is not None else None   # thread and uploaded
         finally:
             self.close()
 
     def close(self):
+        self._stop = True
         if self._thread is not None:
-            self._stop = True
             try:
                 while True:
                     self.q.get_nowait()
