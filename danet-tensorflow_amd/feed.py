@@ -104,7 +104,10 @@ class BatchFeed(object):
         self._stop = False
         self._out = None
         if mode != 'sync':
-            self.copy_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+            self.copy_stream = None
+            if self.cuda:
+                from . import ops
+                self.copy_stream = ops.copy_stream(self.device)
             self.slots = [_Slot() for _ in range(self.depth)]
             self._k = 0
         if mode in ('thread', 'thread-stage'):
