@@ -443,18 +443,23 @@ def _side_streams(dev, n):
 
 
 _copy = {}
+# which stream uploads ride on (feed.BatchFeed): 'side' = the first side stream, 'own' = a stream
+# of their own.  HIP maps streams onto a handful of hardware queues; a third busy stream lands on
+# the main or the side stream's queue depending on creation order and the kernels of the two then
+# serialise: the same loop measured 3.14 or 4.2 ms per cfg-2 step from one stream object to the
+# next (tools/feed_probe.py, profiles/r04_feed_probe.txt).  The side stream exists anyway and is
+# idle at the step boundary, where the feed issues the upload of the next batch.
+COPY_STREAM = _os.environ.get('DANET_COPY_STREAM', 'side')
 
 
 def copy_stream(dev):
-    '''THE upload stream of a device (feed.BatchFeed): created once per process, right behind the
-    side streams.  HIP maps streams onto a handful of hardware queues in creation order; a fresh
-    stream per epoch lands on the main or the side stream's queue now and then and the train step
-    behind it runs 0.5-1 ms slower (tools/feed_probe.py: 3.1-4.1 ms per step from run to run).'''
+    '''the upload stream of a device (created once per process)'''
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     st = _copy.get(key)
     if st is None:
-        _side_streams(dev, max(SIDE_STREAMS, 1))
-        st = _copy[key] = torch.cuda.Stream(device=dev)
+        sides = _side_streams(dev, max(SIDE_STREAMS, 1))
+        st = _copy[key] = sides[0] if (COPY_STREAM == 'side' and SIDE_STREAMS > 0) else \
+            torch.cuda.Stream(device=dev)
     return st
 
 

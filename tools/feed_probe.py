@@ -48,15 +48,13 @@ def run(mode, batches, sw=None, flush=1024):
     sys.setswitchinterval(0.005)
     return dt
 
-# which pool stream the copy stream is: HIP maps streams onto few hardware queues
+# which stream the uploads ride on: HIP maps streams onto few hardware queues
 keep = []
-for skip in range(6):
+for cs in ('side', 'own', 'own', 'own', 'side'):
     ops._copy.clear()
-    for _ in range(skip):
-        keep.append(torch.cuda.Stream(device=dev))
-    print('copy stream = pool stream after %d more: inline %.3f  thread %.3f ms/step'
-          % (skip, run('inline', host), run('thread', host)), flush=True)
-ops._copy.clear()
+    ops.COPY_STREAM = cs
+    print('copy stream = %-4s: inline %.3f  thread %.3f  thread-stage %.3f ms/step'
+          % (cs, run('inline', host), run('thread', host), run('thread-stage', host)), flush=True)
 for name, b in (('T=160 crop', host), ('T=128 nocrop', host128)):
     for mode in ('sync', 'inline', 'thread', 'thread-stage'):
         print('%-13s %-13s %.3f ms/step' % (name, mode, run(mode, b)), flush=True)
