@@ -49,7 +49,7 @@ def train_epoch(model, batches, out=sys.stdout, sync_feed=None):
     if sync_feed is None:
         sync_feed = SYNC_FEED
     src = feed.BatchFeed(batches, model.device, hparams.MAX_TRAIN_LEN,
-                         threaded=False if sync_feed else None)
+                         mode='sync' if sync_feed else None)
     report = feed.StepReport(flush_every=1 if sync_feed else 1024)
     for spectra in src:
         step_fetch = model.train_step(spectra)
@@ -140,7 +140,7 @@ def evaluate(model, dataset, subset, out=sys.stdout, sync_feed=None):
         sync_feed = SYNC_FEED
     src = feed.BatchFeed(dataset.epoch(subset, hparams.BATCH_SIZE * hparams.MAX_N_SIGNAL,
                                        shuffle=False), model.device, None,
-                         threaded=False if sync_feed else None)
+                         mode='sync' if sync_feed else None)
     report = feed.StepReport(flush_every=1 if sync_feed else 1024)
     for spectra in src:
         report.add(model.valid_step(spectra))

@@ -4,22 +4,27 @@ reference (main.py:417-431, :497-500), one batch AHEAD of the step that consumes
 
 The reference builds every batch on the host (dataset iterator -> reshape -> random crop to
 MAX_TRAIN_LEN, main.py:417-426) and hands it to `g_sess.run`, which copies it to the device
-synchronously.  Here a feeder thread does, for batch i+1 while step i is being enqueued and run:
+synchronously.  Here, once step i has been enqueued, the loop does for batch i+1 -- while the
+device is still running the steps it has queued (the host enqueues a step in about a third of the
+time the device needs for it):
 
-    next(dataset iterator)                      (the iterator's own numpy / GPU work)
+    next(dataset iterator)
     draw the crop offset  randint(0, T-L-1)     (same `random` stream, same order as main.py:424-425)
-    cast / crop / reshape into a PINNED staging slot   (one pass over the data; only the cropped
-                                                        frames ever cross PCIe)
-    hipMemcpyAsync on a copy stream + event
+    cast / crop / reshape into a PINNED staging slot   (one pass over the data, 0.3 ms at cfg 2;
+                                                        only the cropped frames ever cross PCIe)
+    hipMemcpyAsync into a fixed device slot on the upload stream + event
 
-and the consumer only makes the compute stream wait for that event.  No arithmetic happens here:
+and the next step only makes the compute stream wait for that event.  No arithmetic happens here:
 the cast real -> complex64 (toy data, main.py:418-421) is a numpy copy into the staging slot.
 
-On a CPU "device" (the host-logic tests' stub model) the feed degenerates to the synchronous
-conversion, in the caller's thread.
+Measured and NOT kept (profiles/r04_feed_probe.txt, profiles/EXPERIMENTS.md): a feeder thread that
+stages and / or uploads (the main thread's enqueue slows from 1.2 to 2.9 ms per step on the GIL and
+the runtime's one-off 10-70 ms stall of a recurrent kernel comes back); an upload stream of its own
+(HIP maps streams onto a handful of hardware queues: depending on creation order the third stream
+shares a queue with the main or the side stream and the step is 1 ms slower -- the uploads ride on
+the existing side stream, which is idle at the step boundary); device buffers from the caching
+allocator (`record_stream`: re-allocation and event polling every step).
 '''
-import queue
-import threading
 from random import randint
 
 import numpy as np
@@ -41,16 +46,11 @@ def to_batch_host(data_pt, crop_len=None):
 
 class _Slot(object):
     '''one pinned staging buffer + one device buffer (both grow-only), the event of the last
-    upload out of / into them, and the event behind the last step that consumed the device
-    buffer.  No caching-allocator traffic per batch: a tensor allocated on the copy stream and
-    handed to the compute stream (`record_stream`) makes the allocator re-allocate and poll
-    events every step (measured: 4.1 instead of 3.1 ms per cfg-2 step).'''
-    __slots__ = ('buf', 'dev', 'event', 'consumed', 'free')
+    upload through them, and the event behind the last step that read the device buffer'''
+    __slots__ = ('buf', 'dev', 'event', 'consumed')
 
     def __init__(self):
         self.buf, self.dev, self.event, self.consumed = None, None, None, None
-        self.free = threading.Event()          # the consumer is done enqueuing readers of `dev`
-        self.free.set()
 
     def stage(self, a, pin=True):
         n = int(np.prod(a.shape))
@@ -70,20 +70,14 @@ class BatchFeed(object):
 
     Yields complex64 [B, C, T', F] tensors on `device`, already ordered behind their upload on
     the stream that is current in the consumer.  A yielded tensor is a view of one of `depth`
-    fixed device buffers: it stays valid until the consumer asks for the next batch but `depth - 1`
-    (copy it to keep it longer).  depth = pinned staging slots = device buffers.
+    fixed device buffers: it stays valid until the consumer asks for the next batch but `depth - 2`
+    (copy it to keep it longer).
 
-    mode (default: env DANET_FEED_MODE or 'inline' on a GPU, 'sync' on a CPU device):
-      'sync'    the reference's literal form: convert, blocking upload, in the caller's thread
-      'inline'  no thread: once step i has been enqueued, batch i+1 is staged into pinned
-                memory and its upload is issued on the copy stream -- the host does that work
-                while the device runs the steps it has queued (the host enqueues a step in
-                about a third of the time the device needs for it)
-      'thread'  a feeder thread runs the dataset iterator, stages AND issues the uploads
-      'thread-stage'  the feeder thread only runs the iterator and stages; the uploads are
-                issued by the consumer (no HIP call ever comes from a second thread)'''
+    mode (default: env DANET_FEED_MODE, else 'ahead' on a GPU and 'sync' on a CPU device):
+      'sync'   the reference's literal form: convert, blocking upload from pageable memory
+      'ahead'  one batch ahead through pinned staging slots, uploads on ops.copy_stream()'''
 
-    def __init__(self, source, device, crop_len=None, depth=3, threaded=None, mode=None):
+    def __init__(self, source, device, crop_len=None, depth=3, mode=None):
         import os
         self.source = source
         self.device = torch.device(device)
@@ -92,30 +86,20 @@ class BatchFeed(object):
         self.cuda = self.device.type == 'cuda'
         self.crop_len = crop_len
         if mode is None:
-            if threaded is not None:            # (round-4 tests: True = thread, False = sync)
-                mode = 'thread' if threaded else 'sync'
-            else:
-                mode = os.environ.get('DANET_FEED_MODE', 'inline') if self.cuda else 'sync'
-        assert mode in ('sync', 'inline', 'thread', 'thread-stage'), mode
+            mode = os.environ.get('DANET_FEED_MODE', 'ahead') if self.cuda else 'sync'
+        assert mode in ('sync', 'ahead'), mode
         self.mode = mode
-        self.depth = max(2, depth)
+        self.depth = max(3, depth)
         self.n = 0
-        self._thread = None
-        self._stop = False
         self._out = None
-        if mode != 'sync':
+        self._k = 0
+        if mode == 'ahead':
+            self.slots = [_Slot() for _ in range(self.depth)]
             self.copy_stream = None
             if self.cuda:
                 from . import ops
                 self.copy_stream = ops.copy_stream(self.device)
-            self.slots = [_Slot() for _ in range(self.depth)]
-            self._k = 0
-        if mode in ('thread', 'thread-stage'):
-            self.q = queue.Queue(maxsize=self.depth - 1)
-            self._thread = threading.Thread(target=self._produce, name='danet-feed', daemon=True)
-            self._thread.start()
 
-    # ---------------------------------------------------------- shared pieces
     def _stage(self, data_pt):
         '''host batch -> (pinned staging tensor, its slot); draws the crop offset'''
         a = to_batch_host(data_pt, self.crop_len)
@@ -124,14 +108,10 @@ class BatchFeed(object):
         return slot.stage(a, pin=self.cuda), slot
 
     def _upload(self, t, slot):
-        '''issue the H2D copy of a staged batch on the copy stream -> (device tensor, slot)'''
+        '''issue the H2D copy of a staged batch on the upload stream -> (device tensor, slot)'''
         if not self.cuda:                       # (host-logic tests: the "upload" is a copy)
             return t.clone(), slot
         n = t.numel()
-        while not slot.free.wait(0.1):          # (feeder thread: the consumer still holds this buffer)
-            if self._stop:
-                return None, slot
-        slot.free.clear()
         if slot.dev is None or slot.dev.numel() < n:
             slot.dev = torch.empty(n, dtype=torch.complex64, device=self.device)
             torch.cuda.current_stream(self.device).synchronize()     # (growth only)
@@ -158,44 +138,7 @@ class BatchFeed(object):
         slot, self._out = self._out, None
         if slot is not None and self.cuda:
             slot.consumed = torch.cuda.current_stream(self.device).record_event()
-            slot.free.set()
 
-    # ------------------------------------------------------------- producer
-    def _produce(self):
-        import contextlib
-        try:
-            if self.cuda:
-                torch.cuda.set_device(self.device)
-            # the iterator's own device work (e.g. a dataset that runs danet_stft) goes to the
-            # copy stream: it must not queue behind the training steps on the compute stream
-            with (torch.cuda.stream(self.copy_stream) if self.cuda else contextlib.nullcontext()):
-                it = iter(self.source)
-                while not self._stop:
-                    try:
-                        data_pt = next(it)
-                    except StopIteration:
-                        break
-                    t, slot = self._stage(data_pt)
-                    self._put(self._upload(t, slot) if self.mode == 'thread' else (t, slot))
-            self._put(None)
-        except BaseException as e:           # surfaces in the consumer
-            self._put(e)
-
-    def _put(self, item):
-        while not self._stop:
-            try:
-                self.q.put(item, timeout=0.1)
-                return
-            except queue.Full:
-                continue
-
-    def _take(self):
-        item = self.q.get()
-        if isinstance(item, BaseException):
-            raise item
-        return item
-
-    # ------------------------------------------------------------- consumer
     def __iter__(self):
         if self.mode == 'sync':
             for data_pt in self.source:
@@ -203,45 +146,18 @@ class BatchFeed(object):
                 self.n += 1
                 yield torch.as_tensor(np.ascontiguousarray(a).astype(np.complex64)).to(self.device)
             return
-        try:
-            if self.mode == 'thread':
-                while True:
-                    item = self._take()
-                    if item is None:
-                        return
-                    yield self._hand_out(*item)
-                    self._consumed()
-            # one batch ahead, uploads issued here: `nxt` is the batch whose upload is in flight
-            if self.mode == 'inline':
-                it = iter(self.source)
+        it = iter(self.source)
 
-                def fetch():
-                    try:
-                        return self._stage(next(it))
-                    except StopIteration:
-                        return None
-            else:
-                fetch = self._take
-            staged = fetch()
-            nxt = self._upload(*staged) if staged is not None else None
-            while nxt is not None:
-                yield self._hand_out(*nxt)        # the consumer enqueues step i ...
-                self._consumed()
-                staged = fetch()                  # ... then batch i+1 is staged / taken from the
-                nxt = self._upload(*staged) if staged is not None else None   # thread and uploaded
-        finally:
-            self.close()
-
-    def close(self):
-        self._stop = True
-        if self._thread is not None:
+        def fetch():
             try:
-                while True:
-                    self.q.get_nowait()
-            except queue.Empty:
-                pass
-            self._thread.join(timeout=5.0)
-            self._thread = None
+                return self._upload(*self._stage(next(it)))
+            except StopIteration:
+                return None
+        nxt = fetch()
+        while nxt is not None:
+            yield self._hand_out(*nxt)            # the consumer enqueues step i ...
+            self._consumed()
+            nxt = fetch()                         # ... then batch i+1 is staged and its upload issued
 
 
 class StepReport(object):

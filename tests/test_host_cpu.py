@@ -277,19 +277,28 @@ def _varlen_batches(hp, n, seed=3):
     return out
 
 
-def test_batch_feed_threaded_equals_synchronous_loop(hp):
-    '''feed.BatchFeed: the one-batch-ahead feeder thread yields exactly the tensors of the
-    reference's synchronous loop (reshape, cast to complex64, random crop to MAX_TRAIN_LEN with
-    the SAME draws from python's `random`, main.py:417-426)'''
+def test_batch_feed_ahead_equals_synchronous_loop(hp):
+    '''feed.BatchFeed: the one-batch-ahead feed yields exactly the tensors of the reference's
+    synchronous loop (reshape, cast to complex64, random crop to MAX_TRAIN_LEN with the SAME draws
+    from python's `random`, main.py:417-426), one iterator item ahead of the consumer'''
     from danet_amd import feed
     _toy_dataset(hp)
     batches = _varlen_batches(hp, 9)
     random.seed(11)
-    sync = [t.clone() for t in feed.BatchFeed(iter(batches), 'cpu', hp.MAX_TRAIN_LEN, threaded=False)]
+    sync = [t.clone() for t in feed.BatchFeed(iter(batches), 'cpu', hp.MAX_TRAIN_LEN, mode='sync')]
     random.seed(11)
-    thr = [t.clone() for t in feed.BatchFeed(iter(batches), 'cpu', hp.MAX_TRAIN_LEN, threaded=True)]
-    assert len(sync) == len(thr) == 9
-    for a, b, (raw,) in zip(sync, thr, batches):
+    pulled = []
+
+    def source():
+        for i, b in enumerate(batches):
+            pulled.append(i)
+            yield b
+    ahead = []
+    for i, t in enumerate(feed.BatchFeed(source(), 'cpu', hp.MAX_TRAIN_LEN, mode='ahead')):
+        assert pulled[-1] == i            # batch i+1 is fetched only after the consumer is back
+        ahead.append(t.clone())
+    assert len(sync) == len(ahead) == 9
+    for a, b, (raw,) in zip(sync, ahead, batches):
         assert a.dtype == b.dtype == torch.complex64 and torch.equal(a, b)
         assert a.shape == (hp.BATCH_SIZE, hp.MAX_N_SIGNAL, min(raw.shape[1], hp.MAX_TRAIN_LEN),
                            hp.FEATURE_SIZE)
@@ -303,26 +312,18 @@ def test_batch_feed_threaded_equals_synchronous_loop(hp):
         assert np.array_equal(a.numpy(), x.astype(np.complex64))
 
 
-def test_batch_feed_propagates_dataset_errors_and_stops(hp):
+def test_batch_feed_propagates_dataset_errors(hp):
     from danet_amd import feed
     _toy_dataset(hp)
 
     def bad():
         yield _varlen_batches(hp, 1)[0]
         raise RuntimeError('corpus file missing')
-    f = feed.BatchFeed(bad(), 'cpu', None, threaded=True)
-    it = iter(f)
+    it = iter(feed.BatchFeed(bad(), 'cpu', None, mode='ahead'))
     next(it)
     with pytest.raises(RuntimeError, match='corpus file missing'):
         next(it)
-    assert f._thread is None                        # joined
-    # a consumer that stops early (exception in the train step) leaves no thread behind
-    f = feed.BatchFeed(iter(_varlen_batches(hp, 50)), 'cpu', None, threaded=True)
-    for i, _ in enumerate(f):
-        if i == 2:
-            break
-    f.close()
-    assert f._thread is None
+    assert list(feed.BatchFeed(iter([]), 'cpu', None, mode='ahead')) == []
 
 
 def test_step_report_equals_running_float_sum():

@@ -49,19 +49,13 @@ def run(mode, batches, sw=None, flush=1024):
     return dt
 
 # which stream the uploads ride on: HIP maps streams onto few hardware queues
-keep = []
-for cs in ('side', 'own', 'own', 'own', 'side'):
+for cs in ('side', 'own', 'own', 'own', 'side', 'side'):
     ops._copy.clear()
     ops.COPY_STREAM = cs
-    print('copy stream = %-4s: inline %.3f  thread %.3f  thread-stage %.3f ms/step'
-          % (cs, run('inline', host), run('thread', host), run('thread-stage', host)), flush=True)
-for name, b in (('T=160 crop', host), ('T=128 nocrop', host128)):
-    for mode in ('sync', 'inline', 'thread', 'thread-stage'):
-        print('%-13s %-13s %.3f ms/step' % (name, mode, run(mode, b)), flush=True)
-print('thread sw=1e-4      %.3f' % run('thread', host, sw=1e-4), flush=True)
-print('thread-stage sw=1e-4 %.3f' % run('thread-stage', host, sw=1e-4), flush=True)
+    print('copy stream = %-4s: ahead %.3f  ahead %.3f  sync %.3f ms/step'
+          % (cs, run('ahead', host), run('ahead', host128), run('sync', host)), flush=True)
 print('sync, metrics deferred %.3f' % run('sync', host, flush=1024), flush=True)
-print('inline, metrics per step %.3f' % run('inline', host, flush=1), flush=True)
+print('ahead, metrics per step %.3f' % run('ahead', host, flush=1), flush=True)
 # host-side cost of staging alone
 sl = feed._Slot()
 a = feed.to_batch_host((host[0],), 128)
