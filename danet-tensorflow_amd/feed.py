@@ -65,6 +65,21 @@ class _Slot(object):
         return t
 
 
+# staging slots are kept per device across feeds (a feed per epoch must not re-pin 25 MB of host
+# memory every time); a second feed on the same device while one is active gets its own
+_slot_cache = {}
+
+
+def _take_slots(key, depth):
+    ent = _slot_cache.get(key)
+    if ent is None or ent['busy'] or len(ent['slots']) != depth:
+        ent = dict(busy=False, slots=[_Slot() for _ in range(depth)])
+        if key not in _slot_cache or not _slot_cache[key]['busy']:
+            _slot_cache[key] = ent
+    ent['busy'] = True
+    return ent
+
+
 class BatchFeed(object):
     '''for spectra in BatchFeed(dataset.epoch(...), device, crop_len): model.train_step(spectra)
 
@@ -94,7 +109,8 @@ class BatchFeed(object):
         self._out = None
         self._k = 0
         if mode == 'ahead':
-            self.slots = [_Slot() for _ in range(self.depth)]
+            self._ent = _take_slots(str(self.device), self.depth)
+            self.slots = self._ent['slots']
             self.copy_stream = None
             if self.cuda:
                 from . import ops
@@ -153,11 +169,14 @@ class BatchFeed(object):
                 return self._upload(*self._stage(next(it)))
             except StopIteration:
                 return None
-        nxt = fetch()
-        while nxt is not None:
-            yield self._hand_out(*nxt)            # the consumer enqueues step i ...
-            self._consumed()
-            nxt = fetch()                         # ... then batch i+1 is staged and its upload issued
+        try:
+            nxt = fetch()
+            while nxt is not None:
+                yield self._hand_out(*nxt)        # the consumer enqueues step i ...
+                self._consumed()
+                nxt = fetch()                     # ... then batch i+1 is staged and its upload issued
+        finally:
+            self._ent['busy'] = False
 
 
 class StepReport(object):
