@@ -49,7 +49,7 @@ PROTOTYPES = {
     'danet_gemm_f32_streamk_kcat': (c_int, [c_p, c_int, c_int, c_int, c_int,
                                             c_int, c_p, c_int, c_p, c_int, c_int, c_p, c_int, c_p, c_int,
                                             c_p, c_int, c_p, c_f32, c_p, c_sz]),
-    'danet_colsum_f32': (c_int, [c_p, c_int, c_int, c_p, c_int, c_p, c_int, c_p, c_f32, c_p, c_sz]),
+    'danet_colsum_f32': (c_int, [c_p, c_int, c_int, c_p, c_int, c_p, c_f32, c_p, c_sz]),
     'danet_lstm_fwd': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_int,
                                c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_sz, c_p, c_int]),
     'danet_lstm_fwd_prefill': (c_int, [c_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_p),

@@ -190,11 +190,8 @@ extern "C" int danet_center(danet_stream_t stream, int B, int T, int D, const fl
 // enough loads in flight; level 2 sums the <= M/COLSUM_ROWS band partials.
 #define COLSUM_ROWS 128
 
-// w != nullptr: row m is weighted by w[m * ldw] (one row of a product W^T A: the ragged last
-// feature row of a weight gradient, see danet_colsum_f32)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(
-    int M, int N, const float* __restrict__ A, int lda, const float* __restrict__ w, int ldw,
-    float* __restrict__ partial) {
+    int M, int N, const float* __restrict__ A, int lda, float* __restrict__ partial) {
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cl;
@@ -202,19 +199,11 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(
   float s0 = 0.f, s1 = 0.f;
   if (col < N) {
     int r = r0 + rl;
-    if (w) {
-      for (; r + 4 < r1; r += 8) {
-        s0 += w[(size_t)r * ldw] * A[(size_t)r * lda + col];
-        s1 += w[(size_t)(r + 4) * ldw] * A[(size_t)(r + 4) * lda + col];
-      }
-      if (r < r1) s0 += w[(size_t)r * ldw] * A[(size_t)r * lda + col];
-    } else {
-      for (; r + 4 < r1; r += 8) {
-        s0 += A[(size_t)r * lda + col];
-        s1 += A[(size_t)(r + 4) * lda + col];
-      }
-      if (r < r1) s0 += A[(size_t)r * lda + col];
+    for (; r + 4 < r1; r += 8) {
+      s0 += A[(size_t)r * lda + col];
+      s1 += A[(size_t)(r + 4) * lda + col];
     }
+    if (r < r1) s0 += A[(size_t)r * lda + col];
   }
   red[rl][cl] = s0 + s1;
   __syncthreads();
@@ -236,16 +225,15 @@ size_t dn_ws_colsum(int M, int N) {
 }
 
 extern "C" int danet_colsum_f32(danet_stream_t stream, int M, int N, const float* A, int lda,
-                                const float* w, int ldw, float* out, float beta, void* ws,
-                                size_t ws_bytes) {
-  DANET_CHECK_ARG(M > 0 && N > 0 && A && out && lda >= N && (!w || ldw >= 1), "colsum: bad args");
+                                float* out, float beta, void* ws, size_t ws_bytes) {
+  DANET_CHECK_ARG(M > 0 && N > 0 && A && out && lda >= N, "colsum: bad args");
   if (!ws || ws_bytes < dn_ws_colsum(M, N)) {
     danet_set_error("colsum: workspace too small");
     return DANET_ERR_WORKSPACE;
   }
   const int nparts = cdiv(M, COLSUM_ROWS);
   dim3 g(cdiv(N, 64), nparts);
-  colsum_partial_kernel<<<g, 256, 0, (hipStream_t)stream>>>(M, N, A, lda, w, ldw, (float*)ws);
+  colsum_partial_kernel<<<g, 256, 0, (hipStream_t)stream>>>(M, N, A, lda, (float*)ws);
   DANET_CHECK_LAUNCH();
   colsum_final_kernel<<<cdiv(N, 64), 64, 0, (hipStream_t)stream>>>(nparts, N, (const float*)ws,
                                                                    out, beta);

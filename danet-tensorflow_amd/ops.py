@@ -132,13 +132,11 @@ GROUPED_DW_WGS = int(__import__('os').environ.get('DANET_GROUPED_DW_WGS', '256')
 GROUPED_GX = int(__import__('os').environ.get('DANET_GROUPED_GX', '512'))   # grid of the grouped gx launch (0: two launches on two streams)
 
 
-def colsum(A, M, N, lda, out, beta=0.0, weight=None, ldw=0):
-    '''out[n] = sum_m A[m][n] (+beta*out); weight: a tensor whose data_ptr() is w[0], row m
-    weighted by w[m*ldw] (one row of a product W^T A)'''
+def colsum(A, M, N, lda, out, beta=0.0):
     L = _L()
     w, wn = _ws(_lib.ws_bytes(_lib.WS_COLSUM, M, N), out.device)
-    check(L.danet_colsum_f32(_lib.stream(), M, N, ptr(_f32(A)), lda, ptr(weight), int(ldw),
-                             ptr(out), float(beta), ptr(w), wn))
+    check(L.danet_colsum_f32(_lib.stream(), M, N, ptr(_f32(A)), lda, ptr(out), float(beta),
+                             ptr(w), wn))
     return out
 
 
@@ -764,7 +762,6 @@ def _overlap_dw(H):
 # BPTT kernel then has the group beside it for a shorter time)
 DW_FORK_EARLY = __import__('os').environ.get('DANET_DW_FORK_EARLY', '0') == '1'
 # bias gradients summed inside the (unfused) BPTT kernel instead of by column-sum launches
-PEEL_DW_ROW = __import__('os').environ.get('DANET_PEEL_DW_ROW', '1') == '1'
 BWD_DB = __import__('os').environ.get('DANET_LSTM_BWD_DB', '1') == '1'
 DB_DEFER = __import__('os').environ.get('DANET_LSTM_DB_DEFER', '1') == '1'
 
@@ -832,31 +829,18 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
         # Hprev(t) = ypad block t (fwd) / block t+2 (bwd)
         return c.ypad.view(-1)[(0 if d == 0 else 2 * B * ldy + H):]
 
-    # input width 128 k + 1 (F = 129 / 257 bins at layer 0): the last feature row would cost a
-    # whole 128-row tile per column block (20 of the bottom layer's 100 tiles at cfg 2) -- it is
-    # taken out of the group and formed by a weighted column sum of da (danet_colsum_f32)
-    peel = PEEL_DW_ROW and D > 128 and D % 128 == 1
-    Dg = D - 1 if peel else D
-
-    def peeled_rows():
-        for d in range(ndir):
-            colsum(das[d], T * B, 4 * H, 4 * H, dWs[d][Dg], beta=1.0 if direct[d][0] else 0.0,
-                   weight=c.x.view(-1)[Dg:], ldw=c.ldx)
-
     def weight_grads_grouped(wgs=GROUPED_DW_WGS, with_bias=True):
         # dWx = X^T da and dWh = Hprev^T da of every direction: one stream-K launch
         probs = []
         for d in range(ndir):
             bW = 1.0 if direct[d][0] else 0.0
-            probs.append((c.x, c.ldx, das[d], 4 * H, dWs[d], 4 * H, Dg, 4 * H, bW))
+            probs.append((c.x, c.ldx, das[d], 4 * H, dWs[d], 4 * H, D, 4 * H, bW))
             probs.append((hprev_of(d), ldy, das[d], 4 * H, dWs[d][D:], 4 * H, H, 4 * H, bW))
         gemm_group(probs, T * B, transA=True, max_workgroups=wgs)
         # (the bias gradients as M = 1 members of the group were measured slower than
         # the two column-sum kernels: +25 us on the group for 128-row tiles with one row)
         if with_bias:
             bias_grads()
-            if peel:
-                peeled_rows()
 
     def bias_grads():
         if db_deferred:
@@ -915,8 +899,6 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
             # the main stream while the column sums (if any) run beside it
             if not db_in_kernel:
                 f.run(1, bias_grads)
-            if peel:
-                f.run(1, peeled_rows)     # beside the group (the GPU is the group's: HBM-bound company)
             weight_grads_grouped(wgs=512, with_bias=False)
             on_main = True
         elif GROUPED_DW and not _overlap_dw(H):

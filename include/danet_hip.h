@@ -215,13 +215,10 @@ int danet_event_create(void** event);
 int danet_event_destroy(void* event);
 int danet_stream_wait_event(danet_stream_t stream, void* event);
 
-/* out[N] = sum_m w[m*ldw] * A[m][n] (+ beta*out); w == NULL: plain column sums (bias
- * gradients).  With w = one column of X it is ONE row of the weight gradient X^T da: a
- * layer whose input width is 128 k + 1 (F = 129 and 257 bins) would otherwise pay a whole
- * 128-row GEMM tile per column block for that row (dWx of layer 0: 20 of 100 tiles).      */
+/* out[N] = sum_m A[m][n] (+ beta*out): bias gradients.                     */
 int danet_colsum_f32(danet_stream_t stream, int M, int N, const float* A,
-                     int lda, const float* w, int ldw, float* out, float beta,
-                     void* ws, size_t ws_bytes);
+                     int lda, float* out, float beta, void* ws,
+                     size_t ws_bytes);
 
 /* ---------------------------------------------------------------- a5-a7
  * Recurrent half of Model.lyr_lstm / _lyr_bilstm (main.py:76-132,
