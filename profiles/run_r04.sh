@@ -1,0 +1,33 @@
+#!/bin/bash
+# Round-4 evidence in one go (GPU box):  bash profiles/run_r04.sh <tag> <git-rev>
+# -> gpurun_out/r04/<tag>_*: un-profiled bench lines of every config, rocprofv3 kernel stats +
+# the lines those profiled runs printed, one step's kernel timeline, PMC traffic (cfg2, cfg4h600),
+# MFMA-busy, the GEMM shapes.
+set -u
+TAG=${1:-x}; REV=${2:-unknown}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/r04
+mkdir -p "$OUT"
+cd "$ROOT"
+for c in cfg2 cfg4 cfg4h600 cfg5 cfg5-kmeans; do
+  python bench.py --config $c --steps 20 --warmup 5 2> "$OUT/${TAG}_bench_$c.err" | tail -1 > "$OUT/${TAG}_bench_$c.json"
+done
+DANET_FORCE_DIST=1 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_cfg2_rccl1.json"
+for c in cfg2 cfg4 cfg4h600 cfg5; do
+  bash profiles/run_rocprof.sh ${TAG}_$c --config $c > "$OUT/${TAG}_rocprof_$c.log" 2>&1
+  cp gpurun_out/prof_${TAG}_$c/kernel_stats.csv "$OUT/${TAG}_kernel_stats_$c.csv" 2>/dev/null
+  grep -E '^\{' gpurun_out/prof_${TAG}_$c/bench.log | tail -1 > "$OUT/${TAG}_bench_under_rocprof_$c.json"
+done
+bash tools/timeline.sh ${TAG} > /dev/null 2>&1
+cp gpurun_out/${TAG}_timeline.txt "$OUT/${TAG}_step_timeline.txt" 2>/dev/null
+bash profiles/run_pmc.sh ${TAG}_cfg2 cfg2 $REV > "$OUT/${TAG}_pmc_cfg2.log" 2>&1
+cp gpurun_out/pmc_${TAG}_cfg2/summary.json "$OUT/${TAG}_pmc_summary.json" 2>/dev/null
+bash profiles/run_pmc.sh ${TAG}_cfg4h600 cfg4h600 $REV > "$OUT/${TAG}_pmc_cfg4h600.log" 2>&1
+cp gpurun_out/pmc_${TAG}_cfg4h600/summary.json "$OUT/${TAG}_pmc_summary_cfg4h600.json" 2>/dev/null
+bash profiles/run_pmc_mfma.sh ${TAG} > "$OUT/${TAG}_pmc_mfma.log" 2>&1
+cp gpurun_out/pmc_mfma_${TAG}/summary.json "$OUT/${TAG}_pmc_mfma_summary.json" 2>/dev/null
+python tools/bench_gemm.py > "$OUT/${TAG}_gemm_shapes.txt" 2>&1
+python tools/lstm_modes.py > "$OUT/${TAG}_lstm_bwd_modes.txt" 2>&1
+python tools/feed_probe.py 100 > "$OUT/${TAG}_feed_probe.txt" 2>&1
+python tools/feed_trace.py ahead 100 3 > "$OUT/${TAG}_feed_trace.txt" 2>&1
+ls -la "$OUT"
