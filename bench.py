@@ -282,11 +282,14 @@ def parity_vs_oracle(hp, model, src, n_check=4):
         with torch.no_grad():
             fo = model.forward(src, fuse_heads=True)
         snr_f, snr_u = float(fo['SNR']), float(out['SNR'])
-        fused = dict(loss_bit_equal=bool(torch.equal(fo['loss'], out['loss'])),
-                     snr_rel_diff=abs(snr_f - snr_u) / max(abs(snr_u), 1e-30),   # (log of chunk sums
-                     perm_idx_equal=bool(torch.equal(fo['perm_idx'], out['perm_idx'])),   # in another order)
-                     loss=float(fo['loss']), snr=snr_f)
-        fused['ok'] = fused['loss_bit_equal'] and fused['snr_rel_diff'] <= 1e-5 and fused['perm_idx_equal']
+        l_f, l_u = float(fo['loss']), float(out['loss'])
+        fused = dict(loss_bit_equal=bool(torch.equal(fo['loss'], out['loss'])),      # (informative:
+                     loss_rel_diff=abs(l_f - l_u) / max(abs(l_u), 1e-30),            # bit-equal at C = 2,
+                     snr_rel_diff=abs(snr_f - snr_u) / max(abs(snr_u), 1e-30),       # another order of
+                     perm_idx_equal=bool(torch.equal(fo['perm_idx'], out['perm_idx'])),   # the chunk sums
+                     loss=l_f, snr=snr_f)                                            # at C = 3)
+        fused['ok'] = (fused['loss_rel_diff'] <= 1e-6 and fused['snr_rel_diff'] <= 1e-5 and
+                       fused['perm_idx_equal'])
         rep['fused_heads'] = fused
         rep['ok'] = bool(rep['ok'] and fused['ok'])
     return rep, rep['masks']['hip_vs_f64']['mse']
@@ -303,7 +306,7 @@ def _fill_parity(res, rep, mse, model):
     res['parity'] = dict(
         rule='err(HIP,f64) <= max(1e-4, 2*err(f32 oracle,f64)); err = max|a-b|/max|b|; '
              '4 mixtures of batch 0 at the final (trained) parameters; fused separator+loss '
-             'kernels (the ones train_step runs): loss and permutation bit-equal to the unfused ones, SNR to 1e-5',
+             'kernels (the ones train_step runs): permutation equal to the unfused ones, loss to 1e-6, SNR to 1e-5',
         **{k: dict(hip=rep[k]['hip_vs_f64']['max_rel'], f32=rep[k]['f32_vs_f64']['max_rel'],
                    hip_rms=rep[k]['hip_vs_f64']['rms_rel'], f32_rms=rep[k]['f32_vs_f64']['rms_rel'],
                    ok=rep[k]['ok']) for k in ('embed', 'attrs', 'masks', 'sep_pwr')},

@@ -1124,34 +1124,19 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
   }
 }
 
-// dW_d[f][c] (+)= sum over the G clusters of direction d of their partial; same for db
-__global__ __launch_bounds__(256) void lstm_dw_reduce_kernel(
-    const float* __restrict__ dwslab, const float* __restrict__ dbslab, float* dW0, float* dW1,
-    float* db0, float* db1, int G, int Din, int Dp, int NF, int NFP, int H4, float beta) {
+// db_d[c] (+)= sum over the G clusters of direction d of their partial (fixed order: deterministic)
+__global__ __launch_bounds__(256) void lstm_db_reduce_kernel(
+    const float* __restrict__ dbslab, float* db0, float* db1, int G, int H4, float beta) {
   const int dir = blockIdx.y;
-  float* dW = dir ? dW1 : dW0;
   float* db = dir ? db1 : db0;
   const int q4 = H4 / 4;
-  const int64_t n4 = (int64_t)NF * q4;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4 + q4;
-       i += (int64_t)gridDim.x * 256) {
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < q4; j += gridDim.x * 256) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (i < n4) {
-      const int row = (int)(i / q4), c4 = (int)(i % q4);
-      const int srow = row < Din ? row : row - Din + Dp;      // slab row (padded feature space)
-      for (int g = 0; g < G; ++g)
-        v += reinterpret_cast<const f32x4*>(dwslab + ((size_t)(dir * G + g) * NFP + srow) * H4)[c4];
-      f32x4* o = reinterpret_cast<f32x4*>(dW) + i;
-      if (beta != 0.f) v += *o;
-      *o = v;
-    } else {
-      const int64_t j = i - n4;
-      for (int g = 0; g < G; ++g)
-        v += reinterpret_cast<const f32x4*>(dbslab + (size_t)(dir * G + g) * H4)[j];
-      f32x4* o = reinterpret_cast<f32x4*>(db) + j;
-      if (beta != 0.f) v += *o;
-      *o = v;
-    }
+    for (int g = 0; g < G; ++g)
+      v += reinterpret_cast<const f32x4*>(dbslab + (size_t)(dir * G + g) * H4)[j];
+    f32x4* o = reinterpret_cast<f32x4*>(db) + j;
+    if (beta != 0.f) v += *o;
+    *o = v;
   }
 }
 
@@ -1543,8 +1528,7 @@ extern "C" int danet_lstm_bwd_db_reduce(danet_stream_t stream_, int T, int B, in
   const RsPlan rs = choose_rs_plan(B, H, ndir);
   const float* slab = (const float*)((const char*)ws + align_up(ring_offset(T) + rs.ring_bytes, 256));
   dim3 grid((unsigned)cdiv(H, 256), ndir);
-  lstm_dw_reduce_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(nullptr, slab, nullptr, nullptr, db_f, db_b,
-                                                                rs.G, 0, 0, 0, 0, 4 * H, beta);
+  lstm_db_reduce_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(slab, db_f, db_b, rs.G, 4 * H, beta);
   DANET_CHECK_LAUNCH();
   return DANET_OK;
 }
@@ -1616,8 +1600,7 @@ extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int n
     DANET_CHECK_LAUNCH();
     if (db_f && !(flags & DANET_LSTM_DB_DEFERRED)) {
       dim3 grid((unsigned)cdiv(H, 256), ndir);
-      lstm_dw_reduce_kernel<<<grid, 256, 0, stream>>>(nullptr, a.dbslab, nullptr, nullptr, db_f, db_b,
-                                                      rs.G, 0, 0, 0, 0, 4 * H, beta);
+      lstm_db_reduce_kernel<<<grid, 256, 0, stream>>>(a.dbslab, db_f, db_b, rs.G, 4 * H, beta);
       DANET_CHECK_LAUNCH();
     }
     return DANET_OK;
