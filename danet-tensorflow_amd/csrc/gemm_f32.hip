@@ -40,10 +40,6 @@ struct GemmArgs {
   int kchunk;   // K range per z-slice (multiple of BK)
   int splitk;
   float beta;
-  // optional second operand pair (K-concatenated product C = A B + A2 B2): K slices
-  // z >= split1 take pair 2, K2 elements in chunks of kchunk2
-  const float* A2; const float* B2;
-  int lda2, ldb2, K2, kchunk2, split1;
 };
 
 typedef unsigned v4u __attribute__((__vector_size__(16)));   // see lstm.hip (b128 builtins)
@@ -611,12 +607,11 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int z = wi / nwg;
-  const bool second = z >= g.split1;
-  const float* Ap = second ? g.A2 : g.A;
-  const float* Bp = second ? g.B2 : g.B;
-  const int lda = second ? g.lda2 : g.lda, ldb = second ? g.ldb2 : g.ldb;
-  const int kbeg = second ? (z - g.split1) * g.kchunk2 : z * g.kchunk;
-  const int kend = second ? min(g.K2, kbeg + g.kchunk2) : min(g.K, kbeg + g.kchunk);
+  const float* Ap = g.A;
+  const float* Bp = g.B;
+  const int lda = g.lda, ldb = g.ldb;
+  const int kbeg = z * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -704,42 +699,25 @@ static bool operand_fits(int rows, int cols, int ld) {
 
 static int gemm_launch(hipStream_t stream, int transA, int transB, int M, int N,
                        int K, const float* A, int lda, const float* B, int ldb,
-                       int K2, const float* A2, int lda2, const float* B2, int ldb2,
                        float* C, int ldc, const float* bias, float beta, void* ws,
                        size_t ws_bytes, int max_workgroups) {
   gemm_init_once();
-  DANET_CHECK_ARG(M > 0 && N > 0 && K > 0 && K2 >= 0, "gemm: non-positive shape %d %d %d", M, N, K);
-  DANET_CHECK_ARG(A && B && C && (K2 == 0 || (A2 && B2)), "gemm: null operand");
+  DANET_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: non-positive shape %d %d %d", M, N, K);
+  DANET_CHECK_ARG(A && B && C, "gemm: null operand");
   DANET_CHECK_ARG(beta == 0.f || beta == 1.f, "gemm: beta must be 0 or 1");
   DANET_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N,
                   "gemm: leading dimension too small");
-  DANET_CHECK_ARG(K2 == 0 || (lda2 >= (transA ? M : K2) && ldb2 >= (transB ? K2 : N)),
-                  "gemm: leading dimension of the second pair too small");
   DANET_CHECK_ARG(operand_fits(transA ? K : M, transA ? M : K, lda) &&
-                  operand_fits(transB ? N : K, transB ? K : N, ldb) &&
-                  (K2 == 0 || (operand_fits(transA ? K2 : M, transA ? M : K2, lda2) &&
-                               operand_fits(transB ? N : K2, transB ? K2 : N, ldb2))),
+                  operand_fits(transB ? N : K, transB ? K : N, ldb),
                   "gemm: an operand spans 2 GiB or more");
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.beta = beta;
-  g.A2 = A2; g.B2 = B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;
-  int stot = choose_splitk(M, N, K + K2);
-  if (K2 > 0 && stot < 2) stot = 2;
-  int s1 = stot, s2 = 0;
-  if (K2 > 0) {
-    s1 = (int)((double)stot * K / (K + K2) + 0.5);
-    if (s1 < 1) s1 = 1;
-    if (s1 > stot - 1) s1 = stot - 1;
-    s2 = stot - s1;
-  }
-  const int kchunk = cdiv(cdiv(K, s1), BK) * BK;
-  s1 = cdiv(K, kchunk);
-  int kchunk2 = BK;
-  if (K2 > 0) { kchunk2 = cdiv(cdiv(K2, s2), BK) * BK; s2 = cdiv(K2, kchunk2); }
-  const int splitk = s1 + s2;
-  g.splitk = splitk; g.kchunk = kchunk; g.kchunk2 = kchunk2; g.split1 = s1; g.slab = nullptr;
+  const int stot = choose_splitk(M, N, K);
+  const int kchunk = cdiv(cdiv(K, stot), BK) * BK;
+  const int splitk = cdiv(K, kchunk);
+  g.splitk = splitk; g.kchunk = kchunk; g.slab = nullptr;
   if (splitk > 1) {
     const size_t need = (size_t)splitk * M * N * sizeof(float);
     if (!ws || ws_bytes < need) {
@@ -752,8 +730,7 @@ static int gemm_launch(hipStream_t stream, int transA, int transB, int M, int N,
   if (max_workgroups > 0 && nblocks > max_workgroups) nblocks = max_workgroups;
   dim3 grid(nblocks, 1, 1), block(256);
   const bool ak = !transA, bk = (transB != 0);
-  const bool dma = dma_env(1) && dma_operand_ok(A, lda, ak, K) && dma_operand_ok(B, ldb, bk, K) &&
-                   (K2 == 0 || (dma_operand_ok(A2, lda2, ak, K2) && dma_operand_ok(B2, ldb2, bk, K2)));
+  const bool dma = dma_env(1) && dma_operand_ok(A, lda, ak, K) && dma_operand_ok(B, ldb, bk, K);
 #define GEMM_LAUNCH(D_)                                                                          \
   do {                                                                                           \
     if (ak && !bk) gemm_f32_kernel<true, false, D_><<<grid, block, GEMM_SMEM_BYTES, stream>>>(g);        \
@@ -779,7 +756,7 @@ extern "C" int danet_gemm_f32(danet_stream_t stream_, int transA, int transB,
                               const float* bias, float beta, void* ws,
                               size_t ws_bytes, int max_workgroups) {
   return gemm_launch((hipStream_t)stream_, transA, transB, M, N, K, A, lda, B, ldb,
-                     0, nullptr, 0, nullptr, 0, C, ldc, bias, beta, ws, ws_bytes, max_workgroups);
+                     C, ldc, bias, beta, ws, ws_bytes, max_workgroups);
 }
 
 // ---------------------------------------------------------------------------
@@ -885,7 +862,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_sk_kernel(SkArgs sk) {
     g.M = pr.M; g.N = pr.N; g.K = sk.K; g.lda = pr.lda; g.ldb = pr.ldb; g.ldc = pr.ldc;
     g.beta = pr.beta;
     g.slab = nullptr; g.splitk = 1; g.kchunk = sk.K;
-    g.A2 = nullptr; g.B2 = nullptr; g.lda2 = g.ldb2 = g.K2 = 0; g.kchunk2 = BK; g.split1 = 1;
     const int ptile = tile - pr.tile0;
     const int tm = ptile / pr.tiles_n, tn = ptile % pr.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
