@@ -289,3 +289,61 @@ def test_g5_live_oracle_matches_committed_fixtures(name):
     assert any(k.startswith('grad:') for k in errs)
     bad = {k: e for k, e in errs.items() if not e <= 1e-11}
     assert not bad, bad
+
+
+# ------------------------------------------------------------------ round 4: inference fetches
+def test_infer_forward_agrees_with_the_train_graph_and_numpy_oracle():
+    '''oracle/torch_ref.infer_forward (main.py:384-385, :333-335, :685-690) == the pieces of the
+    training graph evaluated on the mixture alone, and == the numpy oracle's functions (two
+    restatements must agree): embedding, anchor attractors, masks, separated spectra'''
+    import torch
+    from oracle import torch_ref as R
+    rng = np.random.RandomState(3)
+    B, C, T, F, E, H, L, A = 2, 2, 9, 5, 3, 4, 2, 4
+    params = O.init_bilstm_params(rng, F, E, H=H, L=L)
+    params['global/infer_estimator/anchors'] = rng.randn(A, E)
+    src = rng.randn(B, C, T, F) + 1j * rng.randn(B, C, T, F)
+    mix = src.sum(axis=1)
+    cfg = dict(H=H, L=L, E=E, C=C, A=A, infer_est='anchor', separator='dot-softmax-orig')
+    tp = {k: torch.tensor(v, dtype=torch.float64) for k, v in params.items()}
+    r = R.infer_forward(torch.tensor(mix), tp, cfg)
+    fe = O.frontend(mix[:, None])
+    emb = O.bilstm_encoder(fe['mix_log'], params, H, L, E)
+    attr = O.est_anchor(emb, params['global/infer_estimator/anchors'], C)
+    sep_pwr, masks = O.sep_dot(fe['mix_pwr'], attr, emb.reshape(B, -1, E), 'softmax', return_masks=True)
+    sep = O.reattach_phase(sep_pwr, fe['phase'])
+    for got, want in ((r['embed'], emb), (r['attrs'], attr), (r['masks'], masks), (r['sep_pwr'], sep_pwr),
+                      (r['sep'], sep)):
+        assert np.abs(got.numpy() - want).max() <= 1e-11 * (np.abs(want).max() + 1e-30)
+    # softmax masks: the separated spectra add up to the mixture
+    assert np.abs(r['sep'].sum(dim=1).numpy() - mix).max() < 1e-12 * np.abs(mix).max()
+
+
+def test_est_kmeans_restatement():
+    '''oracle/torch_ref.est_kmeans (extension; README.md:216 of the reference has no k-means):
+    0 iterations == the anchor estimator; on two well separated clusters the iterations end at the
+    |mix|-weighted cluster means (app/modules.py:476-482 with estimated assignments); a fixed
+    point stays fixed'''
+    import torch
+    from oracle import torch_ref as R
+    rng = np.random.RandomState(5)
+    T, F, E, A, C = 40, 9, 6, 5, 2
+    centres = rng.randn(C, E) * 3.0
+    assign = rng.randint(0, C, size=(1, T, F))
+    emb = torch.tensor(centres[assign] + 0.05 * rng.randn(1, T, F, E))
+    w = torch.tensor(np.abs(rng.randn(1, T, F)) + 0.1)
+    anchors = torch.tensor(rng.randn(A, E))
+    a0 = R.est_kmeans(emb, anchors, C, w, iters=0)
+    assert torch.equal(a0, R.est_anchor(emb, anchors, C))
+    a10 = R.est_kmeans(emb, anchors, C, w, iters=10)
+    a11 = R.est_kmeans(emb, anchors, C, w, iters=11)
+    assert float((a10 - a11).abs().max()) < 1e-12              # converged: a fixed point
+    ef, wf, lab = emb.reshape(-1, E).numpy(), w.reshape(-1).numpy(), assign.reshape(-1)
+    truth = np.stack([(ef[lab == c] * wf[lab == c][:, None]).sum(0) / (wf[lab == c].sum() + 1e-7)
+                      for c in range(C)])
+    got = a10[0].numpy()
+    # (the start attractors may label the clusters in either order)
+    err = min(np.abs(got - truth).max(), np.abs(got - truth[::-1]).max())
+    start = R.est_anchor(emb, anchors, C)[0].numpy()
+    both_found = len(set(np.argmax(truth @ start.T, axis=1))) == 2
+    assert (not both_found) or err < 1e-6 * np.abs(truth).max()
