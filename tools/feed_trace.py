@@ -27,6 +27,22 @@ def epoch(n):
         yield (host[i % 4],)
 
 
+import gc
+gc_log = []
+_t = [0.0]
+
+
+def _gc_cb(phase, info):
+    if phase == 'start':
+        _t[0] = time.perf_counter()
+    else:
+        gc_log.append((info['generation'], 1e3 * (time.perf_counter() - _t[0]), info['collected']))
+
+
+gc.callbacks.append(_gc_cb)
+if os.environ.get('FEED_TRACE_NOGC') == '1':
+    gc.collect(); gc.disable()
+
 for rep in range(reps):
     src = iter(feed.BatchFeed(epoch(steps), dev, hp.MAX_TRAIN_LEN, mode=mode))
     evs, t_next, t_step = [], [], []
@@ -52,6 +68,13 @@ for rep in range(reps):
           'p90 %.3f | host train_step: median %.3f p90 %.3f' % (
               rep, mode, dt, np.median(gpu), gpu.mean(), np.percentile(gpu, 90), gpu.max(), np.median(tn),
               np.percentile(tn, 90), np.median(ts), np.percentile(ts, 90)), flush=True)
+    worst = int(np.argmax(gpu))
+    print('   worst gpu step #%d: gpu %.2f ms, host next %.2f, host step %.2f (neighbours gpu %s)' % (
+        worst, gpu[worst], tn[worst], ts[worst], ' '.join('%.2f' % v for v in gpu[max(0, worst - 2):worst + 3])))
+    hw = int(np.argmax(tn + ts))
+    print('   worst host iteration #%d: next %.2f + step %.2f ms (gpu %.2f)' % (hw, tn[hw], ts[hw], gpu[hw]))
+    print('   gc during rep: %s' % [(g, round(ms, 2), n) for g, ms, n in gc_log if ms > 0.5][-8:])
+    del gc_log[:]
     print('   gpu[10:34] ' + ' '.join('%.2f' % v for v in gpu[10:34]), flush=True)
     print('   next[10:34] ' + ' '.join('%.2f' % v for v in tn[10:34]), flush=True)
     print('   step[10:34] ' + ' '.join('%.2f' % v for v in ts[10:34]), flush=True)
