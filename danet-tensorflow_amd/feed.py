@@ -46,15 +46,18 @@ def to_batch_host(data_pt, crop_len=None):
 
 class _Slot(object):
     '''one pinned staging buffer + one device buffer (both grow-only), the event of the last
-    upload through them, and the event behind the last step that read the device buffer'''
-    __slots__ = ('buf', 'dev', 'event', 'consumed')
+    upload through them, and the event behind the last step that read the device buffer.  The
+    two events are created once and re-recorded (no event object is created or destroyed per
+    step: every runtime allocation inside the loop is a chance for the one-off stall of DESIGN 5)'''
+    __slots__ = ('buf', 'dev', 'event', 'consumed', 'uploaded', 'read')
 
     def __init__(self):
         self.buf, self.dev, self.event, self.consumed = None, None, None, None
+        self.uploaded = self.read = False      # has `event` / `consumed` been recorded yet
 
     def stage(self, a, pin=True):
         n = int(np.prod(a.shape))
-        if self.event is not None:
+        if self.uploaded:
             self.event.synchronize()           # the previous H2D copy out of this slot is done
         if self.buf is None or self.buf.numel() < n:
             self.buf = torch.empty(max(n, 1), dtype=torch.complex64)
@@ -132,13 +135,14 @@ class BatchFeed(object):
             slot.dev = torch.empty(n, dtype=torch.complex64, device=self.device)
             torch.cuda.current_stream(self.device).synchronize()     # (growth only)
         d = slot.dev[:n].view(t.shape)
+        if slot.event is None:
+            slot.event, slot.consumed = torch.cuda.Event(), torch.cuda.Event()
         with torch.cuda.stream(self.copy_stream):
-            if slot.consumed is not None:       # the step that read this buffer last has finished
+            if slot.read:                       # the step that read this buffer last has finished
                 self.copy_stream.wait_event(slot.consumed)
             d.copy_(t, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.copy_stream)
-        slot.event = ev
+            slot.event.record(self.copy_stream)
+        slot.uploaded = True
         return d, slot
 
     def _hand_out(self, d, slot):
@@ -153,7 +157,8 @@ class BatchFeed(object):
         stream now -- mark the point after which that batch's device buffer may be rewritten'''
         slot, self._out = self._out, None
         if slot is not None and self.cuda:
-            slot.consumed = torch.cuda.current_stream(self.device).record_event()
+            slot.consumed.record(torch.cuda.current_stream(self.device))
+            slot.read = True
 
     def __iter__(self):
         if self.mode == 'sync':

@@ -269,7 +269,7 @@ TIMEOUT_MSG = ('persistent LSTM kernel: an inter-workgroup hand-off timed out --
 
 
 class _DeviceStatus(object):
-    __slots__ = ('dev', 'word', 'own', 'host_mapped', 'slots', 'queue', 'n', 'retired')
+    __slots__ = ('dev', 'word', 'own', 'host_mapped', 'slots', 'queue', 'n', 'retired', 'events')
 
     def __init__(self, dev):
         self.dev = dev
@@ -282,6 +282,7 @@ class _DeviceStatus(object):
         self.queue = _collections.deque()     # (event, slot or -1, may_raise)
         self.n = 0
         self.retired = 0
+        self.events = []                      # ring of re-recorded step events (created once)
 
 
 _status = {}
@@ -365,8 +366,19 @@ def poll_status(dev):
         _retire(st, block=True)
 
 
-def _record_event():
-    ev = torch.cuda.Event()
+def _record_event(st):
+    '''the event of the step just enqueued, from a ring of MAX_STEPS_IN_FLIGHT + 2 events that
+    are created once and re-recorded: an entry is reused only after the step it stood for has
+    been retired (the queue never holds more than MAX_STEPS_IN_FLIGHT entries)'''
+    ring = getattr(st, 'events', None)
+    if ring is None:                          # (tests build the record by hand)
+        ring = st.events = []
+    n = max(MAX_STEPS_IN_FLIGHT, 1) + 2
+    if len(ring) < n:
+        ring.append(torch.cuda.Event())
+        ev = ring[-1]
+    else:
+        ev = ring[st.n % n]
     ev.record()
     return ev
 
@@ -383,7 +395,7 @@ def step_done(dev, collective_consistent=True):
         slot = st.n % st.slots.shape[0]
         st.slots[slot].copy_(st.word, non_blocking=True)
     st.n += 1
-    st.queue.append((_record_event(), slot, collective_consistent))
+    st.queue.append((_record_event(st), slot, collective_consistent))
 
 
 def check_status(dev=None):

@@ -365,7 +365,7 @@ st = object.__new__(ops._DeviceStatus)
 st.dev, st.own = torch.device('cuda', 0), torch.zeros(4, dtype=torch.int32)
 st.word, st.host_mapped = grad_store[n:].view(torch.int32), False
 st.slots = torch.zeros(ops.MAX_STEPS_IN_FLIGHT + 2, 4, dtype=torch.int32)
-st.queue, st.n, st.retired = collections.deque(), 0, 0
+st.queue, st.n, st.retired, st.events = collections.deque(), 0, 0, []
 ops._status[0] = st
 torch.cuda.synchronize = lambda *a, **k: None
 rng = np.random.RandomState(100 + rank)       # how far "this rank's GPU" happens to be: differs per rank
@@ -375,7 +375,7 @@ class FakeEvent(object):
         return bool(rng.rand() < 0.5)
     def synchronize(self):
         pass
-ops._record_event = lambda: FakeEvent()
+ops._record_event = lambda st=None: FakeEvent()
 FAULT_STEP = 6
 raised_at, steps_enqueued = None, 0
 for step in range(20):
