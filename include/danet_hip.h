@@ -169,7 +169,7 @@ int danet_gemm_f32(danet_stream_t stream, int transA, int transB,
  * share of the (tile, k-iteration) space of their XCD band; cut tiles are finished
  * in-kernel in a fixed order (bit-reproducible, no second kernel).  Faster than
  * danet_gemm_f32 for a product that has the GPU to itself (critical-path dX / dYc),
- * slower when several products share the CUs.  `ws` (>= the _workspace_bytes value,
+ * slower when several products share the CUs.  `ws` (>= DANET_WS_GEMM_STREAMK bytes,
  * 16-B aligned) must be zero-initialised once and then only ever be used by this
  * function: it keeps the hand-off flags of earlier launches.  `ws` >=
  * DANET_WS_GEMM_STREAMK bytes.                                                 */
