@@ -1,9 +1,8 @@
 #!/usr/bin/env python
-'''GPU box: PROTOTYPE of fp32 products on the bf16 matrix cores (tools/csrc/gemm_x6.hip: operands
-split into three bf16 pieces in the kernel, six piece products, fp32 accumulation) next to the
-product's exact-fp32 kernels, on the step's NT shapes: error against the float64 product and time.
-Builds tools/csrc/libgemm_x6.so on demand (hipcc).       python tools/bench_gemm_x6.py'''
-import ctypes, os, subprocess, sys
+'''GPU box: PROTOTYPE of fp32 products on the bf16 matrix cores (tools/csrc/gemm_x6.hip, built on
+demand with hipcc) next to the product's exact-fp32 kernels on the step's NT shapes: error against the
+float64 product and time.  python tools/bench_gemm_x6.py'''
+import os, sys
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +11,9 @@ import __graft_entry__ as g
 g.load_package()
 from danet_amd import ops, _lib
 
+
+
+import ctypes, subprocess
 SRC = os.path.join(ROOT, 'tools', 'csrc', 'gemm_x6.hip')
 LIB = os.path.join(ROOT, 'tools', 'csrc', 'libgemm_x6.so')
 if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
@@ -20,13 +22,26 @@ if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
                            '-x', 'hip', SRC, '-o', LIB])
 X = ctypes.CDLL(LIB)
 c_p, c_i = ctypes.c_void_p, ctypes.c_int
-X.danet_gemm_x6_nt.argtypes = [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_i]
+X.danet_split3_bf16.argtypes = [c_p, ctypes.c_int64, c_p, c_p, c_p, c_p]
+X.danet_gemm_x6_nt.argtypes = [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_i,
+                               c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p, ctypes.c_size_t]
+_ws = torch.empty(64 << 20, dtype=torch.uint8, device='cuda')
 
 
-def x6(A1, B1, C, M, N, K1, A2=None, B2=None, K2=0):
-    rc = X.danet_gemm_x6_nt(_lib.stream(), M, N, K1, A1.data_ptr(), K1, B1.data_ptr(), K1, K2,
-                            A2.data_ptr() if A2 is not None else None, K2,
-                            B2.data_ptr() if B2 is not None else None, K2, C.data_ptr(), N)
+class _Split3(object):
+    @staticmethod
+    def split3(x):
+        out = torch.empty(3, x.numel(), dtype=torch.int16, device=x.device)
+        assert X.danet_split3_bf16(_lib.stream(), x.numel(), x.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                                   out[2].data_ptr()) == 0
+        return out[0], out[1], out[2]
+
+
+def x6(A1, B1p, C, M, N, K1, A2=None, B2p=None, K2=0):
+    b2 = B2p if B2p is not None else (None, None, None)
+    p = lambda t: t.data_ptr() if t is not None else None
+    rc = X.danet_gemm_x6_nt(_lib.stream(), M, N, K1, A1.data_ptr(), K1, p(B1p[0]), p(B1p[1]), p(B1p[2]), K1,
+                            K2, p(A2), K2, p(b2[0]), p(b2[1]), p(b2[2]), K2, C.data_ptr(), N, _ws.data_ptr(), _ws.numel())
     assert rc == 0, rc
 
 
@@ -58,7 +73,9 @@ for name, M, N, K1, K2 in SHAPES:
         A2, B2 = torch.randn(M, K2, device='cuda', generator=gen), torch.randn(N, K2, device='cuda', generator=gen)
         ref = ref + A2.double() @ B2.double().t()
     C6, C32 = torch.empty(M, N, device='cuda'), torch.empty(M, N, device='cuda')
-    x6(A1, B1, C6, M, N, K1, A2, B2, K2)
+    B1p = _Split3.split3(B1)
+    B2p = _Split3.split3(B2) if K2 else None
+    x6(A1, B1p, C6, M, N, K1, A2, B2p, K2)
     if K2:
         f32 = lambda: ops.gemm_kcat(A1, K1, B1, K1, K1, A2, K2, B2, K2, K2, C32, M, N, N, transB=True, streamk=K1 % 16 == 0)
     else:
@@ -67,7 +84,8 @@ for name, M, N, K1, K2 in SHAPES:
     e6 = float((C6.double() - ref).abs().max() / ref.abs().max())
     e32 = float((C32.double() - ref).abs().max() / ref.abs().max())
     fl = 2.0 * M * N * (K1 + K2)
-    t6 = timeit(lambda: x6(A1, B1, C6, M, N, K1, A2, B2, K2))
+    t6 = timeit(lambda: x6(A1, B1p, C6, M, N, K1, A2, B2p, K2))
+    tsplit = timeit(lambda: _Split3.split3(B1))
     t32 = timeit(f32)
-    print('%-12s M=%5d N=%5d K=%5d+%-5d  x6 %7.1f us %6.1f TFLOP/s err %.1e | fp32 %7.1f us %6.1f TFLOP/s err %.1e | %.2fx'
-          % (name, M, N, K1, K2, t6, fl / t6 / 1e6, e6, t32, fl / t32 / 1e6, e32, t32 / t6), flush=True)
+    print('%-12s M=%5d N=%5d K=%5d+%-5d  x6 %7.1f us %6.1f TFLOP/s err %.1e | fp32 %7.1f us %6.1f TFLOP/s err %.1e | %.2fx | split(B1) %.1f us'
+          % (name, M, N, K1, K2, t6, fl / t6 / 1e6, e6, t32, fl / t32 / 1e6, e32, t32 / t6, tsplit), flush=True)
