@@ -181,7 +181,8 @@ class BatchFeed(object):
                 self._consumed()
                 nxt = fetch()                     # ... then batch i+1 is staged and its upload issued
         finally:
-            self._ent['busy'] = False
+            self._consumed()                      # (a consumer that left the loop early: its last
+            self._ent['busy'] = False             # batch's buffer is protected all the same)
 
 
 class StepReport(object):
