@@ -13,6 +13,7 @@ trainables) on the same 32 mixtures.
 Tolerance: gradients 2e-4 relative to the tensor's max (fp32 path vs float64 authority), loss and
 SNR 1e-4 relative, permutation indices exact.
 '''
+import os
 import time
 
 import numpy as np
@@ -173,3 +174,100 @@ def test_train_loop_async_feed_equals_synchronous_loop_bit_for_bit(hp):
     for k in rep_s:
         assert rep_s[k] == rep_a[k], (k, rep_s[k], rep_a[k])       # bit for bit
     assert np.array_equal(p_s, p_a)
+
+
+# ------------------------------------------------ data parallel, 2 ranks, the HIP path (one GPU)
+_DP2_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+import __graft_entry__ as g; g.load_package()
+from danet_amd import dist, ops
+from danet_amd.hparams import hparams
+from danet_amd.model import Model
+torch.cuda.set_device(0)                      # both ranks share the one GPU of the box
+dev = torch.device('cuda', 0)
+ops.prepare_streams(dev)
+torch.distributed.init_process_group('gloo')  # (RCCL refuses two ranks on one device; the Model
+rank, world = dist.rank(), dist.world_size()  #  code under test is backend-agnostic)
+assert world == 2 and dist.is_dist()
+hparams.reset()
+hparams.load(%(hp)r)
+hparams.digest()
+model = Model('dp2', device=dev, seed=11).build()          # rank 0's parameters are broadcast
+model.keep_grads = True
+src = np.load(os.path.join(os.environ['DP_OUT'], 'src.npy'))
+B = hparams.BATCH_SIZE
+mine = torch.as_tensor(src[rank * B:(rank + 1) * B]).to(dev)
+p0 = model.param_dict()
+out = model.train_step(mine)
+torch.cuda.synchronize()
+model.check_status()
+# the bucket now holds the SUM over the ranks (1/world is folded into the optimiser kernel)
+np.savez(os.path.join(os.environ['DP_OUT'], 'rank%%d.npz' %% rank), loss=float(out['loss']),
+         collectives=model.collectives_per_step(), status_tail=model._grad_store[-4:].cpu().numpy(),
+         **{'g:' + k: v for k, v in model.grad_dict().items()},
+         **{'p0:' + k: v for k, v in p0.items()},
+         **{'p1:' + k: v for k, v in model.param_dict().items()})
+for _ in range(3):                            # a few more steps: replicas must stay identical
+    model.train_step(mine)
+torch.cuda.synchronize()
+flat = model._flat.detach().clone()
+other = [torch.empty_like(flat) for _ in range(2)]
+torch.distributed.all_gather(other, flat)
+assert torch.equal(other[0], other[1]), 'replicas drifted apart'
+torch.distributed.destroy_process_group()
+'''
+
+
+def test_data_parallel_two_ranks_on_the_hip_path(hp, tmp_path):
+    '''Model under torch.distributed with world_size 2 on the REAL kernels (both ranks on this
+    box's one GPU, gloo moving the device buffers: RCCL cannot put two ranks on one device):
+    shard by batch -> ONE all-reduce of the flat bucket -> 1/world inside the optimiser kernel.
+    The summed bucket / 2 equals the gradient of ONE process on the global batch (the loss is a
+    batch mean, app/ops.py:430), the step's parameters agree, the hand-off status words rode
+    the bucket, and the replicas stay bit-identical over further steps.'''
+    import subprocess
+    import sys
+    from danet_amd.model import Model
+    hpd = dict(BATCH_SIZE=4, MAX_N_SIGNAL=2, FFT_SIZE=64, FFT_STRIDE=16, EMBED_SIZE=8, NUM_LSTM_LAYERS=2,
+               LSTM_HDIM=32, NUM_ANCHOR=4, ENCODER_TYPE='bilstm-orig', TRAIN_ESTIMATOR_METHOD='anchor',
+               INFER_ESTIMATOR_METHOD='anchor', SEPARATOR_TYPE='dot-softmax-orig')
+    rng = np.random.RandomState(21)
+    src = ((rng.randn(8, 2, 24, 33) + 1j * rng.randn(8, 2, 24, 33)) * 4).astype(np.complex64)
+    np.save(tmp_path / 'src.npy', src)
+    script = tmp_path / 'dp2_worker.py'
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script.write_text(_DP2_WORKER % dict(root=ROOT, hp=hpd))
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', DP_OUT=str(tmp_path))
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                          '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+    r = [np.load(tmp_path / ('rank%d.npz' % i)) for i in range(2)]
+    # one process, the global batch of 8, same initial parameters
+    hp.load(dict(hpd, BATCH_SIZE=8))
+    hp.digest()
+    model = Model('dp2', device='cuda', seed=11).build()
+    model.keep_grads = True
+    p0 = model.param_dict()
+    out = model.train_step(torch.as_tensor(src).cuda())
+    torch.cuda.synchronize()
+    g, p1 = model.grad_dict(), model.param_dict()
+    assert int(r[0]['collectives']) == 1 and not r[0]['status_tail'].any() and not r[1]['status_tail'].any()
+    assert abs(0.5 * (float(r[0]['loss']) + float(r[1]['loss'])) - float(out['loss'])) < 1e-5 * abs(float(out['loss']))
+    for k in p0:
+        assert np.array_equal(r[0]['p0:' + k], p0[k]) and np.array_equal(r[1]['p0:' + k], p0[k]), k
+        assert np.array_equal(r[0]['g:' + k], r[1]['g:' + k]), k            # the same reduced bucket
+        a, b = 0.5 * r[0]['g:' + k], g[k]
+        assert np.abs(a - b).max() <= 2e-5 * (np.abs(b).max() + 1e-30), ('grad', k)
+        assert np.array_equal(r[0]['p1:' + k], r[1]['p1:' + k]), k
+        # Adam's first step is lr * sign-like: compare where the gradient is not at rounding level
+        big = np.abs(b) > 1e-3 * np.abs(b).max()
+        assert np.abs(r[0]['p1:' + k] - p1[k])[big].max() <= 1e-6 + 1e-4 * float(hp.LR), ('param', k)
