@@ -216,6 +216,28 @@ flat = model._flat.detach().clone()
 other = [torch.empty_like(flat) for _ in range(2)]
 torch.distributed.all_gather(other, flat)
 assert torch.equal(other[0], other[1]), 'replicas drifted apart'
+# a hand-off timeout on ONE rank (fault injection: workgroup 0 of its recurrent launches exits
+# without publishing): the status word rides in the gradient all-reduce, so BOTH ranks must raise
+# DanetHipError, at the admission of the SAME step
+from danet_amd import _lib
+model.check_status()
+start = model.step_count
+FAULT_AT = 2
+raised_at = None
+for i in range(12):
+    if rank == 1 and i == FAULT_AT:
+        _lib.set_option('lstm_fault_inject', 1)
+        _lib.set_option('lstm_spin_limit', 2048)
+    try:
+        model.train_step(mine)
+    except _lib.DanetHipError:
+        raised_at = model.step_count - start
+        break
+    if rank == 1 and i == FAULT_AT:
+        _lib.set_option('lstm_fault_inject', 0)
+        _lib.set_option('lstm_spin_limit', 0)
+open(os.path.join(os.environ['DP_OUT'], 'fault%%d.txt' %% rank), 'w').write(str(raised_at))
+torch.cuda.synchronize()
 torch.distributed.destroy_process_group()
 '''
 
@@ -251,6 +273,10 @@ def test_data_parallel_two_ranks_on_the_hip_path(hp, tmp_path):
                          capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
     r = [np.load(tmp_path / ('rank%d.npz' % i)) for i in range(2)]
+    # the injected timeout: both ranks raised, at the same step (fault step + MAX_STEPS_IN_FLIGHT)
+    from danet_amd import ops
+    raised = [(tmp_path / ('fault%d.txt' % i)).read_text() for i in range(2)]
+    assert raised[0] == raised[1] == str(2 + ops.MAX_STEPS_IN_FLIGHT), raised
     # one process, the global batch of 8, same initial parameters
     hp.load(dict(hpd, BATCH_SIZE=8))
     hp.digest()
