@@ -313,6 +313,12 @@ def _fill_parity(res, rep, mse, model):
         perm_idx_equal=rep['perm_idx_equal'], fused_heads=rep.get('fused_heads'))
 
 
+# functional test of the N > 1 path on a 1-GPU box (tests/test_gpu_round4.py): every rank uses
+# device 0 and the group is gloo (RCCL refuses two ranks on one device).  The line it prints is
+# marked and is NOT a measurement.
+SHARED_GPU_TEST = os.environ.get('DANET_BENCH_TEST_SHARED_GPU') == '1'
+
+
 def free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -328,6 +334,8 @@ def maybe_spawn(args):
     if args.gpus == 1 and os.environ.get('DANET_FORCE_DIST') != '1':
         return
     n_vis = torch.cuda.device_count()
+    if SHARED_GPU_TEST:
+        n_vis = args.gpus
     if n_vis < args.gpus:
         raise SystemExit('bench.py --gpus %d: only %d GPU(s) visible' % (args.gpus, n_vis))
     env = dict(os.environ)
@@ -371,7 +379,7 @@ def main():
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    local_rank = 0 if SHARED_GPU_TEST else int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, 'WORLD_SIZE=%d but --gpus %d' % (world, args.gpus)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
@@ -383,7 +391,10 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29511')
         # the side streams must exist before the RCCL communicator (ops.prepare_streams)
         ops.prepare_streams(device)
-        torch.distributed.init_process_group('nccl', device_id=device)
+        if SHARED_GPU_TEST:
+            torch.distributed.init_process_group('gloo')
+        else:
+            torch.distributed.init_process_group('nccl', device_id=device)
         assert torch.distributed.get_world_size() == args.gpus, \
             'RCCL group has %d ranks, --gpus %d' % (torch.distributed.get_world_size(), args.gpus)
     hp = setup_hparams(args, cfg)
@@ -404,6 +415,8 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except OSError:
             pass
+        if SHARED_GPU_TEST:
+            res['test_mode'] = 'ranks share ONE GPU over gloo: functional test of the N > 1 path, not a measurement'
         print(json.dumps(res), flush=True)
         if res.get('parity_ok') is False:
             # the line above is still the record; a parity failure fails the run

@@ -297,3 +297,29 @@ def test_data_parallel_two_ranks_on_the_hip_path(hp, tmp_path):
         # Adam's first step is lr * sign-like: compare where the gradient is not at rounding level
         big = np.abs(b) > 1e-3 * np.abs(b).max()
         assert np.abs(r[0]['p1:' + k] - p1[k])[big].max() <= 1e-6 + 1e-4 * float(hp.LR), ('param', k)
+
+
+def test_bench_two_ranks_functional(tmp_path):
+    '''`python bench.py --gpus 2` end to end on this 1-GPU box (DANET_BENCH_TEST_SHARED_GPU=1: both
+    ranks on device 0 over gloo -- a FUNCTIONAL run of the N > 1 path the driver takes on a
+    multi-GPU node, not a measurement): the launcher spawns two ranks, both time the same K steps,
+    rank 0 prints one JSON line with the whole-job value (2 x per-rank units / max-over-ranks time),
+    one collective per step, weak scaling, and the e2e loop runs on every rank'''
+    import json
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DANET_BENCH_TEST_SHARED_GPU='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'DANET_FORCE_DIST'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4',
+                          '--warmup', '1', '--no-cpu-baseline', '--batch', '8', '--frames', '32'],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res['n_gpus'] == 2 and res['rccl_ranks'] == 2 and res['scaling'] == 'weak'
+    assert res['config']['global_batch'] == 16 and res['config']['parallelism'] == 'dp2'
+    assert res['config']['collectives_per_step'] == 1 and res['allreduce_ms_standalone'] > 0
+    per_step = 8 * 32 * 64 / 8000.0
+    assert abs(res['value'] - 2 * per_step / (res['ms_per_step'] * 1e-3)) < 1e-2 * res['value']
+    assert res['e2e']['ms_per_step'] > 0 and 'test_mode' in res
