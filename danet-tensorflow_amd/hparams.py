@@ -84,11 +84,6 @@ class Hyperparameter:
     Contains hyperparameter settings (reference: app/hparams.py:15-127)
     '''
     pattern = r'[A-Z_]+'
-    encoder_registry = {}
-    estimator_registry = {}
-    separator_registry = {}
-    ozer_registry = {}
-    dataset_registry = {}
 
     def __init__(self):
         self.__dict__.update(DEFAULTS)
@@ -134,61 +129,50 @@ class Hyperparameter:
         self.__dict__.clear()
         self.__dict__.update(DEFAULTS)
 
-    # decorators & getters (reference: app/hparams.py:72-120)
-    @classmethod
-    def register_encoder(cls_, name):
-        def wrapper(cls):
-            cls_.encoder_registry[name] = cls
-            return cls
-        return wrapper
-
-    def get_encoder(self):
-        return type(self).encoder_registry[self.ENCODER_TYPE]
-
-    @classmethod
-    def register_estimator(cls_, name):
-        def wrapper(cls):
-            cls_.estimator_registry[name] = cls
-            return cls
-        return wrapper
-
-    def get_estimator(self, name):
-        return type(self).estimator_registry[name]
-
-    @classmethod
-    def register_separator(cls_, name):
-        def wrapper(cls):
-            cls_.separator_registry[name] = cls
-            return cls
-        return wrapper
-
-    def get_separator(self, name):
-        return type(self).separator_registry[name]
-
-    @classmethod
-    def register_optimizer(cls_, name):
-        def wrapper(fn):
-            cls_.ozer_registry[name] = fn
-            return fn
-        return wrapper
-
-    def get_optimizer(self):
-        return type(self).ozer_registry[self.OPTIMIZER_TYPE]
-
-    @classmethod
-    def register_dataset(cls_, name):
-        def wrapper(fn):
-            cls_.dataset_registry[name] = fn
-            return fn
-        return wrapper
-
-    def get_dataset(self):
-        return type(self).dataset_registry[self.DATASET_TYPE]
-
     def get_regularizer(self):
         # reference builds tf.contrib l1/l2 regularisers (app/hparams.py:122-127)
         # whose losses are never added to the training loss; a no-op here.
         return None
+
+
+# Plugin registries (reference: app/hparams.py:72-120).  One row per plugin
+# kind: (kind, registry attribute, hyperparameter that names the active
+# plugin or None when the getter takes the name).  The decorators and
+# getters the reference spells out one by one are generated from the table.
+_PLUGIN_KINDS = (
+    ('encoder', 'encoder_registry', 'ENCODER_TYPE'),
+    ('estimator', 'estimator_registry', None),
+    ('separator', 'separator_registry', None),
+    ('optimizer', 'ozer_registry', 'OPTIMIZER_TYPE'),
+    ('dataset', 'dataset_registry', 'DATASET_TYPE'),
+)
+
+
+def _install_plugin_kind(kind, attr, selector):
+    table = {}
+    setattr(Hyperparameter, attr, table)
+
+    def register(cls, name):
+        def keep(obj):
+            table[name] = obj
+            return obj
+        return keep
+    register.__name__ = 'register_' + kind
+    register.__doc__ = 'decorator: add a %s plugin under `name`' % kind
+    setattr(Hyperparameter, register.__name__, classmethod(register))
+
+    if selector is None:
+        def get(self, name):
+            return table[name]
+    else:
+        def get(self):
+            return table[getattr(self, selector)]
+    get.__name__ = 'get_' + kind
+    setattr(Hyperparameter, get.__name__, get)
+
+
+for _row in _PLUGIN_KINDS:
+    _install_plugin_kind(*_row)
 
 
 hparams = Hyperparameter()
