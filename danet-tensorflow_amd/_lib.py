@@ -18,6 +18,12 @@ LIB_PATH = os.environ.get('DANET_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libd
 c_int, c_i64, c_f32, c_sz, c_p = (ctypes.c_int, ctypes.c_int64, ctypes.c_float,
                                   ctypes.c_size_t, ctypes.c_void_p)
 
+class GemmPack(ctypes.Structure):
+    '''danet_gemm_pack_t (include/danet_hip.h)'''
+    _fields_ = [('src', c_p), ('stride_n', ctypes.c_longlong), ('stride_k', ctypes.c_longlong),
+                ('N', c_int), ('K', c_int), ('out', c_p), ('out_bytes', c_sz)]
+
+
 class GemmProblem(ctypes.Structure):
     '''danet_gemm_problem_t (include/danet_hip.h)'''
     _fields_ = [('A', c_p), ('lda', c_int), ('B', c_p), ('ldb', c_int), ('C', c_p), ('ldc', c_int),
@@ -49,6 +55,9 @@ PROTOTYPES = {
     'danet_gemm_f32_streamk_kcat': (c_int, [c_p, c_int, c_int, c_int, c_int,
                                             c_int, c_p, c_int, c_p, c_int, c_int, c_p, c_int, c_p, c_int,
                                             c_p, c_int, c_p, c_f32, c_p, c_sz]),
+    'danet_gemm_pack_weights': (c_int, [c_p, c_int, ctypes.POINTER(GemmPack)]),
+    'danet_gemm_x6': (c_int, [c_p, c_int, c_int, c_int, c_p, c_int, c_p, c_int, c_p, c_int, c_p,
+                              c_p, c_int, c_p, c_sz]),
     'danet_colsum_f32': (c_int, [c_p, c_int, c_int, c_p, c_int, c_p, c_f32, c_p, c_sz]),
     'danet_lstm_fwd': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_int,
                                c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_sz, c_p, c_int]),
@@ -130,7 +139,7 @@ def load():
             fn = getattr(lib, name)      # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.danet_abi_version() != 4:
+        if lib.danet_abi_version() != 5:
             raise DanetHipError('libdanet_hip.so ABI version mismatch')
         _lib = lib
         apply_env_options()
@@ -175,7 +184,8 @@ def check(rc):
 
 # DANET_WS_* (include/danet_hip.h)
 (WS_ISTFT, WS_GEMM, WS_GEMM_STREAMK, WS_COLSUM, WS_LSTM, WS_ATTRACTOR_TRUTH, WS_ATTRACTOR_ANCHOR,
- WS_SEPARATE_BWD, WS_SEPARATE_PIT, WS_SEPARATE_PIT_RECORDS, WS_PIT_MSE, WS_CENTER_MEAN) = range(12)
+ WS_SEPARATE_BWD, WS_SEPARATE_PIT, WS_SEPARATE_PIT_RECORDS, WS_PIT_MSE, WS_CENTER_MEAN,
+ WS_GEMM_X6, WS_GEMM_PACK) = range(14)
 
 
 def ws_bytes(op, *dims):

@@ -1008,6 +1008,11 @@ extern "C" int danet_gemm_next_launch_stop_event(void* event) {
   g_stop_event = (hipEvent_t)event;
   return DANET_OK;
 }
+hipEvent_t dn_take_stop_event() {            // (gemm_x6.hip)
+  hipEvent_t e = g_stop_event;
+  g_stop_event = nullptr;
+  return e;
+}
 extern "C" int danet_event_create(void** event) {
   DANET_CHECK_ARG(event != nullptr, "event_create: null pointer");
   hipEvent_t e = nullptr;
@@ -1039,8 +1044,7 @@ static int sk_launch(danet_stream_t stream_, int transA, int transB, int K, int 
   // packet instead of a separate hipEventRecord behind it (tools/csrc/event_gap.hip: the record costs
   // the stream 4.4 us before its next kernel, the attached event 1.1 us).  Consumed HERE, before
   // any check can return: a rejected call must not leave it armed for an unrelated later launch.
-  hipEvent_t stop = g_stop_event;
-  g_stop_event = nullptr;
+  hipEvent_t stop = dn_take_stop_event();
   hipStream_t stream = (hipStream_t)stream_;
   DANET_CHECK_ARG(probs && nprob >= 1 && nprob <= SK_MAX_PROBLEMS, "gemm group: 1..%d problems",
                   SK_MAX_PROBLEMS);

@@ -1,0 +1,444 @@
+// fp32 products on the BF16 matrix cores (gfx950): C = A B^T (+ A2 B2^T) with fp32 operands and an
+// fp32-accurate result, for the step's products whose B operand is a WEIGHT (the output projection,
+// dYc, dX: DESIGN.md 3.2).
+//
+// Every fp32 value is EXACTLY hi + mid + lo with three bf16 pieces of 8 significant bits (hi = x
+// rounded to 8 bits, mid = the remainder rounded to 8 bits, lo = what is left), and the six largest
+// of the nine piece products are accumulated in fp32:
+//     A B^T ~ Ahi Bhi + (Ahi Bmid + Amid Bhi) + (Ahi Blo + Alo Bhi + Amid Bmid)
+// The dropped products are < 2^-25 |a||b| each: the result is as close to the float64 product as an
+// fp32 FMA chain's (tools/bf16x_split_accuracy.py; tests/test_gpu_gemm_x6.py).
+// v_mfma_f32_32x32x16_bf16 runs at 16x the rate of v_mfma_f32_32x32x2_f32; six of them per 16 k
+// replace eight fp32 instructions -> 2.7x the matrix-core throughput of gemm_f32.hip.
+//
+// Where the operands travel:
+//   A [M][lda] fp32, K-contiguous (an activation): global -> registers -> split -> LDS piece images;
+//   B (a weight): packed once per optimizer step by danet_gemm_pack_weights into the matrix
+//     instruction's own operand layout -- [piece][32-column tile][k16 step][lane] x 16 bytes -- and
+//     loaded by each wave straight from global memory / L2 into its fragment registers, one k-step
+//     ahead.  B never touches LDS: the LDS pipe carries A only (0.25 fragment reads per matrix
+//     instruction).
+// Tile per workgroup 128 x 128 x 16, 4 waves as 2 x 2 with 2 x 2 MFMA tiles of 32 x 32 each, two
+// workgroups per CU, three LDS stages; products with too few tiles for the GPU are cut along K into
+// `splitk` slices whose partial tiles a second kernel sums in slice order (deterministic).
+#include "common.h"
+#include <hip/hip_ext.h>
+#include "danet_hip.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define XBM 128
+#define XBN 128
+#define XBK 16
+#define XIMG (XBM * XBK * 2)            // bytes of one piece image: 128 rows x 16 k x bf16 = 4 KB
+#define XSTAGE (3 * XIMG)               // A hi/mid/lo: 12 KB
+#define X6_SMEM_BYTES (3 * XSTAGE)           // 3 stages = 36 KB (>= the epilogue's 33.8 KB)
+
+struct X6Args {
+  const float* A[2];
+  const u32x4* Bp[2];                   // [pair] -> packed [3][NT32][KT][64] x 16 bytes
+  int lda[2], K[2], KT[2];
+  int NT32;
+  float* C;                             // splitk == 1: the result; else slab [splitk][M][N]
+  int M, N, ldc, npair, splitk;
+};
+
+// x = hi + mid + lo exactly; hi and mid are x and the remainder ROUNDED to 8 significant bits (add
+// half an ulp, truncate: |mid| <= 2^-9 |x|, |lo| <= 2^-17 |x|); lo has <= 8 significant bits
+// left, its truncation is exact
+__device__ __forceinline__ void split3(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = (__float_as_uint(x) + 0x8000u) & 0xFFFF0000u;
+  const float r = x - __uint_as_float(h);
+  m = (__float_as_uint(r) + 0x8000u) & 0xFFFF0000u;
+  l = __float_as_uint(r - __uint_as_float(m));
+}
+// the high halves of two words as one word: [hi16(b) | hi16(a)]
+__device__ __forceinline__ uint32_t pack_hi(uint32_t a, uint32_t b) {
+  return __builtin_amdgcn_perm(b, a, 0x07060302u);
+}
+
+// byte offset of (row, 4-k group q in 0..3) inside a piece image: 32-byte rows, the two 16-byte
+// chunks swapped when (row >> 2) is odd -> 8 consecutive rows of one chunk cover all banks
+__device__ __forceinline__ int img_off(int row, int q) {
+  const int c = (q >> 1) ^ ((row >> 2) & 1);
+  return row * 32 + c * 16 + (q & 1) * 8;
+}
+
+__device__ __forceinline__ bf16x8 frag(const char* img, int row, int kb) {
+  const int c = kb ^ ((row >> 2) & 1);
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + row * 32 + c * 16));
+}
+
+#define X6_OOB 0xfffffff0u               // voffset beyond num_records: the buffer load returns 0
+typedef unsigned v4u __attribute__((__vector_size__(16)));
+
+// One k-step of the pipeline, branch-free (a conditionally executed load would make the compiler
+// wait vmcnt(0) where the paths join): matrix instructions on the fragments of tile kt (registers),
+// under them the B fragments and the A LDS fragments of tile kt + 1, the split + LDS store of tile
+// kt + 2 (registers loaded two steps ago) and the global load of tile kt + 4 into the same registers.
+struct X6Ctx {
+  __amdgpu_buffer_rsrc_t rsa[2];
+  const u32x4* bp[2];
+  int lda[2], K[2], KT[2];
+  int nk0, kt1, NT32, ntb, mrem;
+  int srow, sq, lane, fi, kb, wm;
+};
+
+__device__ __forceinline__ void x6_load_a(const X6Ctx& c, int kt, f32x4 (&R)[2]) {
+  const int p = kt >= c.nk0 ? 1 : 0;                          // uniform
+  const int k = (kt - (p ? c.nk0 : 0)) * XBK + c.sq * 4;
+  const int K = p ? c.K[1] : c.K[0], lda = p ? c.lda[1] : c.lda[0];
+  const __amdgpu_buffer_rsrc_t rs = p ? c.rsa[1] : c.rsa[0];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = c.srow + 64 * i;
+    const bool ok = r < c.mrem && k < K && kt < c.kt1;
+    const unsigned off = (unsigned)(r * lda + k) * 4u;
+    R[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : X6_OOB, 0, 0));
+  }
+}
+__device__ __forceinline__ void x6_store_a(char* base, const X6Ctx& c, const f32x4 (&R)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int off = img_off(c.srow + 64 * i, c.sq);
+    uint32_t h[4], m[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split3(R[i][j], h[j], m[j], l[j]);
+    *reinterpret_cast<u32x2*>(base + off) = (u32x2){pack_hi(h[0], h[1]), pack_hi(h[2], h[3])};
+    *reinterpret_cast<u32x2*>(base + XIMG + off) = (u32x2){pack_hi(m[0], m[1]), pack_hi(m[2], m[3])};
+    *reinterpret_cast<u32x2*>(base + 2 * XIMG + off) = (u32x2){pack_hi(l[0], l[1]), pack_hi(l[2], l[3])};
+  }
+}
+__device__ __forceinline__ void x6_load_b(const X6Ctx& c, int kt, u32x4 (&fb)[3][2]) {
+  kt = min(kt, c.kt1 - 1);
+  const int p = kt >= c.nk0 ? 1 : 0;
+  const int ktl = kt - (p ? c.nk0 : 0);
+  const int KT = p ? c.KT[1] : c.KT[0];
+  const u32x4* __restrict__ bp = p ? c.bp[1] : c.bp[0];
+#pragma unroll
+  for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      fb[pc][j] = bp[((size_t)(pc * c.NT32 + c.ntb + j) * KT + ktl) * 64 + c.lane];
+}
+__device__ __forceinline__ void x6_frags_a(const char* sb, const X6Ctx& c, bf16x8 (&fa)[3][2]) {
+#pragma unroll
+  for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[pc][i] = frag(sb + pc * XIMG, c.wm * 64 + i * 32 + c.fi, c.kb);
+}
+
+// the six piece products, small terms first: (A piece, B piece)
+__device__ constexpr int X6_PA[6] = {2, 0, 1, 1, 0, 0};
+__device__ constexpr int X6_PB[6] = {0, 2, 1, 0, 1, 0};
+#define X6_FENCE __builtin_amdgcn_sched_barrier(0);
+
+// One k-step in 24 slots of one matrix instruction each (the four accumulators in turn, an
+// accumulator is reused every 4th instruction); each slot carries a slice of the step's other work
+// behind it and is fenced off from its neighbours, so that the vector-ALU, LDS and memory
+// instructions issue in the shadow of the 32-cycle matrix instructions instead of in front of them:
+//   slots  0-5   B fragment loads of tile kt + 1 (global / L2 -> registers, 16 bytes per lane)
+//   slots  6-11  A fragment reads of tile kt + 1 (LDS -> registers)
+//   slots 12-19  split of the 8 fp32 values of tile kt + 2 this thread staged two steps ago
+//   slots 20-21  pack + LDS store of the two rows' pieces
+//   slots 22-23  global loads of tile kt + 4 into the staging registers
+template <int S>
+__device__ __forceinline__ void x6_mf(f32x16 (&acc)[2][2], const bf16x8 (&fa)[3][2], const u32x4 (&fb)[3][2]) {
+  constexpr int t = S >> 2, i = (S >> 1) & 1, j = S & 1;
+  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[X6_PA[t]][i], __builtin_bit_cast(bf16x8, fb[X6_PB[t]][j]),
+                                                      acc[i][j], 0, 0, 0);
+}
+
+__device__ __forceinline__ void x6_step(const X6Ctx& c, char* xsm, int kt, int srd, int swr, f32x16 (&acc)[2][2],
+                                        f32x4 (&R)[2], const bf16x8 (&fac)[3][2], bf16x8 (&fan)[3][2],
+                                        const u32x4 (&fbc)[3][2], u32x4 (&fbn)[3][2]) {
+  // uniform addressing of the next tile's B fragments
+  const int ktn = min(kt + 1, c.kt1 - 1);
+  const int pn = ktn >= c.nk0 ? 1 : 0;
+  const int ktl = ktn - (pn ? c.nk0 : 0);
+  const int KTn = pn ? c.KT[1] : c.KT[0];
+  const u32x4* __restrict__ bp = (pn ? c.bp[1] : c.bp[0]) + c.lane;
+  const char* srdp = xsm + srd * XSTAGE;
+  char* swrp = xsm + swr * XSTAGE;
+  uint32_t h[2][4], m[2][4], l[2][4];
+#define X6_B(S) x6_mf<S>(acc, fac, fbc); fbn[(S) >> 1][(S) & 1] = bp[((size_t)(((S) >> 1) * c.NT32 + c.ntb + ((S) & 1)) * KTn + ktl) * 64]; X6_FENCE
+  X6_B(0) X6_B(1) X6_B(2) X6_B(3) X6_B(4) X6_B(5)
+#undef X6_B
+#define X6_A(S) x6_mf<S>(acc, fac, fbc); fan[((S) - 6) >> 1][((S) - 6) & 1] = frag(srdp + (((S) - 6) >> 1) * XIMG, c.wm * 64 + (((S) - 6) & 1) * 32 + c.fi, c.kb); X6_FENCE
+  X6_A(6) X6_A(7) X6_A(8) X6_A(9) X6_A(10) X6_A(11)
+#undef X6_A
+#define X6_S(S) x6_mf<S>(acc, fac, fbc); split3(R[((S) - 12) >> 2][((S) - 12) & 3], h[((S) - 12) >> 2][((S) - 12) & 3], m[((S) - 12) >> 2][((S) - 12) & 3], l[((S) - 12) >> 2][((S) - 12) & 3]); X6_FENCE
+  X6_S(12) X6_S(13) X6_S(14) X6_S(15) X6_S(16) X6_S(17) X6_S(18) X6_S(19)
+#undef X6_S
+#define X6_W(S, I) x6_mf<S>(acc, fac, fbc); {                                                              \
+    const int off = img_off(c.srow + 64 * (I), c.sq);                                                      \
+    *reinterpret_cast<u32x2*>(swrp + off) = (u32x2){pack_hi(h[I][0], h[I][1]), pack_hi(h[I][2], h[I][3])};            \
+    *reinterpret_cast<u32x2*>(swrp + XIMG + off) = (u32x2){pack_hi(m[I][0], m[I][1]), pack_hi(m[I][2], m[I][3])};     \
+    *reinterpret_cast<u32x2*>(swrp + 2 * XIMG + off) = (u32x2){pack_hi(l[I][0], l[I][1]), pack_hi(l[I][2], l[I][3])}; } X6_FENCE
+  X6_W(20, 0) X6_W(21, 1)
+#undef X6_W
+  {
+    const int kta = kt + 4;
+    const int p = kta >= c.nk0 ? 1 : 0;
+    const int k = (kta - (p ? c.nk0 : 0)) * XBK + c.sq * 4;
+    const int K = p ? c.K[1] : c.K[0], lda = p ? c.lda[1] : c.lda[0];
+    const __amdgpu_buffer_rsrc_t rs = p ? c.rsa[1] : c.rsa[0];
+#define X6_L(S, I) x6_mf<S>(acc, fac, fbc); {                                                              \
+      const int r = c.srow + 64 * (I);                                                                     \
+      const bool ok = r < c.mrem && k < K && kta < c.kt1;                                                  \
+      R[I] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)(r * lda + k) * 4u : X6_OOB, 0, 0)); } X6_FENCE
+    X6_L(22, 0) X6_L(23, 1)
+#undef X6_L
+  }
+}
+#define X6_STEP(R, FAC, FAN, FBC, FBN)                                                               \
+  { x6_step(c, xsm, kt, srd, swr, acc, R, FAC, FAN, FBC, FBN);                                       \
+    __syncthreads();                                                                                 \
+    ++kt; srd = swr; swr = swr == 2 ? 0 : swr + 1; }
+
+__global__ __launch_bounds__(256, 2) void gemm_x6_nt_kernel(X6Args g) {
+  extern __shared__ __attribute__((aligned(16))) char xsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (g.N + XBN - 1) / XBN;
+  const int nt = ((g.M + XBM - 1) / XBM) * tiles_n;
+  const int z = blockIdx.x / nt;                       // K slice
+  int bid = blockIdx.x % nt;
+  if ((nt & 7) == 0) bid = (bid & 7) * (nt >> 3) + (bid >> 3);     // an XCD walks a band of tiles
+  const int m0 = (bid / tiles_n) * XBM, n0 = (bid % tiles_n) * XBN;
+
+  const int nk0 = (g.K[0] + XBK - 1) / XBK;
+  const int nkt = nk0 + (g.npair > 1 ? (g.K[1] + XBK - 1) / XBK : 0);
+  const int per = (nkt + g.splitk - 1) / g.splitk;
+  const int kt0 = z * per, kt1 = min(nkt, kt0 + per);
+
+  X6Ctx c;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int pp = p < g.npair ? p : 0;
+    const float* base = g.A[pp] + (size_t)m0 * g.lda[pp];
+    const float* end = g.A[pp] + (size_t)(g.M - 1) * g.lda[pp] + g.K[pp];
+    c.rsa[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)((end - base) * 4), 0x00020000);
+    c.bp[p] = g.Bp[pp]; c.lda[p] = g.lda[pp]; c.K[p] = g.K[pp]; c.KT[p] = g.KT[pp];
+  }
+  c.nk0 = nk0; c.kt1 = kt1; c.NT32 = g.NT32; c.ntb = n0 / 32 + wn * 2; c.mrem = g.M - m0;
+  c.srow = tid >> 2; c.sq = tid & 3; c.lane = lane; c.fi = lane & 31; c.kb = lane >> 5; c.wm = wm;
+  const int fi = c.fi, kb = c.kb;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (kt0 < kt1) {
+    // tile t lives in LDS stage (t - kt0) % 3.  Prologue: tiles kt0 and kt0 + 1 in LDS, kt0 + 2 and
+    // kt0 + 3 in registers, the fragments of tile kt0 loaded.
+    f32x4 R0[2], R1[2];
+    u32x4 fbA[3][2], fbB[3][2];
+    bf16x8 faA[3][2], faB[3][2];
+    x6_load_a(c, kt0, R0); x6_load_a(c, kt0 + 1, R1);
+    x6_load_b(c, kt0, fbA);
+    x6_store_a(xsm, c, R0); x6_store_a(xsm + XSTAGE, c, R1);
+    x6_load_a(c, kt0 + 2, R0); x6_load_a(c, kt0 + 3, R1);
+    __syncthreads();
+    x6_frags_a(xsm, c, faA);
+    int kt = kt0, srd = 1, swr = 2;
+    while (kt + 1 < kt1) {
+      X6_STEP(R0, faA, faB, fbA, fbB)
+      X6_STEP(R1, faB, faA, fbB, fbA)
+    }
+    if (kt < kt1) X6_STEP(R0, faA, faB, fbA, fbB)
+  }
+
+  // C/D layout 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  The tile leaves
+  // through the (now free) LDS in two halves of 64 rows as 16-byte stores of full 512-byte row
+  // segments when the destination allows it; 4-byte stores otherwise.
+  float* __restrict__ dst = g.C + (g.splitk > 1 ? (size_t)z * g.M * g.ldc : 0);
+  const bool vec = (g.ldc % 4 == 0) && (((uintptr_t)g.C & 15) == 0) && (n0 + XBN <= g.N);   // uniform
+  if (vec) {
+    float* ct = reinterpret_cast<float*>(xsm);          // [64][XBN + 4]
+    constexpr int LDC_T = XBN + 4;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();
+      if (wm == half) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb) * LDC_T + wn * 64 + j * 32 + fi] = acc[i][j][r];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int rr = (tid >> 5) + 8 * it, c4 = tid & 31;
+        const int row = m0 + half * 64 + rr;
+        if (row < g.M)
+          *reinterpret_cast<f32x4*>(dst + (size_t)row * g.ldc + n0 + c4 * 4) =
+              *reinterpret_cast<const f32x4*>(&ct[rr * LDC_T + c4 * 4]);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + fi;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+        if (row < g.M && col < g.N) dst[(size_t)row * g.ldc + col] = acc[i][j][r];
+      }
+    }
+}
+
+// C[m][n] = sum over the K slices, in slice order (slab rows are dense: ld = N)
+__global__ __launch_bounds__(256) void gemm_x6_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C,
+                                                             int M, int N, int ldc, int splitk) {
+  const int64_t n4 = (int64_t)M * N / 4;
+  const int64_t plane = (int64_t)M * N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 v = reinterpret_cast<const f32x4*>(slab)[i];
+    for (int s = 1; s < splitk; ++s) v += reinterpret_cast<const f32x4*>(slab + s * plane)[i];
+    const int64_t e = i * 4;
+    const int row = (int)(e / N), col = (int)(e % N);
+    *reinterpret_cast<f32x4*>(C + (size_t)row * ldc + col) = v;
+  }
+}
+
+// ------------------------------------------------------------------ weights in operand layout
+// out [3][NT32][KT][64] x 16 bytes: lane l of block (piece, nt, kt) holds the piece's bf16 values of
+// B(n = 32 nt + l % 32, k = 16 kt + 8 (l / 32) + 0..7); B(n, k) = src[n * sn + k * sk]; zero padded.
+// One launch packs every weight of the table: blockIdx.y = weight.
+#define X6_MAX_PACK 16
+struct X6PackJob { const float* src; u32x4* out; int64_t sn, sk; int N, K, NT32, KT; };
+struct X6PackArgs { X6PackJob job[X6_MAX_PACK]; };
+
+__global__ __launch_bounds__(256) void gemm_x6_pack_kernel(X6PackArgs a) {
+  const X6PackJob& q = a.job[blockIdx.y];
+  const int N = q.N, K = q.K, NT32 = q.NT32, KT = q.KT;
+  const float* __restrict__ src = q.src;
+  u32x4* __restrict__ out = q.out;
+  const int64_t sn = q.sn, sk = q.sk;
+  const int64_t total = (int64_t)NT32 * KT * 64;
+  const size_t plane = (size_t)total;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int l = (int)(idx & 63);
+    const int kt = (int)((idx >> 6) % KT), nt = (int)((idx >> 6) / KT);
+    const int n = nt * 32 + (l & 31), k0 = kt * 16 + 8 * (l >> 5);
+    uint32_t h[8], m[8], lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = (n < N && k0 + j < K) ? src[n * sn + (k0 + j) * sk] : 0.f;
+      split3(x, h[j], m[j], lo[j]);
+    }
+    out[idx] = (u32x4){pack_hi(h[0], h[1]), pack_hi(h[2], h[3]), pack_hi(h[4], h[5]), pack_hi(h[6], h[7])};
+    out[plane + idx] = (u32x4){pack_hi(m[0], m[1]), pack_hi(m[2], m[3]), pack_hi(m[4], m[5]), pack_hi(m[6], m[7])};
+    out[2 * plane + idx] = (u32x4){pack_hi(lo[0], lo[1]), pack_hi(lo[2], lo[3]), pack_hi(lo[4], lo[5]), pack_hi(lo[6], lo[7])};
+  }
+}
+
+static int x6_nt32(int N) { return cdiv(N, XBN) * (XBN / 32); }
+size_t dn_ws_gemm_pack(int N, int K) { return (size_t)3 * x6_nt32(N) * cdiv(K, XBK) * 1024; }
+
+extern "C" int danet_gemm_pack_weights(danet_stream_t stream, int n, const danet_gemm_pack_t* jobs) {
+  DANET_CHECK_ARG(jobs && n >= 1, "gemm_pack_weights: empty table");
+  for (int base = 0; base < n; base += X6_MAX_PACK) {
+    const int cnt = min(X6_MAX_PACK, n - base);
+    X6PackArgs a;
+    int64_t most = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const danet_gemm_pack_t& j = jobs[base + i];
+      DANET_CHECK_ARG(j.N > 0 && j.K > 0 && j.src && j.out && (((uintptr_t)j.out) & 15) == 0 &&
+                      j.out_bytes >= dn_ws_gemm_pack(j.N, j.K), "gemm_pack_weights: bad job %d", base + i);
+      X6PackJob& q = a.job[i];
+      q.src = j.src; q.out = (u32x4*)j.out; q.sn = j.stride_n; q.sk = j.stride_k;
+      q.N = j.N; q.K = j.K; q.NT32 = x6_nt32(j.N); q.KT = cdiv(j.K, XBK);
+      most = max(most, (int64_t)q.NT32 * q.KT * 64);
+    }
+    for (int i = cnt; i < X6_MAX_PACK; ++i) a.job[i] = a.job[0];
+    dim3 grid((unsigned)min((int64_t)1024, cdiv64(most, 256)), (unsigned)cnt);
+    gemm_x6_pack_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    DANET_CHECK_LAUNCH();
+  }
+  return DANET_OK;
+}
+
+static int x6_splitk(int M, int N, int nkt) {
+  // cut along K while the tiles alone leave more than a third of the workgroup slots (2 per CU)
+  // empty and every slice keeps >= 24 k-tiles; <= 4 slices
+  const int nt = cdiv(M, XBM) * cdiv(N, XBN);
+  int s = 1;
+  while (s < 4 && nt * s * 3 < 512 * 2 && nkt / (s + 1) >= 24) ++s;
+  return s;
+}
+
+size_t dn_ws_gemm_x6(int M, int N, int K1, int K2) {
+  const int s = x6_splitk(M, N, cdiv(K1, XBK) + cdiv(K2, XBK));
+  return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
+hipEvent_t dn_take_stop_event();   // gemm_f32.hip: the event armed by danet_gemm_next_launch_stop_event
+
+extern "C" int danet_gemm_x6(danet_stream_t stream_, int M, int N,
+                             int K1, const float* A1, int lda1, const void* B1pk,
+                             int K2, const float* A2, int lda2, const void* B2pk,
+                             float* C, int ldc, void* ws, size_t ws_bytes) {
+  // (consumed before any check can return: see sk_launch)
+  hipEvent_t stop = dn_take_stop_event();
+  hipStream_t stream = (hipStream_t)stream_;
+  DANET_CHECK_ARG(M > 0 && N > 0 && K1 > 0 && K2 >= 0 && ldc >= N, "gemm_x6: bad shape");
+  DANET_CHECK_ARG(A1 && B1pk && C && (K2 == 0 || (A2 && B2pk)), "gemm_x6: null operand");
+  if (K1 % 4 || lda1 % 4 || lda1 < K1 || (K2 > 0 && (K2 % 4 || lda2 % 4 || lda2 < K2)) ||
+      ((((uintptr_t)A1 | (uintptr_t)A2) & 15) != 0)) {
+    danet_set_error("gemm_x6: K and lda must be multiples of 4 and A 16-byte aligned (K1=%d K2=%d)", K1, K2);
+    return DANET_ERR_UNSUPPORTED;
+  }
+  DANET_CHECK_ARG(((((uintptr_t)B1pk | (uintptr_t)B2pk) & 15) == 0), "gemm_x6: packed weight alignment");
+  DANET_CHECK_ARG((int64_t)M * lda1 < (1ll << 29) && (K2 == 0 || (int64_t)M * lda2 < (1ll << 29)),
+                  "gemm_x6: an operand spans 2 GiB or more");
+  static const bool once = [] {
+    return hipFuncSetAttribute((const void*)gemm_x6_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               X6_SMEM_BYTES) == hipSuccess; }();
+  (void)once;
+  X6Args g;
+  g.A[0] = A1; g.Bp[0] = (const u32x4*)B1pk; g.lda[0] = lda1; g.K[0] = K1; g.KT[0] = cdiv(K1, XBK);
+  g.A[1] = A2; g.Bp[1] = (const u32x4*)B2pk; g.lda[1] = lda2; g.K[1] = K2; g.KT[1] = cdiv(K2, XBK);
+  g.npair = K2 > 0 ? 2 : 1;
+  g.M = M; g.N = N; g.NT32 = x6_nt32(N);
+  const int nkt = cdiv(K1, XBK) + cdiv(K2, XBK);
+  int s = x6_splitk(M, N, nkt);
+  if (s > 1 && (N % 4 != 0 || ldc % 4 != 0 || ((uintptr_t)C & 15) != 0)) s = 1;   // (the reduce kernel is vectorised)
+  if (s > 1) {
+    const size_t need = (size_t)s * M * N * sizeof(float);
+    if (!ws || ws_bytes < need || ((uintptr_t)ws & 15) != 0) {
+      danet_set_error("gemm_x6: workspace %zu < %zu (or not 16-B aligned)", ws_bytes, need);
+      return DANET_ERR_WORKSPACE;
+    }
+    g.C = (float*)ws; g.ldc = N;
+  } else {
+    g.C = C; g.ldc = ldc;
+  }
+  g.splitk = s;
+  const int nt = cdiv(M, XBM) * cdiv(N, XBN);
+  dim3 grid((unsigned)(nt * s)), block(256);
+  if (s == 1 && stop) hipExtLaunchKernelGGL(gemm_x6_nt_kernel, grid, block, X6_SMEM_BYTES, stream, nullptr, stop, 0, g);
+  else gemm_x6_nt_kernel<<<grid, block, X6_SMEM_BYTES, stream>>>(g);
+  DANET_CHECK_LAUNCH();
+  if (s > 1) {
+    dim3 rgrid((unsigned)min((int64_t)2048, cdiv64((int64_t)M * N / 4, 256)));
+    if (stop) hipExtLaunchKernelGGL(gemm_x6_reduce_kernel, rgrid, block, 0, stream, nullptr, stop, 0,
+                                    (const float*)ws, C, M, N, ldc, s);
+    else gemm_x6_reduce_kernel<<<rgrid, block, 0, stream>>>((const float*)ws, C, M, N, ldc, s);
+    DANET_CHECK_LAUNCH();
+  }
+  return DANET_OK;
+}

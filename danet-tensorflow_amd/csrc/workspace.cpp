@@ -19,9 +19,11 @@ size_t dn_ws_separate_pit(int B, int C, int64_t N, int E);
 size_t dn_ws_separate_pit_records(int B, int64_t N);
 size_t dn_ws_pit_mse(int B, int C, int64_t N);
 int dn_center_mean_elems(int B);
+size_t dn_ws_gemm_x6(int M, int N, int K1, int K2);
+size_t dn_ws_gemm_pack(int N, int K);
 
 extern "C" size_t danet_workspace_bytes(int op, const int64_t* d, int n) {
-  static const int kDims[DANET_WS_COUNT] = {4, 3, 3, 2, 4, 4, 5, 4, 4, 2, 3, 1};
+  static const int kDims[DANET_WS_COUNT] = {4, 3, 3, 2, 4, 4, 5, 4, 4, 2, 3, 1, 4, 2};
   if (op < 0 || op >= DANET_WS_COUNT || !d || n != kDims[op]) {
     danet_set_error("workspace_bytes: op %d takes %d dims, got %d", op,
                     (op >= 0 && op < DANET_WS_COUNT) ? kDims[op] : -1, n);
@@ -47,6 +49,8 @@ extern "C" size_t danet_workspace_bytes(int op, const int64_t* d, int n) {
     case DANET_WS_SEPARATE_PIT_RECORDS: return dn_ws_separate_pit_records((int)d[0], d[1]);
     case DANET_WS_PIT_MSE: return dn_ws_pit_mse((int)d[0], (int)d[1], d[2]);
     case DANET_WS_CENTER_MEAN: return (size_t)dn_center_mean_elems((int)d[0]) * sizeof(float);
+    case DANET_WS_GEMM_X6: return dn_ws_gemm_x6((int)d[0], (int)d[1], (int)d[2], (int)d[3]);
+    case DANET_WS_GEMM_PACK: return dn_ws_gemm_pack((int)d[0], (int)d[1]);
   }
   return (size_t)-1;
 }

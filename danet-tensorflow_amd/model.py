@@ -116,6 +116,7 @@ class Model(object):
         self.ozer.bind(self._flat, self._flat_grad)
         self.built = True
         dist.broadcast_params_(self._flat)
+        ops.weights_written(self._flat)
         return self
 
     def _flatten(self):
@@ -135,6 +136,7 @@ class Model(object):
             self.vars[k] = nv
             off += m
         self._flat, self._flat_grad = flat, grad
+        ops.drop_packs(self.device)       # (the dry run packed weights at their old addresses)
         self._one = torch.ones((), device=self.device)
         # a backward pass outside train_step (tests, user code) leaves gradients behind:
         # autograd's accumulation marks the bucket dirty so the next train_step clears it
@@ -209,6 +211,7 @@ class Model(object):
         self.ozer.step(self.step_count + 1, self.learn_rate, clip=hparams.GRAD_CLIP_THRES,
                        grad_scale=1.0 / dist.world_size(), zero_grad=not self.keep_grads,
                        ranges=ranges)
+        ops.repack_weights(self.device)
         self._early = (ranges, torch.cuda.current_stream(self.device))
         self.early_steps += 1
 
@@ -320,6 +323,7 @@ class Model(object):
             self._early = None
         self.ozer.step(self.step_count, self.learn_rate, clip=hparams.GRAD_CLIP_THRES,
                        grad_scale=grad_scale, zero_grad=not self.keep_grads, ranges=ranges)
+        ops.repack_weights(self.device)    # operand-layout copies of the weights the GEMMs read
         if early_stream is not None:
             # joined AFTER the last piece (disjoint ranges): by now the early piece has long
             # finished, and a wait for an already signalled event costs nothing (waiting first

@@ -102,6 +102,118 @@ def gemm_kcat(A1, lda1, B1, ldb1, K1, A2, lda2, B2, ldb2, K2, C, M, N, ldc,
     return C
 
 
+# fp32 products on the bf16 matrix cores for products whose B operand is a weight (the output
+# projection, dYc, dX; csrc/gemm_x6.hip): the weight is split into three bf16 pieces and laid out in
+# the matrix instruction's operand order ONCE per optimizer step (`repack_weights`), the activation
+# is split inside the kernel.  Same accuracy as the exact-fp32 kernels (six of the nine piece
+# products), 1.6-1.8 x their speed at cfg 2.  DANET_GEMM_X6=0: the exact-fp32 kernels everywhere.
+GEMM_X6 = int(__import__('os').environ.get('DANET_GEMM_X6', '1'))
+
+
+class _PackedWeight(object):
+    __slots__ = ('W', 'N', 'K', 'sn', 'sk', 'lo', 'hi', 'out', 'stale', 'version', 'unused')
+
+    def __init__(self, W, N, K, sn, sk):
+        self.W, self.N, self.K, self.sn, self.sk = W, N, K, sn, sk
+        self.lo = W.data_ptr()
+        self.hi = self.lo + 4 * ((N - 1) * sn + (K - 1) * sk + 1)
+        self.out = torch.empty(_lib.ws_bytes(_lib.WS_GEMM_PACK, N, K), dtype=torch.uint8,
+                               device=W.device)
+        self.stale, self.version, self.unused = True, -1, 0
+
+
+_packs = {}      # device -> {(ptr, N, K, sn, sk): _PackedWeight}
+
+
+def _pack_now(pws):
+    arr = (_lib.GemmPack * len(pws))()
+    for i, pw in enumerate(pws):
+        arr[i].src, arr[i].stride_n, arr[i].stride_k = pw.W.data_ptr(), pw.sn, pw.sk
+        arr[i].N, arr[i].K = pw.N, pw.K
+        arr[i].out, arr[i].out_bytes = pw.out.data_ptr(), pw.out.numel()
+    check(_L().danet_gemm_pack_weights(_lib.stream(), len(pws), arr))
+    for pw in pws:
+        pw.stale, pw.version = False, pw.W._version
+
+
+def packed_weight(W, N, K, sn, sk):
+    '''the operand-layout copy of the weight B(n, k) = W.flat[n * sn + k * sk] (W: a tensor whose
+    data_ptr() is B(0, 0)), packed now if the weight has changed since its last pack'''
+    reg = _packs.setdefault(_dev_key(W.device), {})
+    key = (W.data_ptr(), N, K, sn, sk)
+    pw = reg.get(key)
+    if pw is None:
+        pw = reg[key] = _PackedWeight(W, N, K, sn, sk)
+    pw.unused = 0
+    if pw.stale or pw.version != W._version:
+        _pack_now([pw])
+    return pw.out
+
+
+def weights_written(t):
+    '''a kernel of this library has written the parameter range `t` (torch's version counter
+    does not see such writes): packs that overlap it are stale'''
+    reg = _packs.get(_dev_key(t.device))
+    if reg:
+        lo = t.data_ptr()
+        hi = lo + 4 * t.numel()
+        for pw in reg.values():
+            if pw.lo < hi and lo < pw.hi:
+                pw.stale = True
+
+
+def repack_weights(dev):
+    '''re-pack every stale registered weight of the device in ONE launch on the current stream
+    (the end of an optimizer step); packs nobody has asked for in 8 rounds are dropped'''
+    reg = _packs.get(_dev_key(dev))
+    if not reg:
+        return
+    todo = []
+    for key in list(reg):
+        pw = reg[key]
+        pw.unused += 1
+        if pw.unused > 8:
+            del reg[key]
+        elif pw.stale or pw.version != pw.W._version:
+            todo.append(pw)
+    if todo:
+        _pack_now(todo)
+
+
+def drop_packs(dev):
+    '''forget every packed weight of the device (its parameters have moved)'''
+    _packs.pop(_dev_key(dev), None)
+
+
+def _x6_ok(M, N, *pairs):
+    if not GEMM_X6:
+        return False
+    for A, lda, K in pairs:
+        if K % 4 or lda % 4 or lda < K or A.data_ptr() % 16 or M * lda >= (1 << 29):
+            return False
+    return True
+
+
+def gemm_w(A, lda, W, sn, sk, C, M, N, K, ldc, tag=None, stop_event=None,
+           A2=None, lda2=0, W2=None, K2=0):
+    '''C[M,N] = A B^T (+ A2 B2^T) with B(n, k) = W.flat[n * sn + k * sk] a (packed) weight, on the
+    bf16 matrix cores with fp32 accuracy.  The caller has checked `_x6_ok`.'''
+    L = _L()
+    p1 = packed_weight(W, N, K, sn, sk)
+    p2 = packed_weight(W2, N, K2, sn, sk) if K2 else None
+    need = _lib.ws_bytes(_lib.WS_GEMM_X6, M, N, K, K2)
+    w, wn = _ws(need, C.device)
+    with _lib.timed('gemm_x6', tag):
+        if stop_event is not None:
+            stop_event.arm()
+        check(L.danet_gemm_x6(_lib.stream(), M, N, K, ptr(_f32(A)), lda, ptr(p1),
+                              K2, ptr(_f32(A2)) if K2 else None, lda2, ptr(p2) if K2 else None,
+                              ptr(_f32(C)), ldc, ptr(w), wn))
+        if stop_event is not None:
+            stop_event.attached = True
+    return C
+
+
 def gemm_group(problems, K, transA=False, transB=False, max_workgroups=0):
     '''up to 6 products sharing K and the transpose flags as ONE stream-K launch.
     problems: list of (A, lda, B, ldb, C, ldc, M, N, beta) with tensors whose data_ptr()
@@ -871,6 +983,12 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
             # dX = da_f Wx_f^T + da_b Wx_b^T: one K-concatenated launch (the fork event of the
             # weight-gradient chain rides on it: see ForkEvent)
             sk = (STREAMK & 4) != 0 and (4 * H) % 16 == 0
+            if _x6_ok(T * B, D, (das[0], 4 * H, 4 * H), (das[1], 4 * H, 4 * H)):
+                if attach:
+                    fork_ev[0] = fork_event(dev)
+                gemm_w(das[0], 4 * H, c.Ws[0], 4 * H, 1, dx, T * B, D, 4 * H, D, tag='dX',
+                       stop_event=fork_ev[0], A2=das[1], lda2=4 * H, W2=c.Ws[1], K2=4 * H)
+                return
             if attach and sk:
                 fork_ev[0] = fork_event(dev)
             gemm_kcat(das[0], 4 * H, c.Ws[0], 4 * H, 4 * H, das[1], 4 * H, c.Ws[1], 4 * H, 4 * H,
@@ -1000,8 +1118,11 @@ class RnnEncoderFn(torch.autograd.Function):
         # (hybrid stream-K pays for the projection only with >= 4 tiles per CU: cfg 4, 1312 tiles,
         # 248 -> 238 us; cfg 2, 672 tiles, 126 -> 132 us)
         big = ((B * T + 127) // 128) * ((O + 127) // 128) >= 1024
-        gemm(yc, Wout, embed, B * T, O, D, D, O, O, tag='proj',
-             streamk=(STREAMK & 2) != 0 or (big and STREAMK != 0))           # modules.py:249-255
+        if _x6_ok(B * T, O, (yc, D, D)):
+            gemm_w(yc, D, Wout, 1, O, embed, B * T, O, D, O, tag='proj')     # modules.py:249-255
+        else:
+            gemm(yc, Wout, embed, B * T, O, D, D, O, O, tag='proj',
+                 streamk=(STREAMK & 2) != 0 or (big and STREAMK != 0))
         ctx.ctxs, ctx.yc, ctx.Wout = ctxs, yc, Wout
         ctx.dims = (B, T, F, H, L, ndir, D, O)
         return embed
@@ -1013,9 +1134,13 @@ class RnnEncoderFn(torch.autograd.Function):
         dev = dembed.device
         dWout, direct_out = _grad_target(ctx.Wout, (D, O), dev)
         dyc = torch.empty(B, T, D, device=dev)
-        ev = fork_event(dev) if (STREAMK & 1) != 0 else None
-        gemm(dembed, ctx.Wout, dyc, B * T, D, O, O, O, D, transB=True, streamk=(STREAMK & 1) != 0, tag='dYc',
-             stop_event=ev)                                   # critical path first
+        x6 = _x6_ok(B * T, D, (dembed, O, O))
+        ev = fork_event(dev) if ((STREAMK & 1) != 0 or x6) else None
+        if x6:                                                # critical path first
+            gemm_w(dembed, O, ctx.Wout, O, 1, dyc, B * T, D, O, D, tag='dYc', stop_event=ev)
+        else:
+            gemm(dembed, ctx.Wout, dyc, B * T, D, O, O, O, D, transB=True, streamk=(STREAMK & 1) != 0,
+                 tag='dYc', stop_event=ev)
         with _Fork(dev, 2, defer=True, keep=(dembed, ctx.yc), lazy=True, event=ev) as f:
             if GROUPED_DW:    # alone on its stream under the top layer's BPTT kernel (or serial)
                 ov = _overlap_dw(H)
@@ -1568,3 +1693,4 @@ def adam_clip_step(theta, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, cl
                                     ptr(_f32(grad)), ptr(_f32(m)), ptr(_f32(v)), lr_t, beta1,
                                     beta2, eps, clip if clip else 0.0, grad_scale,
                                     int(bool(zero_grad))))
+    weights_written(theta)

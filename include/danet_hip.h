@@ -46,7 +46,7 @@ extern "C" {
 #define DANET_ERR_UNSUPPORTED (-3)  /* shape outside the compiled envelope     */
 #define DANET_ERR_WORKSPACE (-4)    /* ws too small                            */
 
-#define DANET_ABI_VERSION 4
+#define DANET_ABI_VERSION 5
 
 typedef void* danet_stream_t;
 
@@ -85,6 +85,8 @@ enum {
   DANET_WS_SEPARATE_PIT_RECORDS, /* B, N                    `records` of danet_separate_pit_* */
   DANET_WS_PIT_MSE,              /* B, C, N                 danet_pit_mse_fwd                 */
   DANET_WS_CENTER_MEAN,          /* B                       `mean` of danet_center            */
+  DANET_WS_GEMM_X6,              /* M, N, K1, K2            danet_gemm_x6 (split-K slabs; may be 0) */
+  DANET_WS_GEMM_PACK,            /* N, K                    `out` of a danet_gemm_pack_weights job  */
   DANET_WS_COUNT
 };
 size_t danet_workspace_bytes(int op, const int64_t* dims, int n_dims);
@@ -205,8 +207,31 @@ int danet_gemm_f32_streamk_kcat(danet_stream_t stream, int transA, int transB, i
                                 float* C, int ldc, const float* bias, float beta,
                                 void* ws, size_t ws_bytes);
 
+/* fp32 products on the bf16 matrix cores for products whose B operand is a WEIGHT:
+ * C[M][N] = A1 B1^T (+ A2 B2^T), A* fp32 [M][lda*] K-contiguous activations, B* weights that
+ * danet_gemm_pack_weights has split into three bf16 pieces each (hi + mid + lo == the fp32 value
+ * exactly) and laid out in the matrix instruction's operand order.  Six of the nine piece products
+ * are accumulated in fp32: the result is as close to the exact product as danet_gemm_f32's
+ * (csrc/gemm_x6.hip), at 1.6-1.8 x its speed on the step's projection / dYc / dX shapes.
+ * beta = 0, no bias.  K* and lda* multiples of 4, A* 16-byte aligned: DANET_ERR_UNSUPPORTED
+ * otherwise (the caller falls back to danet_gemm_f32*).  A pack is valid until its weight changes:
+ * the host re-packs after every optimizer step (one launch for the whole table).  An event armed
+ * with danet_gemm_next_launch_stop_event completes with this product, as for stream-K launches.
+ * B(n, k) = src[n * stride_n + k * stride_k]; `out`: DANET_WS_GEMM_PACK(N, K) bytes, 16-B aligned.
+ * `ws`: DANET_WS_GEMM_X6(M, N, K1, K2) bytes.                                                    */
+typedef struct {
+  const float* src; long long stride_n, stride_k;
+  int N, K;
+  void* out; size_t out_bytes;
+} danet_gemm_pack_t;
+int danet_gemm_pack_weights(danet_stream_t stream, int n, const danet_gemm_pack_t* jobs);
+int danet_gemm_x6(danet_stream_t stream, int M, int N,
+                  int K1, const float* A1, int lda1, const void* B1_packed,
+                  int K2, const float* A2, int lda2, const void* B2_packed,
+                  float* C, int ldc, void* ws, size_t ws_bytes);
+
 /* Fork without a separate event record: `event` (danet_event_create, or any hipEvent_t) is attached
- * to the NEXT stream-K launch issued by the calling host thread (danet_gemm_f32_streamk*, consumed by
+ * to the NEXT stream-K or danet_gemm_x6 launch of the calling host thread (consumed by
  * it) and completes with that kernel; another stream then waits with danet_stream_wait_event.  A
  * hipEventRecord behind the launch costs the launching stream ~4 us before its next kernel, the
  * attached event ~1 us (tools/csrc/event_gap.hip).                                             */

@@ -33,7 +33,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), 'missing export: ' + s
     assert set(_lib.PROTOTYPES) == set(syms), set(_lib.PROTOTYPES) ^ set(syms)
-    assert lib.danet_abi_version() == 4
+    assert lib.danet_abi_version() == 5
     assert len(syms) <= 50                  # round 4: the ABI is what ships, not every experiment
     # pure host-side helpers are callable without a GPU
     assert lib.danet_stft_num_frames(8000, 256, 64) == 126
@@ -52,8 +52,12 @@ def test_library_loads_and_exports_every_declared_symbol():
     for op, d in dims.items():
         assert 0 < _lib.ws_bytes(op, *d) < (1 << 32), op
     txt = open(os.path.join(ROOT, 'include', 'danet_hip.h')).read()
-    assert re.search(r'DANET_WS_CENTER_MEAN,[^\n]*\n\s*DANET_WS_COUNT', txt)       # enum order == _lib's
-    assert _lib.WS_CENTER_MEAN == 11
+    assert re.search(r'DANET_WS_GEMM_PACK,[^\n]*\n\s*DANET_WS_COUNT', txt)         # enum order == _lib's
+    assert _lib.WS_CENTER_MEAN == 11 and _lib.WS_GEMM_PACK == 13
+    assert _lib.ws_bytes(_lib.WS_GEMM_X6, 4096, 2580, 600, 0) == 0                # enough tiles: no K slices
+    assert _lib.ws_bytes(_lib.WS_GEMM_X6, 4096, 600, 1200, 1200) % (4096 * 600 * 4) == 0
+    # three bf16 pieces, 128-column panels, 16-k steps: 600 -> 640 columns, 2580 -> 162 steps
+    assert _lib.ws_bytes(_lib.WS_GEMM_PACK, 600, 2580) == 3 * 640 * 162 * 16 * 2
     arr = (ctypes.c_int64 * 3)(1, 2, 3)
     assert lib.danet_workspace_bytes(_lib.WS_LSTM, arr, 3) == ctypes.c_size_t(-1).value
     assert lib.danet_workspace_bytes(99, arr, 3) == ctypes.c_size_t(-1).value
