@@ -195,12 +195,13 @@ def _x6_ok(M, N, *pairs):
 
 
 def gemm_w(A, lda, W, sn, sk, C, M, N, K, ldc, tag=None, stop_event=None,
-           A2=None, lda2=0, W2=None, K2=0):
+           A2=None, lda2=0, W2=None, K2=0, sn2=None, sk2=None):
     '''C[M,N] = A B^T (+ A2 B2^T) with B(n, k) = W.flat[n * sn + k * sk] a (packed) weight, on the
-    bf16 matrix cores with fp32 accuracy.  The caller has checked `_x6_ok`.'''
+    bf16 matrix cores with fp32 accuracy (B2 with strides sn2 / sk2, default: B's).  The caller
+    has checked `_x6_ok`.'''
     L = _L()
     p1 = packed_weight(W, N, K, sn, sk)
-    p2 = packed_weight(W2, N, K2, sn, sk) if K2 else None
+    p2 = packed_weight(W2, N, K2, sn if sn2 is None else sn2, sk if sk2 is None else sk2) if K2 else None
     need = _lib.ws_bytes(_lib.WS_GEMM_X6, M, N, K, K2)
     w, wn = _ws(need, C.device)
     with _lib.timed('gemm_x6', tag):

@@ -45,7 +45,7 @@ def test_x6_product_vs_float64(M, N, K1, K2):
         ref = ref + A2.double() @ W2.double().t()
     C = torch.full((M, N), float('nan'), device='cuda')
     assert ops._x6_ok(M, N, (A1, K1, K1))
-    ops.gemm_w(A1, K1, W1, K1, 1, C, M, N, K1, N, A2=A2, lda2=K2, W2=W2, K2=K2)
+    ops.gemm_w(A1, K1, W1, K1, 1, C, M, N, K1, N, A2=A2, lda2=K2, W2=W2, K2=K2, sn2=K2)
     C32 = torch.empty(M, N, device='cuda')
     ops.gemm(A1, W1, C32, M, N, K1, K1, K1, N, transB=True)
     if K2:
@@ -55,7 +55,7 @@ def test_x6_product_vs_float64(M, N, K1, K2):
     assert e6 <= TOL and e6 <= 3 * e32 + 1e-7, (e6, e32)
     # bit-reproducible (the K slices are summed in slice order)
     C2 = torch.empty_like(C)
-    ops.gemm_w(A1, K1, W1, K1, 1, C2, M, N, K1, N, A2=A2, lda2=K2, W2=W2, K2=K2)
+    ops.gemm_w(A1, K1, W1, K1, 1, C2, M, N, K1, N, A2=A2, lda2=K2, W2=W2, K2=K2, sn2=K2)
     assert torch.equal(C, C2)
 
 
@@ -153,7 +153,7 @@ def test_train_steps_with_and_without_x6_agree(hp, monkeypatch):
         src = _synth(hp, 8, 64, 21)
         losses = [float(model.train_step(src)['loss']) for _ in range(3)]
         torch.cuda.synchronize()
-        res.append((losses, {k: v.clone() for k, v in model.param_dict().items()}))
+        res.append((losses, {k: np.array(v) for k, v in model.param_dict().items()}))
     (l1, p1), (l0, p0) = res
     assert np.allclose(l1, l0, rtol=2e-5), (l1, l0)
     for k in p0:
