@@ -58,6 +58,7 @@ PROTOTYPES = {
     'danet_gemm_pack_weights': (c_int, [c_p, c_int, ctypes.POINTER(GemmPack)]),
     'danet_gemm_x6': (c_int, [c_p, c_int, c_int, c_int, c_p, c_int, c_p, c_int, c_p, c_int, c_p,
                               c_p, c_int, c_p, c_sz]),
+    'danet_gemm_x6_tn_grouped': (c_int, [c_p, c_int, c_int, ctypes.POINTER(GemmProblem), c_p, c_sz]),
     'danet_colsum_f32': (c_int, [c_p, c_int, c_int, c_p, c_int, c_p, c_f32, c_p, c_sz]),
     'danet_lstm_fwd': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_int,
                                c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_sz, c_p, c_int]),
@@ -185,7 +186,7 @@ def check(rc):
 # DANET_WS_* (include/danet_hip.h)
 (WS_ISTFT, WS_GEMM, WS_GEMM_STREAMK, WS_COLSUM, WS_LSTM, WS_ATTRACTOR_TRUTH, WS_ATTRACTOR_ANCHOR,
  WS_SEPARATE_BWD, WS_SEPARATE_PIT, WS_SEPARATE_PIT_RECORDS, WS_PIT_MSE, WS_CENTER_MEAN,
- WS_GEMM_X6, WS_GEMM_PACK) = range(14)
+ WS_GEMM_X6, WS_GEMM_PACK, WS_GEMM_X6_TN) = range(15)
 
 
 def ws_bytes(op, *dims):

@@ -442,3 +442,386 @@ extern "C" int danet_gemm_x6(danet_stream_t stream_, int M, int N,
   }
   return DANET_OK;
 }
+
+// ================================================================== TN: both operands are activations
+// C[M][N] (+)= A^T B with A [K][lda] (M contiguous) and B [K][ldb] (N contiguous): the weight
+// gradients dW = x^T da (K = T*B).  Neither operand can be packed ahead of time and both are K-MAJOR,
+// while the matrix instruction wants 8 consecutive k per lane.  The split pieces are therefore stored
+// in LDS the way they arrive -- 4 consecutive m of one k per thread, as [k/4][m/16][4][16] blocks of
+// bf16 -- and ds_read_b64_tr_b16 (each group of 16 lanes transposes a 4 x 16 block) delivers 4
+// consecutive k of one m per lane; two such reads are one operand (tools/csrc/tr_read_layout.hip
+// checks the recipe through the matrix instruction).  Both LDS directions are conflict-free: the
+// k-rows of a block are rotated by the block's m index, so the 16 lanes of a write that share a k-row
+// hit every bank once; a read instruction takes two adjacent 128-byte blocks per 32 lanes.
+// Up to 6 products sharing K in one launch (a layer's dWx / dWh of both directions), tile per
+// workgroup 128 x 128 x 16, K cut into `splitk` slices summed in slice order by a second kernel.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+#define TIMG 4096                        // one piece image: [16 k][128 m] bf16
+#define TSTAGE (6 * TIMG)                // A hi/mid/lo, B hi/mid/lo: 24 KB
+#define X6T_SMEM_BYTES (3 * TSTAGE)      // 72 KB: two workgroups per CU
+#define X6T_MAX_PROBLEMS 6
+
+struct X6TProblem {
+  const float* A; const float* B; float* C;
+  int lda, ldb, ldc, M, N;
+  float beta;
+  int tile0, tiles_n;
+  long long slab_off;                    // this problem's [M][N] inside a K slice's slab (floats)
+};
+struct X6TArgs {
+  X6TProblem p[X6T_MAX_PROBLEMS];
+  int nprob, K, splitk, tiles;
+  long long slab_stride;                 // floats per K slice
+  float* slab;
+};
+
+// (x0, x1) -> the packed bf16 pairs of their three pieces; v_cvt_pk_bf16_f32 rounds to nearest even,
+// the remainders are exact in fp32 and the third piece has <= 8 significant bits left
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){x0, x1}, bf16x2));
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
+  m = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){r0, r1}, bf16x2));
+  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xFFFF0000u);
+  l = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){s0, s1}, bf16x2));
+}
+
+struct X6TCtx {
+  __amdgpu_buffer_rsrc_t rsa, rsb;
+  int lda, ldb, K, kt1, mrem, nrem;
+  int krow;            // this thread's k row inside a k-tile: 4 wave + lane / 16
+  int mq4;             // first of its 4 columns in load 0: 4 (lane % 16); load 1: + 64
+  int woff;            // byte offset of its 8-byte write inside a piece image (load 0; load 1: + 512)
+  int roffa[2], roffb[2];   // byte offsets of its first transpose read of A tile 0 / 1, B tile 0 / 1
+};
+
+template <bool RAGGED>
+__device__ __forceinline__ f32x4 x6t_load(__amdgpu_buffer_rsrc_t rs, int ld, int rem, int K, int kt, int kt1,
+                                          int krow, int c) {
+  const int k = kt * 16 + krow;
+  const bool ok = kt < kt1 && k < K && c < rem;
+  f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)(k * ld + c) * 4u : X6_OOB, 0, 0));
+  if (RAGGED) {
+#pragma unroll
+    for (int e = 1; e < 4; ++e) v[e] = (c + e < rem) ? v[e] : 0.f;
+  }
+  return v;
+}
+// the four loads of one k-tile: A columns [mq4, +4) and [mq4 + 64, +4), B likewise
+template <bool RAGGED>
+__device__ __forceinline__ void x6t_load_tile(const X6TCtx& c, int kt, f32x4 (&R)[4]) {
+  R[0] = x6t_load<RAGGED>(c.rsa, c.lda, c.mrem, c.K, kt, c.kt1, c.krow, c.mq4);
+  R[1] = x6t_load<RAGGED>(c.rsa, c.lda, c.mrem, c.K, kt, c.kt1, c.krow, c.mq4 + 64);
+  R[2] = x6t_load<RAGGED>(c.rsb, c.ldb, c.nrem, c.K, kt, c.kt1, c.krow, c.mq4);
+  R[3] = x6t_load<RAGGED>(c.rsb, c.ldb, c.nrem, c.K, kt, c.kt1, c.krow, c.mq4 + 64);
+}
+__device__ __forceinline__ void x6t_write(char* stage, const X6TCtx& c, int li, const uint32_t (&h)[2],
+                                          const uint32_t (&m)[2], const uint32_t (&l)[2]) {
+  char* p = stage + (li >> 1) * 3 * TIMG + c.woff + (li & 1) * 512;
+  *reinterpret_cast<u32x2*>(p) = (u32x2){h[0], h[1]};
+  *reinterpret_cast<u32x2*>(p + TIMG) = (u32x2){m[0], m[1]};
+  *reinterpret_cast<u32x2*>(p + 2 * TIMG) = (u32x2){l[0], l[1]};
+}
+__device__ __forceinline__ void x6t_store_tile(char* stage, const X6TCtx& c, const f32x4 (&R)[4]) {
+#pragma unroll
+  for (int li = 0; li < 4; ++li) {
+    uint32_t h[2], m[2], l[2];
+    split_pair(R[li][0], R[li][1], h[0], m[0], l[0]);
+    split_pair(R[li][2], R[li][3], h[1], m[1], l[1]);
+    x6t_write(stage, c, li, h, m, l);
+  }
+}
+// operand fragment: 8 consecutive k of this lane's row through two transpose reads
+__device__ __forceinline__ bf16x8 x6t_frag(const char* img, int roff) {
+  const u16x4 a = __builtin_bit_cast(u16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + roff)));
+  const u16x4 b = __builtin_bit_cast(u16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + roff + 1024)));
+  return __builtin_bit_cast(bf16x8, (u16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
+}
+__device__ __forceinline__ void x6t_frags(const char* stage, const X6TCtx& c, bf16x8 (&fa)[3][2], bf16x8 (&fb)[3][2]) {
+#pragma unroll
+  for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fa[pc][i] = x6t_frag(stage + pc * TIMG, c.roffa[i]);
+      fb[pc][i] = x6t_frag(stage + (3 + pc) * TIMG, c.roffb[i]);
+    }
+}
+
+template <int S>
+__device__ __forceinline__ void x6t_mf(f32x16 (&acc)[2][2], const bf16x8 (&fa)[3][2], const bf16x8 (&fb)[3][2]) {
+  constexpr int t = S >> 2, i = (S >> 1) & 1, j = S & 1;
+  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[X6_PA[t]][i], fb[X6_PB[t]][j], acc[i][j], 0, 0, 0);
+}
+
+// One k-step in 24 fenced slots of one matrix instruction each (cf. x6_step):
+//   slots  0-11  the 12 operand fragments of tile kt + 1 (two transpose reads each)
+//   slots 12-19  split of the 8 value pairs of tile kt + 2 staged two steps ago
+//   slots 20-23  LDS store of one load's pieces + the global load of tile kt + 4 into its registers
+template <bool RAGGED>
+__device__ __forceinline__ void x6t_step(const X6TCtx& c, char* xsm, int kt, int srd, int swr, f32x16 (&acc)[2][2],
+                                         f32x4 (&R)[4], const bf16x8 (&fac)[3][2], const bf16x8 (&fbc)[3][2],
+                                         bf16x8 (&fan)[3][2], bf16x8 (&fbn)[3][2]) {
+  const char* srdp = xsm + srd * TSTAGE;
+  char* swrp = xsm + swr * TSTAGE;
+  uint32_t h[4][2], m[4][2], l[4][2];
+#ifdef X6T_NO_LDSREAD
+#define X6T_FA(S, PC, I) x6t_mf<S>(acc, fac, fbc); fan[PC][I] = fac[PC][I]; X6_FENCE
+#define X6T_FB(S, PC, I) x6t_mf<S>(acc, fac, fbc); fbn[PC][I] = fbc[PC][I]; X6_FENCE
+#else
+#define X6T_FA(S, PC, I) x6t_mf<S>(acc, fac, fbc); fan[PC][I] = x6t_frag(srdp + (PC) * TIMG, c.roffa[I]); X6_FENCE
+#define X6T_FB(S, PC, I) x6t_mf<S>(acc, fac, fbc); fbn[PC][I] = x6t_frag(srdp + (3 + (PC)) * TIMG, c.roffb[I]); X6_FENCE
+#endif
+  X6T_FA(0, 0, 0) X6T_FA(1, 0, 1) X6T_FA(2, 1, 0) X6T_FA(3, 1, 1) X6T_FA(4, 2, 0) X6T_FA(5, 2, 1)
+  X6T_FB(6, 0, 0) X6T_FB(7, 0, 1) X6T_FB(8, 1, 0) X6T_FB(9, 1, 1) X6T_FB(10, 2, 0) X6T_FB(11, 2, 1)
+#undef X6T_FA
+#undef X6T_FB
+#ifdef X6T_NO_SPLIT
+#define X6T_S(S, LI, HF) x6t_mf<S>(acc, fac, fbc); h[LI][HF] = m[LI][HF] = l[LI][HF] = __float_as_uint(R[LI][2 * (HF)]) ^ __float_as_uint(R[LI][2 * (HF) + 1]); X6_FENCE
+#else
+#define X6T_S(S, LI, HF) x6t_mf<S>(acc, fac, fbc); split_pair(R[LI][2 * (HF)], R[LI][2 * (HF) + 1], h[LI][HF], m[LI][HF], l[LI][HF]); X6_FENCE
+#endif
+  X6T_S(12, 0, 0) X6T_S(13, 0, 1) X6T_S(14, 1, 0) X6T_S(15, 1, 1) X6T_S(16, 2, 0) X6T_S(17, 2, 1) X6T_S(18, 3, 0) X6T_S(19, 3, 1)
+#undef X6T_S
+#ifdef X6T_NO_WRITE
+#define X6T_WR(LI) if (c.K < 0) x6t_write(swrp, c, LI, h[LI], m[LI], l[LI]);
+#else
+#define X6T_WR(LI) x6t_write(swrp, c, LI, h[LI], m[LI], l[LI]);
+#endif
+#ifdef X6T_NO_GLOBAL
+#define X6T_KT4 (c.K < 0 ? kt + 4 : c.kt1)
+#else
+#define X6T_KT4 (kt + 4)
+#endif
+#define X6T_W(S, LI) x6t_mf<S>(acc, fac, fbc); X6T_WR(LI)                          \
+  R[LI] = x6t_load<RAGGED>((LI) < 2 ? c.rsa : c.rsb, (LI) < 2 ? c.lda : c.ldb, (LI) < 2 ? c.mrem : c.nrem, c.K, X6T_KT4, \
+                           c.kt1, c.krow, c.mq4 + ((LI) & 1) * 64); X6_FENCE
+  X6T_W(20, 0) X6T_W(21, 1) X6T_W(22, 2) X6T_W(23, 3)
+#undef X6T_W
+}
+
+template <bool RAGGED>
+__global__ __launch_bounds__(256, 2) void gemm_x6_tn_kernel(X6TArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char xsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int z = blockIdx.x / g.tiles;                  // K slice
+  const int t = blockIdx.x % g.tiles;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < X6T_MAX_PROBLEMS; ++i)
+    if (i < g.nprob && t >= g.p[i].tile0) pi = i;      // uniform
+  const X6TProblem& q = g.p[pi];
+  const int tl = t - q.tile0;
+  const int m0 = (tl / q.tiles_n) * 128, n0 = (tl % q.tiles_n) * 128;
+  const int M = q.M, N = q.N, K = g.K;
+
+  const int nkt = (K + 15) / 16;
+  const int per = (nkt + g.splitk - 1) / g.splitk;
+  const int kt0 = z * per, kt1 = min(nkt, kt0 + per);
+
+  X6TCtx c;
+  {
+    const float* ab = q.A + m0;
+    const float* bb = q.B + n0;
+    c.rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ab), 0, (int)(((size_t)(K - 1) * q.lda + (M - m0)) * 4), 0x00020000);
+    c.rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bb), 0, (int)(((size_t)(K - 1) * q.ldb + (N - n0)) * 4), 0x00020000);
+  }
+  c.lda = q.lda; c.ldb = q.ldb; c.K = K; c.kt1 = kt1; c.mrem = M - m0; c.nrem = N - n0;
+  const int kr = lane >> 4, mq = lane & 15;
+  c.krow = 4 * wave + kr;
+  c.mq4 = 4 * mq;
+  // a block's four k-rows sit in slot (k % 4 + m-block) % 4 of its 128 bytes (the transpose read takes
+  // one address per lane, so the rows of a block may be permuted): the 16 lanes of a write that share
+  // a k-row then cover four m-blocks in four different 32-byte slots -- every bank once
+  c.woff = (wave * 8 + (mq >> 2)) * 128 + ((kr + (mq >> 2)) & 3) * 32 + (mq & 3) * 8;
+  {
+    const int i16 = lane & 15, mbit = (lane >> 4) & 1, kh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ba = (wm * 64 + i * 32 + 16 * mbit) >> 4, bb = (wn * 64 + i * 32 + 16 * mbit) >> 4;
+      c.roffa[i] = (2 * kh * 8 + ba) * 128 + (((i16 >> 2) + ba) & 3) * 32 + (i16 & 3) * 8;
+      c.roffb[i] = (2 * kh * 8 + bb) * 128 + (((i16 >> 2) + bb) & 3) * 32 + (i16 & 3) * 8;
+    }
+  }
+  const int fi = lane & 31, kb = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (kt0 < kt1) {
+    f32x4 R0[4], R1[4];
+    bf16x8 faA[3][2], fbA[3][2], faB[3][2], fbB[3][2];
+    x6t_load_tile<RAGGED>(c, kt0, R0); x6t_load_tile<RAGGED>(c, kt0 + 1, R1);
+    x6t_store_tile(xsm, c, R0); x6t_store_tile(xsm + TSTAGE, c, R1);
+    x6t_load_tile<RAGGED>(c, kt0 + 2, R0); x6t_load_tile<RAGGED>(c, kt0 + 3, R1);
+    __syncthreads();
+    x6t_frags(xsm, c, faA, fbA);
+    int kt = kt0, srd = 1, swr = 2;
+#define X6T_STEP(R, FAC, FBC, FAN, FBN)                                                              \
+    { x6t_step<RAGGED>(c, xsm, kt, srd, swr, acc, R, FAC, FBC, FAN, FBN);                            \
+      __syncthreads();                                                                               \
+      ++kt; srd = swr; swr = swr == 2 ? 0 : swr + 1; }
+    while (kt + 1 < kt1) {
+      X6T_STEP(R0, faA, fbA, faB, fbB)
+      X6T_STEP(R1, faB, fbB, faA, fbA)
+    }
+    if (kt < kt1) X6T_STEP(R0, faA, fbA, faB, fbB)
+#undef X6T_STEP
+  }
+
+  // epilogue: the tile leaves through LDS in two halves of 64 rows (16-byte stores of 512-byte row
+  // segments) when the destination allows it; beta = 1 adds what is there (one K slice only:
+  // with slices the reduce kernel applies beta)
+  const bool sliced = g.splitk > 1;
+  float* __restrict__ dst = sliced ? g.slab + (size_t)z * g.slab_stride + q.slab_off : q.C;
+  const int ldc = sliced ? N : q.ldc;
+  const float beta = sliced ? 0.f : q.beta;
+  const bool vec = (ldc % 4 == 0) && (((uintptr_t)dst & 15) == 0) && (n0 + 128 <= N);   // uniform
+  if (vec) {
+    float* ct = reinterpret_cast<float*>(xsm);          // [64][132]
+    constexpr int LDC_T = 132;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();
+      if (wm == half) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb) * LDC_T + wn * 64 + j * 32 + fi] = acc[i][j][r];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int rr = (tid >> 5) + 8 * it, c4 = tid & 31;
+        const int row = m0 + half * 64 + rr;
+        if (row < M) {
+          f32x4* o = reinterpret_cast<f32x4*>(dst + (size_t)row * ldc + n0 + c4 * 4);
+          f32x4 v = *reinterpret_cast<const f32x4*>(&ct[rr * LDC_T + c4 * 4]);
+          if (beta != 0.f) v += *o;
+          *o = v;
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + fi;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+        if (row < M && col < N) {
+          float* o = dst + (size_t)row * ldc + col;
+          *o = acc[i][j][r] + (beta != 0.f ? *o : 0.f);
+        }
+      }
+    }
+}
+
+// C = beta C + the K slices in slice order; blockIdx.y = problem (N % 4 == 0, ldc % 4 == 0)
+__global__ __launch_bounds__(256) void gemm_x6_tn_reduce_kernel(X6TArgs g) {
+  const X6TProblem& q = g.p[blockIdx.y];
+  const int M = q.M, N = q.N, ldc = q.ldc;
+  const float beta = q.beta;
+  const float* __restrict__ slab = g.slab + q.slab_off;
+  const int64_t n4 = (int64_t)M * N / 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 v = reinterpret_cast<const f32x4*>(slab)[i];
+    for (int s = 1; s < g.splitk; ++s) v += reinterpret_cast<const f32x4*>(slab + (size_t)s * g.slab_stride)[i];
+    const int64_t e = i * 4;
+    f32x4* o = reinterpret_cast<f32x4*>(q.C + (size_t)(e / N) * ldc + (e % N));
+    if (beta != 0.f) v += *o;
+    *o = v;
+  }
+}
+
+static int x6t_splitk(int tiles, int K) {
+  // as many K slices as fit the workgroup slots (2 per CU), every slice >= 16 k-steps, <= 8
+  const int nkt = cdiv(K, 16);
+  int s = max(1, min(8, 512 / max(tiles, 1)));
+  while (s > 1 && nkt / s < 16) --s;
+  return s;
+}
+size_t dn_ws_gemm_x6_tn(long long sum_mn, int tiles, int K) {
+  const int s = x6t_splitk(tiles, K);
+  return s > 1 ? (size_t)s * (size_t)sum_mn * sizeof(float) : 0;
+}
+
+extern "C" int danet_gemm_x6_tn_grouped(danet_stream_t stream_, int K, int nprob, const danet_gemm_problem_t* probs,
+                                        void* ws, size_t ws_bytes) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DANET_CHECK_ARG(probs && nprob >= 1 && nprob <= X6T_MAX_PROBLEMS, "gemm_x6_tn: 1..%d problems", X6T_MAX_PROBLEMS);
+  DANET_CHECK_ARG(K > 0, "gemm_x6_tn: non-positive K %d", K);
+  X6TArgs g;
+  int tiles = 0;
+  long long sum_mn = 0;
+  bool ragged = false, slicable = true;
+  for (int i = 0; i < nprob; ++i) {
+    const danet_gemm_problem_t& q = probs[i];
+    DANET_CHECK_ARG(q.M > 0 && q.N > 0 && q.A && q.B && q.C, "gemm_x6_tn: bad problem %d", i);
+    DANET_CHECK_ARG(q.bias == nullptr && (q.beta == 0.f || q.beta == 1.f), "gemm_x6_tn: no bias; beta 0 or 1");
+    DANET_CHECK_ARG(q.lda >= q.M && q.ldb >= q.N && q.ldc >= q.N, "gemm_x6_tn: leading dimension too small");
+    if (q.lda % 4 || q.ldb % 4 || ((((uintptr_t)q.A | (uintptr_t)q.B)) & 15) != 0) {
+      danet_set_error("gemm_x6_tn: lda / ldb must be multiples of 4 and A / B 16-byte aligned (problem %d)", i);
+      return DANET_ERR_UNSUPPORTED;
+    }
+    DANET_CHECK_ARG((long long)K * q.lda < (1ll << 29) && (long long)K * q.ldb < (1ll << 29),
+                    "gemm_x6_tn: an operand spans 2 GiB or more");
+    X6TProblem& p = g.p[i];
+    p.A = q.A; p.B = q.B; p.C = q.C; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.M = q.M; p.N = q.N;
+    p.beta = q.beta;
+    p.tiles_n = cdiv(q.N, 128);
+    p.tile0 = tiles;
+    p.slab_off = sum_mn;
+    tiles += cdiv(q.M, 128) * p.tiles_n;
+    sum_mn += (long long)q.M * q.N;
+    ragged = ragged || (q.M % 4) || (q.N % 4);
+    slicable = slicable && q.N % 4 == 0 && q.ldc % 4 == 0 && (((uintptr_t)q.C) & 15) == 0 && ((long long)q.M * q.N) % 4 == 0;
+  }
+  for (int i = nprob; i < X6T_MAX_PROBLEMS; ++i) g.p[i] = g.p[0];
+  g.nprob = nprob; g.K = K; g.tiles = tiles;
+  int s = slicable ? x6t_splitk(tiles, K) : 1;
+  g.splitk = s;
+  g.slab_stride = sum_mn;
+  g.slab = (float*)ws;
+  if (s > 1) {
+    const size_t need = (size_t)s * (size_t)sum_mn * sizeof(float);
+    if (!ws || ws_bytes < need || ((uintptr_t)ws & 15) != 0) {
+      danet_set_error("gemm_x6_tn: workspace %zu < %zu (or not 16-B aligned)", ws_bytes, need);
+      return DANET_ERR_WORKSPACE;
+    }
+  }
+  static const bool once = [] {
+    return hipFuncSetAttribute((const void*)gemm_x6_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               X6T_SMEM_BYTES) == hipSuccess &&
+           hipFuncSetAttribute((const void*)gemm_x6_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               X6T_SMEM_BYTES) == hipSuccess; }();
+  (void)once;
+  dim3 grid((unsigned)(tiles * s)), block(256);
+  if (ragged) gemm_x6_tn_kernel<true><<<grid, block, X6T_SMEM_BYTES, stream>>>(g);
+  else gemm_x6_tn_kernel<false><<<grid, block, X6T_SMEM_BYTES, stream>>>(g);
+  DANET_CHECK_LAUNCH();
+  if (s > 1) {
+    long long most = 0;
+    for (int i = 0; i < nprob; ++i) most = max(most, (long long)probs[i].M * probs[i].N / 4);
+    dim3 rgrid((unsigned)min((long long)1024, (most + 255) / 256), (unsigned)nprob);
+    gemm_x6_tn_reduce_kernel<<<rgrid, block, 0, stream>>>(g);
+    DANET_CHECK_LAUNCH();
+  }
+  return DANET_OK;
+}

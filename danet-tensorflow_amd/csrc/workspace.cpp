@@ -21,9 +21,10 @@ size_t dn_ws_pit_mse(int B, int C, int64_t N);
 int dn_center_mean_elems(int B);
 size_t dn_ws_gemm_x6(int M, int N, int K1, int K2);
 size_t dn_ws_gemm_pack(int N, int K);
+size_t dn_ws_gemm_x6_tn(long long sum_mn, int tiles, int K);
 
 extern "C" size_t danet_workspace_bytes(int op, const int64_t* d, int n) {
-  static const int kDims[DANET_WS_COUNT] = {4, 3, 3, 2, 4, 4, 5, 4, 4, 2, 3, 1, 4, 2};
+  static const int kDims[DANET_WS_COUNT] = {4, 3, 3, 2, 4, 4, 5, 4, 4, 2, 3, 1, 4, 2, 3};
   if (op < 0 || op >= DANET_WS_COUNT || !d || n != kDims[op]) {
     danet_set_error("workspace_bytes: op %d takes %d dims, got %d", op,
                     (op >= 0 && op < DANET_WS_COUNT) ? kDims[op] : -1, n);
@@ -31,7 +32,8 @@ extern "C" size_t danet_workspace_bytes(int op, const int64_t* d, int n) {
   }
   for (int i = 0; i < n; ++i)
     if (d[i] < 0 || (d[i] > 0x7fffffff && !(i == 2 && op >= DANET_WS_ATTRACTOR_TRUTH) &&
-                     !(i == 1 && op == DANET_WS_SEPARATE_PIT_RECORDS))) {
+                     !(i == 1 && op == DANET_WS_SEPARATE_PIT_RECORDS) &&
+                     !(i == 0 && op == DANET_WS_GEMM_X6_TN))) {
       danet_set_error("workspace_bytes: dim %d of op %d out of range", i, op);
       return (size_t)-1;
     }
@@ -51,6 +53,7 @@ extern "C" size_t danet_workspace_bytes(int op, const int64_t* d, int n) {
     case DANET_WS_CENTER_MEAN: return (size_t)dn_center_mean_elems((int)d[0]) * sizeof(float);
     case DANET_WS_GEMM_X6: return dn_ws_gemm_x6((int)d[0], (int)d[1], (int)d[2], (int)d[3]);
     case DANET_WS_GEMM_PACK: return dn_ws_gemm_pack((int)d[0], (int)d[1]);
+    case DANET_WS_GEMM_X6_TN: return dn_ws_gemm_x6_tn((long long)d[0], (int)d[1], (int)d[2]);
   }
   return (size_t)-1;
 }

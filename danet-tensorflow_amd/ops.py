@@ -107,7 +107,7 @@ def gemm_kcat(A1, lda1, B1, ldb1, K1, A2, lda2, B2, ldb2, K2, C, M, N, ldc,
 # the matrix instruction's operand order ONCE per optimizer step (`repack_weights`), the activation
 # is split inside the kernel.  Same accuracy as the exact-fp32 kernels (six of the nine piece
 # products), 1.6-1.8 x their speed at cfg 2.  DANET_GEMM_X6=0: the exact-fp32 kernels everywhere.
-GEMM_X6 = int(__import__('os').environ.get('DANET_GEMM_X6', '1'))
+GEMM_X6 = int(__import__('os').environ.get('DANET_GEMM_X6', '3'))    # bit 0: weight products, bit 1: weight gradients
 
 
 class _PackedWeight(object):
@@ -186,10 +186,23 @@ def drop_packs(dev):
 
 
 def _x6_ok(M, N, *pairs):
-    if not GEMM_X6:
+    if not (GEMM_X6 & 1):
         return False
     for A, lda, K in pairs:
         if K % 4 or lda % 4 or lda < K or A.data_ptr() % 16 or M * lda >= (1 << 29):
+            return False
+    return True
+
+
+def _x6_tn_ok(problems, K):
+    if not (GEMM_X6 & 2) or len(problems) > 6:
+        return False
+    for pr in problems:
+        A, lda, B, ldb = pr[:4]
+        if len(pr) > 9 and pr[9] is not None:
+            return False
+        if lda % 4 or ldb % 4 or A.data_ptr() % 16 or B.data_ptr() % 16 or \
+                K * max(lda, ldb) >= (1 << 29):
             return False
     return True
 
@@ -220,6 +233,7 @@ def gemm_group(problems, K, transA=False, transB=False, max_workgroups=0):
     problems: list of (A, lda, B, ldb, C, ldc, M, N, beta) with tensors whose data_ptr()
     is element (0,0); an optional 10th entry is the bias vector.'''
     L = _L()
+    x6 = transA and not transB and _x6_tn_ok(problems, K)
     arr = (_lib.GemmProblem * len(problems))()
     keep = []
     for i, pr in enumerate(problems):
@@ -231,6 +245,16 @@ def gemm_group(problems, K, transA=False, transB=False, max_workgroups=0):
         arr[i].C, arr[i].ldc, arr[i].M, arr[i].N = ptr(C), ldc, M, N
         arr[i].bias, arr[i].beta = ptr(bias), float(beta)
     dev = problems[0][4].device
+    if x6:
+        # both operands split inside the kernel (csrc/gemm_x6.hip, TN section); not persistent:
+        # `max_workgroups` does not apply
+        need = _lib.ws_bytes(_lib.WS_GEMM_X6_TN, sum(pr[6] * pr[7] for pr in problems),
+                             sum(((pr[6] + 127) // 128) * ((pr[7] + 127) // 128) for pr in problems), K)
+        w = _lib.workspace(need, dev, tag='gemm_x6_tn') if need else None
+        with _lib.timed('gemm_x6_tn_group'):
+            check(L.danet_gemm_x6_tn_grouped(_lib.stream(), K, len(problems), arr, ptr(w),
+                                             w.numel() if w is not None else 0))
+        return
     w = _lib.workspace(_lib.ws_bytes(_lib.WS_GEMM_STREAMK, 0, 0, K), dev, tag='gemm_sk')
     with _lib.timed('gemm_f32_group'):
         check(L.danet_gemm_f32_streamk_grouped(_lib.stream(), int(transA), int(transB), K,

@@ -87,6 +87,7 @@ enum {
   DANET_WS_CENTER_MEAN,          /* B                       `mean` of danet_center            */
   DANET_WS_GEMM_X6,              /* M, N, K1, K2            danet_gemm_x6 (split-K slabs; may be 0) */
   DANET_WS_GEMM_PACK,            /* N, K                    `out` of a danet_gemm_pack_weights job  */
+  DANET_WS_GEMM_X6_TN,           /* sum M*N, 128x128 tiles, K   danet_gemm_x6_tn_grouped (may be 0)  */
   DANET_WS_COUNT
 };
 size_t danet_workspace_bytes(int op, const int64_t* dims, int n_dims);
@@ -229,6 +230,15 @@ int danet_gemm_x6(danet_stream_t stream, int M, int N,
                   int K1, const float* A1, int lda1, const void* B1_packed,
                   int K2, const float* A2, int lda2, const void* B2_packed,
                   float* C, int ldc, void* ws, size_t ws_bytes);
+
+/* The same arithmetic for up to 6 products C (+)= A^T B that share K, with BOTH operands
+ * activations: A [K][lda] (M contiguous), B [K][ldb] (N contiguous) -- the weight gradients of a
+ * layer, dW = x^T da with K = T*B.  Both operands are split inside the kernel; `bias` must be NULL,
+ * beta 0 or 1.  lda / ldb multiples of 4, A / B 16-byte aligned: DANET_ERR_UNSUPPORTED otherwise.
+ * Deterministic (K slices are summed in slice order).  `ws`: DANET_WS_GEMM_X6_TN(sum of M*N over
+ * the products, sum of ceil(M/128)*ceil(N/128), K) bytes.                                        */
+int danet_gemm_x6_tn_grouped(danet_stream_t stream, int K, int nprob, const danet_gemm_problem_t* probs,
+                             void* ws, size_t ws_bytes);
 
 /* Fork without a separate event record: `event` (danet_event_create, or any hipEvent_t) is attached
  * to the NEXT stream-K or danet_gemm_x6 launch of the calling host thread (consumed by

@@ -52,8 +52,10 @@ def test_library_loads_and_exports_every_declared_symbol():
     for op, d in dims.items():
         assert 0 < _lib.ws_bytes(op, *d) < (1 << 32), op
     txt = open(os.path.join(ROOT, 'include', 'danet_hip.h')).read()
-    assert re.search(r'DANET_WS_GEMM_PACK,[^\n]*\n\s*DANET_WS_COUNT', txt)         # enum order == _lib's
-    assert _lib.WS_CENTER_MEAN == 11 and _lib.WS_GEMM_PACK == 13
+    assert re.search(r'DANET_WS_GEMM_X6_TN,[^\n]*\n\s*DANET_WS_COUNT', txt)         # enum order == _lib's
+    assert _lib.WS_CENTER_MEAN == 11 and _lib.WS_GEMM_PACK == 13 and _lib.WS_GEMM_X6_TN == 14
+    # a BiLSTM layer's four weight-gradient products at cfg 2: 160 tiles -> 3 K slices
+    assert _lib.ws_bytes(_lib.WS_GEMM_X6_TN, 2 * 900 * 1200, 160, 4096) == 3 * 2 * 900 * 1200 * 4
     assert _lib.ws_bytes(_lib.WS_GEMM_X6, 4096, 2580, 600, 0) == 0                # enough tiles: no K slices
     assert _lib.ws_bytes(_lib.WS_GEMM_X6, 4096, 600, 1200, 1200) % (4096 * 600 * 4) == 0
     # three bf16 pieces, 128-column panels, 16-k steps: 600 -> 640 columns, 2580 -> 162 steps

@@ -160,3 +160,60 @@ def test_train_steps_with_and_without_x6_agree(hp, monkeypatch):
         a, b = torch.as_tensor(p1[k]).double(), torch.as_tensor(p0[k]).double()
         close = (a - b).abs() <= 1e-4 * float(b.abs().max()) + 1e-7
         assert float(close.double().mean()) >= 0.999, (k, float(close.double().mean()))
+
+
+# ---------------------------------------------------------------- TN: the weight gradients
+TN_GROUPS = [
+    # (K, [(M, N, lda, ldb, ldc, beta)]): a cfg-2 layer's dWx / dWh of both directions; the bottom
+    # layer's (D = 129: ragged M, one K slice more); dWout; tiny / ragged everything
+    (4096, [(600, 1200, 600, 1200, 1200, 0.0), (600, 1200, 600, 1200, 1200, 1.0),
+            (300, 1200, 600, 1200, 1200, 0.0), (300, 1200, 600, 1200, 1200, 1.0)]),
+    (1024, [(129, 1200, 132, 1200, 1200, 1.0), (300, 1200, 600, 1200, 1200, 0.0)]),
+    (2048, [(600, 2580, 600, 2580, 2580, 0.0)]),
+    (40, [(5, 7, 8, 8, 7, 1.0), (130, 129, 132, 132, 129, 0.0)]),
+    (16, [(128, 128, 128, 128, 128, 0.0)]),
+]
+
+
+@pytest.mark.parametrize('K,shapes', TN_GROUPS)
+def test_x6_tn_group_vs_float64(K, shapes):
+    from danet_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(K + len(shapes))
+    probs, refs, c0s = [], [], []
+    for (M, N, lda, ldb, ldc, beta) in shapes:
+        A = torch.randn(K, lda, device='cuda', generator=g) * torch.exp2(
+            torch.randint(-5, 5, (K, lda), device='cuda', generator=g).float())
+        Bm = torch.randn(K, ldb, device='cuda', generator=g)
+        C = torch.randn(M, ldc, device='cuda', generator=g)
+        c0s.append(C.clone())
+        refs.append(A[:, :M].double().t() @ Bm[:, :N].double() + beta * C[:, :N].double())
+        probs.append((A, lda, Bm, ldb, C, ldc, M, N, beta))
+    assert ops._x6_tn_ok(probs, K)
+    ops.gemm_group(probs, K, transA=True)
+    outs = [pr[4].clone() for pr in probs]
+    for (M, N, lda, ldb, ldc, beta), pr, ref, c0 in zip(shapes, probs, refs, c0s):
+        C = pr[4]
+        assert _err(C[:, :N], ref) <= TOL, (M, N, _err(C[:, :N], ref))
+        if ldc > N:
+            assert torch.equal(C[:, N:], c0[:, N:])          # nothing written beyond N
+    # the exact-fp32 group on the same operands, and bit-reproducibility of the x6 one
+    for pr, c0 in zip(probs, c0s):
+        pr[4].copy_(c0)
+    ops.gemm_group(probs, K, transA=True)
+    for pr, o in zip(probs, outs):
+        assert torch.equal(pr[4], o)
+
+
+def test_x6_tn_transposition_and_identity():
+    '''transpose-detecting: A = one-hot rows picks single rows of B exactly (the split is exact),
+    and an asymmetric pattern lands at [m][n], not [n][m]'''
+    from danet_amd import ops
+    K, M, N = 64, 64, 96
+    A = torch.zeros(K, M, device='cuda')
+    A[torch.arange(M), torch.arange(M)] = 1.0                # A^T B = B[:M]
+    g = torch.Generator(device='cuda').manual_seed(4)
+    Bm = torch.randn(K, N, device='cuda', generator=g) * torch.exp2(
+        torch.randint(-20, 20, (K, N), device='cuda', generator=g).float())
+    C = torch.empty(M, N, device='cuda')
+    ops.gemm_group([(A, M, Bm, N, C, N, M, N, 0.0)], K, transA=True)
+    assert torch.equal(C, Bm[:M])
