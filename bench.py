@@ -44,6 +44,8 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+# fp32 products as six bf16 piece products (csrc/gemm_x6.hip): the dense bf16 peak / 6
+PEAK_X6_TFLOPS = 2516.6 / 6
 PEAK_HBM_GBS = 8000.0
 
 CONFIGS = {
@@ -613,16 +615,24 @@ def run_train(args, cfg, hp, device, rank, world, use_dist):
         if not bwd_fused[l]:
             gemm_flops += per + 2 * (2.0 * B * T * H * 4 * H)    # dWx, dWh
     gemm_flops += 3 * 2.0 * B * T * 2 * H * F * E            # projection, dWout, dYc
-    if 'gemm_f32' in prof_all:
-        gn, gms = prof_all['gemm_f32']
-        if 'gemm_f32_group' in prof_all:       # grouped launches
-            gn, gms = gn + prof_all['gemm_f32_group'][0], gms + prof_all['gemm_f32_group'][1]
+    gtimers = [k for k in ('gemm_f32', 'gemm_f32_group', 'gemm_x6', 'gemm_x6_tn_group') if k in prof_all]
+    if gtimers:
+        gn = sum(prof_all[k][0] for k in gtimers)
+        gms = sum(prof_all[k][1] for k in gtimers)
+        x6_ms = sum(prof_all[k][1] for k in gtimers if k.startswith('gemm_x6'))
         gach = gemm_flops * nb / (gms * 1e-3) / 1e12
-        roofline['gemm_f32'] = dict(kernel='gemm_f32_kernel', bound='mfma',
-                                    achieved=round(gach, 2), peak=PEAK_F32_MFMA_TFLOPS,
-                                    unit='TFLOP/s', frac=round(gach / PEAK_F32_MFMA_TFLOPS, 4),
+        # priced against the peak of the instruction mix that ran: time-weighted between the exact
+        # fp32 matrix instructions and six bf16 piece products per fp32 product
+        gpeak = (PEAK_X6_TFLOPS * x6_ms + PEAK_F32_MFMA_TFLOPS * (gms - x6_ms)) / gms
+        roofline['gemm_f32'] = dict(kernel='gemm_x6_*_kernel + gemm_f32_*_kernel' if x6_ms else 'gemm_f32_kernel',
+                                    bound='mfma', achieved=round(gach, 2), peak=round(gpeak, 1),
+                                    unit='TFLOP/s (fp32-equivalent)', frac=round(gach / gpeak, 4),
+                                    x6_time_share=round(x6_ms / gms, 3),
                                     note='sum over the %d launches of a step, timed in-step '
-                                         '(instrumented pass; some run concurrently)' % (gn // nb))
+                                         '(instrumented pass; some run concurrently); fp32 operands '
+                                         'and fp32-accurate results throughout: the x6 kernels form '
+                                         'each product from six bf16 piece products '
+                                         '(csrc/gemm_x6.hip)' % (gn // nb))
     est = hp.TRAIN_ESTIMATOR_METHOD
     res = dict(metric='mixture-seconds/s (train step)', value=round(value, 2),
                unit='mixture-seconds/s', n_gpus=world, steps=args.steps, warmup=args.warmup,

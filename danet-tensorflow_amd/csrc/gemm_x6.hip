@@ -71,6 +71,14 @@ __device__ __forceinline__ bf16x8 frag(const char* img, int row, int kb) {
   return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + row * 32 + c * 16));
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin; work item = the position this workgroup would have
+// if every XCD took a CONTIGUOUS eighth of the item list instead: neighbours in the list (tiles that
+// share an operand panel and a K slice) then share one XCD's L2 instead of fetching the panel 8 times.
+__device__ __forceinline__ int x6_xcd_item(int b, int W) {
+  const int x = b & 7, i = b >> 3, q = W >> 3, r = W & 7;
+  return x * q + min(x, r) + i;
+}
+
 #define X6_OOB 0xfffffff0u               // voffset beyond num_records: the buffer load returns 0
 typedef unsigned v4u __attribute__((__vector_size__(16)));
 
@@ -204,9 +212,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_nt_kernel(X6Args g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = (g.N + XBN - 1) / XBN;
   const int nt = ((g.M + XBM - 1) / XBM) * tiles_n;
-  const int z = blockIdx.x / nt;                       // K slice
-  int bid = blockIdx.x % nt;
-  if ((nt & 7) == 0) bid = (bid & 7) * (nt >> 3) + (bid >> 3);     // an XCD walks a band of tiles
+  const int item = x6_xcd_item(blockIdx.x, gridDim.x);
+  const int z = item / nt;                             // K slice
+  const int bid = item % nt;
   const int m0 = (bid / tiles_n) * XBM, n0 = (bid % tiles_n) * XBN;
 
   const int nk0 = (g.K[0] + XBK - 1) / XBK;
@@ -609,8 +617,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_tn_kernel(X6TArgs g) {
   extern __shared__ __attribute__((aligned(16))) char xsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int z = blockIdx.x / g.tiles;                  // K slice
-  const int t = blockIdx.x % g.tiles;
+  const int item = x6_xcd_item(blockIdx.x, gridDim.x);
+  const int z = item / g.tiles;                        // K slice
+  const int t = item % g.tiles;
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < X6T_MAX_PROBLEMS; ++i)

@@ -217,3 +217,4 @@ def test_x6_tn_transposition_and_identity():
     C = torch.empty(M, N, device='cuda')
     ops.gemm_group([(A, M, Bm, N, C, N, M, N, 0.0)], K, transA=True)
     assert torch.equal(C, Bm[:M])
+

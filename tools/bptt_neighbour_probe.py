@@ -96,7 +96,16 @@ def main():
         tb, tn = sorted(tb[2:]), sorted(tn[2:])
         return tb[len(tb) // 2], tn[len(tn) // 2]
 
+    def group_x6():
+        ops.GEMM_X6 = 3
+        try:
+            group_fp32(0)()
+        finally:
+            ops.GEMM_X6 = 1
+
+    ops.GEMM_X6 = 1
     for name, nb in (('alone', None), ('fp32 group, 256 workgroups (the step)', group_fp32(256)),
+                     ('x6 TN group (the same four products)', group_x6),
                      ('fp32 group, 128 workgroups', group_fp32(128)),
                      ('x6 NT, 1 launch (same flops)', x6(1)), ('x6 NT, 3 launches', x6(3)),
                      ('x6 NT, 6 launches', x6(6))):
