@@ -57,7 +57,7 @@ PROTOTYPES = {
                                             c_p, c_int, c_p, c_f32, c_p, c_sz]),
     'danet_gemm_pack_weights': (c_int, [c_p, c_int, ctypes.POINTER(GemmPack)]),
     'danet_gemm_x6': (c_int, [c_p, c_int, c_int, c_int, c_p, c_int, c_p, c_int, c_p, c_int, c_p,
-                              c_p, c_int, c_p, c_sz]),
+                              c_p, c_int, c_p, c_p, c_sz]),
     'danet_gemm_x6_tn_grouped': (c_int, [c_p, c_int, c_int, ctypes.POINTER(GemmProblem), c_p, c_sz]),
     'danet_colsum_f32': (c_int, [c_p, c_int, c_int, c_p, c_int, c_p, c_f32, c_p, c_sz]),
     'danet_lstm_fwd': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_int,

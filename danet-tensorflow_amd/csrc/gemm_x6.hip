@@ -42,6 +42,7 @@ struct X6Args {
   int lda[2], K[2], KT[2];
   int NT32;
   float* C;                             // splitk == 1: the result; else slab [splitk][M][N]
+  const float* bias;                    // [N] added to every row, or null (splitk > 1: by the reduce kernel)
   int M, N, ldc, npair, splitk;
 };
 
@@ -267,7 +268,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_nt_kernel(X6Args g) {
   // through the (now free) LDS in two halves of 64 rows as 16-byte stores of full 512-byte row
   // segments when the destination allows it; 4-byte stores otherwise.
   float* __restrict__ dst = g.C + (g.splitk > 1 ? (size_t)z * g.M * g.ldc : 0);
-  const bool vec = (g.ldc % 4 == 0) && (((uintptr_t)g.C & 15) == 0) && (n0 + XBN <= g.N);   // uniform
+  const float* __restrict__ bias = g.splitk > 1 ? nullptr : g.bias;
+  const bool vec = (g.ldc % 4 == 0) && (((uintptr_t)g.C & 15) == 0) && (n0 + XBN <= g.N) &&
+                   (!bias || ((uintptr_t)bias & 15) == 0);                                  // uniform
   if (vec) {
     float* ct = reinterpret_cast<float*>(xsm);          // [64][XBN + 4]
     constexpr int LDC_T = XBN + 4;
@@ -288,9 +291,11 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_nt_kernel(X6Args g) {
       for (int it = 0; it < 8; ++it) {
         const int rr = (tid >> 5) + 8 * it, c4 = tid & 31;
         const int row = m0 + half * 64 + rr;
-        if (row < g.M)
-          *reinterpret_cast<f32x4*>(dst + (size_t)row * g.ldc + n0 + c4 * 4) =
-              *reinterpret_cast<const f32x4*>(&ct[rr * LDC_T + c4 * 4]);
+        if (row < g.M) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(&ct[rr * LDC_T + c4 * 4]);
+          if (bias) v += *reinterpret_cast<const f32x4*>(bias + n0 + c4 * 4);
+          *reinterpret_cast<f32x4*>(dst + (size_t)row * g.ldc + n0 + c4 * 4) = v;
+        }
       }
     }
     return;
@@ -303,14 +308,15 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_nt_kernel(X6Args g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
-        if (row < g.M && col < g.N) dst[(size_t)row * g.ldc + col] = acc[i][j][r];
+        if (row < g.M && col < g.N) dst[(size_t)row * g.ldc + col] = acc[i][j][r] + (bias ? bias[col] : 0.f);
       }
     }
 }
 
 // C[m][n] = sum over the K slices, in slice order (slab rows are dense: ld = N)
 __global__ __launch_bounds__(256) void gemm_x6_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C,
-                                                             int M, int N, int ldc, int splitk) {
+                                                             int M, int N, int ldc, int splitk,
+                                                             const float* __restrict__ bias) {
   const int64_t n4 = (int64_t)M * N / 4;
   const int64_t plane = (int64_t)M * N;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -318,6 +324,7 @@ __global__ __launch_bounds__(256) void gemm_x6_reduce_kernel(const float* __rest
     for (int s = 1; s < splitk; ++s) v += reinterpret_cast<const f32x4*>(slab + s * plane)[i];
     const int64_t e = i * 4;
     const int row = (int)(e / N), col = (int)(e % N);
+    if (bias) v += (f32x4){bias[col], bias[col + 1], bias[col + 2], bias[col + 3]};
     *reinterpret_cast<f32x4*>(C + (size_t)row * ldc + col) = v;
   }
 }
@@ -399,7 +406,7 @@ hipEvent_t dn_take_stop_event();   // gemm_f32.hip: the event armed by danet_gem
 extern "C" int danet_gemm_x6(danet_stream_t stream_, int M, int N,
                              int K1, const float* A1, int lda1, const void* B1pk,
                              int K2, const float* A2, int lda2, const void* B2pk,
-                             float* C, int ldc, void* ws, size_t ws_bytes) {
+                             float* C, int ldc, const float* bias, void* ws, size_t ws_bytes) {
   // (consumed before any check can return: see sk_launch)
   hipEvent_t stop = dn_take_stop_event();
   hipStream_t stream = (hipStream_t)stream_;
@@ -421,7 +428,7 @@ extern "C" int danet_gemm_x6(danet_stream_t stream_, int M, int N,
   g.A[0] = A1; g.Bp[0] = (const u32x4*)B1pk; g.lda[0] = lda1; g.K[0] = K1; g.KT[0] = cdiv(K1, XBK);
   g.A[1] = A2; g.Bp[1] = (const u32x4*)B2pk; g.lda[1] = lda2; g.K[1] = K2; g.KT[1] = cdiv(K2, XBK);
   g.npair = K2 > 0 ? 2 : 1;
-  g.M = M; g.N = N; g.NT32 = x6_nt32(N);
+  g.M = M; g.N = N; g.NT32 = x6_nt32(N); g.bias = bias;
   const int nkt = cdiv(K1, XBK) + cdiv(K2, XBK);
   int s = x6_splitk(M, N, nkt);
   if (s > 1 && (N % 4 != 0 || ldc % 4 != 0 || ((uintptr_t)C & 15) != 0)) s = 1;   // (the reduce kernel is vectorised)
@@ -444,8 +451,8 @@ extern "C" int danet_gemm_x6(danet_stream_t stream_, int M, int N,
   if (s > 1) {
     dim3 rgrid((unsigned)min((int64_t)2048, cdiv64((int64_t)M * N / 4, 256)));
     if (stop) hipExtLaunchKernelGGL(gemm_x6_reduce_kernel, rgrid, block, 0, stream, nullptr, stop, 0,
-                                    (const float*)ws, C, M, N, ldc, s);
-    else gemm_x6_reduce_kernel<<<rgrid, block, 0, stream>>>((const float*)ws, C, M, N, ldc, s);
+                                    (const float*)ws, C, M, N, ldc, s, bias);
+    else gemm_x6_reduce_kernel<<<rgrid, block, 0, stream>>>((const float*)ws, C, M, N, ldc, s, bias);
     DANET_CHECK_LAUNCH();
   }
   return DANET_OK;

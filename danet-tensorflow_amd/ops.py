@@ -208,7 +208,7 @@ def _x6_tn_ok(problems, K):
 
 
 def gemm_w(A, lda, W, sn, sk, C, M, N, K, ldc, tag=None, stop_event=None,
-           A2=None, lda2=0, W2=None, K2=0, sn2=None, sk2=None):
+           A2=None, lda2=0, W2=None, K2=0, sn2=None, sk2=None, bias=None):
     '''C[M,N] = A B^T (+ A2 B2^T) with B(n, k) = W.flat[n * sn + k * sk] a (packed) weight, on the
     bf16 matrix cores with fp32 accuracy (B2 with strides sn2 / sk2, default: B's).  The caller
     has checked `_x6_ok`.'''
@@ -222,7 +222,7 @@ def gemm_w(A, lda, W, sn, sk, C, M, N, K, ldc, tag=None, stop_event=None,
             stop_event.arm()
         check(L.danet_gemm_x6(_lib.stream(), M, N, K, ptr(_f32(A)), lda, ptr(p1),
                               K2, ptr(_f32(A2)) if K2 else None, lda2, ptr(p2) if K2 else None,
-                              ptr(_f32(C)), ldc, ptr(w), wn))
+                              ptr(_f32(C)), ldc, ptr(bias), ptr(w), wn))
         if stop_event is not None:
             stop_event.attached = True
     return C
@@ -868,7 +868,12 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs, x_pad_zero=False, ypad=None, ws=N
                 ptr(gates[0]), ptr(gates[-1]), ptr(cells[0]), ptr(cells[-1]), ptr(ws), wn,
                 ptr(status_word(dev)), flags))
     else:
-        if GROUPED_GX and ndir == 2:
+        if _x6_ok(T * B, 4 * H, (x, ldx, D)):
+            # hoisted input half [x]Wx + b (app/ops.py:139-142) on the packed weight, one launch per
+            # direction; `gates[d]` is later overwritten in place by g,i,f,o
+            for d in range(ndir):
+                gemm_w(x, ldx, Ws[d], 1, 4 * H, gates[d], T * B, 4 * H, D, 4 * H, tag='gx', bias=bs[d])
+        elif GROUPED_GX and ndir == 2:
             # hoisted input half of ops.lyr_lstm_flat's [x,h]W+b (app/ops.py:139-142) of both
             # directions as one grouped stream-K launch (nothing else runs at this point of the
             # forward pass: 2 x 320 tiles fill 512 workgroups evenly; -1.5% per step vs two

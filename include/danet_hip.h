@@ -214,7 +214,7 @@ int danet_gemm_f32_streamk_kcat(danet_stream_t stream, int transA, int transB, i
  * exactly) and laid out in the matrix instruction's operand order.  Six of the nine piece products
  * are accumulated in fp32: the result is as close to the exact product as danet_gemm_f32's
  * (csrc/gemm_x6.hip), at 1.6-1.8 x its speed on the step's projection / dYc / dX shapes.
- * beta = 0, no bias.  K* and lda* multiples of 4, A* 16-byte aligned: DANET_ERR_UNSUPPORTED
+ * beta = 0; optional bias [N] added to every row.  K* and lda* multiples of 4, A* 16-byte aligned: DANET_ERR_UNSUPPORTED
  * otherwise (the caller falls back to danet_gemm_f32*).  A pack is valid until its weight changes:
  * the host re-packs after every optimizer step (one launch for the whole table).  An event armed
  * with danet_gemm_next_launch_stop_event completes with this product, as for stream-K launches.
@@ -229,7 +229,7 @@ int danet_gemm_pack_weights(danet_stream_t stream, int n, const danet_gemm_pack_
 int danet_gemm_x6(danet_stream_t stream, int M, int N,
                   int K1, const float* A1, int lda1, const void* B1_packed,
                   int K2, const float* A2, int lda2, const void* B2_packed,
-                  float* C, int ldc, void* ws, size_t ws_bytes);
+                  float* C, int ldc, const float* bias, void* ws, size_t ws_bytes);
 
 /* The same arithmetic for up to 6 products C (+)= A^T B that share K, with BOTH operands
  * activations: A [K][lda] (M contiguous), B [K][ldb] (N contiguous) -- the weight gradients of a

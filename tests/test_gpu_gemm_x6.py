@@ -218,3 +218,18 @@ def test_x6_tn_transposition_and_identity():
     ops.gemm_group([(A, M, Bm, N, C, N, M, N, 0.0)], K, transA=True)
     assert torch.equal(C, Bm[:M])
 
+
+
+@pytest.mark.parametrize('M,N,K', [(4096, 2400, 1200), (1251, 1200, 600), (100, 36, 4100), (77, 130, 40)])
+def test_x6_bias_and_k_major_weight(M, N, K):
+    '''the hoisted input half of an LSTM layer: gates = x Wx + b with Wx stored [K][N]
+    (stride_n = 1); sliced (few tiles, long K) and unsliced launches, vector and scalar epilogues'''
+    from danet_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(M + N)
+    A = torch.randn(M, K, device='cuda', generator=g)
+    W = torch.randn(K, N, device='cuda', generator=g) * 0.05
+    bias = torch.randn(N, device='cuda', generator=g)
+    C = torch.empty(M, N, device='cuda')
+    ops.gemm_w(A, K, W, 1, N, C, M, N, K, N, bias=bias)
+    ref = A.double() @ W.double() + bias.double()
+    assert _err(C, ref) <= TOL
