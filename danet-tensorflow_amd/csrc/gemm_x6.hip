@@ -55,6 +55,18 @@ __device__ __forceinline__ void split3(float x, uint32_t& h, uint32_t& m, uint32
   m = (__float_as_uint(r) + 0x8000u) & 0xFFFF0000u;
   l = __float_as_uint(r - __uint_as_float(m));
 }
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// (x0, x1) -> the packed bf16 pairs of their three pieces; v_cvt_pk_bf16_f32 rounds to nearest even,
+// the remainders are exact in fp32 and the third piece has <= 8 significant bits left
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){x0, x1}, bf16x2));
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
+  m = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){r0, r1}, bf16x2));
+  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xFFFF0000u);
+  l = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){s0, s1}, bf16x2));
+}
+
 // the high halves of two words as one word: [hi16(b) | hi16(a)]
 __device__ __forceinline__ uint32_t pack_hi(uint32_t a, uint32_t b) {
   return __builtin_amdgcn_perm(b, a, 0x07060302u);
@@ -112,12 +124,12 @@ __device__ __forceinline__ void x6_store_a(char* base, const X6Ctx& c, const f32
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int off = img_off(c.srow + 64 * i, c.sq);
-    uint32_t h[4], m[4], l[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) split3(R[i][j], h[j], m[j], l[j]);
-    *reinterpret_cast<u32x2*>(base + off) = (u32x2){pack_hi(h[0], h[1]), pack_hi(h[2], h[3])};
-    *reinterpret_cast<u32x2*>(base + XIMG + off) = (u32x2){pack_hi(m[0], m[1]), pack_hi(m[2], m[3])};
-    *reinterpret_cast<u32x2*>(base + 2 * XIMG + off) = (u32x2){pack_hi(l[0], l[1]), pack_hi(l[2], l[3])};
+    uint32_t h[2], m[2], l[2];
+    split_pair(R[i][0], R[i][1], h[0], m[0], l[0]);
+    split_pair(R[i][2], R[i][3], h[1], m[1], l[1]);
+    *reinterpret_cast<u32x2*>(base + off) = (u32x2){h[0], h[1]};
+    *reinterpret_cast<u32x2*>(base + XIMG + off) = (u32x2){m[0], m[1]};
+    *reinterpret_cast<u32x2*>(base + 2 * XIMG + off) = (u32x2){l[0], l[1]};
   }
 }
 __device__ __forceinline__ void x6_load_b(const X6Ctx& c, int kt, u32x4 (&fb)[3][2]) {
@@ -150,7 +162,7 @@ __device__ constexpr int X6_PB[6] = {0, 2, 1, 0, 1, 0};
 // instructions issue in the shadow of the 32-cycle matrix instructions instead of in front of them:
 //   slots  0-5   B fragment loads of tile kt + 1 (global / L2 -> registers, 16 bytes per lane)
 //   slots  6-11  A fragment reads of tile kt + 1 (LDS -> registers)
-//   slots 12-19  split of the 8 fp32 values of tile kt + 2 this thread staged two steps ago
+//   slots 12-19  split of the 4 value pairs of tile kt + 2 this thread staged two steps ago (every other slot)
 //   slots 20-21  pack + LDS store of the two rows' pieces
 //   slots 22-23  global loads of tile kt + 4 into the staging registers
 template <int S>
@@ -171,21 +183,23 @@ __device__ __forceinline__ void x6_step(const X6Ctx& c, char* xsm, int kt, int s
   const u32x4* __restrict__ bp = (pn ? c.bp[1] : c.bp[0]) + c.lane;
   const char* srdp = xsm + srd * XSTAGE;
   char* swrp = xsm + swr * XSTAGE;
-  uint32_t h[2][4], m[2][4], l[2][4];
+  uint32_t h[2][2], m[2][2], l[2][2];
 #define X6_B(S) x6_mf<S>(acc, fac, fbc); fbn[(S) >> 1][(S) & 1] = bp[((size_t)(((S) >> 1) * c.NT32 + c.ntb + ((S) & 1)) * KTn + ktl) * 64]; X6_FENCE
   X6_B(0) X6_B(1) X6_B(2) X6_B(3) X6_B(4) X6_B(5)
 #undef X6_B
 #define X6_A(S) x6_mf<S>(acc, fac, fbc); fan[((S) - 6) >> 1][((S) - 6) & 1] = frag(srdp + (((S) - 6) >> 1) * XIMG, c.wm * 64 + (((S) - 6) & 1) * 32 + c.fi, c.kb); X6_FENCE
   X6_A(6) X6_A(7) X6_A(8) X6_A(9) X6_A(10) X6_A(11)
 #undef X6_A
-#define X6_S(S) x6_mf<S>(acc, fac, fbc); split3(R[((S) - 12) >> 2][((S) - 12) & 3], h[((S) - 12) >> 2][((S) - 12) & 3], m[((S) - 12) >> 2][((S) - 12) & 3], l[((S) - 12) >> 2][((S) - 12) & 3]); X6_FENCE
-  X6_S(12) X6_S(13) X6_S(14) X6_S(15) X6_S(16) X6_S(17) X6_S(18) X6_S(19)
+#define X6_M(S) x6_mf<S>(acc, fac, fbc); X6_FENCE
+#define X6_S(S, I, HF) x6_mf<S>(acc, fac, fbc); split_pair(R[I][2 * (HF)], R[I][2 * (HF) + 1], h[I][HF], m[I][HF], l[I][HF]); X6_FENCE
+  X6_S(12, 0, 0) X6_M(13) X6_S(14, 0, 1) X6_M(15) X6_S(16, 1, 0) X6_M(17) X6_S(18, 1, 1) X6_M(19)
 #undef X6_S
+#undef X6_M
 #define X6_W(S, I) x6_mf<S>(acc, fac, fbc); {                                                              \
     const int off = img_off(c.srow + 64 * (I), c.sq);                                                      \
-    *reinterpret_cast<u32x2*>(swrp + off) = (u32x2){pack_hi(h[I][0], h[I][1]), pack_hi(h[I][2], h[I][3])};            \
-    *reinterpret_cast<u32x2*>(swrp + XIMG + off) = (u32x2){pack_hi(m[I][0], m[I][1]), pack_hi(m[I][2], m[I][3])};     \
-    *reinterpret_cast<u32x2*>(swrp + 2 * XIMG + off) = (u32x2){pack_hi(l[I][0], l[I][1]), pack_hi(l[I][2], l[I][3])}; } X6_FENCE
+    *reinterpret_cast<u32x2*>(swrp + off) = (u32x2){h[I][0], h[I][1]};                                     \
+    *reinterpret_cast<u32x2*>(swrp + XIMG + off) = (u32x2){m[I][0], m[I][1]};                              \
+    *reinterpret_cast<u32x2*>(swrp + 2 * XIMG + off) = (u32x2){l[I][0], l[I][1]}; } X6_FENCE
   X6_W(20, 0) X6_W(21, 1)
 #undef X6_W
   {
@@ -470,9 +484,7 @@ extern "C" int danet_gemm_x6(danet_stream_t stream_, int M, int N,
 // hit every bank once; a read instruction takes two adjacent 128-byte blocks per 32 lanes.
 // Up to 6 products sharing K in one launch (a layer's dWx / dWh of both directions), tile per
 // workgroup 128 x 128 x 16, K cut into `splitk` slices summed in slice order by a second kernel.
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
 typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -495,16 +507,6 @@ struct X6TArgs {
   long long slab_stride;                 // floats per K slice
   float* slab;
 };
-
-// (x0, x1) -> the packed bf16 pairs of their three pieces; v_cvt_pk_bf16_f32 rounds to nearest even,
-// the remainders are exact in fp32 and the third piece has <= 8 significant bits left
-__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
-  h = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){x0, x1}, bf16x2));
-  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
-  m = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){r0, r1}, bf16x2));
-  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xFFFF0000u);
-  l = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){s0, s1}, bf16x2));
-}
 
 struct X6TCtx {
   __amdgpu_buffer_rsrc_t rsa, rsb;

@@ -27,6 +27,10 @@ cp gpurun_out/pmc_${TAG}_cfg4h600/summary.json "$OUT/${TAG}_pmc_summary_cfg4h600
 bash profiles/run_pmc_mfma.sh ${TAG} > "$OUT/${TAG}_pmc_mfma.log" 2>&1
 cp gpurun_out/pmc_mfma_${TAG}/summary.json "$OUT/${TAG}_pmc_mfma_summary.json" 2>/dev/null
 python tools/bench_gemm.py > "$OUT/${TAG}_gemm_shapes.txt" 2>&1
+python tools/bench_gemm_x6_nt.py > "$OUT/${TAG}_gemm_x6_nt.txt" 2>&1
+python tools/bench_gemm_x6_tn.py > "$OUT/${TAG}_gemm_x6_tn.txt" 2>&1
+python tools/bptt_neighbour_probe.py > "$OUT/${TAG}_bptt_neighbour.txt" 2>&1
+DANET_GEMM_X6=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_cfg2_exact_fp32_gemms.json"
 python tools/lstm_modes.py > "$OUT/${TAG}_lstm_bwd_modes.txt" 2>&1
 python tools/feed_probe.py 100 > "$OUT/${TAG}_feed_probe.txt" 2>&1
 python tools/feed_trace.py ahead 100 3 > "$OUT/${TAG}_feed_trace.txt" 2>&1
