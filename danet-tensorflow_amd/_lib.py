@@ -74,7 +74,7 @@ PROTOTYPES = {
                                c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_sz, c_p, c_int]),
     'danet_lstm_bwd_db_supported': (c_int, [c_int, c_int, c_int, c_int]),
     'danet_lstm_bwd_db_reduce': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_p, c_f32, c_p, c_sz]),
-    'danet_gemm_next_launch_stop_event': (c_int, [c_p]),
+    'danet_next_launch_events': (c_int, [c_p, c_p]),
     'danet_event_create': (c_int, [ctypes.POINTER(c_p)]),
     'danet_event_destroy': (c_int, [c_p]),
     'danet_stream_wait_event': (c_int, [c_p, c_p]),
@@ -257,26 +257,53 @@ def profile_stop():
     return out
 
 
+# labels whose ONE kernel launch carries the event pair on its own dispatch packet
+# (danet_next_launch_events) instead of two event records around the call: the recurrent kernels.
+# A record in front of the launch delays it by a few microseconds, enough for the side stream's
+# weight-gradient group to get its workgroups onto the CUs first -- the persistent kernel then
+# starts piecemeal and the bracket reads 50 us more than the kernel takes in an untimed step.
+ATTACHED_LABELS = frozenset(('lstm_fwd', 'lstm_bwd'))
+_aux_stream = None
+
+
+def _timing_event():
+    '''a timing-enabled event whose native handle exists (torch creates it on first record; that
+    record goes to a stream nobody else uses)'''
+    global _aux_stream
+    if _aux_stream is None:
+        _aux_stream = torch.cuda.Stream()
+    e = torch.cuda.Event(enable_timing=True)
+    e.record(_aux_stream)
+    return e
+
+
 class timed(object):
     '''with timed('label'): <one library call>  -- records a start/end event pair
     on the current stream (the stream the kernels are launched on) when
-    profiling is enabled; free otherwise.'''
-    __slots__ = ('label', 'tag', 'a')
+    profiling is enabled; free otherwise.  Labels in ATTACHED_LABELS: the pair rides on the
+    call's own kernel launch.'''
+    __slots__ = ('label', 'tag', 'a', 'b')
 
     def __init__(self, label, tag=None):
         self.label, self.tag = label, tag
 
     def __enter__(self):
-        self.a = None
+        self.a = self.b = None
         if _prof is not None and _prof_on and (_prof_only is None or self.label in _prof_only):
-            self.a = torch.cuda.Event(enable_timing=True)
-            self.a.record()
+            if self.label in ATTACHED_LABELS:
+                self.a, self.b = _timing_event(), _timing_event()
+                check(load().danet_next_launch_events(self.a.cuda_event, self.b.cuda_event))
+            else:
+                self.a = torch.cuda.Event(enable_timing=True)
+                self.a.record()
         return self
 
     def __exit__(self, *exc):
         if self.a is not None and _prof is not None:
-            b = torch.cuda.Event(enable_timing=True)
-            b.record()
+            b = self.b
+            if b is None:
+                b = torch.cuda.Event(enable_timing=True)
+                b.record()
             _prof.setdefault(self.label, []).append((self.a, b))
             if self.tag:      # per-call-site breakdown next to the per-entry-point total
                 _prof.setdefault(self.label + ':' + self.tag, []).append((self.a, b))

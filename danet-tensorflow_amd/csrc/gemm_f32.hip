@@ -1000,17 +1000,23 @@ size_t dn_ws_gemm_streamk(int M, int N, int K) {
 }
 
 // Event plumbing for hosts that fork side streams behind a stream-K launch: the event given to
-// danet_gemm_next_launch_stop_event is attached to the NEXT stream-K launch of the calling host thread
+// danet_next_launch_events is attached to the NEXT stream-K launch of the calling host thread
 // (consumed by it); danet_event_* wrap the runtime's calls so that a ctypes host needs no second
 // library handle.
+static thread_local hipEvent_t g_start_event = nullptr;
 static thread_local hipEvent_t g_stop_event = nullptr;
-extern "C" int danet_gemm_next_launch_stop_event(void* event) {
-  g_stop_event = (hipEvent_t)event;
+extern "C" int danet_next_launch_events(void* start, void* stop) {
+  g_start_event = (hipEvent_t)start;
+  g_stop_event = (hipEvent_t)stop;
   return DANET_OK;
 }
-hipEvent_t dn_take_stop_event() {            // (gemm_x6.hip)
-  hipEvent_t e = g_stop_event;
-  g_stop_event = nullptr;
+void dn_take_launch_events(hipEvent_t* start, hipEvent_t* stop) {   // (lstm.hip)
+  *start = g_start_event; *stop = g_stop_event;
+  g_start_event = nullptr; g_stop_event = nullptr;
+}
+hipEvent_t dn_take_stop_event() {            // (gemm_x6.hip; a start event is dropped)
+  hipEvent_t a, e;
+  dn_take_launch_events(&a, &e);
   return e;
 }
 extern "C" int danet_event_create(void** event) {
@@ -1040,7 +1046,7 @@ static int sk_launch(danet_stream_t stream_, int transA, int transB, int K, int 
   static std::atomic<unsigned> launch_seq{0x5eed0000u};
   static const bool lds_ok = [] { GEMM_FOR_ALL_VARIANTS(gemm_f32_sk_kernel, gemm_allow_lds); return true; }();
   (void)lds_ok;
-  // a caller-supplied event (danet_gemm_next_launch_stop_event) rides on this launch's own dispatch
+  // a caller-supplied event (danet_next_launch_events) rides on this launch's own dispatch
   // packet instead of a separate hipEventRecord behind it (tools/csrc/event_gap.hip: the record costs
   // the stream 4.4 us before its next kernel, the attached event 1.1 us).  Consumed HERE, before
   // any check can return: a rejected call must not leave it armed for an unrelated later launch.
@@ -1155,7 +1161,7 @@ extern "C" int danet_gemm_f32_streamk_kcat(danet_stream_t stream_, int transA, i
                                            int K2, const float* A2, int lda2, const float* B2, int ldb2,
                                            float* C, int ldc, const float* bias, float beta,
                                            void* ws, size_t ws_bytes) {
-  if (K2 <= 0) g_stop_event = nullptr;       // (an armed event dies with the rejected call)
+  if (K2 <= 0) (void)dn_take_stop_event();   // (an armed event dies with the rejected call)
   DANET_CHECK_ARG(K2 > 0, "gemm_streamk_kcat: K2 must be positive");
   danet_gemm_problem_t q;
   q.A = A1; q.lda = lda1; q.B = B1; q.ldb = ldb1; q.C = C; q.ldc = ldc; q.M = M; q.N = N;

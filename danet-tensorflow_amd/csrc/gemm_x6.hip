@@ -415,7 +415,7 @@ size_t dn_ws_gemm_x6(int M, int N, int K1, int K2) {
   return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
-hipEvent_t dn_take_stop_event();   // gemm_f32.hip: the event armed by danet_gemm_next_launch_stop_event
+hipEvent_t dn_take_stop_event();   // gemm_f32.hip: the event armed by danet_next_launch_events
 
 extern "C" int danet_gemm_x6(danet_stream_t stream_, int M, int N,
                              int K1, const float* A1, int lda1, const void* B1pk,

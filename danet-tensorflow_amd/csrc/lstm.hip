@@ -34,8 +34,21 @@
 // the status word (ws word 0) instead of hanging.
 #include "common.h"
 #include "options.h"
+#include <hip/hip_ext.h>
 #include <atomic>
 #include <stdlib.h>
+
+// Events armed with danet_next_launch_events ride on the recurrent kernel's own dispatch packet
+// (start / stop time stamps of exactly that kernel: bench.py times the kernels this way, a
+// hipEventRecord in front of the launch would let the side stream's work overtake it).  Every
+// entry point takes them first thing, so a rejected call leaves nothing armed.
+void dn_take_launch_events(hipEvent_t* start, hipEvent_t* stop);   // gemm_f32.hip
+#define DN_LAUNCH_EV(K_, GRID_, BLOCK_, LDS_, STREAM_, ARGS_)                                        \
+  do {                                                                                               \
+    if (ev_start || ev_stop)                                                                         \
+      hipExtLaunchKernelGGL(K_, dim3(GRID_), dim3(BLOCK_), LDS_, STREAM_, ev_start, ev_stop, 0, ARGS_); \
+    else K_<<<GRID_, BLOCK_, LDS_, STREAM_>>>(ARGS_);                                                \
+  } while (0)
 
 #define LSTM_UNITS_FWD 8    // hidden units per workgroup (x4 gates = 32 columns)
 #define SPIN_LIMIT (1u << 20)
@@ -1358,6 +1371,8 @@ extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int n
                               float* ypad, int ldy, float* gates_f, float* gates_b,
                               float* cell_f, float* cell_b, void* ws, size_t ws_bytes,
                               int32_t* status, int flags) {
+  hipEvent_t ev_start, ev_stop;
+  dn_take_launch_events(&ev_start, &ev_stop);
   hipStream_t stream = (hipStream_t)stream_;
   int rc = lstm_check_common(T, B, H, ndir, ws, ws_bytes);
   if (rc) return rc;
@@ -1399,7 +1414,7 @@ extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int n
   do {                                                                               \
     DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_kernel<MTV, NWV, UNV>,  \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));                   \
-    lstm_fwd_kernel<MTV, NWV, UNV><<<nblk, 64 * NWV, pl.lds, stream>>>(a);           \
+    DN_LAUNCH_EV((lstm_fwd_kernel<MTV, NWV, UNV>), nblk, 64 * NWV, pl.lds, stream, a); \
   } while (0)
   // tiny batch (the B = 1 demo / inference path): GEMV on the vector ALU instead of 1/16-used
   // MFMA tiles.  DANET_LSTM_FWD_SMALL=0 keeps the MFMA kernel.
@@ -1409,8 +1424,8 @@ extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int n
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_small_kernel<1>,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (B == 1) lstm_fwd_small_kernel<1><<<ndir * pl.P, 256, lds, stream>>>(a);
-    else lstm_fwd_small_kernel<4><<<ndir * pl.P, 256, lds, stream>>>(a);
+    if (B == 1) DN_LAUNCH_EV(lstm_fwd_small_kernel<1>, ndir * pl.P, 256, lds, stream, a);
+    else DN_LAUNCH_EV(lstm_fwd_small_kernel<4>, ndir * pl.P, 256, lds, stream, a);
     DANET_CHECK_LAUNCH();
     return DANET_OK;
   }
@@ -1451,6 +1466,8 @@ extern "C" int danet_lstm_fwd_fused(danet_stream_t stream_, int T, int B, int H,
                                     float* ypad, int ldy, float* gates_f, float* gates_b,
                                     float* cell_f, float* cell_b, void* ws, size_t ws_bytes,
                                     int32_t* status, int flags) {
+  hipEvent_t ev_start, ev_stop;
+  dn_take_launch_events(&ev_start, &ev_stop);
   hipStream_t stream = (hipStream_t)stream_;
   int rc = lstm_check_common(T, B, H, ndir, ws, ws_bytes);
   if (rc) return rc;
@@ -1492,7 +1509,7 @@ extern "C" int danet_lstm_fwd_fused(danet_stream_t stream_, int T, int B, int H,
   do {                                                                                   \
     DANET_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fwd_fx_kernel<W_, E_>,         \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
-    lstm_fwd_fx_kernel<W_, E_><<<nblk, 256, lds, stream>>>(a);                           \
+    DN_LAUNCH_EV((lstm_fwd_fx_kernel<W_, E_>), nblk, 256, lds, stream, a);               \
   } while (0)
   // the early groups must fit the gate phase (~0.5 us = 4-5 groups), the window groups the
   // exchange wait (~1 us = 9 groups); measured at D = 600: 7 + 6 loses 0.27 us per step at the
@@ -1540,6 +1557,8 @@ extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int n
                               const float* cell_f, const float* cell_b,
                               float* da_f, float* da_b, float* db_f, float* db_b, float beta,
                               void* ws, size_t ws_bytes, int32_t* status, int flags) {
+  hipEvent_t ev_start, ev_stop;
+  dn_take_launch_events(&ev_start, &ev_stop);
   if (db_f) {
     DANET_CHECK_ARG(ndir == 1 || db_b, "lstm_bwd: null db pointer");
     DANET_CHECK_ARG((((uintptr_t)db_f | (uintptr_t)db_b) & 15) == 0, "lstm_bwd: db must be 16-B aligned");
@@ -1590,7 +1609,7 @@ extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int n
         if (g2 <= num_cus()) { a.xmap = 2; nblk = g2; }
       }
     }
-#define LAUNCH_RS(UV, NTWV) lstm_bwd_rs_kernel<UV, NTWV><<<nblk, 512, 0, stream>>>(a)
+#define LAUNCH_RS(UV, NTWV) DN_LAUNCH_EV((lstm_bwd_rs_kernel<UV, NTWV>), nblk, 512, 0, stream, a)
 #define LAUNCH_RS_U(UV)                                          \
     switch (rs.NTW) {                                            \
       case 1: LAUNCH_RS(UV, 1); break; case 2: LAUNCH_RS(UV, 2); break; \

@@ -623,7 +623,7 @@ def prepare_streams(dev):
     torch.cuda.synchronize(dev)
 
 
-# An event that rides on a stream-K launch's own dispatch packet (danet_gemm_next_launch_stop_event)
+# An event that rides on a stream-K launch's own dispatch packet (danet_next_launch_events)
 # instead of a hipEventRecord behind it: the record costs the launching stream ~4.4 us before its
 # next kernel, the attached event ~1.1 us, and the side chain starts ~3.7 us earlier
 # (tools/csrc/event_gap.hip).  Raw events from a small rotating pool per device (a slot is reused
@@ -642,7 +642,7 @@ class ForkEvent(object):
         '''the NEXT stream-K launch of this host thread completes the event; `attached` is set
         by the caller once that launch has been accepted (a rejected launch consumes the armed
         event inside the library and nothing may wait for it)'''
-        check(_L().danet_gemm_next_launch_stop_event(self.handle))
+        check(_L().danet_next_launch_events(None, self.handle))
 
 
 def fork_event(dev):

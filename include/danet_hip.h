@@ -217,7 +217,7 @@ int danet_gemm_f32_streamk_kcat(danet_stream_t stream, int transA, int transB, i
  * beta = 0; optional bias [N] added to every row.  K* and lda* multiples of 4, A* 16-byte aligned: DANET_ERR_UNSUPPORTED
  * otherwise (the caller falls back to danet_gemm_f32*).  A pack is valid until its weight changes:
  * the host re-packs after every optimizer step (one launch for the whole table).  An event armed
- * with danet_gemm_next_launch_stop_event completes with this product, as for stream-K launches.
+ * with danet_next_launch_events completes with this product, as for stream-K launches.
  * B(n, k) = src[n * stride_n + k * stride_k]; `out`: DANET_WS_GEMM_PACK(N, K) bytes, 16-B aligned.
  * `ws`: DANET_WS_GEMM_X6(M, N, K1, K2) bytes.                                                    */
 typedef struct {
@@ -240,12 +240,16 @@ int danet_gemm_x6(danet_stream_t stream, int M, int N,
 int danet_gemm_x6_tn_grouped(danet_stream_t stream, int K, int nprob, const danet_gemm_problem_t* probs,
                              void* ws, size_t ws_bytes);
 
-/* Fork without a separate event record: `event` (danet_event_create, or any hipEvent_t) is attached
- * to the NEXT stream-K or danet_gemm_x6 launch of the calling host thread (consumed by
- * it) and completes with that kernel; another stream then waits with danet_stream_wait_event.  A
- * hipEventRecord behind the launch costs the launching stream ~4 us before its next kernel, the
- * attached event ~1 us (tools/csrc/event_gap.hip).                                             */
-int danet_gemm_next_launch_stop_event(void* event);
+/* Events that ride on a kernel's own dispatch packet instead of separate hipEventRecord calls:
+ * `start` / `stop` (hipEvent_t; either may be NULL) are attached to the NEXT launch the calling host
+ * thread makes through danet_gemm_f32_streamk*, danet_gemm_x6 (stop only; a start event is dropped)
+ * or danet_lstm_fwd / danet_lstm_fwd_fused / danet_lstm_bwd (both), and are consumed by that call
+ * even if it fails.  Uses: (1) fork without an event record -- another stream waits for `stop` with
+ * danet_stream_wait_event; a hipEventRecord behind the launch costs the launching stream ~4 us
+ * before its next kernel, the attached event ~1 us (tools/csrc/event_gap.hip); (2) timing a
+ * recurrent kernel from its own start / stop time stamps (events created with timing enabled),
+ * which does not delay the launch relative to work on other streams.                           */
+int danet_next_launch_events(void* start, void* stop);
 int danet_event_create(void** event);
 int danet_event_destroy(void* event);
 int danet_stream_wait_event(danet_stream_t stream, void* event);
