@@ -659,6 +659,24 @@ def fork_event(dev):
     return ForkEvent(pool['ev'][pool['i']])
 
 
+# A deferred side chain (a weight-gradient group) and the main stream's next kernel (the next layer's
+# persistent BPTT kernel) become runnable at the same instant: when the launch the fork event rides on
+# completes.  Nothing orders the two dispatches, and in ~4 % of the launches the group got its 480
+# workgroups onto the CUs first: the BPTT kernel, whose workgroups exchange partials every time step,
+# then starts piecemeal and takes 470-500 us instead of 360 (tools/bptt_hist.sh).  One tiny kernel
+# in front of the group on the SIDE stream (a few microseconds of dispatch + run) lets the BPTT
+# kernel's workgroups go first; it costs the main stream nothing.  DANET_FORK_SPACER=0 switches it off.
+FORK_SPACER = __import__('os').environ.get('DANET_FORK_SPACER', '1') == '1'
+_spacer_buf = {}
+
+
+def _spacer(dev):
+    t = _spacer_buf.get(_dev_key(dev))
+    if t is None:
+        t = _spacer_buf[_dev_key(dev)] = torch.zeros(64, device=dev)
+    t.zero_()
+
+
 class _Fork(object):
     '''with _Fork(dev, n) as f:  f.run(i, fn)  -> fn runs on chain i
     (chain 0 = the current stream, chain i>0 = side stream i-1); join on exit.'''
@@ -710,6 +728,8 @@ class _Fork(object):
             if q:
                 self.keep = tuple(self.keep) + tuple(k for _f, k in q)
                 _flush_lazy(s.device)  # queued small kernels ride on this fork's event
+            elif self.defer and self.event is not None and FORK_SPACER:
+                _spacer(s.device)
             return fn()
 
     def after_all(self, fn, wait_main=False):
