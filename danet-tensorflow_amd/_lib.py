@@ -236,6 +236,8 @@ def profile_start(only=None):
     '''only: optional set of labels to time (every event pair costs ~1 us of stream
     time, so a timed benchmark region instruments just the kernel it reports)'''
     global _prof, _prof_only
+    if torch.cuda.is_available():
+        prepare_timing(64)          # (a no-op after prepare_timing())
     _prof = {}
     _prof_only = set(only) if only else None
 
@@ -264,11 +266,33 @@ def profile_stop():
 # starts piecemeal and the bracket reads 50 us more than the kernel takes in an untimed step.
 ATTACHED_LABELS = frozenset(('lstm_fwd', 'lstm_bwd'))
 _aux_stream = None
+_event_pool = []
 
 
 def _timing_event():
     '''a timing-enabled event whose native handle exists (torch creates it on first record; that
-    record goes to a stream nobody else uses)'''
+    record goes to a stream nobody else uses).  profile_start() fills a pool, so that a timed
+    region creates neither a stream nor events (a stream created inside a 20-step region cost it
+    5-6 ms on some boxes).'''
+    global _aux_stream
+    if _event_pool:
+        return _event_pool.pop()
+    return _timing_event_new()
+
+
+def prepare_timing(n=384):
+    '''create the side stream and a pool of timing events NOW (call before the warm-up steps of a
+    benchmark: creating them, and the synchronisation behind it, must not sit at the start of a
+    timed region)'''
+    made = False
+    while len(_event_pool) < n:
+        _event_pool.append(_timing_event_new())
+        made = True
+    if made:
+        torch.cuda.synchronize()
+
+
+def _timing_event_new():
     global _aux_stream
     if _aux_stream is None:
         _aux_stream = torch.cuda.Stream()
