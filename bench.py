@@ -47,6 +47,12 @@ PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 # fp32 products as six bf16 piece products (csrc/gemm_x6.hip): the dense bf16 peak / 6
 PEAK_X6_TFLOPS = 2516.6 / 6
 PEAK_HBM_GBS = 8000.0
+DTYPE_NOTE = ('fp32 tensors, fp32 accumulation, fp32-accurate results everywhere.  The large products '
+              '(projection, dYc, dX, weight gradients, hoisted LSTM input halves) are formed on the bf16 '
+              'matrix cores from an EXACT three-way split of every fp32 operand (hi + mid + lo bf16 pieces; '
+              'six of the nine piece products, the dropped ones < 2^-25 |a||b|): error against float64 at or '
+              'below the exact-fp32 matrix instructions\' (tests/test_gpu_gemm_x6.py, parity block of this '
+              'line; DESIGN.md 3.2).  DANET_GEMM_X6=0 runs the same step on v_mfma_f32_* only.')
 
 CONFIGS = {
     'cfg2': dict(kind='train', batch=32, frames=128, layers=3, hdim=300,
@@ -641,6 +647,7 @@ def run_train(args, cfg, hp, device, rank, world, use_dist):
                unit='mixture-seconds/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=round(1e3 * dt / args.steps, 3), higher_is_better=True,
                scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+               dtype_note=DTYPE_NOTE,
                config=dict(workload='%s: synthetic 8 kHz %d-spk, FFT %d/%d (%d bins), T=%d, '
                                     '%dx%d BiLSTM, E=%d, %s estimator%s, %s, B=%d/GPU'
                                     % (args.config, C, hp.FFT_SIZE, hp.FFT_STRIDE, F, T, L, H, E, est,
@@ -828,7 +835,7 @@ def run_infer(args, cfg, hp, device, rank, world, use_dist):
     res = dict(metric='mixture-seconds/s (inference, demo path)', value=round(world * mix_s * args.steps / dt, 2),
                 unit='mixture-seconds/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                 ms_per_step=round(1e3 * dt / args.steps, 3), higher_is_better=True,
-                scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                scaling='weak', vs_baseline=None, dtype='f32', data='synthetic', dtype_note=DTYPE_NOTE,
                 config=dict(workload='%s: synthetic %d Hz %d-spk utterance of %.1f s, FFT %d/%d (%d bins), '
                                      'T=%d, %dx%d BiLSTM, E=%d, %s estimator, B=1: stft -> infer -> istft'
                                      % (args.config, hp.SMPRATE, hp.MAX_N_SIGNAL, mix_s, N, S, F, T, L, H,
