@@ -233,3 +233,28 @@ def test_x6_bias_and_k_major_weight(M, N, K):
     ops.gemm_w(A, K, W, 1, N, C, M, N, K, N, bias=bias)
     ref = A.double() @ W.double() + bias.double()
     assert _err(C, ref) <= TOL
+
+
+def test_launch_events_time_a_recurrent_kernel_and_are_consumed(hp):
+    '''danet_next_launch_events(start, stop): the pair rides on the next recurrent launch (what
+    bench.py's roofline uses): the elapsed time is that kernel's, inside the host-side bracket; the
+    slot is empty afterwards (the following launch does not touch the events again)'''
+    from danet_amd import _lib, ops
+    from test_gpu_fullsize import _setup, _synth
+    model = _setup(hp, BATCH_SIZE=32, MAX_TRAIN_LEN=64)
+    src = _synth(hp, 32, 64, 3)
+    model.train_step(src)
+    torch.cuda.synchronize()
+    _lib.profile_start(only=('lstm_bwd',))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    model.train_step(src)
+    e1.record()
+    prof = _lib.profile_stop()
+    n, ms = prof['lstm_bwd']
+    assert n == hp.NUM_LSTM_LAYERS
+    assert 0.05 * n < ms < e0.elapsed_time(e1)              # three BPTT kernels inside one step
+    # nothing is left armed: an un-profiled step runs and the status stays clean
+    model.train_step(src)
+    torch.cuda.synchronize()
+    assert ops.lstm_status_ok()
