@@ -586,36 +586,17 @@ __device__ __forceinline__ void x6t_step(const X6TCtx& c, char* xsm, int kt, int
   const char* srdp = xsm + srd * TSTAGE;
   char* swrp = xsm + swr * TSTAGE;
   uint32_t h[4][2], m[4][2], l[4][2];
-#ifdef X6T_NO_LDSREAD
-#define X6T_FA(S, PC, I) x6t_mf<S>(acc, fac, fbc); fan[PC][I] = fac[PC][I]; X6_FENCE
-#define X6T_FB(S, PC, I) x6t_mf<S>(acc, fac, fbc); fbn[PC][I] = fbc[PC][I]; X6_FENCE
-#else
 #define X6T_FA(S, PC, I) x6t_mf<S>(acc, fac, fbc); fan[PC][I] = x6t_frag(srdp + (PC) * TIMG, c.roffa[I]); X6_FENCE
 #define X6T_FB(S, PC, I) x6t_mf<S>(acc, fac, fbc); fbn[PC][I] = x6t_frag(srdp + (3 + (PC)) * TIMG, c.roffb[I]); X6_FENCE
-#endif
   X6T_FA(0, 0, 0) X6T_FA(1, 0, 1) X6T_FA(2, 1, 0) X6T_FA(3, 1, 1) X6T_FA(4, 2, 0) X6T_FA(5, 2, 1)
   X6T_FB(6, 0, 0) X6T_FB(7, 0, 1) X6T_FB(8, 1, 0) X6T_FB(9, 1, 1) X6T_FB(10, 2, 0) X6T_FB(11, 2, 1)
 #undef X6T_FA
 #undef X6T_FB
-#ifdef X6T_NO_SPLIT
-#define X6T_S(S, LI, HF) x6t_mf<S>(acc, fac, fbc); h[LI][HF] = m[LI][HF] = l[LI][HF] = __float_as_uint(R[LI][2 * (HF)]) ^ __float_as_uint(R[LI][2 * (HF) + 1]); X6_FENCE
-#else
 #define X6T_S(S, LI, HF) x6t_mf<S>(acc, fac, fbc); split_pair(R[LI][2 * (HF)], R[LI][2 * (HF) + 1], h[LI][HF], m[LI][HF], l[LI][HF]); X6_FENCE
-#endif
   X6T_S(12, 0, 0) X6T_S(13, 0, 1) X6T_S(14, 1, 0) X6T_S(15, 1, 1) X6T_S(16, 2, 0) X6T_S(17, 2, 1) X6T_S(18, 3, 0) X6T_S(19, 3, 1)
 #undef X6T_S
-#ifdef X6T_NO_WRITE
-#define X6T_WR(LI) if (c.K < 0) x6t_write(swrp, c, LI, h[LI], m[LI], l[LI]);
-#else
-#define X6T_WR(LI) x6t_write(swrp, c, LI, h[LI], m[LI], l[LI]);
-#endif
-#ifdef X6T_NO_GLOBAL
-#define X6T_KT4 (c.K < 0 ? kt + 4 : c.kt1)
-#else
-#define X6T_KT4 (kt + 4)
-#endif
-#define X6T_W(S, LI) x6t_mf<S>(acc, fac, fbc); X6T_WR(LI)                          \
-  R[LI] = x6t_load<RAGGED>((LI) < 2 ? c.rsa : c.rsb, (LI) < 2 ? c.lda : c.ldb, (LI) < 2 ? c.mrem : c.nrem, c.K, X6T_KT4, \
+#define X6T_W(S, LI) x6t_mf<S>(acc, fac, fbc); x6t_write(swrp, c, LI, h[LI], m[LI], l[LI]);          \
+  R[LI] = x6t_load<RAGGED>((LI) < 2 ? c.rsa : c.rsb, (LI) < 2 ? c.lda : c.ldb, (LI) < 2 ? c.mrem : c.nrem, c.K, kt + 4, \
                            c.kt1, c.krow, c.mq4 + ((LI) & 1) * 64); X6_FENCE
   X6T_W(20, 0) X6T_W(21, 1) X6T_W(22, 2) X6T_W(23, 3)
 #undef X6T_W
