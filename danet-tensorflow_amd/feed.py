@@ -4,9 +4,10 @@ reference (main.py:417-431, :497-500), one batch AHEAD of the step that consumes
 
 The reference builds every batch on the host (dataset iterator -> reshape -> random crop to
 MAX_TRAIN_LEN, main.py:417-426) and hands it to `g_sess.run`, which copies it to the device
-synchronously.  Here, once step i has been enqueued, the loop does for batch i+1 -- while the
+synchronously.  Here, once step i has been enqueued, the loop does for batch i+2 -- while the
 device is still running the steps it has queued (the host enqueues a step in about a third of the
-time the device needs for it):
+time the device needs for it; batch i+1 went through the same before step i was enqueued, so its
+upload sits IN FRONT of step i's work on the upload stream):
 
     next(dataset iterator)
     draw the crop offset  randint(0, T-L-1)     (same `random` stream, same order as main.py:424-425)
@@ -22,7 +23,7 @@ stages and / or uploads (the main thread's enqueue slows from 1.2 to 2.9 ms per 
 the runtime's one-off 10-70 ms stall of a recurrent kernel comes back); an upload stream of its own
 (HIP maps streams onto a handful of hardware queues: depending on creation order the third stream
 shares a queue with the main or the side stream and the step is 1 ms slower -- the uploads ride on
-the existing side stream, which is idle at the step boundary); device buffers from the caching
+the existing side stream, which is idle during the forward pass); device buffers from the caching
 allocator (`record_stream`: re-allocation and event polling every step).
 '''
 from random import randint
@@ -93,7 +94,8 @@ class BatchFeed(object):
 
     mode (default: env DANET_FEED_MODE, else 'ahead' on a GPU and 'sync' on a CPU device):
       'sync'   the reference's literal form: convert, blocking upload from pageable memory
-      'ahead'  one batch ahead through pinned staging slots, uploads on ops.copy_stream()'''
+      'ahead'  through pinned staging slots, uploads on ops.copy_stream(), issued one step early
+               (batch i+1 is on its way before step i is enqueued)'''
 
     def __init__(self, source, device, crop_len=None, depth=3, mode=None):
         import os
@@ -174,12 +176,26 @@ class BatchFeed(object):
                 return self._upload(*self._stage(next(it)))
             except StopIteration:
                 return None
+            except Exception as e:     # raised when the batch's turn comes, not one batch early
+                return e
         try:
-            nxt = fetch()
-            while nxt is not None:
-                yield self._hand_out(*nxt)        # the consumer enqueues step i ...
+            # the upload of batch i+1 is ISSUED before the consumer enqueues step i, so on the
+            # device it runs during step i's forward pass (the upload stream is idle then) and not
+            # behind step i's side-stream work -- with a 2.8 ms step an upload queued behind the
+            # last weight-gradient group finished only just before the step did.  Batch i+2 is
+            # staged (0.3 ms of host time) while step i runs; its upload waits on the device for
+            # the step that last read its buffer (i-1).
+            def live(x):
+                return x is not None and not isinstance(x, Exception)
+            cur = fetch()
+            nxt = fetch() if live(cur) else None
+            while cur is not None:
+                if isinstance(cur, Exception):
+                    raise cur
+                yield self._hand_out(*cur)        # the consumer enqueues step i ...
                 self._consumed()
-                nxt = fetch()                     # ... then batch i+1 is staged and its upload issued
+                cur = nxt
+                nxt = fetch() if live(cur) else None         # ... then batch i+2 is staged and issued
         finally:
             self._consumed()                      # (a consumer that left the loop early: its last
             self._ent['busy'] = False             # batch's buffer is protected all the same)

@@ -278,9 +278,10 @@ def _varlen_batches(hp, n, seed=3):
 
 
 def test_batch_feed_ahead_equals_synchronous_loop(hp):
-    '''feed.BatchFeed: the one-batch-ahead feed yields exactly the tensors of the reference's
-    synchronous loop (reshape, cast to complex64, random crop to MAX_TRAIN_LEN with the SAME draws
-    from python's `random`, main.py:417-426), one iterator item ahead of the consumer'''
+    '''feed.BatchFeed: the feed yields exactly the tensors of the reference's synchronous loop
+    (reshape, cast to complex64, random crop to MAX_TRAIN_LEN with the SAME draws from python's
+    `random`, main.py:417-426); batch i+1 has been fetched (its upload issued) before the consumer
+    gets batch i, batch i+2 is fetched only after the consumer is back'''
     from danet_amd import feed
     _toy_dataset(hp)
     batches = _varlen_batches(hp, 9)
@@ -295,7 +296,7 @@ def test_batch_feed_ahead_equals_synchronous_loop(hp):
             yield b
     ahead = []
     for i, t in enumerate(feed.BatchFeed(source(), 'cpu', hp.MAX_TRAIN_LEN, mode='ahead')):
-        assert pulled[-1] == i            # batch i+1 is fetched only after the consumer is back
+        assert pulled[-1] == min(i + 1, 8)
         ahead.append(t.clone())
     assert len(sync) == len(ahead) == 9
     for a, b, (raw,) in zip(sync, ahead, batches):
