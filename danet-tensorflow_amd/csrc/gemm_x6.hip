@@ -401,13 +401,29 @@ extern "C" int danet_gemm_pack_weights(danet_stream_t stream, int n, const danet
   return DANET_OK;
 }
 
+// How many K slices?  `tiles` workgroups of `nkt` k-steps each on 512 slots (2 per CU).  Model of the
+// launch, in units of one whole tile's time: the workgroups run in rounds of 512; a last round that
+// fills a fraction f of the slots still takes 0.55 + 0.45 f of a round (its workgroups have the CUs
+// to themselves but hide less latency); s slices divide a workgroup's time by s and cost the slab
+// traffic of s partial tiles per tile plus one more launch (calibrated on the TN groups of cfg 2 and
+// cfg 4: 0.032 tile-times per slice for tiles / nkt = 1, i.e. a short-K product with a large output
+// is never sliced).  Measured against it: 160 tiles x 150-256 steps -> 3 (2 / 4: +15 %), 100 -> 5,
+// 105 -> 4, 570 x 256 -> 2-3 (1: +2 % of the cfg-4h600 step), 266 x 256 -> 3.
+static int x6_slices(int tiles, int nkt, int min_steps, int max_slices) {
+  double best = 1e30;
+  int bs = 1;
+  for (int s = 1; s <= max_slices; ++s) {
+    if (s > 1 && nkt / s < min_steps) break;
+    const double r = (double)tiles * s / 512.0;
+    const double whole = (double)(long long)r, frac = r - whole;
+    const double rounds = whole + (frac > 0.0 ? 0.55 + 0.45 * frac : 0.0);
+    const double cost = rounds / s + (s > 1 ? 0.02 + 0.032 * tiles / max(nkt, 1) * (s - 1) : 0.0);
+    if (cost < best - 1e-9) { best = cost; bs = s; }
+  }
+  return bs;
+}
 static int x6_splitk(int M, int N, int nkt) {
-  // cut along K while the tiles alone leave more than a third of the workgroup slots (2 per CU)
-  // empty and every slice keeps >= 24 k-tiles; <= 4 slices
-  const int nt = cdiv(M, XBM) * cdiv(N, XBN);
-  int s = 1;
-  while (s < 4 && nt * s * 3 < 512 * 2 && nkt / (s + 1) >= 24) ++s;
-  return s;
+  return x6_slices(cdiv(M, XBM) * cdiv(N, XBN), nkt, 12, 4);
 }
 
 size_t dn_ws_gemm_x6(int M, int N, int K1, int K2) {
@@ -749,13 +765,7 @@ __global__ __launch_bounds__(256) void gemm_x6_tn_reduce_kernel(X6TArgs g) {
   }
 }
 
-static int x6t_splitk(int tiles, int K) {
-  // as many K slices as fit the workgroup slots (2 per CU), every slice >= 16 k-steps, <= 8
-  const int nkt = cdiv(K, 16);
-  int s = max(1, min(8, 512 / max(tiles, 1)));
-  while (s > 1 && nkt / s < 16) --s;
-  return s;
-}
+static int x6t_splitk(int tiles, int K) { return x6_slices(tiles, cdiv(K, 16), 16, 8); }
 size_t dn_ws_gemm_x6_tn(long long sum_mn, int tiles, int K) {
   const int s = x6t_splitk(tiles, K);
   return s > 1 ? (size_t)s * (size_t)sum_mn * sizeof(float) : 0;
