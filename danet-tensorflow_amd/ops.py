@@ -922,14 +922,17 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs, x_pad_zero=False, ypad=None, ws=N
 # main stream?  Under: the group is hidden but the BPTT kernel beside it slows down for as long as
 # the overlap lasts.  Measured: H = 300 (cfg 2 / cfg 4) 3.61 / 5.13 ms per step overlapped vs
 # 3.90 / 5.62 serial; H = 600 (cfg 4 as written) 14.3 overlapped vs 13.7 serial (the group lasts
-# 0.9-1.3 ms there and costs the BPTT kernel 0.7 ms).  'auto' = overlap up to H = 384.
+# 0.9-1.3 ms there and costs the BPTT kernel 0.7 ms).  'auto' = overlap up to H = 384 with the
+# exact-fp32 groups, always with the groups on the bf16 matrix cores (round 4).
 DW_OVERLAP = __import__('os').environ.get('DANET_DW_OVERLAP', 'auto')
 
 
 def _overlap_dw(H):
     if DW_OVERLAP in ('0', '1'):
         return DW_OVERLAP == '1'
-    return H <= 384
+    # (with the groups on the bf16 matrix cores the overlap wins at H = 600 as well: cfg 4 as
+    # written 9.66 overlapped vs 9.86 serial on the same box, BPTT 674 vs 575 us)
+    return H <= 384 or bool(GEMM_X6 & 2)
 
 
 # experiment: fork the weight-gradient group BEFORE dX (the two GEMMs share the GPU, the next
