@@ -20,7 +20,8 @@ BUILD = os.path.join(CSRC, 'build')
 LIB = os.path.join(CSRC, 'libdanet_hip.so')
 ARCH = 'gfx950'
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE,
+# -fvisibility=hidden: only what include/danet_hip.h declares (inside its visibility pragma) is exported
+FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-I' + INCLUDE,
          '-I' + CSRC, '-Wno-unused-result']
 # extra -D switches for A/B builds, e.g. DANET_BUILD_DEFS='-DBK=32' (use --force)
 FLAGS += os.environ.get('DANET_BUILD_DEFS', '').split()
@@ -39,19 +40,27 @@ def _headers_mtime():
     return m
 
 
-def _compile(src, force, hdr_m):
-    obj = os.path.join(BUILD, os.path.splitext(src)[0] + '.o')
+def _compile(src, force, hdr_m, bdir=BUILD, defs=()):
+    obj = os.path.join(bdir, os.path.splitext(src)[0] + '.o')
     sp = os.path.join(CSRC, src)
     if (not force and os.path.exists(obj)
             and os.path.getmtime(obj) > max(os.path.getmtime(sp), hdr_m)):
         return obj, False
-    cmd = [HIPCC] + FLAGS + ['-c', sp, '-o', obj]
+    cmd = [HIPCC] + FLAGS + list(defs) + ['-c', sp, '-o', obj]
     if src.endswith('.hip'):
         cmd[1:1] = ['-x', 'hip']
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))
     return obj, True
+
+
+def _link(objs, out):
+    cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC',
+           '-Wl,--version-script=' + os.path.join(CSRC, 'exports.map'), '-o', out] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
 
 
 def build(force=False, verbose=True):
@@ -63,43 +72,31 @@ def build(force=False, verbose=True):
     objs = [o for o, _ in res]
     rebuilt = any(r for _, r in res)
     if rebuilt or not os.path.exists(LIB):
-        cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
+        _link(objs, LIB)
     if verbose:
         print('libdanet_hip.so: %s (%d objects, %s)' % (
             LIB, len(objs), 'rebuilt' if rebuilt else 'up to date'))
     return LIB
 
 
-def build_trace():
-    '''diagnostic variant csrc/libdanet_hip_trace.so (-DDANET_LSTM_TRACE): the
-    persistent LSTM kernels time-stamp every step (tools/trace_lstm.py)'''
-    out = os.path.join(CSRC, 'libdanet_hip_trace.so')
-    srcs = [os.path.join(CSRC, f) for f in _sources()]
-    cmd = [HIPCC] + FLAGS + ['-DDANET_LSTM_TRACE', '-shared', '-o', out]
-    for sp in srcs:
-        cmd += (['-x', 'hip', sp] if sp.endswith('.hip') else ['-x', 'c++', sp])
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError('trace build failed:\n%s\n%s' % (r.stdout, r.stderr))
-    return out
-
-
 def build_variant(name, defs):
     '''A/B variant csrc/libdanet_hip_<name>.so compiled with extra -D switches (e.g.
-    name='accmath', defs=['-DDANET_LSTM_ACCURATE_MATH']); loaded instead of the product
-    library when DANET_LIB_PATH points at it (tests / tools only).'''
+    name='accmath', defs=['-DDANET_LSTM_ACCURATE_MATH']; name='trace',
+    defs=['-DDANET_LSTM_TRACE']: the persistent LSTM kernels time-stamp every step,
+    tools/trace_lstm.py); loaded instead of the product library when DANET_LIB_PATH points at it
+    (tests / tools only).  Objects under csrc/build_<name>/.'''
     out = os.path.join(CSRC, 'libdanet_hip_%s.so' % name)
-    srcs = [os.path.join(CSRC, f) for f in _sources()]
-    cmd = [HIPCC] + FLAGS + list(defs) + ['-shared', '-o', out]
-    for sp in srcs:
-        cmd += (['-x', 'hip', sp] if sp.endswith('.hip') else ['-x', 'c++', sp])
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError('variant build failed:\n%s\n%s' % (r.stdout, r.stderr))
+    bdir = os.path.join(CSRC, 'build_' + name)
+    os.makedirs(bdir, exist_ok=True)
+    srcs = _sources()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        res = list(ex.map(lambda s: _compile(s, True, 0.0, bdir, defs), srcs))
+    _link([o for o, _ in res], out)
     return out
+
+
+def build_trace():
+    return build_variant('trace', ['-DDANET_LSTM_TRACE'])
 
 
 if __name__ == '__main__':

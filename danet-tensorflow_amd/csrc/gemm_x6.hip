@@ -23,6 +23,7 @@
 // `splitk` slices whose partial tiles a second kernel sums in slice order (deterministic).
 #include "common.h"
 #include <hip/hip_ext.h>
+#include <atomic>
 #include "danet_hip.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -433,6 +434,19 @@ size_t dn_ws_gemm_x6(int M, int N, int K1, int K2) {
 
 hipEvent_t dn_take_stop_event();   // gemm_f32.hip: the event armed by danet_next_launch_events
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: set it once per (kernel,
+// device) -- `done` = the kernel's bit mask of devices that have it; a failed set is an error
+static hipError_t x6_set_lds(const void* fn, int bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_relaxed) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_relaxed);
+  return e;
+}
+
 extern "C" int danet_gemm_x6(danet_stream_t stream_, int M, int N,
                              int K1, const float* A1, int lda1, const void* B1pk,
                              int K2, const float* A2, int lda2, const void* B2pk,
@@ -450,10 +464,8 @@ extern "C" int danet_gemm_x6(danet_stream_t stream_, int M, int N,
   DANET_CHECK_ARG(((((uintptr_t)B1pk | (uintptr_t)B2pk) & 15) == 0), "gemm_x6: packed weight alignment");
   DANET_CHECK_ARG((int64_t)M * lda1 < (1ll << 29) && (K2 == 0 || (int64_t)M * lda2 < (1ll << 29)),
                   "gemm_x6: an operand spans 2 GiB or more");
-  static const bool once = [] {
-    return hipFuncSetAttribute((const void*)gemm_x6_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               X6_SMEM_BYTES) == hipSuccess; }();
-  (void)once;
+  { static std::atomic<unsigned long long> done{0};
+    DANET_CHECK_HIP(x6_set_lds((const void*)gemm_x6_nt_kernel, X6_SMEM_BYTES, done)); }
   X6Args g;
   g.A[0] = A1; g.Bp[0] = (const u32x4*)B1pk; g.lda[0] = lda1; g.K[0] = K1; g.KT[0] = cdiv(K1, XBK);
   g.A[1] = A2; g.Bp[1] = (const u32x4*)B2pk; g.lda[1] = lda2; g.K[1] = K2; g.KT[1] = cdiv(K2, XBK);
@@ -815,12 +827,9 @@ extern "C" int danet_gemm_x6_tn_grouped(danet_stream_t stream_, int K, int nprob
       return DANET_ERR_WORKSPACE;
     }
   }
-  static const bool once = [] {
-    return hipFuncSetAttribute((const void*)gemm_x6_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               X6T_SMEM_BYTES) == hipSuccess &&
-           hipFuncSetAttribute((const void*)gemm_x6_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               X6T_SMEM_BYTES) == hipSuccess; }();
-  (void)once;
+  { static std::atomic<unsigned long long> done[2];
+    DANET_CHECK_HIP(x6_set_lds((const void*)gemm_x6_tn_kernel<false>, X6T_SMEM_BYTES, done[0]));
+    DANET_CHECK_HIP(x6_set_lds((const void*)gemm_x6_tn_kernel<true>, X6T_SMEM_BYTES, done[1])); }
   dim3 grid((unsigned)(tiles * s)), block(256);
   if (ragged) gemm_x6_tn_kernel<true><<<grid, block, X6T_SMEM_BYTES, stream>>>(g);
   else gemm_x6_tn_kernel<false><<<grid, block, X6T_SMEM_BYTES, stream>>>(g);

@@ -45,9 +45,14 @@ def init_from_env(backend='nccl', device=None):
 
 
 def broadcast_params_(flat, src=0):
-    '''identical initial parameters on every rank'''
+    '''identical parameters on every rank.  A c10d collective writes `flat` without touching
+    torch's version counter, so the operand-layout copies of the weights (ops.packed_weight) are
+    marked stale HERE -- otherwise a receiving rank would keep multiplying with its pre-broadcast
+    packs (e.g. the NaN weights a restore was meant to replace).'''
     if is_dist():
         dist.broadcast(flat, src=src)
+        from . import ops
+        ops.weights_written(flat)
     return flat
 
 

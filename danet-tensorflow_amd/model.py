@@ -404,6 +404,15 @@ class Model(object):
                 v.copy_(torch.as_tensor(data[k]).to(self.device))
         return True
 
+    def weights_written(self):
+        '''REQUIRED after any write to the parameters that torch's version counter does not see
+        (`param.data` arithmetic, c10d collectives, an external optimizer or kernel writing
+        through raw pointers): marks the operand-layout copies of the weights (ops.packed_weight,
+        read by the projection / dYc / dX / gx products) stale, so the next product re-packs them.
+        In-place torch ops on the variables themselves and this package's own optimizer step need
+        no call.'''
+        ops.weights_written(self._flat)
+
     def load_param_dict(self, di):
         '''set variables from {tf_variable_name: ndarray} (tests / oracle parity)'''
         with torch.no_grad():

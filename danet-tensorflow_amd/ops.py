@@ -1343,6 +1343,8 @@ _lazy = {}          # device index -> [(fn, keep)]
 
 
 def _dev_key(dev):
+    if dev is not None and dev.type != 'cuda':
+        return dev.type                    # (host tensors: the data-parallel CPU tests)
     return dev.index if (dev is not None and dev.index is not None) else torch.cuda.current_device()
 
 

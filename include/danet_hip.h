@@ -39,6 +39,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden and linked against csrc/exports.map: exactly the
+ * entry points declared between this push and the pop at the end of the file are exported
+ * (`nm -D libdanet_hip.so` shows danet_* and nothing else of the library's own).              */
+#pragma GCC visibility push(default)
 
 #define DANET_OK 0
 #define DANET_ERR_ARG (-1)          /* bad shape / null pointer / misalignment */
@@ -503,6 +507,7 @@ int danet_adam_clip_step(danet_stream_t stream, int64_t n, float* theta,
                          float beta1, float beta2, float eps, float clip,
                          float grad_scale, int zero_grad);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

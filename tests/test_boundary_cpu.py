@@ -35,6 +35,13 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert set(_lib.PROTOTYPES) == set(syms), set(_lib.PROTOTYPES) ^ set(syms)
     assert lib.danet_abi_version() == 5
     assert len(syms) <= 50                  # round 4: the ABI is what ships, not every experiment
+    # ... and NOTHING else of the library's own is exported (-fvisibility=hidden + csrc/exports.map):
+    # the dynamic symbol table holds the declared entry points only
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True)
+    exported = sorted(l.split()[-1] for l in out.stdout.splitlines() if l.strip())
+    assert exported and all(e.startswith('danet_') for e in exported), [e for e in exported if not e.startswith('danet_')][:5]
+    assert set(exported) == set(syms), set(exported) ^ set(syms)
     # pure host-side helpers are callable without a GPU
     assert lib.danet_stft_num_frames(8000, 256, 64) == 126
     assert lib.danet_stft_num_frames(160000, 512, 128) == 1251

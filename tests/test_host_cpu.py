@@ -181,6 +181,21 @@ ok = ok and (rank != 1 or m.saved == [])     # only rank 0 writes files
 t = m._flat.clone()
 torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
 ok = ok and bool(torch.equal(t, m._flat)) and float(m._flat[0]) == 4 * nb - nb
+# ADVICE r4: the restore's broadcast reaches the other ranks through a c10d collective, which does
+# not bump torch's version counter -- dist.broadcast_params_ itself must mark the packed weights
+# that overlap the received range stale (rank 1 would otherwise keep its pre-restore packs)
+from danet_amd import ops
+w = torch.zeros(64) + rank
+pw = object.__new__(ops._PackedWeight)
+pw.W, pw.lo, pw.hi, pw.stale, pw.version, pw.unused = w, w.data_ptr() + 16, w.data_ptr() + 64, False, w._version, 0
+other = torch.zeros(8)
+po = object.__new__(ops._PackedWeight)
+po.W, po.lo, po.hi, po.stale, po.version, po.unused = other, other.data_ptr(), other.data_ptr() + 32, False, 0, 0
+ops._packs[ops._dev_key(w.device)] = {'w': pw, 'other': po}
+v0 = w._version
+dist.broadcast_params_(w)
+ok = ok and float(w[5]) == 0.0 and pw.stale and not po.stale and (rank == 0 or w._version == v0 or pw.stale)
+ops._packs.clear()
 # identical learning-rate history on both ranks (decisions taken on the rank-mean loss)
 lr = torch.tensor(m.lr_log + [0.0] * (8 - len(m.lr_log)))
 lr2 = lr.clone(); torch.distributed.all_reduce(lr2, op=torch.distributed.ReduceOp.MAX)
