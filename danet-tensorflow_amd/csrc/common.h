@@ -9,7 +9,25 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
 #define DANET_WAVE 64
+
+// fp32 products on the bf16 matrix cores (csrc/gemm_x6.hip; the recurrent half of
+// lstm_fwd_fx_kernel): every fp32 value is EXACTLY hi + mid + lo with three bf16 pieces of 8
+// significant bits.  (x0, x1) -> the packed bf16 pairs of their pieces (x0 in the low half):
+// v_cvt_pk_bf16_f32 rounds to nearest even, the remainders are exact in fp32 and the third piece
+// has <= 8 significant bits left.
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){x0, x1}, bf16x2v));
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
+  m = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){r0, r1}, bf16x2v));
+  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xFFFF0000u);
+  l = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){s0, s1}, bf16x2v));
+}
 
 extern "C" void danet_set_error(const char* fmt, ...);
 

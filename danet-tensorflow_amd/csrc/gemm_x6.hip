@@ -56,17 +56,7 @@ __device__ __forceinline__ void split3(float x, uint32_t& h, uint32_t& m, uint32
   m = (__float_as_uint(r) + 0x8000u) & 0xFFFF0000u;
   l = __float_as_uint(r - __uint_as_float(m));
 }
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// (x0, x1) -> the packed bf16 pairs of their three pieces; v_cvt_pk_bf16_f32 rounds to nearest even,
-// the remainders are exact in fp32 and the third piece has <= 8 significant bits left
-__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
-  h = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){x0, x1}, bf16x2));
-  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
-  m = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){r0, r1}, bf16x2));
-  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xFFFF0000u);
-  l = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){s0, s1}, bf16x2));
-}
+// (split_pair: csrc/common.h)
 
 // the high halves of two words as one word: [hi16(b) | hi16(a)]
 __device__ __forceinline__ uint32_t pack_hi(uint32_t a, uint32_t b) {

@@ -532,9 +532,21 @@ struct LstmFwdFxArgs {
 // AHEAD while waves 0 and 1 do the gate math of the previous step (the 128 owner threads are all in
 // waves 0 and 1; waves 2 and 3 used to idle through that phase).  k-group of (wave, window g) =
 // g * 4 + wave; of (wave >= 2, early e) = 4 * CHX + 2 * e + wave - 2.
+//
+// Round 5: the RECURRENT half runs on the bf16 matrix cores.  h_{t-1} * Wh on v_mfma_f32_16x16x4_f32
+// was 40 dependent-issue matrix instructions of 32 clocks per wave and step (0.58 us, all of it
+// behind the exchange).  Both operands are now split EXACTLY into three bf16 pieces (csrc/common.h
+// split_pair; six of the nine piece products accumulated in fp32, the dropped ones < 2^-25 |h||w|:
+// the arithmetic of csrc/gemm_x6.hip) and one v_mfma_f32_16x16x32_bf16 covers 32 k in 17 clocks: 36
+// instructions.  The exchange is untouched (fp32 words in the layer's output buffer, the same five
+// 16-byte loads per lane): a lane's two 4-float fragments of k-groups 2b and 2b+1 ARE the 8 k of its
+// A operand in k-block b -- the weights are laid out for that k set.  (Splitting at the PRODUCER instead, with
+// the pieces as the exchange payload, was built first and lost 0.7 us per step to the hand-off:
+// profiles/r05_b_fwd_producer_split.txt.)
 template <int CHX, int CHE>
 __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
   constexpr int NW = 4, CH = FWD_CH;
+  constexpr int NB = (CH + 1) / 2;      // k-blocks of 32 = pairs of 16-k groups per wave
 #ifdef FX_CHA_ABS
   constexpr int CHA = FX_CHA_ABS < CHX ? FX_CHA_ABS : CHX;
 #else
@@ -588,16 +600,26 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
   const int fr = lane & 15, fq = lane >> 4;
   const int NG = a.KP / 16;
 
-  // stationary fragments: recurrent half (from LDS) and input half (straight from global)
-  f32x4 wreg[CH][2];
+  // stationary fragments: recurrent half (bf16 pieces, from LDS) and input half (straight from global).
+  // B operand of v_mfma_f32_16x16x32_bf16: lane (n = lane % 16, kq = lane / 16) holds column n's
+  // weights of the 8 k this lane GROUP's A fragments carry in k-block b: elements 0..3 = k-group 2b,
+  // elements 4..7 = k-group 2b+1, k = 16 (g * NW + wave) + 4 kq + j each.
+  uint32_t wreg[NB][3][2][4];
 #pragma unroll
-  for (int g = 0; g < CH; ++g) {
-    const int kg = g * NW + wave;
-    const int k4 = (kg < NG ? kg : 0) * 4 + fq;
-    wreg[g][0] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + fr) * 4]);
-    wreg[g][1] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * 32 + 16 + fr) * 4]);
-    if (kg >= NG) { wreg[g][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; wreg[g][1] = wreg[g][0]; }
-  }
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      float w[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int g = 2 * b + (e >> 2);
+        const int k = (g * NW + wave) * 16 + fq * 4 + (e & 3);
+        w[e] = (g < CH && k < a.KP) ? Wl[((k >> 2) * 32 + nt * 16 + fr) * 4 + (k & 3)] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        split_pair(w[2 * q], w[2 * q + 1], wreg[b][0][nt][q], wreg[b][1][nt][q], wreg[b][2][nt][q]);
+    }
   f32x4 wx[CHX][2];
 #pragma unroll
   for (int g = 0; g < CHX; ++g) {
@@ -765,29 +787,51 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
 #pragma unroll
     for (int g = 0; g < CHE; ++g) xne[g] = (v4u){0u, 0u, 0u, 0u};
     __builtin_amdgcn_sched_barrier(0);
+    // pieces of k-block b: [piece] x 4 words = the lane's 8 k as bf16 (groups 2b | 2b+1)
+#define FX_SPLIT(B_, DST_)                                                                       \
+    do {                                                                                         \
+      const f32x4 lo_ = __builtin_bit_cast(f32x4, av[2 * (B_)]);                                 \
+      const f32x4 hi_ = (2 * (B_) + 1 < CH) ? __builtin_bit_cast(f32x4, av[(2 * (B_) + 1 < CH) ? 2 * (B_) + 1 : 0]) \
+                                            : (f32x4){0.f, 0.f, 0.f, 0.f};                       \
+      split_pair(lo_[0], lo_[1], DST_[0][0], DST_[1][0], DST_[2][0]);                            \
+      split_pair(lo_[2], lo_[3], DST_[0][1], DST_[1][1], DST_[2][1]);                            \
+      split_pair(hi_[0], hi_[1], DST_[0][2], DST_[1][2], DST_[2][2]);                            \
+      split_pair(hi_[2], hi_[3], DST_[0][3], DST_[1][3], DST_[2][3]);                            \
+    } while (0)
+    uint32_t ap[NB][3][4];
+    FX_SPLIT(0, ap[0]);
 #pragma unroll
-    for (int g = 0; g < CH; ++g) {
-      const f32x4 af = __builtin_bit_cast(f32x4, av[g]);
-      const f32x4 w0 = wreg[g][0], w1 = wreg[g][1];
+    for (int b = 0; b < NB; ++b) {
+      if (b > 0) FX_SPLIT(b, ap[b]);
+      // six piece products per column tile, small terms first (A piece, B piece); the two column
+      // tiles alternate, each on two accumulators
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[0][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], w0[j], acc[0][j & 1], 0, 0, 0);
-        acc[1][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], w1[j], acc[1][j & 1], 0, 0, 0);
+      for (int t6 = 0; t6 < 6; ++t6) {
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#define FX_OP(P_) __builtin_bit_cast(bf16x8v, (u32x4v){(P_)[0], (P_)[1], (P_)[2], (P_)[3]})
+        const bf16x8v af = FX_OP(ap[b][PA[t6]]);
+        acc[0][t6 & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, FX_OP(wreg[b][PB[t6]][0]), acc[0][t6 & 1], 0, 0, 0);
+        acc[1][t6 & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, FX_OP(wreg[b][PB[t6]][1]), acc[1][t6 & 1], 0, 0, 0);
+#undef FX_OP
       }
+      // (interleaving the next block's split with these matrix instructions -- sched_group_barrier,
+      // one MFMA : three VALU -- was measured SLOWER, 0.73 -> 0.83 us for this phase: an issue slot
+      // between two back-to-back 16x16x32 instructions costs more than the split hides)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = g; i < CHX; i += CH)
+      for (int i = b; i < CHX; i += NB)
         xn[i] = __builtin_amdgcn_raw_buffer_load_b128(
             xres, (!have || xoff[i] == 0xFFFFFFFFu) ? xbytes : xoff[i] + (unsigned)tn * xblk, 0, 0);
       // (waves 0 and 1 skip the early groups' loads: even an out-of-range load costs issue time)
       if (early) {
 #pragma unroll
-        for (int i = g; i < CHE; i += CH)
+        for (int i = b; i < CHE; i += NB)
           xne[i] = __builtin_amdgcn_raw_buffer_load_b128(
               xres, (!have || xoffe[i] == 0xFFFFFFFFu) ? xbytes : xoffe[i] + (unsigned)tn * xblk, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+#undef FX_SPLIT
     // cross-wave reduction.  D layout 16x16: col = lane&15, row = 4*(lane>>4)+r
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
