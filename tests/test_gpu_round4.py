@@ -323,3 +323,9 @@ def test_bench_two_ranks_functional(tmp_path):
     per_step = 8 * 32 * 64 / 8000.0
     assert abs(res['value'] - 2 * per_step / (res['ms_per_step'] * 1e-3)) < 1e-2 * res['value']
     assert res['e2e']['ms_per_step'] > 0 and 'test_mode' in res
+    # one run settles the gradient-reduction schedule: all three timed in the same
+    # process group, next to the step without any reduction
+    sc = res['schedules']
+    assert set(sc['ms_per_step']) == {'0', 'tail', '1'} and all(v > 0 for v in sc['ms_per_step'].values())
+    assert sc['no_reduction_ms_per_step'] > 0 and set(sc['exposed_comm_ms']) == {'0', 'tail', '1'}
+    assert 'timed_region_note' in res
