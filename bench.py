@@ -361,7 +361,7 @@ def _fill_parity(res, rep, mse, model):
         perm_idx_equal=rep['perm_idx_equal'], fused_heads=rep.get('fused_heads'))
 
 
-# functional test of the N > 1 path on a 1-GPU box (tests/test_gpu_round4.py): every rank uses
+# functional test of the N > 1 path on a 1-GPU box (tests/test_gpu_dist.py): every rank uses
 # device 0 and the group is gloo (RCCL refuses two ranks on one device).  The line it prints is
 # marked and is NOT a measurement.
 SHARED_GPU_TEST = os.environ.get('DANET_BENCH_TEST_SHARED_GPU') == '1'

@@ -147,6 +147,39 @@ def load():
     return _lib
 
 
+# ---- switches ------------------------------------------------------------------
+# USER switches (README): DANET_GEMM_X6, DANET_LSTM_FWD_FUSED, DANET_SIDE_STREAMS, DANET_FEED_MODE,
+# DANET_OVERLAP_ALLREDUCE, DANET_MAX_STEPS_IN_FLIGHT, DANET_STATUS_HOST, DANET_FUSE_HEADS,
+# DANET_LSTM_SPIN_LIMIT, DANET_LSTM_FAULT_INJECT, DANET_LIB_PATH (+ three of bench.py).  Everything
+# else -- the schedule knobs of the exact-fp32 fallback kernels, placement and fork details, the
+# remaining library options -- is an EXPERT setting behind ONE variable:
+#     DANET_EXPERT="streamk=5,grouped_dw=0,gemm_yield=8"
+# (names: the lower-case module constants of ops.py / model.py that call `expert()`, and the library
+# options of csrc/options.h).  Defaults are the shipped, measured configuration.
+_expert = None
+
+
+def expert(name, default):
+    '''value of the expert setting `name` (DANET_EXPERT="name=value,...") or `default`, as
+    type(default)'''
+    global _expert
+    if _expert is None:
+        _expert = {}
+        for item in os.environ.get('DANET_EXPERT', '').split(','):
+            if item.strip():
+                k, _, v = item.partition('=')
+                _expert[k.strip().lower()] = v.strip()
+    v = _expert.get(name.lower())
+    if v is None:
+        return default
+    if isinstance(default, bool):
+        return v not in ('0', 'false', 'no', '')
+    return type(default)(v)
+
+
+USER_OPTIONS = ('lstm_fwd_fused', 'lstm_spin_limit', 'lstm_fault_inject')   # library options with a DANET_<NAME> variable
+
+
 # ---- library options ---------------------------------------------------------
 # The C library never reads the environment (include/danet_hip.h); the DANET_* overrides of
 # its options live HERE: option `lstm_fwd_fused` <- env DANET_LSTM_FWD_FUSED, applied when the
@@ -161,8 +194,10 @@ def apply_env_options():
     lib = _lib
     lib.danet_reset_options()
     for name in option_names():
-        v = os.environ.get('DANET_' + name.upper())
-        if v is not None and v.strip() != '':
+        v = os.environ.get('DANET_' + name.upper()) if name in USER_OPTIONS else None
+        if v is None or v.strip() == '':
+            v = expert(name, '')
+        if v != '':
             check(lib.danet_set_option(name.encode(), int(v)))
 
 

@@ -29,9 +29,9 @@ from . import utils
 from .model import Model
 
 
-# DANET_SYNC_FEED=1: the reference's literal loop (blocking upload, a host read of every metric
+# DANET_FEED_MODE=sync (or --sync-feed): the reference's literal loop (blocking upload, a host read of every metric
 # every step) instead of the one-batch-ahead feed
-SYNC_FEED = os.environ.get('DANET_SYNC_FEED', '0') == '1'
+SYNC_FEED = os.environ.get('DANET_FEED_MODE', 'ahead') == 'sync'      # (also: --sync-feed)
 
 
 def _dict_format(di):

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from .hparams import hparams
-from . import ops
+from . import _lib, ops
 from . import modules  # noqa: F401  (registers the plugins)
 from . import ozers    # noqa: F401  (registers the optimisers)
 from . import dist
@@ -164,7 +164,7 @@ class Model(object):
             cls = dist.GradBuckets if mode == '1' else dist.TailOverlap
             self._buckets = cls(self._grad_store if dist.is_dist() else grad, offs)
             ops.add_grad_ready_hook(self._buckets.hook)
-        # early optimizer step (opt-in: DANET_EARLY_ADAM=1): once the bottom encoder layer's BPTT
+        # early optimizer step (opt-in: DANET_EXPERT early_adam=1): once the bottom encoder layer's BPTT
         # kernel has been issued every other gradient is final (and, under data parallelism with
         # the 'tail' schedule, reduced), so clip + Adam over everything outside that layer's range
         # can run on the side stream under the bottom layer's kernels; after backward only the
@@ -174,7 +174,7 @@ class Model(object):
         # the 188 MB Adam stream beside the bottom layer's weight-gradient group costs the group
         # more than the 33 us the single update takes afterwards) -> off by default.
         self._early_hooked = False
-        self._early_adam = os.environ.get('DANET_EARLY_ADAM', '0') == '1'
+        self._early_adam = _lib.expert('early_adam', False)
         if dist.is_dist():
             # the status word rides in the gradient all-reduce: every rank sees the same value
             ops.set_status_word(self.device, self._grad_store[n:].view(torch.int32))

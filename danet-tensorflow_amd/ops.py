@@ -41,7 +41,7 @@ def _ws(nbytes, dev):
 # ms per step): dX 133 -> 117 (3.273 -> 3.241), dYc 142 -> 125 (-> 3.265), both 3.228; the
 # output projection (672 tiles, K = 600) LOSES on it (126 -> 132: two workgroups per CU instead
 # of three, and 160 of its tiles need a fix-up) and stays on the tile kernel.
-STREAMK = int(__import__('os').environ.get('DANET_STREAMK', '5'))
+STREAMK = _lib.expert('streamk', 5)
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, beta=0.0,
@@ -262,11 +262,11 @@ def gemm_group(problems, K, transA=False, transB=False, max_workgroups=0):
                                                ptr(w), w.numel()))
 
 
-# weight gradients of a BiLSTM layer as one grouped stream-K launch (DANET_GROUPED_DW=0:
+# weight gradients of a BiLSTM layer as one grouped stream-K launch (DANET_EXPERT grouped_dw=0:
 # four split-K launches + reduce kernels)
-GROUPED_DW = int(__import__('os').environ.get('DANET_GROUPED_DW', '1'))
-GROUPED_DW_WGS = int(__import__('os').environ.get('DANET_GROUPED_DW_WGS', '256'))
-GROUPED_GX = int(__import__('os').environ.get('DANET_GROUPED_GX', '512'))   # grid of the grouped gx launch (0: two launches on two streams)
+GROUPED_DW = _lib.expert('grouped_dw', 1)
+GROUPED_DW_WGS = _lib.expert('grouped_dw_wgs', 256)
+GROUPED_GX = _lib.expert('grouped_gx', 512)   # grid of the grouped gx launch (0: two launches on two streams)
 
 
 def colsum(A, M, N, lda, out, beta=0.0):
@@ -580,7 +580,7 @@ SIDE_STREAMS = int(__import__('os').environ.get('DANET_SIDE_STREAMS', '1'))
 # persistent-workgroup cap for GEMMs that run under a BPTT kernel (per chain; 0 = off).
 # Measured at cfg 2: caps of 32..96 all LOSE (5.4-7.1 ms/step vs 5.2 uncapped): the
 # interference is fabric contention on the exchange hops, not CU placement.
-OVERLAP_GEMM_WGS = int(__import__('os').environ.get('DANET_OVERLAP_GEMM_WGS', '0'))
+OVERLAP_GEMM_WGS = _lib.expert('overlap_gemm_wgs', 0)
 
 
 def _side_streams(dev, n):
@@ -598,7 +598,7 @@ _copy = {}
 # serialise: the same loop measured 3.14 or 4.2 ms per cfg-2 step from one stream object to the
 # next (tools/feed_probe.py, profiles/r04_feed_probe.txt).  The side stream exists anyway and is
 # idle at the step boundary, where the feed issues the upload of the next batch.
-COPY_STREAM = _os.environ.get('DANET_COPY_STREAM', 'side')
+COPY_STREAM = _lib.expert('copy_stream', 'side')
 
 
 def copy_stream(dev):
@@ -628,7 +628,7 @@ def prepare_streams(dev):
 # next kernel, the attached event ~1.1 us, and the side chain starts ~3.7 us earlier
 # (tools/csrc/event_gap.hip).  Raw events from a small rotating pool per device (a slot is reused
 # dozens of launches later; the host keeps at most MAX_STEPS_IN_FLIGHT steps queued).
-FORK_ATTACH = __import__('os').environ.get('DANET_FORK_ATTACH', '1') == '1'
+FORK_ATTACH = _lib.expert('fork_attach', True)
 _fork_event_pool = {}
 
 
@@ -665,8 +665,8 @@ def fork_event(dev):
 # workgroups onto the CUs first: the BPTT kernel, whose workgroups exchange partials every time step,
 # then starts piecemeal and takes 470-500 us instead of 360 (tools/bptt_hist.sh).  One tiny kernel
 # in front of the group on the SIDE stream (a few microseconds of dispatch + run) lets the BPTT
-# kernel's workgroups go first; it costs the main stream nothing.  DANET_FORK_SPACER=0 switches it off.
-FORK_SPACER = __import__('os').environ.get('DANET_FORK_SPACER', '1') == '1'
+# kernel's workgroups go first; it costs the main stream nothing.  DANET_EXPERT fork_spacer=0 switches it off.
+FORK_SPACER = _lib.expert('fork_spacer', True)
 _spacer_buf = {}
 
 
@@ -796,7 +796,7 @@ def _fire_grad_ready(tag, params):
 # elementwise accumulate kernel less per parameter; outside the scope every backward returns
 # ordinary gradient tensors, so torch.autograd.grad / double backward / foreign optimisers see
 # standard autograd behaviour.  (2) the gradient-ready hooks above fire.
-DIRECT_GRADS = __import__('os').environ.get('DANET_DIRECT_GRADS', '1') == '1'
+DIRECT_GRADS = _lib.expert('direct_grads', True)
 _fast_depth = [0]
 
 
@@ -924,7 +924,7 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs, x_pad_zero=False, ypad=None, ws=N
 # 3.90 / 5.62 serial; H = 600 (cfg 4 as written) 14.3 overlapped vs 13.7 serial (the group lasts
 # 0.9-1.3 ms there and costs the BPTT kernel 0.7 ms).  'auto' = overlap up to H = 384 with the
 # exact-fp32 groups, always with the groups on the bf16 matrix cores (round 4).
-DW_OVERLAP = __import__('os').environ.get('DANET_DW_OVERLAP', 'auto')
+DW_OVERLAP = _lib.expert('dw_overlap', 'auto')
 
 
 def _overlap_dw(H):
@@ -937,10 +937,10 @@ def _overlap_dw(H):
 
 # experiment: fork the weight-gradient group BEFORE dX (the two GEMMs share the GPU, the next
 # BPTT kernel then has the group beside it for a shorter time)
-DW_FORK_EARLY = __import__('os').environ.get('DANET_DW_FORK_EARLY', '0') == '1'
+DW_FORK_EARLY = _lib.expert('dw_fork_early', False)
 # bias gradients summed inside the (unfused) BPTT kernel instead of by column-sum launches
-BWD_DB = __import__('os').environ.get('DANET_LSTM_BWD_DB', '1') == '1'
-DB_DEFER = __import__('os').environ.get('DANET_LSTM_DB_DEFER', '1') == '1'
+BWD_DB = _lib.expert('lstm_bwd_db', True)
+DB_DEFER = _lib.expert('lstm_db_defer', True)
 
 
 def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=None):
@@ -1306,12 +1306,12 @@ TRUTH_MODES = {'truth': 0, 'truth-threshold': 1, 'truth-weighted': 2}
 # backward runs first (it consumes the attractors): it leaves its dembed here and the
 # estimator's backward -- whose kernels accumulate (`dembed += ...`) -- adds into that
 # buffer in place and returns no gradient of its own.  DANET_FUSE_DEMBED=0 disables.
-FUSE_DEMBED = int(__import__('os').environ.get('DANET_FUSE_DEMBED', '1'))
+FUSE_DEMBED = _lib.expert('fuse_dembed', 1)
 # Inside Model.train_step (heads chain) with the anchor estimator: the fused separator + loss
 # backward produces only dattr and the estimator's backward forms the WHOLE embedding gradient in
 # one pass (danet_attractor_anchor_bwd_embed_sep) -- the separator's term is not written to HBM
 # and read back.  DANET_HEADS_RECOMPUTE=0: the two-pass accumulate-in-place form.
-HEADS_RECOMPUTE = int(__import__('os').environ.get('DANET_HEADS_RECOMPUTE', '1'))
+HEADS_RECOMPUTE = _lib.expert('heads_recompute', 1)
 
 
 # "Heads chain" scope (entered by Model.train_step around forward + backward): inside it the two

@@ -399,14 +399,22 @@ def test_library_never_reads_the_environment_and_options_abi(monkeypatch):
     _lib.set_option('lstm_fwd_fused', 0)
     assert lib.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 600) == 0
     monkeypatch.delenv('DANET_LSTM_FWD_FUSED')
-    # ... and the Python layer applies DANET_<NAME> through the setter
-    monkeypatch.setenv('DANET_GEMM_YIELD', '24')
+    # ... and the Python layer applies the USER options' DANET_<NAME> through the setter; every other
+    # option is an expert setting behind the ONE variable DANET_EXPERT="name=value,..."
+    monkeypatch.setenv('DANET_GEMM_YIELD', '24')           # not a user switch any more: ignored
+    monkeypatch.setenv('DANET_LSTM_SPIN_LIMIT', '4096')
+    monkeypatch.setenv('DANET_EXPERT', 'gemm_yield=20, streamk=7,fork_spacer=0')
+    _lib._expert = None
     _lib.apply_env_options()
-    assert _lib.get_option('gemm_yield') == 24 and _lib.get_option('gemm_dma') == 3
-    assert _lib.get_option('lstm_fwd_fused') == -1
-    monkeypatch.delenv('DANET_GEMM_YIELD')
+    assert _lib.get_option('gemm_yield') == 20 and _lib.get_option('gemm_dma') == 3
+    assert _lib.get_option('lstm_fwd_fused') == -1 and _lib.get_option('lstm_spin_limit') == 4096
+    assert _lib.expert('streamk', 5) == 7 and _lib.expert('fork_spacer', True) is False
+    assert _lib.expert('grouped_dw', 1) == 1 and _lib.expert('copy_stream', 'side') == 'side'
+    for k in ('DANET_GEMM_YIELD', 'DANET_LSTM_SPIN_LIMIT', 'DANET_EXPERT'):
+        monkeypatch.delenv(k)
+    _lib._expert = None
     _lib.apply_env_options()
-    assert _lib.get_option('gemm_yield') == 16
+    assert _lib.get_option('gemm_yield') == 16 and _lib.get_option('lstm_spin_limit') == 0
     assert lib.danet_set_option(b'no_such_option', 1) == -1
     assert b'unknown option' in lib.danet_last_error()
     v = ctypes.c_int(0)

@@ -1,34 +1,232 @@
 '''
-Round 4 (run with -m gpu): the oracle next to the EXACT kernel path bench.py times, at full size.
-
-`Model.train_step` at BASELINE cfg 2 / cfg 4 with B = 32, T = 128 takes: the fused-input
-persistent forward (B >= 24, H <= 384) or the hoisted GEMM + persistent forward (H = 600), the
-reduce-scatter BPTT with twins and in-kernel bias sums, the stream-K / K-concatenated / grouped
-GEMMs, the fused separator + PIT kernels with the separator-term recompute, `fast_backward`
-accumulation into the flat bucket and the side-stream finalizers.  Every parameter gradient, the
-loss, the SNR and the permutation indices of ONE such step are compared with the float64 torch-CPU
-restatement (oracle/torch_ref.py) of main.py:208-337 + :354-358 (`compute_gradients` over all
-trainables) on the same 32 mixtures.
-
-Tolerance: gradients 2e-4 relative to the tensor's max (fp32 path vs float64 authority), loss and
-SNR 1e-4 relative, permutation indices exact.
+GPU tests (run with -m gpu): data parallelism on the HIP path: reduction schedules, two ranks on one GPU, the bench spawn path.
+Filed by component in round 5 (they used to live in test_gpu_round2/3/4.py; the helpers of each
+former file keep a _r2 / _r3 / _r4 suffix).
 '''
-import os
-import time
 
-import numpy as np
+
 import pytest
-import torch
-
-from oracle import torch_ref as R
-from test_gpu_fullsize import _setup, _synth, _cfg, relerr
 
 pytestmark = pytest.mark.gpu
-GTOL = 2e-4
+
+
+# ----------------------------------------------------------------------------
+# from test_gpu_round2.py
+# ----------------------------------------------------------------------------
+
+
+import json
+
+
+import os
+
+
+import random
+
+
+import subprocess
+
+
+import sys
+
+
+import numpy as np
+
+
+import pytest
+
+
+import torch
+
+
+from oracle import danet_oracle as O
+
+
+from oracle import torch_ref as R
+
+
+TOL_r2 = 1e-4
+
+
+ROOT_r2 = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def relerr_r2(a, b):
+    a = np.asarray(a); b = np.asarray(b)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def cu_r2(x, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(x)).to('cuda', dtype)
 
 
 @pytest.fixture(autouse=True)
-def _lstm_status():
+def _lstm_status_r2():
+    yield
+    from danet_amd import ops
+    torch.cuda.synchronize()
+    assert ops.lstm_status_ok(), 'persistent LSTM kernel reported a hand-off timeout'
+
+
+def _small_model_r2(hp, seed=3, **kw):
+    from danet_amd.model import Model
+    base = dict(BATCH_SIZE=4, MAX_N_SIGNAL=2, FFT_SIZE=64, FFT_STRIDE=16, EMBED_SIZE=4,
+                NUM_LSTM_LAYERS=2, LSTM_HDIM=16, NUM_ANCHOR=4, ENCODER_TYPE='bilstm-orig',
+                TRAIN_ESTIMATOR_METHOD='anchor', INFER_ESTIMATOR_METHOD='anchor',
+                SEPARATOR_TYPE='dot-softmax-orig')
+    base.update(kw)
+    hp.load(base)
+    hp.digest()
+    return Model('r2', device='cuda', seed=seed).build()
+
+
+def _rand_src_r2(hp, T, seed=0, scale=4.0):
+    rng = np.random.RandomState(seed)
+    B, C, F = hp.BATCH_SIZE, hp.MAX_N_SIGNAL, hp.FEATURE_SIZE
+    return ((rng.randn(B, C, T, F) + 1j * rng.randn(B, C, T, F)) * scale).astype(np.complex64)
+
+
+def _cfg_r2(hp, **kw):
+    d = dict(H=hp.LSTM_HDIM, L=hp.NUM_LSTM_LAYERS, E=hp.EMBED_SIZE, C=hp.MAX_N_SIGNAL,
+             A=hp.NUM_ANCHOR, train_est=hp.TRAIN_ESTIMATOR_METHOD,
+             infer_est=hp.INFER_ESTIMATOR_METHOD, separator=hp.SEPARATOR_TYPE,
+             encoder=hp.ENCODER_TYPE)
+    d.update(kw)
+    return d
+
+
+class _FakeWork(object):
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
+# ------------------------------- forward with the input projection fused into the scan
+def _lstm_ref_r2(x, Ws, bs, H, dy):
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    Wt = [torch.tensor(W, dtype=torch.float64, requires_grad=True) for W in Ws]
+    bt = [torch.tensor(b, dtype=torch.float64, requires_grad=True) for b in bs]
+    outs = [R.lstm_scan(xt, Wt[0], bt[0], H)]
+    if len(Ws) == 2:
+        outs.append(R.lstm_scan(xt, Wt[1], bt[1], H, reverse=True))
+    y = torch.cat(outs, dim=-1)
+    (y * torch.tensor(dy)).sum().backward()
+    return y.detach().numpy(), xt.grad.numpy(), [w.grad.numpy() for w in Wt], [b.grad.numpy() for b in bt]
+
+
+def test_reduction_schedules_respect_stream_order(hp, monkeypatch):
+    '''A 1-rank RCCL all-reduce is an identity, so it cannot show a bucket that is reduced
+    before its gradients are complete.  Stand-in collective with the stream semantics of
+    ProcessGroupNCCL (its own stream, which waits for the caller's current stream; work.wait()
+    joins it back) that DOUBLES its tensor: every schedule must then produce exactly 2 x the
+    gradient; a piece doubled before a late contribution lands gives g1*2 + g2 instead.  A
+    long burst of unrelated GEMMs keeps the side streams busy so that stream order, not luck,
+    decides.'''
+    from danet_amd import dist as ddist, ops
+    from danet_amd.model import Model
+    coll = torch.cuda.Stream()
+
+    def fake_all_reduce(t, op=None, async_op=False):
+        ev = torch.cuda.current_stream().record_event()
+        coll.wait_event(ev)
+        with torch.cuda.stream(coll):
+            t.mul_(2.0)
+            done = coll.record_event()
+        w = _FakeWork(done)
+        if not async_op:
+            w.wait()
+            return None
+        return w
+
+    monkeypatch.setattr(ddist, 'is_dist', lambda: True)
+    monkeypatch.setattr(ddist, 'world_size', lambda: 1)
+    monkeypatch.setattr(ddist.dist, 'all_reduce', fake_all_reduce)
+    monkeypatch.setattr(ddist.dist, 'broadcast', lambda t, src=0: None)
+    grads = {}
+    for mode in ('0', 'tail', '1'):
+        monkeypatch.setenv('DANET_OVERLAP_ALLREDUCE', mode)
+        hp.reset()
+        model = _small_model_r2(hp, BATCH_SIZE=32, FFT_SIZE=256, FFT_STRIDE=64, EMBED_SIZE=20,
+                             NUM_LSTM_LAYERS=3, LSTM_HDIM=300, NUM_ANCHOR=6)
+        model.keep_grads = True
+        model.set_learn_rate(0.0)
+        src = torch.as_tensor(_rand_src_r2(hp, 48, 1)).cuda()
+        for _ in range(2):
+            model.train_step(src)
+        torch.cuda.synchronize()
+        grads[mode] = {k: v.copy() for k, v in model.grad_dict().items()}
+        if mode != '0':
+            assert model._buckets.launched == (2 if mode == 'tail' else 2 * 4)
+        del model
+    for mode in ('tail', '1'):
+        for k in grads['0']:
+            assert np.array_equal(grads[mode][k], grads['0'][k]), (mode, k)
+    # and '0' really is 2 x the plain gradient
+    hp.reset()
+    monkeypatch.setenv('DANET_OVERLAP_ALLREDUCE', '0')
+    monkeypatch.setattr(ddist, 'is_dist', lambda: False)
+    model = _small_model_r2(hp, BATCH_SIZE=32, FFT_SIZE=256, FFT_STRIDE=64, EMBED_SIZE=20,
+                         NUM_LSTM_LAYERS=3, LSTM_HDIM=300, NUM_ANCHOR=6)
+    model.keep_grads = True
+    model.set_learn_rate(0.0)
+    src = torch.as_tensor(_rand_src_r2(hp, 48, 1)).cuda()
+    for _ in range(2):
+        model.train_step(src)
+    g1 = model.grad_dict()
+    for k in g1:
+        assert np.array_equal(2.0 * g1[k], grads['0'][k]), k
+
+
+def test_bench_spawn_path_one_rank():
+    '''plain `python bench.py --gpus 1` with DANET_FORCE_DIST=1 re-executes itself under
+    torch.distributed.run (the path `--gpus N` takes) and reports the RCCL group'''
+    env = dict(os.environ, DANET_FORCE_DIST='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT_r2, 'bench.py'), '--gpus', '1', '--steps', '4',
+                          '--warmup', '1', '--no-cpu-baseline'],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT_r2)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res['n_gpus'] == 1 and res['rccl_ranks'] == 1 and res['value'] > 0
+    assert res['allreduce_ms_standalone'] is not None
+    assert res['config']['workload'].startswith('cfg2')
+    assert res['roofline']['events_in_timed_region'] is True
+
+
+# ----------------------------------------------------------------------------
+# from test_gpu_round4.py
+# ----------------------------------------------------------------------------
+
+
+import os
+
+
+import time
+
+
+import numpy as np
+
+
+import pytest
+
+
+import torch
+
+
+from oracle import torch_ref as R
+
+
+from test_gpu_fullsize import _setup, _synth, _cfg, relerr
+
+
+GTOL_r4 = 2e-4
+
+
+@pytest.fixture(autouse=True)
+def _lstm_status_r4():
     # the float64 oracle's per-timestep products are tiny: on a 256-thread host torch's intra-op
     # pool makes them 8x SLOWER than 16 threads do (56 s vs 7 s for one cfg-2 step)
     import os
@@ -41,14 +239,14 @@ def _lstm_status():
     assert ops.lstm_status_ok(), 'persistent LSTM kernel reported a hand-off timeout'
 
 
-def _oracle_step(src, params, cfg):
+def _oracle_step_r4(src, params, cfg):
     tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params.items()}
     r = R.model_forward(src.cpu().to(torch.complex128), tp, cfg)
     r['loss'].backward()
     return r, tp
 
 
-def _train_step_vs_oracle(hp, model, src, min_checked):
+def _train_step_vs_oracle_r4(hp, model, src, min_checked):
     from danet_amd import ops
     model.keep_grads = True                  # the optimiser leaves the bucket readable
     assert model.fuse_heads                  # the path bench.py times
@@ -57,7 +255,7 @@ def _train_step_vs_oracle(hp, model, src, min_checked):
     torch.cuda.synchronize()
     assert ops.lstm_status_ok()
     t0 = time.time()
-    ref, tp = _oracle_step(src, params, _cfg(hp))
+    ref, tp = _oracle_step_r4(src, params, _cfg(hp))
     print('float64 oracle forward+backward: %.1f s' % (time.time() - t0))
     assert relerr(float(out['loss']), float(ref['loss'].detach())) < 1e-4
     assert relerr(float(out['SNR']), float(ref['SNR'].detach())) < 1e-4
@@ -69,115 +267,15 @@ def _train_step_vs_oracle(hp, model, src, min_checked):
             continue
         worst[k] = relerr(g[k], tp[k].grad.numpy())
         checked += 1
-    bad = {k: v for k, v in worst.items() if not v < GTOL}
+    bad = {k: v for k, v in worst.items() if not v < GTOL_r4}
     print('worst gradient error: %s' % max(worst.items(), key=lambda kv: kv[1]).__repr__())
     assert not bad, bad
     assert checked >= min_checked, checked
     return out, ref
 
 
-def test_cfg2_b32_train_step_gradients_vs_oracle(hp):
-    '''BASELINE configs[1] exactly as bench.py runs it: B = 32, T = 128, 3 x 300, anchor
-    estimator, dot-softmax.  13 BiLSTM tensors + W_out + anchors.'''
-    from danet_amd import _lib
-    model = _setup(hp, BATCH_SIZE=32)
-    L = _lib.load()
-    # the kernels the timed step takes at this shape
-    assert L.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 132) == 1
-    assert L.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 600) == 1
-    assert L.danet_lstm_bwd_db_supported(128, 32, 300, 2) == 1
-    src = _synth(hp, 32, 128, 1337)
-    out, ref = _train_step_vs_oracle(hp, model, src, min_checked=14)
-    # (the fused path returns the permutation through the side-stream finalizer)
-    with torch.no_grad():
-        o2 = model.forward(src, fuse_heads=True)        # parameters have moved: only a smoke check
-    assert int(o2['perm_idx'].min()) >= 0 and int(o2['perm_idx'].max()) <= 1
-
-
-def test_cfg2_b32_perm_idx_and_trajectory_vs_oracle(hp):
-    '''permutation indices of the fused path at B = 32 (read before the optimiser moves anything:
-    forward only), then THREE train steps against three float64 TF1-Adam steps of the oracle
-    (main.py:359-363): the loss trajectory must agree'''
-    model = _setup(hp, BATCH_SIZE=32)
-    src = _synth(hp, 32, 128, 2024)
-    params = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True)
-              for k, v in model.param_dict().items()}
-    with torch.no_grad():
-        o = model.forward(src, fuse_heads=True)
-        r0 = R.model_forward(src.cpu().to(torch.complex128), params, _cfg(hp))
-    assert np.array_equal(o['perm_idx'].cpu().numpy(), r0['perm_idx'].numpy())
-    m = {k: torch.zeros_like(v) for k, v in params.items()}
-    v = {k: torch.zeros_like(p) for k, p in params.items()}
-    for t in range(1, 4):
-        got = float(model.train_step(src)['loss'])
-        for p in params.values():
-            p.grad = None
-        r = R.model_forward(src.cpu().to(torch.complex128), params, _cfg(hp))
-        r['loss'].backward()
-        assert relerr(got, float(r['loss'])) < 2e-4, (t, got, float(r['loss']))
-        R.tf_adam_step_(params, {k: p.grad for k, p in params.items()}, m, v, t, float(hp.LR),
-                        clip=float(hp.GRAD_CLIP_THRES))
-
-
-def test_cfg4_b32_train_step_gradients_vs_oracle(hp):
-    '''BASELINE configs[3] at H = 300: C = 3, E = 40, L = 4, truth-weighted training estimator
-    (6 permutations; the separator-term recompute runs inside danet_attractor_truth_bwd_sep)'''
-    model = _setup(hp, BATCH_SIZE=32, MAX_N_SIGNAL=3, EMBED_SIZE=40, NUM_LSTM_LAYERS=4,
-                   TRAIN_ESTIMATOR_METHOD='truth-weighted')
-    src = _synth(hp, 32, 128, 4)
-    out, ref = _train_step_vs_oracle(hp, model, src, min_checked=17)
-
-
-def test_cfg4_h600_b32_train_step_gradients_vs_oracle(hp):
-    '''BASELINE configs[3] as written (4 x 600): hoisted input GEMM + persistent forward, BPTT at
-    H = 600, weight-gradient groups serial on the main stream.  Every layer's gradients (bottom
-    and top included) against the oracle.'''
-    model = _setup(hp, BATCH_SIZE=32, MAX_N_SIGNAL=3, EMBED_SIZE=40, NUM_LSTM_LAYERS=4,
-                   LSTM_HDIM=600, TRAIN_ESTIMATOR_METHOD='truth-weighted')
-    src = _synth(hp, 32, 128, 6)
-    out, ref = _train_step_vs_oracle(hp, model, src, min_checked=17)
-
-
-def test_train_loop_async_feed_equals_synchronous_loop_bit_for_bit(hp):
-    '''cli.train_epoch (main.py:413-436): the one-batch-ahead pinned feed + deferred metric reads
-    produce EXACTLY the epoch metrics and parameters of the reference's literal loop (blocking
-    upload, float() of every metric every step) on the same batches and `random` stream'''
-    import io
-    import random
-    from danet_amd import cli
-    from danet_amd.model import Model
-
-    def run(sync):
-        hp.reset()
-        hp.load(dict(BATCH_SIZE=8, MAX_N_SIGNAL=2, FFT_SIZE=256, FFT_STRIDE=64, EMBED_SIZE=20,
-                     NUM_LSTM_LAYERS=2, LSTM_HDIM=300, NUM_ANCHOR=6, MAX_TRAIN_LEN=64,
-                     ENCODER_TYPE='bilstm-orig', TRAIN_ESTIMATOR_METHOD='anchor',
-                     INFER_ESTIMATOR_METHOD='anchor', SEPARATOR_TYPE='dot-softmax-orig'))
-        hp.digest()
-        model = Model('loop', device='cuda', seed=5).build()
-        rng = np.random.RandomState(0)
-        host = []
-        for i in range(12):                      # ragged lengths: some cropped, some not
-            T = [96, 64, 80, 50][i % 4]
-            a = (rng.randn(16, T, hp.FEATURE_SIZE) + 1j * rng.randn(16, T, hp.FEATURE_SIZE))
-            host.append(((30 * a).astype(np.complex64),))
-        random.seed(9)
-        out = io.StringIO()
-        rep, n = cli.train_epoch(model, iter(host), out, sync_feed=sync)
-        model.check_status()
-        return rep, n, out.getvalue(), model._flat.detach().cpu().numpy().copy()
-
-    rep_s, n_s, ticks_s, p_s = run(True)
-    rep_a, n_a, ticks_a, p_a = run(False)
-    assert n_s == n_a == 12 and ticks_s == ticks_a == ':' * 12
-    assert list(rep_s) == list(rep_a) == ['loss', 'SNR', 'LR']
-    for k in rep_s:
-        assert rep_s[k] == rep_a[k], (k, rep_s[k], rep_a[k])       # bit for bit
-    assert np.array_equal(p_s, p_a)
-
-
 # ------------------------------------------------ data parallel, 2 ranks, the HIP path (one GPU)
-_DP2_WORKER = r'''
+_DP2_WORKER_r4 = r'''
 import os, sys
 sys.path.insert(0, %(root)r)
 import numpy as np, torch
@@ -260,7 +358,7 @@ def test_data_parallel_two_ranks_on_the_hip_path(hp, tmp_path):
     np.save(tmp_path / 'src.npy', src)
     script = tmp_path / 'dp2_worker.py'
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script.write_text(_DP2_WORKER % dict(root=ROOT, hp=hpd))
+    script.write_text(_DP2_WORKER_r4 % dict(root=ROOT, hp=hpd))
     import socket
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))

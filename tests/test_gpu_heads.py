@@ -1,0 +1,317 @@
+'''
+GPU tests (run with -m gpu): estimators, separators and the fused separator + PIT-loss kernels.
+Filed by component in round 5 (they used to live in test_gpu_round2/3/4.py; the helpers of each
+former file keep a _r2 / _r3 / _r4 suffix).
+'''
+
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+# ----------------------------------------------------------------------------
+# from test_gpu_round2.py
+# ----------------------------------------------------------------------------
+
+
+import json
+
+
+import os
+
+
+import random
+
+
+import subprocess
+
+
+import sys
+
+
+import numpy as np
+
+
+import pytest
+
+
+import torch
+
+
+from oracle import danet_oracle as O
+
+
+from oracle import torch_ref as R
+
+
+TOL_r2 = 1e-4
+
+
+ROOT_r2 = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def relerr_r2(a, b):
+    a = np.asarray(a); b = np.asarray(b)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def cu_r2(x, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(x)).to('cuda', dtype)
+
+
+@pytest.fixture(autouse=True)
+def _lstm_status_r2():
+    yield
+    from danet_amd import ops
+    torch.cuda.synchronize()
+    assert ops.lstm_status_ok(), 'persistent LSTM kernel reported a hand-off timeout'
+
+
+def _small_model_r2(hp, seed=3, **kw):
+    from danet_amd.model import Model
+    base = dict(BATCH_SIZE=4, MAX_N_SIGNAL=2, FFT_SIZE=64, FFT_STRIDE=16, EMBED_SIZE=4,
+                NUM_LSTM_LAYERS=2, LSTM_HDIM=16, NUM_ANCHOR=4, ENCODER_TYPE='bilstm-orig',
+                TRAIN_ESTIMATOR_METHOD='anchor', INFER_ESTIMATOR_METHOD='anchor',
+                SEPARATOR_TYPE='dot-softmax-orig')
+    base.update(kw)
+    hp.load(base)
+    hp.digest()
+    return Model('r2', device='cuda', seed=seed).build()
+
+
+def _rand_src_r2(hp, T, seed=0, scale=4.0):
+    rng = np.random.RandomState(seed)
+    B, C, F = hp.BATCH_SIZE, hp.MAX_N_SIGNAL, hp.FEATURE_SIZE
+    return ((rng.randn(B, C, T, F) + 1j * rng.randn(B, C, T, F)) * scale).astype(np.complex64)
+
+
+def _cfg_r2(hp, **kw):
+    d = dict(H=hp.LSTM_HDIM, L=hp.NUM_LSTM_LAYERS, E=hp.EMBED_SIZE, C=hp.MAX_N_SIGNAL,
+             A=hp.NUM_ANCHOR, train_est=hp.TRAIN_ESTIMATOR_METHOD,
+             infer_est=hp.INFER_ESTIMATOR_METHOD, separator=hp.SEPARATOR_TYPE,
+             encoder=hp.ENCODER_TYPE)
+    d.update(kw)
+    return d
+
+
+class _FakeWork(object):
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
+# ------------------------------- forward with the input projection fused into the scan
+def _lstm_ref_r2(x, Ws, bs, H, dy):
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    Wt = [torch.tensor(W, dtype=torch.float64, requires_grad=True) for W in Ws]
+    bt = [torch.tensor(b, dtype=torch.float64, requires_grad=True) for b in bs]
+    outs = [R.lstm_scan(xt, Wt[0], bt[0], H)]
+    if len(Ws) == 2:
+        outs.append(R.lstm_scan(xt, Wt[1], bt[1], H, reverse=True))
+    y = torch.cat(outs, dim=-1)
+    (y * torch.tensor(dy)).sum().backward()
+    return y.detach().numpy(), xt.grad.numpy(), [w.grad.numpy() for w in Wt], [b.grad.numpy() for b in bt]
+
+
+def test_cfg5_kmeans_at_full_length(hp):
+    '''cfg 5 with the k-means estimator at T = 1251 (16 kHz, FFT 512/128, B = 1).  The
+    estimator is an extension (README.md:216: not in the reference), so it is checked
+    against the oracle's float64 restatement (oracle/torch_ref.py est_kmeans) of what
+    modules.KMeansEstimator documents: start from
+    the anchor estimator's attractors, KMEANS_ITERS times assign every bin to the attractor
+    with the largest dot product and recompute |mix|-weighted means.  On an embedding with
+    two well-separated clusters that ends at the weighted cluster means whenever both
+    clusters received a start attractor; through the whole model the masks sum to one.'''
+    from danet_amd.model import Model
+    from danet_amd import datasets, utils, ops
+    hp.load(dict(BATCH_SIZE=1, MAX_N_SIGNAL=2, FFT_SIZE=512, FFT_STRIDE=128, SMPRATE=16000,
+                 EMBED_SIZE=20, NUM_LSTM_LAYERS=4, LSTM_HDIM=300, NUM_ANCHOR=6,
+                 ENCODER_TYPE='bilstm-orig', TRAIN_ESTIMATOR_METHOD='truth-weighted',
+                 INFER_ESTIMATOR_METHOD='kmeans', SEPARATOR_TYPE='dot-softmax-orig'))
+    hp.digest()
+    model = Model('c5k', device='cuda', seed=7).build()
+    T, F, E = 1251, 257, 20
+    rng = np.random.RandomState(3)
+    centres = rng.randn(2, E) * 2.0
+    assign = rng.randint(0, 2, size=(1, T, F))
+    emb = (centres[assign] + 0.05 * rng.randn(1, T, F, E)).astype(np.float32)
+    w = (np.abs(rng.randn(1, T, F)) + 0.1).astype(np.float32)
+    got = model.valid_estimator(cu_r2(emb), s_mix_pwr=cu_r2(w)).cpu().numpy()[0]      # [2, E]
+    anchors = model.vars['global/infer_estimator/anchors']
+    a_attr, _, _ = ops.AnchorAttractorFn.apply(cu_r2(emb), anchors.detach(), 2)
+    # the oracle's float64 restatement of the extension (oracle/torch_ref.py est_kmeans)
+    from oracle import torch_ref as R
+    attr = R.est_kmeans(torch.tensor(emb, dtype=torch.float64),
+                        anchors.detach().cpu().double(), 2, torch.tensor(w, dtype=torch.float64),
+                        int(hp.KMEANS_ITERS), float(hp.EPS))[0].numpy()
+    ef, wf = emb.reshape(-1, E).astype(np.float64), w.reshape(-1).astype(np.float64)
+    assert relerr_r2(got, attr) < 1e-4
+    truth = np.stack([(ef[assign.reshape(-1) == c] * wf[assign.reshape(-1) == c][:, None]).sum(0)
+                      / (wf[assign.reshape(-1) == c].sum() + hp.EPS) for c in range(2)])
+    if len(set(np.argmax(truth @ a_attr.cpu().numpy()[0].T.astype(np.float64), axis=1))) == 2:
+        order = [0, 1] if np.abs(got[0] - truth[0]).sum() < np.abs(got[0] - truth[1]).sum() else [1, 0]
+        assert relerr_r2(got, truth[order]) < 1e-3
+    # whole inference chain on a real-length utterance
+    w1 = datasets.speech_shaped_wave(rng, 160000, 16000, phase=0.3)
+    w2 = datasets.speech_shaped_wave(rng, 160000, 16000, phase=2.1)
+    X = utils.stft(torch.as_tensor((w1 + w2).astype(np.float32)).cuda())
+    assert tuple(X.shape) == (T, F)
+    sep = model.infer(X[None])
+    assert tuple(sep.shape) == (1, 2, T, F) and bool(torch.isfinite(torch.view_as_real(sep)).all())
+    assert relerr_r2(sep.sum(1)[0].cpu().numpy(), X.cpu().numpy()) < 1e-5
+
+
+# ----------------------------------------------------------------------------
+# from test_gpu_round3.py
+# ----------------------------------------------------------------------------
+
+
+import threading
+
+
+import numpy as np
+
+
+import pytest
+
+
+import torch
+
+
+def cu_r3(x, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(x)).to('cuda', dtype)
+
+
+def relerr_r3(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+@pytest.mark.parametrize('act', [0, 1])
+@pytest.mark.parametrize('mode', [0, 1])
+@pytest.mark.parametrize('B,C,T,F,E', [(3, 2, 9, 33, 20), (2, 3, 17, 129, 40), (1, 1, 5, 7, 4),
+                                       (2, 2, 40, 129, 20), (2, 2, 11, 33, 16), (2, 3, 9, 17, 7),
+                                       (1, 2, 300, 129, 33)])   # E != EP: the guarded row accesses
+def test_fused_separator_pit_matches_unfused_and_oracle(act, mode, B, C, T, F, E):
+    '''danet_separate_pit_fwd / _bwd (separator + phase re-attach + PIT-MSE + SNR in one pass,
+    app/modules.py:548-603 -> main.py:281-290 -> app/ops.py:374-431) against (i) the two-kernel
+    HIP path -- same arithmetic per bin, so loss / SNR agree to reduction-order rounding and
+    the permutation index and dembed / dattr match tightly -- and (ii) the float64 oracle'''
+    from danet_amd import ops
+    from oracle import danet_oracle as O
+    rng = np.random.RandomState(B * 1000 + C * 100 + T + E + act * 7 + mode)
+    N = T * F
+    embed = (rng.randn(B, N, E) * 0.7).astype(np.float32)
+    attr = (rng.randn(B, C, E) * 0.8).astype(np.float32)
+    src = ((rng.randn(B, C, T, F) + 1j * rng.randn(B, C, T, F)) * 4).astype(np.complex64)
+    src[:, :, 0] = 0                                       # an all-zero frame (padded batches)
+    fe = O.frontend(src)
+    cu_r3 = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
+    mix_pwr = cu_r3(fe['mix_pwr'].astype(np.float32))
+    ph = np.stack([np.cos(fe['phase']), np.sin(fe['phase'])], -1).astype(np.float32)
+    phasor = cu_r3(ph)
+    s_src = cu_r3(src)
+
+    def run(fused):
+        e = cu_r3(embed).requires_grad_(True)
+        a = cu_r3(attr).requires_grad_(True)
+        if fused:
+            loss, _, idx, snr = ops.separate_pit_loss(mix_pwr, a, e, s_src, phasor, act, mode=mode, eps=1e-7)
+        else:
+            sep, _ = ops.SeparateFn.apply(mix_pwr, a, e, act, False)
+            loss, _, idx, snr = ops.pit_mse_loss(s_src, sep, phasor, mode=mode, eps=1e-7)
+        loss.backward()
+        torch.cuda.synchronize()
+        return (float(loss), float(snr), idx.cpu().numpy(), e.grad.cpu().numpy(), a.grad.cpu().numpy())
+
+    lf, sf, pf, def_, daf = run(True)
+    lu, su, pu, deu, dau = run(False)
+    assert np.array_equal(pf, pu)
+    assert abs(lf - lu) <= 2e-6 * abs(lu) and abs(sf - su) <= 1e-5 * max(abs(su), 1.0), (lf, lu, sf, su)
+    # (C = 1: the softmax mask is identically 1 and both gradients are exact zeros up to
+    # cancellation noise -- compare on the scale of the incoming gradient instead)
+    gscale = float(np.abs(src).max()) / (B * N)
+    assert np.abs(def_ - deu).max() <= 1e-6 * np.abs(deu).max() + 1e-6 * gscale, \
+        (np.abs(def_ - deu).max(), np.abs(deu).max())
+    assert np.abs(daf - dau).max() <= 2e-5 * np.abs(dau).max() + 1e-5 * gscale * N ** 0.5, \
+        (np.abs(daf - dau).max(), np.abs(dau).max())
+    # oracle (float64): loss and permutation
+    sep64, _ = O.sep_dot(fe['mix_pwr'], attr.astype(np.float64), embed.astype(np.float64),
+                         'softmax' if act == 0 else 'sigmoid', return_masks=True)
+    if mode == 0:
+        est = O.reattach_phase(sep64, fe['phase'])
+        lo, _, io, _ = O.pit_mse_loss(src.astype(np.complex128), est)
+    else:
+        lo, _, io, _ = O.pit_mse_loss(fe['src_pwr'], sep64)
+    # (C = 1, mode 0: estimate == mixture == the one source, the loss is rounding noise)
+    assert abs(lf - lo) <= 1e-4 * abs(lo) + 1e-9 * float(np.mean(np.abs(src) ** 2))
+    assert np.array_equal(pf, io)
+
+
+def test_train_step_uses_fused_heads_and_matches_unfused(hp):
+    '''Model.train_step takes the fused separator + loss kernels; three steps give the same
+    parameters as the unfused path to rounding'''
+    from danet_amd.model import Model
+    res = []
+    for fuse in (True, False):
+        hp.reset()
+        hp.load(dict(BATCH_SIZE=3, MAX_N_SIGNAL=2, FFT_SIZE=32, FFT_STRIDE=8, EMBED_SIZE=8,
+                     NUM_LSTM_LAYERS=2, LSTM_HDIM=16, NUM_ANCHOR=4, ENCODER_TYPE='bilstm-orig',
+                     TRAIN_ESTIMATOR_METHOD='anchor', INFER_ESTIMATOR_METHOD='anchor',
+                     SEPARATOR_TYPE='dot-softmax-orig'))
+        hp.digest()
+        model = Model('fh', device='cuda', seed=11).build()
+        model.fuse_heads = fuse
+        rng = np.random.RandomState(3)
+        src = torch.as_tensor(((rng.randn(3, 2, 10, 17) + 1j * rng.randn(3, 2, 10, 17)) * 5)
+                              .astype(np.complex64)).cuda()
+        out = None
+        for _ in range(3):
+            out = model.train_step(src)
+        res.append((float(out['loss']), model.param_dict()))
+        if fuse:
+            o = model.forward(src, fuse_heads=True)
+            assert 'sep_pwr' not in o and 'loss' in o
+    assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[1][0])
+    for k in res[0][1]:
+        a, b = res[0][1][k], res[1][1][k]
+        assert np.abs(a - b).max() <= 1e-4 * (np.abs(b).max() + 1e-12), k
+
+
+@pytest.mark.parametrize('E', [20, 6])      # 6: E != EP, the guarded row accesses
+@pytest.mark.parametrize('est,sepn,C', [('anchor', 'dot-softmax-orig', 2), ('truth-weighted', 'dot-softmax-orig', 3),
+                                        ('truth', 'dot-sigmoid-orig', 2), ('truth-threshold', 'dot-softmax-orig', 2)])
+def test_estimator_backward_recomputes_the_separator_term(hp, monkeypatch, est, sepn, C, E):
+    '''inside train_step with the anchor estimator the fused separator + loss backward only
+    produces dattr and danet_attractor_anchor_bwd_embed_sep forms the whole embedding gradient
+    in one pass (the separator's term is not written to HBM and read back): same additions in the
+    same order -> the parameters after three steps equal the two-pass form's'''
+    from danet_amd.model import Model
+    from danet_amd import ops
+    res = []
+    for recompute in (1, 0):
+        monkeypatch.setattr(ops, 'HEADS_RECOMPUTE', recompute)
+        hp.reset()
+        hp.load(dict(BATCH_SIZE=4, MAX_N_SIGNAL=C, FFT_SIZE=64, FFT_STRIDE=16, EMBED_SIZE=E,
+                     NUM_LSTM_LAYERS=2, LSTM_HDIM=16, NUM_ANCHOR=6, ENCODER_TYPE='bilstm-orig',
+                     TRAIN_ESTIMATOR_METHOD=est, INFER_ESTIMATOR_METHOD='anchor',
+                     SEPARATOR_TYPE=sepn))
+        hp.digest()
+        model = Model('rc', device='cuda', seed=3).build()
+        model.keep_grads = True
+        rng = np.random.RandomState(5)
+        src = torch.as_tensor(((rng.randn(4, C, 70, 33) + 1j * rng.randn(4, C, 70, 33)) * 5)
+                              .astype(np.complex64)).cuda()
+        for _ in range(3):
+            out = model.train_step(src)
+        torch.cuda.synchronize()
+        res.append((float(out['loss']), model.param_dict(), model.grad_dict()))
+    assert res[0][0] == res[1][0]
+    for k in res[0][1]:
+        a, b = res[0][2][k], res[1][2][k]
+        assert np.abs(a - b).max() <= 1e-6 * (np.abs(b).max() + 1e-30), ('grad', k)
+        a, b = res[0][1][k], res[1][1][k]
+        assert np.abs(a - b).max() <= 1e-6 * (np.abs(b).max() + 1e-30), ('param', k)

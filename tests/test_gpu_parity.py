@@ -150,7 +150,7 @@ def test_gemm_streamk_grouped(K, shapes, ta, tb):
                                              (64, 300, 16, 17, 1, 0), (257, 129, 700, 90, 1, 1)])
 def test_gemm_kcat(M, N, K1, K2, ta, tb):
     '''ops.gemm_kcat without stream-K (two accumulating tile-kernel products): C = A1 B1 + A2 B2
-    (+bias)(+beta C); the stream-K one-launch form is tested in test_gpu_round3'''
+    (+bias)(+beta C); the stream-K one-launch form is tested in test_gpu_gemm.py'''
     from danet_amd import ops
     rng = np.random.RandomState(M + N + K1 + K2)
     mk = lambda K: (rng.randn(K, M) if ta else rng.randn(M, K), rng.randn(N, K) if tb else rng.randn(K, N))

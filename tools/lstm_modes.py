@@ -3,7 +3,7 @@
 
     python tools/lstm_modes.py [B T H]
 
-For each (DANET_LSTM_XMAP, DANET_LSTM_PLAIN) it times danet_lstm_fwd / _bwd
+For each BPTT geometry (library options lstm_bwd_u / lstm_bwd_s / lstm_xmap) it times danet_lstm_fwd / _bwd
 standalone and checks the outputs bit-exactly against the default mode.
 '''
 import os
