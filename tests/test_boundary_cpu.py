@@ -126,24 +126,27 @@ def test_product_package_never_imports_the_oracle():
 
 # ------------------------------------------------------------------ hparams
 def test_hparams_surface_matches_reference_default_json(hp):
-    # the reference's key list (default.json:2-40) with its values
-    ref = dict(FLOATX='float32', INTX='int32', FFT_SIZE=256, FFT_STRIDE=64, SMPRATE=8000,
-               BATCH_SIZE=32, MAX_N_SIGNAL=2, LENGTH_ALIGN=4, MAX_TRAIN_LEN=128, EMBED_SIZE=20,
-               RELU_LEAKAGE=0.3, EPS=1e-7, DROPOUT_KEEP_PROB=1.0, REG_SCALE=1e-2, REG_TYPE='L2',
-               LR=3e-4, LR_DECAY=0.8, LR_DECAY_TYPE=None, NUM_EPOCH_PER_LR_DECAY=10,
-               GRAD_CLIP_THRES=100.0, TRAIN_ESTIMATOR_METHOD='truth-weighted',
-               INFER_ESTIMATOR_METHOD='anchor', NUM_ANCHOR=6, ENCODER_TYPE='toy',
-               SEPARATOR_TYPE='dot-sigmoid-orig', OPTIMIZER_TYPE='adam', DATASET_TYPE='toy',
-               SUMMARY_DIR='./logs', SUMMARY_TITLE='Test 1', DEBUG=False)
-    for k, v in ref.items():
-        assert getattr(hp, k) == v, k
+    # tests/golden/hparams_ref.{json,npz}: what the REFERENCE's own Hyperparameter.load_json + digest
+    # (app/hparams.py:26-69) make of its default.json -- every key with its value, the derived
+    # COMPLEXX / FEATURE_SIZE and the bit pattern of the evaluated FFT_WND (make_golden_hparams.py)
+    gold = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'hparams_ref.json')))
+    wnd = np.load(os.path.join(ROOT, 'tests', 'golden', 'hparams_ref.npz'))
+    assert len(gold['loaded']) == 31
+    for k, v in gold['loaded'].items():
+        if k != 'FFT_WND':                                     # (ours keeps the expression, as the reference does until digest)
+            assert getattr(hp, k) == v, k
     assert hp.NUM_LSTM_LAYERS == 4 and hp.LSTM_HDIM == 300      # reference hard-codes these
+    for name in gold['registries'] + gold['accessors']:
+        if name != 'get_regularizer':                          # (REG_* are dead in the reference: main.py never calls it)
+            assert hasattr(hp, name), name
     hp.digest()
-    assert hp.COMPLEXX == 'complex64' and hp.FEATURE_SIZE == 129
-    assert hp.FFT_WND.dtype == np.float32 and hp.FFT_WND.shape == (256,)
+    assert hp.COMPLEXX == gold['derived']['COMPLEXX'] and hp.FEATURE_SIZE == gold['derived']['FEATURE_SIZE']
+    assert str(hp.FFT_WND.dtype) == gold['derived']['FFT_WND_dtype']
+    assert np.array_equal(hp.FFT_WND.view(np.uint32), wnd['FFT_WND_256'].view(np.uint32))     # bit for bit
     hp.load(dict(FFT_SIZE=512))
     hp.digest()                                                # re-derives from the expression
-    assert hp.FEATURE_SIZE == 257 and hp.FFT_WND.shape == (512,)
+    assert hp.FEATURE_SIZE == gold['derived_fft512']['FEATURE_SIZE']
+    assert np.array_equal(hp.FFT_WND.view(np.uint32), wnd['FFT_WND_512'].view(np.uint32))
     with pytest.raises(NameError):
         hp.load({'lower_case': 1})
     with pytest.raises(AssertionError):
