@@ -459,8 +459,9 @@ def main():
     # configs[3] as written (4 x 600, 3-spk, truth-weighted: cfg4h600) and configs[4] (10 s inference:
     # cfg5) -- ride along as short sub-records so that they are driver-observed too; cfg 2 stays
     # the headline `value`.  Same code paths as `--config cfg4h600 / cfg5`, fewer steps, one CPU row.
+    # (diagnostic invocations -- --no-cpu-baseline / --no-parity-check, as the profiling scripts use -- skip them)
     if (args.config == 'cfg2' and world == 1 and not use_dist and not args.no_also and not explicit_shape
-            and res is not None):
+            and not args.no_cpu_baseline and not args.no_parity_check and res is not None):
         res['also'] = {}
         for name in ('cfg4h600', 'cfg5'):
             t_a = time.perf_counter()
