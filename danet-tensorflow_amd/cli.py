@@ -45,7 +45,11 @@ def train_epoch(model, batches, out=sys.stdout, sync_feed=None):
     cropped and uploaded one step ahead (feed.BatchFeed), the per-step metrics stay on the device
     until the epoch mean is read (feed.StepReport).  sync_feed=True is the reference's literal
     form -- blocking upload, `float()` of every metric every step -- kept for the equality test
-    and `bench.py --e2e --sync-feed`.  Returns (OrderedDict of epoch means, number of batches).'''
+    and `bench.py --e2e --sync-feed`.  Returns (OrderedDict of epoch means, number of batches).
+    LIFETIME of a batch tensor in the 'ahead' mode: it is a view of one of three reused device
+    buffers and is overwritten by the upload of the batch after the next one -- anything kept
+    beyond the step that consumes it (e.g. `model.debug_fetches['input']` under hparams.DEBUG) must
+    be cloned by the caller; Model.train_step itself keeps nothing.'''
     if sync_feed is None:
         sync_feed = SYNC_FEED
     src = feed.BatchFeed(batches, model.device, hparams.MAX_TRAIN_LEN,

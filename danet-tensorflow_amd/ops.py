@@ -927,12 +927,15 @@ def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs, x_pad_zero=False, ypad=None, ws=N
 DW_OVERLAP = _lib.expert('dw_overlap', 'auto')
 
 
-def _overlap_dw(H):
+def _overlap_dw(H, tn_ok=True):
+    '''tn_ok: this group's products will actually take the bf16-matrix-core TN kernel
+    (`_x6_tn_ok`); a group that falls back to the exact-fp32 stream-K kernels is overlapped only
+    up to H = 384 (the combination measured slower above that)'''
     if DW_OVERLAP in ('0', '1'):
         return DW_OVERLAP == '1'
     # (with the groups on the bf16 matrix cores the overlap wins at H = 600 as well: cfg 4 as
     # written 9.66 overlapped vs 9.86 serial on the same box, BPTT 674 vs 575 us)
-    return H <= 384 or bool(GEMM_X6 & 2)
+    return H <= 384 or (bool(GEMM_X6 & 2) and tn_ok)
 
 
 # experiment: fork the weight-gradient group BEFORE dX (the two GEMMs share the GPU, the next
@@ -974,8 +977,18 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
     # dX -> next BPTT) when a side chain is forked behind this launch anyway
     # (not for the bottom layer: its weight-gradient group takes every CU on the main stream
     # and the side chain's reduce would sit behind it for the group's whole duration)
+    def group_problems():
+        # dWx = X^T da and dWh = Hprev^T da of every direction (Hprev(t) = ypad block t (fwd) / t+2 (bwd))
+        probs = []
+        for d in range(ndir):
+            bW = 1.0 if direct[d][0] else 0.0
+            hprev = c.ypad.view(-1)[(0 if d == 0 else 2 * B * ldy + H):]
+            probs.append((c.x, c.ldx, das[d], 4 * H, dWs[d], 4 * H, D, 4 * H, bW))
+            probs.append((hprev, ldy, das[d], 4 * H, dWs[d][D:], 4 * H, H, 4 * H, bW))
+        return probs
+    overlap = _overlap_dw(H, _x6_tn_ok(group_problems(), T * B))
     db_deferred = (db_in_kernel and DB_DEFER and GROUPED_DW and SIDE_STREAMS > 0 and
-                   need_dx and _overlap_dw(H))
+                   need_dx and overlap)
     with _lib.timed('lstm_bwd'):
         check(L.danet_lstm_bwd(
             _lib.stream(), T, B, H, ndir, ptr(_f32(dy)), ndir * H,
@@ -1007,13 +1020,8 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
         return c.ypad.view(-1)[(0 if d == 0 else 2 * B * ldy + H):]
 
     def weight_grads_grouped(wgs=GROUPED_DW_WGS, with_bias=True):
-        # dWx = X^T da and dWh = Hprev^T da of every direction: one stream-K launch
-        probs = []
-        for d in range(ndir):
-            bW = 1.0 if direct[d][0] else 0.0
-            probs.append((c.x, c.ldx, das[d], 4 * H, dWs[d], 4 * H, D, 4 * H, bW))
-            probs.append((hprev_of(d), ldy, das[d], 4 * H, dWs[d][D:], 4 * H, H, 4 * H, bW))
-        gemm_group(probs, T * B, transA=True, max_workgroups=wgs)
+        # dWx = X^T da and dWh = Hprev^T da of every direction: one launch
+        gemm_group(group_problems(), T * B, transA=True, max_workgroups=wgs)
         # (the bias gradients as M = 1 members of the group were measured slower than
         # the two column-sum kernels: +25 us on the group for 128-row tiles with one row)
         if with_bias:
@@ -1060,7 +1068,7 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
     # (`join_deferred`).
     fork_early = DW_FORK_EARLY and need_dx and GROUPED_DW
     if need_dx and not fork_early:
-        input_grad(attach=GROUPED_DW and _overlap_dw(H))
+        input_grad(attach=GROUPED_DW and overlap)
     hooks = bool(GRAD_READY_HOOKS) and _fast() and layer_tag is not None and \
         all(a and b for a, b in direct)
     if hooks and not need_dx:
@@ -1084,7 +1092,7 @@ def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=No
                 f.run(1, bias_grads)
             weight_grads_grouped(wgs=512, with_bias=False)
             on_main = True
-        elif GROUPED_DW and not _overlap_dw(H):
+        elif GROUPED_DW and not overlap:
             weight_grads_grouped(wgs=512)      # serial: alone on the main stream, whole GPU
             on_main = True
         elif GROUPED_DW:
@@ -1196,7 +1204,7 @@ class RnnEncoderFn(torch.autograd.Function):
                  tag='dYc', stop_event=ev)
         with _Fork(dev, 2, defer=True, keep=(dembed, ctx.yc), lazy=True, event=ev) as f:
             if GROUPED_DW:    # alone on its stream under the top layer's BPTT kernel (or serial)
-                ov = _overlap_dw(H)
+                ov = _overlap_dw(H, _x6_tn_ok([(ctx.yc, D, dembed, O, dWout, O, D, O, 0.0)], B * T))
                 f.run(1 if ov else 0, lambda: gemm_group(
                     [(ctx.yc, D, dembed, O, dWout, O, D, O, 1.0 if direct_out else 0.0)], B * T,
                     transA=True, max_workgroups=GROUPED_DW_WGS if ov else 512))
