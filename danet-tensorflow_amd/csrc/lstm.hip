@@ -137,15 +137,23 @@ __device__ __forceinline__ bool spin_fail(unsigned& spins, int* status, int lane
 // default; UN = 12 serves wide layers (H = 600): 50 instead of 75 workgroups per cluster make
 // 16-row clusters fit the GPU (200 workgroups), which halves the h_{t-1} payload every workgroup
 // reads per step (38 instead of 77 KB) and its MFMA count (120 instead of 160 per wave).
+// Round 5: the product runs on the bf16 matrix cores like the fused kernel's recurrent half (six bf16
+// piece products per fp32 product, split_pair in csrc/common.h, the exchange untouched): a lane's two
+// 4-float fragments of k-groups 2b and 2b+1 are the 8 k of its A operand in k-block b.  At H = 600 the
+// fp32 instructions were 120 x 32 clocks per wave and step of a 4.6 us step; 90 x 17 + the split now.
+// k-groups are taken in chunks of FWD_CHP = 6 (three k-blocks) whose loads fly together; the weight
+// pieces of a wave's first chunk are stationary in registers, those of later chunks (H > 384) in LDS,
+// already in operand order ([wave][block][piece][column tile][lane] x 16 bytes).
+#define FWD_CHP 6
 template <int MT, int NW, int UN>
 __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
-  constexpr int CH = (FWD_CH * 4 + NW - 1) / NW;
+  constexpr int CH = FWD_CHP, NBC = CH / 2;          // k-groups / k-blocks per chunk
   constexpr int NCOL = 4 * UN, NT = NCOL / 16;
   static_assert(NCOL % 16 == 0 && 16 * MT * UN <= 64 * NW, "ownership map: one thread per (row, unit)");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // smem: weights [KP/4][NCOL][4] | red [NW waves][16*MT][NCOL+1]
-  float* Wl = smem;
-  float* red = smem + (size_t)a.KP * NCOL;
+  // smem: red [NW waves][16*MT][NCOL+1] | weight pieces of the chunks behind the first
+  float* red = smem;
+  u32x4v* Wp = reinterpret_cast<u32x4v*>(smem + ((NW * 16 * MT * (NCOL + 1) + 3) & ~3));
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bid = blockIdx.x;
@@ -157,19 +165,6 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
   const int H = a.H, B = a.B, T = a.T;
   const int u0 = p * UN;
   const int b0 = grp * (16 * MT);
-
-  // ---- stationary weights: Wl[(k/4)*NCOL + n][k%4], n = gate*UN + u ----------
-  {
-    const float* W = a.Wh[dir];
-    for (int idx = tid; idx < a.KP * NCOL; idx += 64 * NW) {
-      const int k = idx / NCOL, n = idx % NCOL;
-      const int gate = n / UN, u = u0 + (n % UN);
-      float v = 0.f;
-      if (k < H && u < H) v = W[(size_t)k * a.ldw + gate * H + u];
-      Wl[((k >> 2) * NCOL + n) * 4 + (k & 3)] = v;
-    }
-  }
-  __syncthreads();
 
   const unsigned ybytes = (unsigned)((size_t)(T + 2) * B * a.ldy * sizeof(float));
   const __amdgpu_buffer_rsrc_t yres = make_rsrc(a.ypad, ybytes);
@@ -183,21 +178,41 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
   // A-fragment addressing: lane (r = lane&15, q = lane>>4)
   const int fr = lane & 15, fq = lane >> 4;
   const int NG = a.KP / 16;
+  const int NGW = (NG + NW - 1) / NW;                 // k-groups per wave
+  const int NBW = (NGW + 1) / 2;                      // k-blocks per wave
 
-  // The weights are stationary: this lane's B fragments of the wave's first
-  // CH k-groups go to registers ONCE (2*CH float4), so the per-step MFMA
-  // chain never waits on an LDS read (measured: MFMA phase 0.93 -> see
-  // profiles/README.md); later chunks (H > 320) still read LDS.
-  f32x4 wreg[CH][NT];
+  // B fragment of (wave, k-block b, column tile nt) for lane (n = fr, kq = fq): elements 0..3 =
+  // k-group 2b of this wave, 4..7 = k-group 2b+1, k = 16 (g * NW + wave) + 4 kq + j; three pieces
+  auto wfrag = [&](int b, int nt, uint32_t (&o)[3][4]) {
+    const float* W = a.Wh[dir];
+    const int n = nt * 16 + fr;
+    const int gate = n / UN, u = u0 + (n % UN);
+    float w[8];
 #pragma unroll
-  for (int g = 0; g < CH; ++g) {
-    const int kg = g * NW + wave;
-    const int k4 = (kg < NG ? kg : 0) * 4 + fq;
+    for (int e = 0; e < 8; ++e) {
+      const int k = ((2 * b + (e >> 2)) * NW + wave) * 16 + fq * 4 + (e & 3);
+      w[e] = (k < H && u < H) ? W[(size_t)k * a.ldw + gate * H + u] : 0.f;
+    }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-      wreg[g][nt] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * NCOL + nt * 16 + fr) * 4]);
-  }
+    for (int q = 0; q < 4; ++q) split_pair(w[2 * q], w[2 * q + 1], o[0][q], o[1][q], o[2][q]);
+  };
+  uint32_t wreg[NBC][NT][3][4];
+#pragma unroll
+  for (int b = 0; b < NBC; ++b)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wfrag(b, nt, wreg[b][nt]);
+  for (int b = NBC; b < NBW; ++b)
+    for (int nt = 0; nt < NT; ++nt) {
+      uint32_t o[3][4];
+      wfrag(b, nt, o);
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        Wp[(((size_t)wave * (NBW - NBC) + (b - NBC)) * 3 + pc) * NT * 64 + nt * 64 + lane] =
+            (u32x4v){o[pc][0], o[pc][1], o[pc][2], o[pc][3]};
+    }
+  __syncthreads();
 
+#define FW_OP(P_) __builtin_bit_cast(bf16x8v, (u32x4v){(P_)[0], (P_)[1], (P_)[2], (P_)[3]})
   for (int s = 0; s < T; ++s) {
     const int t = dir ? (T - 1 - s) : s;
     const int blk_prev = dir ? (t + 2) : t;  // ypad block holding h_{prev}
@@ -211,17 +226,17 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
       for (int gte = 0; gte < 4; ++gte) gxv[gte] = gp[gte * H];
     }
 
-    f32x4 acc[MT][NT];
+    f32x4 acc[MT][NT][2];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt][0] = acc[mt][nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // step 0 multiplies the zero initial state (main.py:108-123): skip it.
     // This wave's k-groups are wave, wave+4, ...; all of a chunk's 16-B loads
     // are issued together and re-issued until every word has been published.
     if (s > 0) {
-      for (int g0 = 0; g0 * NW + wave < NG; g0 += CH) {
+      for (int g0 = 0; g0 < NGW; g0 += CH) {
         v4u av[CH][MT];
         unsigned spins = 0;
         for (;;) {
@@ -246,46 +261,54 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
           if (spin_fail(spins, a.status, lane, a.spin_limit)) break;
         }
         TRACE(1); TRACE_VAL(6, spins);
-        // NO per-group branch here: a branch splits the accumulator chain into
-        // basic blocks and the compiler then moves the accumulators AGPR<->VGPR
-        // around every group (measured 2x on the MFMA phase).  Groups past NG
-        // multiply zeros (their loads were out of range) by finite weights.
-        f32x4 wq[CH][NT];
-        if (g0 == 0) {
+        // NO per-block branch below: a branch splits the accumulator chain into basic blocks
+        // (measured 2x on the matrix phase with the fp32 instructions).  Blocks past the wave's
+        // last multiply zeros (their loads were out of range) by finite weights.
 #pragma unroll
-          for (int g = 0; g < CH; ++g)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wq[g][nt] = wreg[g][nt];
-        } else {
-#pragma unroll
-          for (int g = 0; g < CH; ++g) {
-            const int kg = (g0 + g) * NW + wave;
-            const int k4 = (kg < NG ? kg : 0) * 4 + fq;
+        for (int b = 0; b < NBC; ++b) {
+          uint32_t wq[NT][3][4];
+          if (g0 == 0) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              wq[g][nt] = *reinterpret_cast<const f32x4*>(&Wl[(k4 * NCOL + nt * 16 + fr) * 4]);
+#pragma unroll
+              for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) wq[nt][pc][q] = wreg[b][nt][pc][q];
+          } else {
+            const int bb = min(g0 / 2 + b, NBW - 1) - NBC;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+              for (int pc = 0; pc < 3; ++pc) {
+                const u32x4v v = Wp[(((size_t)wave * (NBW - NBC) + bb) * 3 + pc) * NT * 64 + nt * 64 + lane];
+                wq[nt][pc][0] = v[0]; wq[nt][pc][1] = v[1]; wq[nt][pc][2] = v[2]; wq[nt][pc][3] = v[3];
+              }
           }
-        }
 #pragma unroll
-        for (int g = 0; g < CH; ++g) {
-          {
-            // NB: bit_cast the WHOLE vector -- __builtin_bit_cast(float, vec[j])
-            // on a vector element reads element 0 for every j (hipcc 7.2)
-            f32x4 af[MT];
+          for (int mt = 0; mt < MT; ++mt) {
+            // NB: bit_cast the WHOLE vector (hipcc 7.2 reads element 0 for every element otherwise)
+            const f32x4 lo = __builtin_bit_cast(f32x4, av[2 * b][mt]);
+            const f32x4 hi = __builtin_bit_cast(f32x4, av[2 * b + 1][mt]);
+            uint32_t ap[3][4];
+            split_pair(lo[0], lo[1], ap[0][0], ap[1][0], ap[2][0]);
+            split_pair(lo[2], lo[3], ap[0][1], ap[1][1], ap[2][1]);
+            split_pair(hi[0], hi[1], ap[0][2], ap[1][2], ap[2][2]);
+            split_pair(hi[2], hi[3], ap[0][3], ap[1][3], ap[2][3]);
+            // six piece products per column tile, small terms first (A piece, B piece)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) af[mt] = __builtin_bit_cast(f32x4, av[g][mt]);
+            for (int t6 = 0; t6 < 6; ++t6) {
+              constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+              const bf16x8v af = FW_OP(ap[PA[t6]]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], wq[g][nt][j], acc[mt][nt], 0, 0, 0);
+              for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt][t6 & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, FW_OP(wq[nt][PB[t6]]),
+                                                                              acc[mt][nt][t6 & 1], 0, 0, 0);
             }
           }
         }
       }
     }
+
 
     TRACE(2);
     // cross-wave reduction.  D layout 16x16: col = lane&15, row = 4*(lane>>4)+r
@@ -295,7 +318,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          red[(wave * 16 * MT + mt * 16 + 4 * fq + r) * (NCOL + 1) + nt * 16 + fr] = acc[mt][nt][r];
+          red[(wave * 16 * MT + mt * 16 + 4 * fq + r) * (NCOL + 1) + nt * 16 + fr] = acc[mt][nt][0][r] + acc[mt][nt][1][r];
     __syncthreads();
     TRACE(3);
 
@@ -1282,7 +1305,11 @@ static LstmPlan make_plan(int B, int H, int ndir) {
   }
   pl.G = cdiv(B, 16 * pl.MT);
   pl.NW = 4;             // one wave per SIMD
-  pl.lds = ((size_t)pl.KP * 4 * pl.UN + (size_t)pl.NW * 16 * pl.MT * (4 * pl.UN + 1)) * sizeof(float);
+  // red [NW][16 MT][NCOL + 1] + the weight pieces of the k-blocks behind a wave's first three
+  // ([NW][blocks - 3][3 pieces][NCOL / 16 column tiles][64 lanes] x 16 bytes; none up to H = 384)
+  { const int ngw = cdiv(pl.KP / 16, pl.NW), nbw = (ngw + 1) / 2;
+    pl.lds = (((size_t)pl.NW * 16 * pl.MT * (4 * pl.UN + 1) + 3) & ~(size_t)3) * sizeof(float) +
+             (size_t)pl.NW * (nbw > 3 ? nbw - 3 : 0) * 3 * (4 * pl.UN / 16) * 64 * 16; }
   return pl;
 }
 
