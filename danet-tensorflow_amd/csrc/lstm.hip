@@ -1016,13 +1016,22 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
 
   // stationary weights: lane (fr, fq) of tile `tl` holds Wh[tl*16 + fr][own column
   // k0 .. k0+3], k0 = kg*16 + fq*4 (the same K permutation as the B operand below)
-  f32x4 wreg[NTW][KG];
+  // BF (U = 32, the wide layers: 64 + matrix instructions of 32 clocks per wave and step): the product
+  // runs on the bf16 matrix cores like the forward kernels' (six bf16 piece products per fp32
+  // product, split_pair): k-block b = k-groups 2b | 2b+1, the weight pieces stationary, da_t split by
+  // every wave from the LDS tile.  At U <= 16 the split would cost what the 16 -> 12 shorter
+  // instructions save, so those geometries keep v_mfma_f32_16x16x4_f32.
+  constexpr bool BF = (U >= 32);
+  constexpr int KB = KG / 2;
+  f32x4 wreg[BF ? 1 : NTW][BF ? 1 : KG];
+  uint32_t wregp[BF ? NTW : 1][BF ? KB : 1][3][4];
   {
     const float* W = a.Wh[dir];
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
       const int tl = tw + S * (wave + NW * i);
       const int unit_i = tl * 16 + fr;
+      f32x4 wf[KG];
 #pragma unroll
       for (int kg = 0; kg < KG; ++kg) {
         const int k0 = kg * 16 + fq * 4;
@@ -1030,7 +1039,19 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
         f32x4 w = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (tl < a.NT && unit_i < H && u0 + j0 < H)
           w = *reinterpret_cast<const f32x4*>(&W[(size_t)unit_i * a.ldw + gate * H + u0 + j0]);
-        wreg[i][kg] = w;
+        wf[kg] = w;
+      }
+      if constexpr (BF) {
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+          split_pair(wf[2 * b][0], wf[2 * b][1], wregp[i][b][0][0], wregp[i][b][1][0], wregp[i][b][2][0]);
+          split_pair(wf[2 * b][2], wf[2 * b][3], wregp[i][b][0][1], wregp[i][b][1][1], wregp[i][b][2][1]);
+          split_pair(wf[2 * b + 1][0], wf[2 * b + 1][1], wregp[i][b][0][2], wregp[i][b][1][2], wregp[i][b][2][2]);
+          split_pair(wf[2 * b + 1][2], wf[2 * b + 1][3], wregp[i][b][0][3], wregp[i][b][1][3], wregp[i][b][2][3]);
+        }
+      } else {
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) wreg[i][kg] = wf[kg];
       }
     }
   }
@@ -1147,14 +1168,37 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
       for (int i = 0; i < NTW; ++i)
 #pragma unroll
         for (int c = 0; c < NACC; ++c) acc2[i][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (BF) {
+#define BW_OP(P_) __builtin_bit_cast(bf16x8v, (u32x4v){(P_)[0], (P_)[1], (P_)[2], (P_)[3]})
 #pragma unroll
-      for (int kg = 0; kg < KG; ++kg)
+        for (int b = 0; b < KB; ++b) {
+          uint32_t bp[3][4];
+          split_pair(bq[2 * b][0], bq[2 * b][1], bp[0][0], bp[1][0], bp[2][0]);
+          split_pair(bq[2 * b][2], bq[2 * b][3], bp[0][1], bp[1][1], bp[2][1]);
+          split_pair(bq[2 * b + 1][0], bq[2 * b + 1][1], bp[0][2], bp[1][2], bp[2][2]);
+          split_pair(bq[2 * b + 1][2], bq[2 * b + 1][3], bp[0][3], bp[1][3], bp[2][3]);
+          // small terms first: (weight piece, da piece)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+          for (int t6 = 0; t6 < 6; ++t6) {
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            const bf16x8v bf = BW_OP(bp[PB[t6]]);
 #pragma unroll
-          for (int i = 0; i < NTW; ++i)
-            acc2[i][j % NACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                wreg[i][kg][j], bq[kg][j], acc2[i][j % NACC], 0, 0, 0);
+            for (int i = 0; i < NTW; ++i)
+              acc2[i][t6 % NACC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BW_OP(wregp[i][b][PA[t6]]), bf,
+                                                                            acc2[i][t6 % NACC], 0, 0, 0);
+          }
+        }
+#undef BW_OP
+      } else {
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < NTW; ++i)
+              acc2[i][j % NACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                  wreg[i][kg][j], bq[kg][j], acc2[i][j % NACC], 0, 0, 0);
+      }
       f32x4 acc[NTW];
 #pragma unroll
       for (int i = 0; i < NTW; ++i) {
