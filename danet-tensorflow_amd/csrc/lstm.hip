@@ -1016,12 +1016,11 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
 
   // stationary weights: lane (fr, fq) of tile `tl` holds Wh[tl*16 + fr][own column
   // k0 .. k0+3], k0 = kg*16 + fq*4 (the same K permutation as the B operand below)
-  // BF (U = 32, the wide layers: 64 + matrix instructions of 32 clocks per wave and step): the product
-  // runs on the bf16 matrix cores like the forward kernels' (six bf16 piece products per fp32
-  // product, split_pair): k-block b = k-groups 2b | 2b+1, the weight pieces stationary, da_t split by
-  // every wave from the LDS tile.  At U <= 16 the split would cost what the 16 -> 12 shorter
-  // instructions save, so those geometries keep v_mfma_f32_16x16x4_f32.
-  constexpr bool BF = (U >= 32);
+  // BF (U >= 16): the product runs on the bf16 matrix cores like the forward kernels' (six bf16 piece
+  // products per fp32 product, split_pair): k-block b = k-groups 2b | 2b+1, the weight pieces
+  // stationary, da_t split by every wave from the LDS tile.  Measured: U = 32 (H = 600) 661 -> 591 us per
+  // launch, U = 16 (cfg 2) 352 -> 342 us in the step (300 alone); U = 8 keeps v_mfma_f32_16x16x4_f32.
+  constexpr bool BF = (U >= 16);
   constexpr int KB = KG / 2;
   f32x4 wreg[BF ? 1 : NTW][BF ? 1 : KG];
   uint32_t wregp[BF ? NTW : 1][BF ? KB : 1][3][4];

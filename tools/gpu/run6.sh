@@ -1,3 +1,11 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -6
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+python bench.py > gpurun_out/default.json 2> gpurun_out/default.err; echo rc=$?
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/default.json').read().strip().splitlines()[-1])
+print(d['ms_per_step'], d['value'], d['parity_ok'], d['roofline']['frac'], d['roofline']['lstm_fwd_us'], d['roofline']['lstm_bwd_us'], d['e2e']['ms_per_step'], d['mask_max_abs_err_vs_oracle'], d['mask_err_f32_oracle'])
+for k,v in d.get('also',{}).items():
+    print(k, v['ms_per_step'], v['value'], v.get('parity_ok'), v['roofline'].get('frac'), v['wall_s'])
+PY
