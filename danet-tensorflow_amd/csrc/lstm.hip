@@ -563,7 +563,11 @@ struct LstmFwdFxArgs {
 // the arithmetic of csrc/gemm_x6.hip) and one v_mfma_f32_16x16x32_bf16 covers 32 k in 17 clocks: 36
 // instructions.  The exchange is untouched (fp32 words in the layer's output buffer, the same five
 // 16-byte loads per lane): a lane's two 4-float fragments of k-groups 2b and 2b+1 ARE the 8 k of its
-// A operand in k-block b -- the weights are laid out for that k set.  (Splitting at the PRODUCER instead, with
+// A operand in k-block b -- the weights are laid out for that k set.  The INPUT half follows the same
+// scheme (x stays fp32 in memory, the same loads; a window / early k-block = two of the wave's window /
+// early k-groups): 66 instead of 88 matrix instructions per wave and step at D = 600, 17 instead of 32
+// clocks each, behind 36 vector instructions of split per k-block -- 2.74 -> 2.53 us per time step.
+// (Splitting at the PRODUCER instead, with
 // the pieces as the exchange payload, was built first and lost 0.7 us per step to the hand-off:
 // profiles/r05_b_fwd_producer_split.txt.)
 template <int CHX, int CHE>
@@ -571,9 +575,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
   constexpr int NW = 4, CH = FWD_CH;
   constexpr int NB = (CH + 1) / 2;      // k-blocks of 32 = pairs of 16-k groups per wave
 #ifdef FX_CHA_ABS
-  constexpr int CHA = FX_CHA_ABS < CHX ? FX_CHA_ABS : CHX;
+  constexpr int XBA = FX_CHA_ABS < CHX / 2 ? FX_CHA_ABS : CHX / 2;
 #else
-  constexpr int CHA = FX_CHA_NUM * (CHX + 3) / 4;   // k-groups of the input half done before the exchange loads
+  constexpr int XBA = 1;   // k-blocks of the input half done before the exchange loads are issued (0: retries)
 #endif
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // smem: recurrent weights [KP/4][32][4] (read once into registers) | red [NW][16][33]
@@ -643,41 +647,35 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
       for (int q = 0; q < 4; ++q)
         split_pair(w[2 * q], w[2 * q + 1], wreg[b][0][nt][q], wreg[b][1][nt][q], wreg[b][2][nt][q]);
     }
-  f32x4 wx[CHX][2];
+  // input half: the same six-piece arithmetic, k-block b = window k-groups 2b | 2b+1 of this wave
+  // (early list: early k-groups 2b | 2b+1; an odd last group is paired with zeros)
+  static_assert(CHX % 2 == 0, "window k-groups are paired into k-blocks");
+  constexpr int XBW = CHX / 2, XBE = (CHE + 1) / 2;
+  auto wxfrag = [&](int kga, int kgb, bool on, int nt, uint32_t (&o)[3][4]) {
+    const int n = nt * 16 + fr;
+    const int gate = n >> 3, u = u0 + (n & 7);
+    float w[8];
 #pragma unroll
-  for (int g = 0; g < CHX; ++g) {
-    const int k0 = (g * NW + wave) * 16 + fq * 4;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int n = nt * 16 + fr;
-      const int gate = n >> 3, u = u0 + (n & 7);
-      f32x4 w = {0.f, 0.f, 0.f, 0.f};
-      if (u < H) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (k0 + j < D) w[j] = Wd[(size_t)(k0 + j) * a.ldw + gate * H + u];
-      }
-      wx[g][nt] = w;
+    for (int e = 0; e < 8; ++e) {
+      const int kg = (e < 4) ? kga : kgb;
+      const int k = kg * 16 + fq * 4 + (e & 3);
+      w[e] = (on && kg >= 0 && u < H && k < D) ? Wd[(size_t)k * a.ldw + gate * H + u] : 0.f;
     }
-  }
-
-  f32x4 wxe[CHE][2];
 #pragma unroll
-  for (int g = 0; g < CHE; ++g) {
-    const int k0 = (NW * CHX + 2 * g + (wave - 2)) * 16 + fq * 4;
+    for (int q = 0; q < 4; ++q) split_pair(w[2 * q], w[2 * q + 1], o[0][q], o[1][q], o[2][q]);
+  };
+  uint32_t wx[XBW][2][3][4];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int n = nt * 16 + fr;
-      const int gate = n >> 3, u = u0 + (n & 7);
-      f32x4 w = {0.f, 0.f, 0.f, 0.f};
-      if (early && u < H) {
+  for (int b = 0; b < XBW; ++b)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (k0 + j < D) w[j] = Wd[(size_t)(k0 + j) * a.ldw + gate * H + u];
-      }
-      wxe[g][nt] = w;
-    }
-  }
+    for (int nt = 0; nt < 2; ++nt) wxfrag((2 * b) * NW + wave, (2 * b + 1) * NW + wave, true, nt, wx[b][nt]);
+  uint32_t wxe[XBE][2][3][4];
+#pragma unroll
+  for (int b = 0; b < XBE; ++b)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+      wxfrag(NW * CHX + 2 * (2 * b) + (wave - 2), (2 * b + 1 < CHE) ? NW * CHX + 2 * (2 * b + 1) + (wave - 2) : -1,
+             early, nt, wxe[b][nt]);
 
   // byte offsets of this lane's x / h fragments within one time block (out of range -> 0)
   unsigned xoff[CHX], xoffe[CHE], hcol[CH];
@@ -721,25 +719,25 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
     for (int g = 0; g < CHE; ++g) asm volatile("" : "+v"(xce[g]));
   }
 
-#define FX_GX(g)                                                                               \
+#define FX_OPX(P_) __builtin_bit_cast(bf16x8v, (u32x4v){(P_)[0], (P_)[1], (P_)[2], (P_)[3]})
+  // one k-block of the input half: split the lane's two x fragments, twelve matrix instructions
+#define FX_BLOCKX(XLO_, XHI_, W_, ACC_)                                                        \
   do {                                                                                         \
-    const f32x4 xf_ = __builtin_bit_cast(f32x4, xc[g]);                                        \
-    const f32x4 w0_ = wx[g][0], w1_ = wx[g][1];                                                \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
-      acc[0][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf_[j], w0_[j], acc[0][j & 1], 0, 0, 0); \
-      acc[1][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf_[j], w1_[j], acc[1][j & 1], 0, 0, 0); \
+    const f32x4 lo_ = __builtin_bit_cast(f32x4, XLO_), hi_ = __builtin_bit_cast(f32x4, XHI_);  \
+    uint32_t xp_[3][4];                                                                        \
+    split_pair(lo_[0], lo_[1], xp_[0][0], xp_[1][0], xp_[2][0]);                               \
+    split_pair(lo_[2], lo_[3], xp_[0][1], xp_[1][1], xp_[2][1]);                               \
+    split_pair(hi_[0], hi_[1], xp_[0][2], xp_[1][2], xp_[2][2]);                               \
+    split_pair(hi_[2], hi_[3], xp_[0][3], xp_[1][3], xp_[2][3]);                               \
+    _Pragma("unroll") for (int t6 = 0; t6 < 6; ++t6) {                                         \
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};                    \
+      const bf16x8v af_ = FX_OPX(xp_[PA[t6]]);                                                 \
+      ACC_[0][t6 & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af_, FX_OPX(W_[0][PB[t6]]), ACC_[0][t6 & 1], 0, 0, 0); \
+      ACC_[1][t6 & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af_, FX_OPX(W_[1][PB[t6]]), ACC_[1][t6 & 1], 0, 0, 0); \
     }                                                                                          \
   } while (0)
-
-#define FX_GXE(g)                                                                              \
-  do {                                                                                         \
-    const f32x4 xf_ = __builtin_bit_cast(f32x4, xce[g]);                                       \
-    const f32x4 w0_ = wxe[g][0], w1_ = wxe[g][1];                                              \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
-      accn[0][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf_[j], w0_[j], accn[0][j & 1], 0, 0, 0); \
-      accn[1][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf_[j], w1_[j], accn[1][j & 1], 0, 0, 0); \
-    }                                                                                          \
-  } while (0)
+#define FX_GX(b) FX_BLOCKX(xc[2 * (b)], xc[2 * (b) + 1], wx[b], acc)
+#define FX_GXE(b) FX_BLOCKX(xce[2 * (b)], ((2 * (b) + 1 < CHE) ? xce[(2 * (b) + 1 < CHE) ? 2 * (b) + 1 : 0] : (v4u){0u, 0u, 0u, 0u}), wxe[b], accn)
 
   // early groups of step 0
   f32x4 accn[2][2];
@@ -750,7 +748,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
   }
   if (early) {
 #pragma unroll
-    for (int g = 0; g < CHE; ++g) FX_GXE(g);
+    for (int b = 0; b < XBE; ++b) FX_GXE(b);
   }
 
   for (int s = 0; s < T; ++s) {
@@ -766,7 +764,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
     }
     // (a) first quarter of the input half
 #pragma unroll
-    for (int g = 0; g < CHA; ++g) FX_GX(g);
+    for (int b = 0; b < XBA; ++b) FX_GX(b);
     __builtin_amdgcn_sched_barrier(0);
     // (b) exchange loads of h_{t-1} (step 0: out of range -> zeros)
     v4u av[CH];
@@ -780,7 +778,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
     TRACE_AT(0, 1);
     // (c) rest of the input half while the loads fly
 #pragma unroll
-    for (int g = CHA; g < CHX; ++g) FX_GX(g);
+    for (int b = XBA; b < XBW; ++b) FX_GX(b);
     __builtin_amdgcn_sched_barrier(0);
     TRACE_AT(0, 2);
 
@@ -883,7 +881,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
     // waves 2 and 3: early groups of the NEXT step, beside the gate math of waves 0 and 1
     if (early && s + 1 < T) {
 #pragma unroll
-      for (int g = 0; g < CHE; ++g) FX_GXE(g);
+      for (int b = 0; b < XBE; ++b) FX_GXE(b);
     }
 
     if (owner) {
@@ -913,6 +911,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
   }
 #undef FX_GX
 #undef FX_GXE
+#undef FX_BLOCKX
+#undef FX_OPX
 }
 
 // ---------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 DANET_LSTM_FWD_FUSED=1 timeout 300 python tools/trace_lstm.py 2>&1 | sed -n 2,17p
-timeout 900 python -m pytest tests/test_gpu_round2.py tests/test_gpu_properties.py -x -q 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_gpu_lstm.py tests/test_gpu_properties.py tests/test_gpu_parity.py -x -q 2>&1 | tail -2
 timeout 300 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-e2e 2>gpurun_out/b.err | python -c "
 import sys,json
 for l in sys.stdin:
