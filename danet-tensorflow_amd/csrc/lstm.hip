@@ -649,8 +649,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
     }
   // input half: the same six-piece arithmetic, k-block b = window k-groups 2b | 2b+1 of this wave
   // (early list: early k-groups 2b | 2b+1; an odd last group is paired with zeros)
+  // XBF: at D <= 160 (CHX = 2, the bottom layer: 10 k-groups in all) the fp32 instructions stay -- one
+  // k-block of split + 12 instructions in front of the exchange loads is longer than the 8 fp32
+  // instructions it replaces, and that layer's step got 0.3 us slower with it (304 -> 324 us per launch)
+  constexpr bool XBF = CHX >= 4;
   static_assert(CHX % 2 == 0, "window k-groups are paired into k-blocks");
-  constexpr int XBW = CHX / 2, XBE = (CHE + 1) / 2;
+  constexpr int XBW = XBF ? CHX / 2 : 1, XBE = XBF ? (CHE + 1) / 2 : 1;
   auto wxfrag = [&](int kga, int kgb, bool on, int nt, uint32_t (&o)[3][4]) {
     const int n = nt * 16 + fr;
     const int gate = n >> 3, u = u0 + (n & 7);
@@ -666,16 +670,53 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
   };
   uint32_t wx[XBW][2][3][4];
 #pragma unroll
-  for (int b = 0; b < XBW; ++b)
+  for (int b = 0; b < (XBF ? XBW : 0); ++b)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) wxfrag((2 * b) * NW + wave, (2 * b + 1) * NW + wave, true, nt, wx[b][nt]);
   uint32_t wxe[XBE][2][3][4];
 #pragma unroll
-  for (int b = 0; b < XBE; ++b)
+  for (int b = 0; b < (XBF ? XBE : 0); ++b)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
       wxfrag(NW * CHX + 2 * (2 * b) + (wave - 2), (2 * b + 1 < CHE) ? NW * CHX + 2 * (2 * b + 1) + (wave - 2) : -1,
              early, nt, wxe[b][nt]);
+
+  // (fp32 fragments for the narrow input of the bottom layer, see XBF)
+  f32x4 wxf[XBF ? 1 : CHX][2];
+#pragma unroll
+  for (int g = 0; g < (XBF ? 0 : CHX); ++g) {
+    const int k0 = (g * NW + wave) * 16 + fq * 4;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int n = nt * 16 + fr;
+      const int gate = n >> 3, u = u0 + (n & 7);
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+      if (u < H) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (k0 + j < D) w[j] = Wd[(size_t)(k0 + j) * a.ldw + gate * H + u];
+      }
+      wxf[g][nt] = w;
+    }
+  }
+
+  f32x4 wxef[XBF ? 1 : CHE][2];
+#pragma unroll
+  for (int g = 0; g < (XBF ? 0 : CHE); ++g) {
+    const int k0 = (NW * CHX + 2 * g + (wave - 2)) * 16 + fq * 4;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int n = nt * 16 + fr;
+      const int gate = n >> 3, u = u0 + (n & 7);
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+      if (early && u < H) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (k0 + j < D) w[j] = Wd[(size_t)(k0 + j) * a.ldw + gate * H + u];
+      }
+      wxef[g][nt] = w;
+    }
+  }
 
   // byte offsets of this lane's x / h fragments within one time block (out of range -> 0)
   unsigned xoff[CHX], xoffe[CHE], hcol[CH];
@@ -736,6 +777,15 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
       ACC_[1][t6 & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af_, FX_OPX(W_[1][PB[t6]]), ACC_[1][t6 & 1], 0, 0, 0); \
     }                                                                                          \
   } while (0)
+#define FX_GROUPF(X_, W_, ACC_)                                                                \
+  do {                                                                                         \
+    const f32x4 xf_ = __builtin_bit_cast(f32x4, X_);                                           \
+    const f32x4 w0_ = W_[0], w1_ = W_[1];                                                      \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
+      ACC_[0][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf_[j], w0_[j], ACC_[0][j & 1], 0, 0, 0); \
+      ACC_[1][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf_[j], w1_[j], ACC_[1][j & 1], 0, 0, 0); \
+    }                                                                                          \
+  } while (0)
 #define FX_GX(b) FX_BLOCKX(xc[2 * (b)], xc[2 * (b) + 1], wx[b], acc)
 #define FX_GXE(b) FX_BLOCKX(xce[2 * (b)], ((2 * (b) + 1 < CHE) ? xce[(2 * (b) + 1 < CHE) ? 2 * (b) + 1 : 0] : (v4u){0u, 0u, 0u, 0u}), wxe[b], accn)
 
@@ -747,8 +797,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
     accn[nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   if (early) {
+    if constexpr (XBF) {
 #pragma unroll
-    for (int b = 0; b < XBE; ++b) FX_GXE(b);
+      for (int b = 0; b < XBE; ++b) FX_GXE(b);
+    } else {
+#pragma unroll
+      for (int g = 0; g < CHE; ++g) FX_GROUPF(xce[g], wxef[g], accn);
+    }
   }
 
   for (int s = 0; s < T; ++s) {
@@ -763,8 +818,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
       acc[nt][1] = accn[nt][1];
     }
     // (a) first quarter of the input half
+    if constexpr (XBF) {
 #pragma unroll
-    for (int b = 0; b < XBA; ++b) FX_GX(b);
+      for (int b = 0; b < XBA; ++b) FX_GX(b);
+    } else {
+#pragma unroll
+      for (int g = 0; g < (CHX + 3) / 4; ++g) FX_GROUPF(xc[g], wxf[g], acc);
+    }
     __builtin_amdgcn_sched_barrier(0);
     // (b) exchange loads of h_{t-1} (step 0: out of range -> zeros)
     v4u av[CH];
@@ -777,8 +837,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     TRACE_AT(0, 1);
     // (c) rest of the input half while the loads fly
+    if constexpr (XBF) {
 #pragma unroll
-    for (int b = XBA; b < XBW; ++b) FX_GX(b);
+      for (int b = XBA; b < XBW; ++b) FX_GX(b);
+    } else {
+#pragma unroll
+      for (int g = (CHX + 3) / 4; g < CHX; ++g) FX_GROUPF(xc[g], wxf[g], acc);
+    }
     __builtin_amdgcn_sched_barrier(0);
     TRACE_AT(0, 2);
 
@@ -880,8 +945,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
     }
     // waves 2 and 3: early groups of the NEXT step, beside the gate math of waves 0 and 1
     if (early && s + 1 < T) {
+      if constexpr (XBF) {
 #pragma unroll
-      for (int b = 0; b < XBE; ++b) FX_GXE(b);
+        for (int b = 0; b < XBE; ++b) FX_GXE(b);
+      } else {
+#pragma unroll
+        for (int g = 0; g < CHE; ++g) FX_GROUPF(xce[g], wxef[g], accn);
+      }
     }
 
     if (owner) {
@@ -912,6 +982,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
 #undef FX_GX
 #undef FX_GXE
 #undef FX_BLOCKX
+#undef FX_GROUPF
 #undef FX_OPX
 }
 
