@@ -1178,17 +1178,20 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
       v4u av[RS_NI_MAX];
       unsigned spins = 0;
       for (;;) {
-        bool ok = true;
 #pragma unroll
         for (int i = 0; i < RS_NI_MAX; ++i)
           if (i < a.NI) av[i] = load_sc1_b128(rres, off[i]);
+        // every word must carry the expected phase in bit 0: one OR tree (phase 0) and one AND tree
+        // (phase 1; out-of-range loads return zeros and are masked in) over all words, ONE test --
+        // instead of a test and a scalar AND per load
+        unsigned orall = 0u, andall = 0xFFFFFFFFu;
 #pragma unroll
         for (int i = 0; i < RS_NI_MAX; ++i)
           if (i < a.NI) {
-            const unsigned mm = par ? ~(av[i][0] & av[i][1] & av[i][2] & av[i][3])
-                                    : (av[i][0] | av[i][1] | av[i][2] | av[i][3]);
-            ok &= (off[i] == rbytes) || !(mm & 1u);
+            orall |= (av[i][0] | av[i][1]) | (av[i][2] | av[i][3]);
+            andall &= ((av[i][0] & av[i][1]) & (av[i][2] & av[i][3])) | ((off[i] == rbytes) ? 0xFFFFFFFFu : 0u);
           }
+        const bool ok = par ? ((andall & 1u) != 0u) : ((orall & 1u) == 0u);
         if (__all(ok)) break;
         if (spin_fail(spins, a.status, lane, a.spin_limit)) break;
       }

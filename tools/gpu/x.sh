@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-DANET_LSTM_FWD_FUSED=1 python tools/trace_lstm.py 2>&1 | sed -n 2,24p | grep -v "barrier\|to_next"
 timeout 900 python -m pytest tests/test_gpu_lstm.py tests/test_gpu_parity.py tests/test_gpu_properties.py -x -q 2>&1 | tail -2
 b() { python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-e2e --no-parity-check 2>/dev/null | python -c "
 import sys,json
@@ -10,3 +9,4 @@ for l in sys.stdin:
     print('$1', d['ms_per_step'], d['roofline'].get('lstm_fwd_us'), d['roofline'].get('lstm_bwd_us'))
 "; }
 b new; b new
+python tools/bptt_neighbour_probe.py 2>&1 | sed -n 2,4p
