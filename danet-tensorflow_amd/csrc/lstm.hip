@@ -36,6 +36,7 @@
 #include "options.h"
 #include <hip/hip_ext.h>
 #include <atomic>
+#include <type_traits>
 #include <stdlib.h>
 
 // Events armed with danet_next_launch_events ride on the recurrent kernel's own dispatch packet
@@ -1150,6 +1151,77 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
   float dc_state = 0.f;
   float dbacc[4] = {0.f, 0.f, 0.f, 0.f};   // bias gradient: this (row, unit)'s da summed over time
 
+  // ring addressing without per-step multiplies or divisions: byte offsets inside a slot are fixed,
+  // the slot and its phase are counters
+  const unsigned slot_bytes = (unsigned)(slot_floats * sizeof(float));
+  unsigned rd_off[RS_NI_MAX];
+  bool rd_ok[RS_NI_MAX];
+#pragma unroll
+  for (int i = 0; i < RS_NI_MAX; ++i) {
+    const int q = qq + PPR * i;
+    rd_ok[i] = q < P;
+    rd_off[i] = (unsigned)(((size_t)cl * P + q) * a.NT * 1024) + xoff;
+  }
+  unsigned pub_off[NTW];
+  bool pub_ok[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    const int tl = tw + S * (wave + NW * i);
+    pub_ok[i] = tl < a.NT;
+    pub_off[i] = (unsigned)((((size_t)cl * P + p) * a.NT + tl) * 1024) + (unsigned)((fr * 16 + fq * 4) * 4);
+  }
+  unsigned pslot = 0u, ppar = 0u, rslot = 0u, rpar = 0u;
+
+  // the owner's saved activations of the current timestep: pointers that walk the time axis
+  // (no 64-bit multiplies per step)
+  const int tfirst = dir ? 0 : (T - 1);
+  const ptrdiff_t tdir = dir ? 1 : -1;
+  const ptrdiff_t gstep = tdir * (ptrdiff_t)B * (4 * H), cstep = tdir * (ptrdiff_t)B * H,
+                  ystep = tdir * (ptrdiff_t)B * a.lddy, cprev_d = cstep;
+  const size_t orow0 = owner ? ((size_t)tfirst * B + bg) : 0;
+  const size_t ounit = owner ? unit : 0;
+  const float* gp = a.gates[dir] + orow0 * (4 * H) + ounit;
+  const float* cp = a.cell[dir] + orow0 * H + ounit;
+  const float* dyp = a.dy + orow0 * a.lddy + (owner ? dir * H + unit : 0);
+  float* dp = a.da[dir] + orow0 * (4 * H) + ounit;
+
+  // wait for the NI partial sums of this thread's chunk published in ring slot `sbase`, phase `par`;
+  // their sum goes to psum
+  auto exchange = [&](auto ni_c, const unsigned sbase, const unsigned par, const int s) {
+    (void)s;   // the trace build stamps by step
+    constexpr int NI = decltype(ni_c)::value;
+    unsigned off[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) off[i] = rd_ok[i] ? sbase + rd_off[i] : rbytes;   // out of range: zeros
+    v4u av[NI];
+    unsigned spins = 0;
+    for (;;) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) av[i] = load_sc1_b128(rres, off[i]);
+      // every word must carry the expected phase in bit 0: one OR tree (phase 0) and one AND tree
+      // (phase 1; out-of-range loads return zeros and are masked in) over all words, ONE test --
+      // instead of a test and a scalar AND per load
+      unsigned orall = 0u, andall = 0xFFFFFFFFu;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        orall |= (av[i][0] | av[i][1]) | (av[i][2] | av[i][3]);
+        andall &= ((av[i][0] & av[i][1]) & (av[i][2] & av[i][3])) | (rd_ok[i] ? 0u : 0xFFFFFFFFu);
+      }
+      const bool ok = par ? ((andall & 1u) != 0u) : ((orall & 1u) == 0u);
+      if (__all(ok)) break;
+      if (spin_fail(spins, a.status, lane, a.spin_limit)) break;
+    }
+    TRACE(1); TRACE_VAL(6, spins);
+    f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      v4u w = av[i];
+      w[0] &= ~1u; w[1] &= ~1u; w[2] &= ~1u; w[3] &= ~1u;   // (out of range = zeros already)
+      sum += __builtin_bit_cast(f32x4, w);
+    }
+    *reinterpret_cast<f32x4*>(&psum[qq * OWN + within * 4]) = sum;
+  };
+
   for (int s = 0; s < T; ++s) {
     const int t = dir ? s : (T - 1 - s);
     const int t_cprev = dir ? (t + 1) : (t - 1);
@@ -1157,55 +1229,24 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
     TRACE(0);
     float gv[4] = {0.f, 0.f, 0.f, 0.f}, cv = 0.f, cpv = 0.f, dyv = 0.f;
     if (owner) {
-      const float* gp = a.gates[dir] + ((size_t)t * B + bg) * (4 * H) + unit;
       gv[0] = gp[0]; gv[1] = gp[H]; gv[2] = gp[2 * H]; gv[3] = gp[3 * H];
-      cv = a.cell[dir][((size_t)t * B + bg) * H + unit];
-      if (t_cprev >= 0 && t_cprev < T) cpv = a.cell[dir][((size_t)t_cprev * B + bg) * H + unit];
-      dyv = a.dy[((size_t)t * B + bg) * a.lddy + dir * H + unit];
+      cv = cp[0];
+      if (t_cprev >= 0 && t_cprev < T) cpv = cp[cprev_d];
+      dyv = dyp[0];
     }
 
     if (s > 0) {
-      const int slot = (s - 1) % a.D;
-      const unsigned par = (unsigned)(((s - 1) / a.D) & 1);
-      unsigned off[RS_NI_MAX];
-#pragma unroll
-      for (int i = 0; i < RS_NI_MAX; ++i) {
-        const int q = qq + PPR * i;
-        off[i] = rbytes;   // out of range: no such producer (contributes 0)
-        if (q < P)
-          off[i] = (unsigned)((((size_t)slot * ncl + cl) * P + q) * a.NT * 1024) + xoff;
+      // NI (loads per thread and poll) is a launch constant: one switch per step onto code with
+      // the count compiled in -- a runtime bound on every load, test and add was a chain of a
+      // dozen scalar branches per poll
+      switch (a.NI) {
+        case 1: exchange(std::integral_constant<int, 1>{}, rslot * slot_bytes, rpar, s); break;
+        case 2: exchange(std::integral_constant<int, 2>{}, rslot * slot_bytes, rpar, s); break;
+        case 3: exchange(std::integral_constant<int, 3>{}, rslot * slot_bytes, rpar, s); break;
+        case 4: exchange(std::integral_constant<int, 4>{}, rslot * slot_bytes, rpar, s); break;
+        case 5: exchange(std::integral_constant<int, 5>{}, rslot * slot_bytes, rpar, s); break;
+        default: exchange(std::integral_constant<int, 6>{}, rslot * slot_bytes, rpar, s); break;
       }
-      v4u av[RS_NI_MAX];
-      unsigned spins = 0;
-      for (;;) {
-#pragma unroll
-        for (int i = 0; i < RS_NI_MAX; ++i)
-          if (i < a.NI) av[i] = load_sc1_b128(rres, off[i]);
-        // every word must carry the expected phase in bit 0: one OR tree (phase 0) and one AND tree
-        // (phase 1; out-of-range loads return zeros and are masked in) over all words, ONE test --
-        // instead of a test and a scalar AND per load
-        unsigned orall = 0u, andall = 0xFFFFFFFFu;
-#pragma unroll
-        for (int i = 0; i < RS_NI_MAX; ++i)
-          if (i < a.NI) {
-            orall |= (av[i][0] | av[i][1]) | (av[i][2] | av[i][3]);
-            andall &= ((av[i][0] & av[i][1]) & (av[i][2] & av[i][3])) | ((off[i] == rbytes) ? 0xFFFFFFFFu : 0u);
-          }
-        const bool ok = par ? ((andall & 1u) != 0u) : ((orall & 1u) == 0u);
-        if (__all(ok)) break;
-        if (spin_fail(spins, a.status, lane, a.spin_limit)) break;
-      }
-      TRACE(1); TRACE_VAL(6, spins);
-      f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < RS_NI_MAX; ++i)
-        if (i < a.NI) {
-          v4u w = av[i];
-          if (off[i] == rbytes) w = (v4u){0u, 0u, 0u, 0u};
-          w[0] &= ~1u; w[1] &= ~1u; w[2] &= ~1u; w[3] &= ~1u;
-          sum += __builtin_bit_cast(f32x4, w);
-        }
-      *reinterpret_cast<f32x4*>(&psum[qq * OWN + within * 4]) = sum;
     }
     __syncthreads();
     TRACE(2);
@@ -1285,26 +1326,25 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
         if (NACC == 4) acc[i] += acc2[i][2] + acc2[i][3];
       }
       TRACE(4);
-      const int slot = s % a.D;
-      const unsigned ppub = (unsigned)((s / a.D) & 1);
+      const unsigned ppub = ppar;
 #pragma unroll
       for (int i = 0; i < NTW; ++i) {
-        const int tl = tw + S * (wave + NW * i);
         unsigned o = rbytes;   // out of range: dropped
-        if (tl < a.NT)
-          o = (unsigned)(((((size_t)slot * ncl + cl) * P + p) * a.NT + tl) * 1024) +
-              (unsigned)((fr * 16 + fq * 4) * 4);
+        if (pub_ok[i]) o = pslot * slot_bytes + pub_off[i];
         v4u w = __builtin_bit_cast(v4u, acc[i]);
         w[0] = (w[0] & ~1u) | ppub; w[1] = (w[1] & ~1u) | ppub;
         w[2] = (w[2] & ~1u) | ppub; w[3] = (w[3] & ~1u) | ppub;
         store_sc1_b128(rres, o, w);
       }
     }
+    // step s + 1 reads what step s published; the publishing slot walks the ring, its phase flips per lap
+    rslot = pslot; rpar = ppar;
+    if (++pslot == (unsigned)a.D) { pslot = 0u; ppar ^= 1u; }
     // da_t is only read by later kernels: plain stores, off the critical path
     if (owner && tw == 0) {
-      float* dp = a.da[dir] + ((size_t)t * B + bg) * (4 * H) + unit;
       dp[0] = dav[0]; dp[H] = dav[1]; dp[2 * H] = dav[2]; dp[3 * H] = dav[3];
     }
+    gp += gstep; dp += gstep; cp += cstep; dyp += ystep;
     TRACE(5);
   }
   // partial db of the cluster (twin 0): the own 4U da columns summed over the 16 rows, so the
