@@ -25,17 +25,33 @@
 #include <hip/hip_ext.h>
 #include <atomic>
 #include "danet_hip.h"
+#include "options.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-#define XBM 128
 #define XBN 128
+#define X6_OOB 0xfffffff0u               // voffset beyond num_records: the buffer load returns 0
 #define XBK 16
-#define XIMG (XBM * XBK * 2)            // bytes of one piece image: 128 rows x 16 k x bf16 = 4 KB
-#define XSTAGE (3 * XIMG)               // A hi/mid/lo: 12 KB
-#define X6_SMEM_BYTES (3 * XSTAGE)           // 3 stages = 36 KB (>= the epilogue's 33.8 KB)
+
+// Geometry of the NT kernel for MI 32-row matrix tiles per wave along M: the workgroup tile is
+// (64 MI) x 128 x 16, its 4 waves sit 2 x 2 with (32 MI) x 64 each -- MI x 2 accumulator tiles.
+//   MI = 2: 128-row tiles, 256 registers per lane, two workgroups per CU
+//   MI = 3 / 4: 192 / 256-row tiles, one workgroup per CU: a B fragment (global / L2 -> registers,
+//     never shared between waves) feeds MI matrix instructions instead of two, which takes the
+//     kernel off the L1 / L2 bandwidth bound of the 128-row tile (48 KB of B fragments per CU and
+//     k-step at two workgroups: > 64 B / clock at full matrix rate)
+template <int MI> struct X6Geo {
+  static constexpr int BM = 64 * MI;
+  static constexpr int IMG = BM * XBK * 2;      // bytes of one piece image: BM rows x 16 k x bf16
+  static constexpr int STAGE = 3 * IMG;         // A hi / mid / lo
+  static constexpr int LDC_T = XBN + 4;
+  static constexpr int EPI = 32 * MI * LDC_T * 4;   // the epilogue's staging of one wave row's rows
+  static constexpr int SMEM = 3 * STAGE > EPI ? 3 * STAGE : EPI;   // 3 stages
+  static constexpr int NS = 12 * MI;            // matrix instructions per wave and k-step
+  static constexpr int WG_PER_CU = MI == 2 ? 2 : 1;
+};
 
 struct X6Args {
   const float* A[2];
@@ -56,7 +72,18 @@ __device__ __forceinline__ void split3(float x, uint32_t& h, uint32_t& m, uint32
   m = (__float_as_uint(r) + 0x8000u) & 0xFFFF0000u;
   l = __float_as_uint(r - __uint_as_float(m));
 }
-// (split_pair: csrc/common.h)
+// (split_pair: csrc/common.h.)  The same split written on 2-vectors, so that both subtractions are
+// one packed instruction each: 9 vector instructions per pair of values.  On gfx950 a vector
+// instruction and a matrix instruction of one SIMD do not overlap (tools/csrc/mfma_bf16_rate.hip), so
+// every vector instruction of the k-loop is paid in matrix-core time.
+__device__ __forceinline__ f32x2v pk_sub(f32x2v a, f32x2v b) { return a - b; }
+__device__ __forceinline__ void split_pair_pk(f32x2v x, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2v));
+  const f32x2v r = pk_sub(x, (f32x2v){__uint_as_float(h << 16), __uint_as_float(h & 0xFFFF0000u)});
+  m = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2v));
+  const f32x2v t = pk_sub(r, (f32x2v){__uint_as_float(m << 16), __uint_as_float(m & 0xFFFF0000u)});
+  l = __builtin_bit_cast(uint32_t, __builtin_convertvector(t, bf16x2v));
+}
 
 // the high halves of two words as one word: [hi16(b) | hi16(a)]
 __device__ __forceinline__ uint32_t pack_hi(uint32_t a, uint32_t b) {
@@ -83,7 +110,6 @@ __device__ __forceinline__ int x6_xcd_item(int b, int W) {
   return x * q + min(x, r) + i;
 }
 
-#define X6_OOB 0xfffffff0u               // voffset beyond num_records: the buffer load returns 0
 typedef unsigned v4u __attribute__((__vector_size__(16)));
 
 // One k-step of the pipeline, branch-free (a conditionally executed load would make the compiler
@@ -92,35 +118,51 @@ typedef unsigned v4u __attribute__((__vector_size__(16)));
 // kt + 2 (registers loaded two steps ago) and the global load of tile kt + 4 into the same registers.
 struct X6Ctx {
   __amdgpu_buffer_rsrc_t rsa[2];
+  __amdgpu_buffer_rsrc_t rsb[2];      // the packed weights: fragment f of a pair at byte f * 1024 + 16 lane
   const u32x4* bp[2];
   int lda[2], K[2], KT[2];
   int nk0, kt1, NT32, ntb, mrem;
   int srow, sq, lane, fi, kb, wm;
+  // the k-loop's staging loads: byte offset of this thread's (row i, k group sq) inside pair `apair`
+  // (X6_OOB for rows beyond M); the k-tile's offset travels in the instruction's scalar offset
+  unsigned avo[4];
 };
+template <int MI>
+__device__ __forceinline__ void x6_row_offsets(X6Ctx& c, int p) {
+  const int lda = p ? c.lda[1] : c.lda[0];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int r = c.srow + 64 * i;
+    c.avo[i] = r < c.mrem ? (unsigned)(r * lda + c.sq * 4) * 4u : X6_OOB;
+  }
+}
 
-__device__ __forceinline__ void x6_load_a(const X6Ctx& c, int kt, f32x4 (&R)[2]) {
+template <int MI>
+__device__ __forceinline__ void x6_load_a(const X6Ctx& c, int kt, f32x4 (&R)[MI]) {
   const int p = kt >= c.nk0 ? 1 : 0;                          // uniform
   const int k = (kt - (p ? c.nk0 : 0)) * XBK + c.sq * 4;
   const int K = p ? c.K[1] : c.K[0], lda = p ? c.lda[1] : c.lda[0];
   const __amdgpu_buffer_rsrc_t rs = p ? c.rsa[1] : c.rsa[0];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < MI; ++i) {
     const int r = c.srow + 64 * i;
     const bool ok = r < c.mrem && k < K && kt < c.kt1;
     const unsigned off = (unsigned)(r * lda + k) * 4u;
     R[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : X6_OOB, 0, 0));
   }
 }
-__device__ __forceinline__ void x6_store_a(char* base, const X6Ctx& c, const f32x4 (&R)[2]) {
+template <int MI>
+__device__ __forceinline__ void x6_store_a(char* base, const X6Ctx& c, const f32x4 (&R)[MI]) {
+  constexpr int IMG = X6Geo<MI>::IMG;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < MI; ++i) {
     const int off = img_off(c.srow + 64 * i, c.sq);
     uint32_t h[2], m[2], l[2];
     split_pair(R[i][0], R[i][1], h[0], m[0], l[0]);
     split_pair(R[i][2], R[i][3], h[1], m[1], l[1]);
     *reinterpret_cast<u32x2*>(base + off) = (u32x2){h[0], h[1]};
-    *reinterpret_cast<u32x2*>(base + XIMG + off) = (u32x2){m[0], m[1]};
-    *reinterpret_cast<u32x2*>(base + 2 * XIMG + off) = (u32x2){l[0], l[1]};
+    *reinterpret_cast<u32x2*>(base + IMG + off) = (u32x2){m[0], m[1]};
+    *reinterpret_cast<u32x2*>(base + 2 * IMG + off) = (u32x2){l[0], l[1]};
   }
 }
 __device__ __forceinline__ void x6_load_b(const X6Ctx& c, int kt, u32x4 (&fb)[3][2]) {
@@ -135,93 +177,120 @@ __device__ __forceinline__ void x6_load_b(const X6Ctx& c, int kt, u32x4 (&fb)[3]
     for (int j = 0; j < 2; ++j)
       fb[pc][j] = bp[((size_t)(pc * c.NT32 + c.ntb + j) * KT + ktl) * 64 + c.lane];
 }
-__device__ __forceinline__ void x6_frags_a(const char* sb, const X6Ctx& c, bf16x8 (&fa)[3][2]) {
+template <int MI>
+__device__ __forceinline__ void x6_frags_a(const char* sb, const X6Ctx& c, bf16x8 (&fa)[3][MI]) {
 #pragma unroll
   for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) fa[pc][i] = frag(sb + pc * XIMG, c.wm * 64 + i * 32 + c.fi, c.kb);
+    for (int i = 0; i < MI; ++i) fa[pc][i] = frag(sb + pc * X6Geo<MI>::IMG, c.wm * 32 * MI + i * 32 + c.fi, c.kb);
 }
 
 // the six piece products, small terms first: (A piece, B piece)
 __device__ constexpr int X6_PA[6] = {2, 0, 1, 1, 0, 0};
 __device__ constexpr int X6_PB[6] = {0, 2, 1, 0, 1, 0};
+__host__ __device__ constexpr int x6_pa(int t) { return t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0; }
+__host__ __device__ constexpr int x6_pb(int t) { return t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0; }
 #define X6_FENCE __builtin_amdgcn_sched_barrier(0);
 
-// One k-step in 24 slots of one matrix instruction each (the four accumulators in turn, an
-// accumulator is reused every 4th instruction); each slot carries a slice of the step's other work
-// behind it and is fenced off from its neighbours, so that the vector-ALU, LDS and memory
-// instructions issue in the shadow of the 32-cycle matrix instructions instead of in front of them:
+// One k-step in 12 MI slots of one matrix instruction each (the 2 MI accumulators in turn, piece
+// product by piece product); each slot carries a slice of the step's other work behind it and is
+// fenced off from its neighbours, so that the vector-ALU, LDS and memory instructions issue in the
+// shadow of the 32-cycle matrix instructions instead of in front of them.  MI = 2 (24 slots):
 //   slots  0-5   B fragment loads of tile kt + 1 (global / L2 -> registers, 16 bytes per lane)
-//   slots  6-11  A fragment reads of tile kt + 1 (LDS -> registers)
-//   slots 12-19  split of the 4 value pairs of tile kt + 2 this thread staged two steps ago (every other slot)
-//   slots 20-21  pack + LDS store of the two rows' pieces
-//   slots 22-23  global loads of tile kt + 4 into the staging registers
-template <int S>
-__device__ __forceinline__ void x6_mf(f32x16 (&acc)[2][2], const bf16x8 (&fa)[3][2], const u32x4 (&fb)[3][2]) {
-  constexpr int t = S >> 2, i = (S >> 1) & 1, j = S & 1;
-  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[X6_PA[t]][i], __builtin_bit_cast(bf16x8, fb[X6_PB[t]][j]),
-                                                      acc[i][j], 0, 0, 0);
-}
-
-__device__ __forceinline__ void x6_step(const X6Ctx& c, char* xsm, int kt, int srd, int swr, f32x16 (&acc)[2][2],
-                                        f32x4 (&R)[2], const bf16x8 (&fac)[3][2], bf16x8 (&fan)[3][2],
+//   slots  6-11  A fragment reads of tile kt + 1 (LDS -> registers)                     [3 MI slots]
+//   slots 12-19  split of the value pairs of tile kt + 2 this thread staged two steps ago (every
+//                other slot)                                                            [4 MI slots]
+//   slots 20-21  pack + LDS store of the rows' pieces                                   [MI slots]
+//   slots 22-23  global loads of tile kt + 4 into the staging registers                 [MI slots]
+template <int MI, int SRD, int SWR>
+__device__ __forceinline__ void x6_step(X6Ctx& c, char* xsm, int kt, int srd, int swr, f32x16 (&acc)[MI][2],
+                                        f32x4 (&R)[MI], const bf16x8 (&fac)[3][MI], bf16x8 (&fan)[3][MI],
                                         const u32x4 (&fbc)[3][2], u32x4 (&fbn)[3][2]) {
-  // uniform addressing of the next tile's B fragments
+  typedef X6Geo<MI> G;
+  constexpr int S_A = 6, S_SP = S_A + 3 * MI, S_W = S_SP + 4 * MI, S_L = S_W + MI, S_E = S_L + MI;
+  static_assert(S_E <= G::NS, "slot plan");
+  // uniform addressing of the next tile's B fragments: fragment (piece, column tile, k-tile) of a
+  // pair is 1 KB at ((piece * NT32 + column tile) * KT + k-tile) * 1024 -- all of it in the load's
+  // SCALAR offset, the lane's 16 bytes in a loop-invariant register: no vector instruction
   const int ktn = min(kt + 1, c.kt1 - 1);
   const int pn = ktn >= c.nk0 ? 1 : 0;
   const int ktl = ktn - (pn ? c.nk0 : 0);
   const int KTn = pn ? c.KT[1] : c.KT[0];
-  const u32x4* __restrict__ bp = (pn ? c.bp[1] : c.bp[0]) + c.lane;
-  const char* srdp = xsm + srd * XSTAGE;
-  char* swrp = xsm + swr * XSTAGE;
-  uint32_t h[2][2], m[2][2], l[2][2];
-#define X6_B(S) x6_mf<S>(acc, fac, fbc); fbn[(S) >> 1][(S) & 1] = bp[((size_t)(((S) >> 1) * c.NT32 + c.ntb + ((S) & 1)) * KTn + ktl) * 64]; X6_FENCE
-  X6_B(0) X6_B(1) X6_B(2) X6_B(3) X6_B(4) X6_B(5)
-#undef X6_B
-#define X6_A(S) x6_mf<S>(acc, fac, fbc); fan[((S) - 6) >> 1][((S) - 6) & 1] = frag(srdp + (((S) - 6) >> 1) * XIMG, c.wm * 64 + (((S) - 6) & 1) * 32 + c.fi, c.kb); X6_FENCE
-  X6_A(6) X6_A(7) X6_A(8) X6_A(9) X6_A(10) X6_A(11)
-#undef X6_A
-#define X6_M(S) x6_mf<S>(acc, fac, fbc); X6_FENCE
-#define X6_S(S, I, HF) x6_mf<S>(acc, fac, fbc); split_pair(R[I][2 * (HF)], R[I][2 * (HF) + 1], h[I][HF], m[I][HF], l[I][HF]); X6_FENCE
-  X6_S(12, 0, 0) X6_M(13) X6_S(14, 0, 1) X6_M(15) X6_S(16, 1, 0) X6_M(17) X6_S(18, 1, 1) X6_M(19)
-#undef X6_S
-#undef X6_M
-#define X6_W(S, I) x6_mf<S>(acc, fac, fbc); {                                                              \
-    const int off = img_off(c.srow + 64 * (I), c.sq);                                                      \
-    *reinterpret_cast<u32x2*>(swrp + off) = (u32x2){h[I][0], h[I][1]};                                     \
-    *reinterpret_cast<u32x2*>(swrp + XIMG + off) = (u32x2){m[I][0], m[I][1]};                              \
-    *reinterpret_cast<u32x2*>(swrp + 2 * XIMG + off) = (u32x2){l[I][0], l[I][1]}; } X6_FENCE
-  X6_W(20, 0) X6_W(21, 1)
-#undef X6_W
-  {
-    const int kta = kt + 4;
-    const int p = kta >= c.nk0 ? 1 : 0;
-    const int k = (kta - (p ? c.nk0 : 0)) * XBK + c.sq * 4;
-    const int K = p ? c.K[1] : c.K[0], lda = p ? c.lda[1] : c.lda[0];
-    const __amdgpu_buffer_rsrc_t rs = p ? c.rsa[1] : c.rsa[0];
-#define X6_L(S, I) x6_mf<S>(acc, fac, fbc); {                                                              \
-      const int r = c.srow + 64 * (I);                                                                     \
-      const bool ok = r < c.mrem && k < K && kta < c.kt1;                                                  \
-      R[I] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)(r * lda + k) * 4u : X6_OOB, 0, 0)); } X6_FENCE
-    X6_L(22, 0) X6_L(23, 1)
-#undef X6_L
+  const __amdgpu_buffer_rsrc_t rsbn = pn ? c.rsb[1] : c.rsb[0];
+  const unsigned bo0 = (unsigned)(c.ntb * KTn + ktl) * 1024u, bop = (unsigned)(c.NT32 * KTn) * 1024u, boj = (unsigned)KTn * 1024u;
+  const unsigned lane16 = (unsigned)c.lane * 16u;
+  // (the LDS stages are compile-time constants -- the k-loop is unrolled over the 3 stages x 2
+  // register sets -- so every LDS address is a loop-invariant register + an immediate)
+  // SRD < 0: the stages are run-time values (the loop's tail)
+  const char* srdp = xsm + (SRD >= 0 ? SRD : srd) * G::STAGE;
+  char* swrp = xsm + (SRD >= 0 ? SWR : swr) * G::STAGE;
+  // ... and of the staging loads of tile kt + 4: row offsets in registers (recomputed when the tile
+  // belongs to the other pair), the k-tile in the scalar offset, validity of this thread's k group
+  // (a ragged last tile, a tile beyond the slice) as one compare
+  const int kta = kt + 4;
+  const int pa = kta >= c.nk0 ? 1 : 0;
+  if (kta == c.nk0) {                    // the first tile of the second pair (the asm keeps it a branch)
+    asm volatile("" ::: "memory");
+    x6_row_offsets<MI>(c, 1);
+  }
+  const int ktla = kta - (pa ? c.nk0 : 0);
+  const int Ka = pa ? c.K[1] : c.K[0];
+  const __amdgpu_buffer_rsrc_t rsaa = pa ? c.rsa[1] : c.rsa[0];
+  const int klim = kta < c.kt1 ? Ka - ktla * XBK : 0;            // k values of the tile that exist
+  const bool kok = c.sq * 4 < klim;
+  const unsigned aso = kta < c.kt1 ? (unsigned)ktla * (XBK * 4u) : 0u;
+  uint32_t h[MI][2], m[MI][2], l[MI][2];
+#pragma unroll
+  for (int S = 0; S < G::NS; ++S) {
+    const int t = S / (2 * MI), i = (S >> 1) % MI, j = S & 1;
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fac[x6_pa(t)][i], __builtin_bit_cast(bf16x8, fbc[x6_pb(t)][j]),
+                                                        acc[i][j], 0, 0, 0);
+    if (S < S_A) {
+      fbn[S >> 1][S & 1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+          rsbn, lane16, bo0 + (S >> 1) * bop + (S & 1) * boj, 0));
+    } else if (S < S_SP) {
+      const int a = S - S_A, pc = a / MI, ii = a % MI;
+      fan[pc][ii] = frag(srdp + pc * G::IMG, c.wm * 32 * MI + ii * 32 + c.fi, c.kb);
+    } else if (S < S_W) {
+      const int a = S - S_SP;
+      if ((a & 1) == 0) {
+        const int I = a >> 2, HF = (a >> 1) & 1;
+        split_pair_pk(HF ? __builtin_shufflevector(R[I], R[I], 2, 3) : __builtin_shufflevector(R[I], R[I], 0, 1), h[I][HF], m[I][HF], l[I][HF]);
+      }
+    } else if (S < S_L) {
+      const int I = S - S_W;
+      const int off = img_off(c.srow + 64 * I, c.sq);
+      *reinterpret_cast<u32x2*>(swrp + off) = (u32x2){h[I][0], h[I][1]};
+      *reinterpret_cast<u32x2*>(swrp + G::IMG + off) = (u32x2){m[I][0], m[I][1]};
+      *reinterpret_cast<u32x2*>(swrp + 2 * G::IMG + off) = (u32x2){l[I][0], l[I][1]};
+    } else if (S < S_E) {
+      const int I = S - S_L;
+      R[I] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsaa, kok ? c.avo[I] : X6_OOB, aso, 0));
+    }
+    X6_FENCE
   }
 }
-#define X6_STEP(R, FAC, FAN, FBC, FBN)                                                               \
-  { x6_step(c, xsm, kt, srd, swr, acc, R, FAC, FAN, FBC, FBN);                                       \
+#define X6_STEP(SRD, SWR, R, FAC, FAN, FBC, FBN)                                                     \
+  { x6_step<MI, SRD, SWR>(c, xsm, kt, srd, swr, acc, R, FAC, FAN, FBC, FBN);                         \
+    __syncthreads();                                                                                 \
+    ++kt; }
+#define X6_STEP_RT(R, FAC, FAN, FBC, FBN)                                                            \
+  { x6_step<MI, -1, -1>(c, xsm, kt, srd, swr, acc, R, FAC, FAN, FBC, FBN);                           \
     __syncthreads();                                                                                 \
     ++kt; srd = swr; swr = swr == 2 ? 0 : swr + 1; }
 
-__global__ __launch_bounds__(256, 2) void gemm_x6_nt_kernel(X6Args g) {
+template <int MI>
+__global__ __launch_bounds__(256, X6Geo<MI>::WG_PER_CU) void gemm_x6_nt_kernel(X6Args g) {
+  typedef X6Geo<MI> G;
   extern __shared__ __attribute__((aligned(16))) char xsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = (g.N + XBN - 1) / XBN;
-  const int nt = ((g.M + XBM - 1) / XBM) * tiles_n;
+  const int nt = ((g.M + G::BM - 1) / G::BM) * tiles_n;
   const int item = x6_xcd_item(blockIdx.x, gridDim.x);
   const int z = item / nt;                             // K slice
   const int bid = item % nt;
-  const int m0 = (bid / tiles_n) * XBM, n0 = (bid % tiles_n) * XBN;
+  const int m0 = (bid / tiles_n) * G::BM, n0 = (bid % tiles_n) * XBN;
 
   const int nk0 = (g.K[0] + XBK - 1) / XBK;
   const int nkt = nk0 + (g.npair > 1 ? (g.K[1] + XBK - 1) / XBK : 0);
@@ -236,14 +305,16 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_nt_kernel(X6Args g) {
     const float* end = g.A[pp] + (size_t)(g.M - 1) * g.lda[pp] + g.K[pp];
     c.rsa[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)((end - base) * 4), 0x00020000);
     c.bp[p] = g.Bp[pp]; c.lda[p] = g.lda[pp]; c.K[p] = g.K[pp]; c.KT[p] = g.KT[pp];
+    c.rsb[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(g.Bp[pp]), 0, 3 * g.NT32 * g.KT[pp] * 1024, 0x00020000);
   }
   c.nk0 = nk0; c.kt1 = kt1; c.NT32 = g.NT32; c.ntb = n0 / 32 + wn * 2; c.mrem = g.M - m0;
   c.srow = tid >> 2; c.sq = tid & 3; c.lane = lane; c.fi = lane & 31; c.kb = lane >> 5; c.wm = wm;
   const int fi = c.fi, kb = c.kb;
+  x6_row_offsets<MI>(c, kt0 + 4 >= nk0 ? 1 : 0);
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -252,39 +323,47 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_nt_kernel(X6Args g) {
   if (kt0 < kt1) {
     // tile t lives in LDS stage (t - kt0) % 3.  Prologue: tiles kt0 and kt0 + 1 in LDS, kt0 + 2 and
     // kt0 + 3 in registers, the fragments of tile kt0 loaded.
-    f32x4 R0[2], R1[2];
+    f32x4 R0[MI], R1[MI];
     u32x4 fbA[3][2], fbB[3][2];
-    bf16x8 faA[3][2], faB[3][2];
-    x6_load_a(c, kt0, R0); x6_load_a(c, kt0 + 1, R1);
+    bf16x8 faA[3][MI], faB[3][MI];
+    x6_load_a<MI>(c, kt0, R0); x6_load_a<MI>(c, kt0 + 1, R1);
     x6_load_b(c, kt0, fbA);
-    x6_store_a(xsm, c, R0); x6_store_a(xsm + XSTAGE, c, R1);
-    x6_load_a(c, kt0 + 2, R0); x6_load_a(c, kt0 + 3, R1);
+    x6_store_a<MI>(xsm, c, R0); x6_store_a<MI>(xsm + G::STAGE, c, R1);
+    x6_load_a<MI>(c, kt0 + 2, R0); x6_load_a<MI>(c, kt0 + 3, R1);
     __syncthreads();
-    x6_frags_a(xsm, c, faA);
+    x6_frags_a<MI>(xsm, c, faA);
     int kt = kt0, srd = 1, swr = 2;
-    while (kt + 1 < kt1) {
-      X6_STEP(R0, faA, faB, fbA, fbB)
-      X6_STEP(R1, faB, faA, fbB, fbA)
+    while (kt + 5 < kt1) {               // 3 stages x 2 register sets: back where it started
+      X6_STEP(1, 2, R0, faA, faB, fbA, fbB)
+      X6_STEP(2, 0, R1, faB, faA, fbB, fbA)
+      X6_STEP(0, 1, R0, faA, faB, fbA, fbB)
+      X6_STEP(1, 2, R1, faB, faA, fbB, fbA)
+      X6_STEP(2, 0, R0, faA, faB, fbA, fbB)
+      X6_STEP(0, 1, R1, faB, faA, fbB, fbA)
     }
-    if (kt < kt1) X6_STEP(R0, faA, faB, fbA, fbB)
+    while (kt + 1 < kt1) {
+      X6_STEP_RT(R0, faA, faB, fbA, fbB)
+      X6_STEP_RT(R1, faB, faA, fbB, fbA)
+    }
+    if (kt < kt1) X6_STEP_RT(R0, faA, faB, fbA, fbB)
   }
 
   // C/D layout 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  The tile leaves
-  // through the (now free) LDS in two halves of 64 rows as 16-byte stores of full 512-byte row
-  // segments when the destination allows it; 4-byte stores otherwise.
+  // through the (now free) LDS, one wave row's 32 MI rows at a time, as 16-byte stores of full
+  // 512-byte row segments when the destination allows it; 4-byte stores otherwise.
   float* __restrict__ dst = g.C + (g.splitk > 1 ? (size_t)z * g.M * g.ldc : 0);
   const float* __restrict__ bias = g.splitk > 1 ? nullptr : g.bias;
   const bool vec = (g.ldc % 4 == 0) && (((uintptr_t)g.C & 15) == 0) && (n0 + XBN <= g.N) &&
                    (!bias || ((uintptr_t)bias & 15) == 0);                                  // uniform
   if (vec) {
-    float* ct = reinterpret_cast<float*>(xsm);          // [64][XBN + 4]
-    constexpr int LDC_T = XBN + 4;
+    float* ct = reinterpret_cast<float*>(xsm);          // [32 MI][XBN + 4]
+    constexpr int LDC_T = G::LDC_T;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       __syncthreads();
       if (wm == half) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -293,9 +372,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_nt_kernel(X6Args g) {
       }
       __syncthreads();
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
+      for (int it = 0; it < 4 * MI; ++it) {
         const int rr = (tid >> 5) + 8 * it, c4 = tid & 31;
-        const int row = m0 + half * 64 + rr;
+        const int row = m0 + half * 32 * MI + rr;
         if (row < g.M) {
           f32x4 v = *reinterpret_cast<const f32x4*>(&ct[rr * LDC_T + c4 * 4]);
           if (bias) v += *reinterpret_cast<const f32x4*>(bias + n0 + c4 * 4);
@@ -306,13 +385,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_nt_kernel(X6Args g) {
     return;
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n0 + wn * 64 + j * 32 + fi;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+        const int row = m0 + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
         if (row < g.M && col < g.N) dst[(size_t)row * g.ldc + col] = acc[i][j][r] + (bias ? bias[col] : 0.f);
       }
     }
@@ -413,12 +492,30 @@ static int x6_slices(int tiles, int nkt, int min_steps, int max_slices) {
   }
   return bs;
 }
-static int x6_splitk(int M, int N, int nkt) {
-  return x6_slices(cdiv(M, XBM) * cdiv(N, XBN), nkt, 12, 4);
+// The NT kernel's plan: rows per workgroup tile (64 MI) and K slices.  MI = 2 unless pinned: the
+// taller tiles were built to take the kernel off what looked like an L1 / L2 bandwidth bound (half
+// the B-fragment traffic per matrix instruction, one workgroup per CU) and measured NO faster
+// anywhere (profiles/r05_i_gemm_x6_nt_plans.txt: 4096^3 678.6 us at MI = 4 vs 680.8 at MI = 2; the
+// step's shapes 0-10 % slower, they have too few 256-row tiles).  What bounds the kernel is the
+// vector ALU: on gfx950 a vector instruction and a matrix instruction of one SIMD do not overlap
+// (tools/csrc/mfma_bf16_rate.hip, profiles/r05_i_mfma_bf16_rate.txt: 48 matrix instructions + 102
+// vector instructions per wave run at exactly 1536 / (1536 + 4 * 102) of the matrix-only rate, one
+// or two waves per SIMD alike), and the in-kernel split of A is 1.8 vector instructions per matrix
+// instruction whatever the tile shape.  option gemm_x6_plan = MI + 16 * slices pins either.
+struct X6Plan { int mi, s; };
+static X6Plan x6_plan(int M, int N, int nkt) {
+  const int pin = danet_opt(OPT_GEMM_X6_PLAN);
+  const int pin_mi = pin & 15, pin_s = pin >> 4;
+  X6Plan p;
+  p.mi = (pin_mi >= 2 && pin_mi <= 4) ? pin_mi : 2;
+  const int tiles = cdiv(M, 64 * p.mi) * cdiv(N, XBN);
+  // (one workgroup per CU at MI > 2: the model's 512 slots hold twice the tiles)
+  p.s = pin_s >= 1 ? min(pin_s, max(nkt, 1)) : x6_slices(p.mi == 2 ? tiles : 2 * tiles, nkt, 12, 4);
+  return p;
 }
 
 size_t dn_ws_gemm_x6(int M, int N, int K1, int K2) {
-  const int s = x6_splitk(M, N, cdiv(K1, XBK) + cdiv(K2, XBK));
+  const int s = x6_plan(M, N, cdiv(K1, XBK) + cdiv(K2, XBK)).s;
   return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
@@ -454,15 +551,14 @@ extern "C" int danet_gemm_x6(danet_stream_t stream_, int M, int N,
   DANET_CHECK_ARG(((((uintptr_t)B1pk | (uintptr_t)B2pk) & 15) == 0), "gemm_x6: packed weight alignment");
   DANET_CHECK_ARG((int64_t)M * lda1 < (1ll << 29) && (K2 == 0 || (int64_t)M * lda2 < (1ll << 29)),
                   "gemm_x6: an operand spans 2 GiB or more");
-  { static std::atomic<unsigned long long> done{0};
-    DANET_CHECK_HIP(x6_set_lds((const void*)gemm_x6_nt_kernel, X6_SMEM_BYTES, done)); }
   X6Args g;
   g.A[0] = A1; g.Bp[0] = (const u32x4*)B1pk; g.lda[0] = lda1; g.K[0] = K1; g.KT[0] = cdiv(K1, XBK);
   g.A[1] = A2; g.Bp[1] = (const u32x4*)B2pk; g.lda[1] = lda2; g.K[1] = K2; g.KT[1] = cdiv(K2, XBK);
   g.npair = K2 > 0 ? 2 : 1;
   g.M = M; g.N = N; g.NT32 = x6_nt32(N); g.bias = bias;
   const int nkt = cdiv(K1, XBK) + cdiv(K2, XBK);
-  int s = x6_splitk(M, N, nkt);
+  const X6Plan plan = x6_plan(M, N, nkt);
+  int s = plan.s;
   if (s > 1 && (N % 4 != 0 || ldc % 4 != 0 || ((uintptr_t)C & 15) != 0)) s = 1;   // (the reduce kernel is vectorised)
   if (s > 1) {
     const size_t need = (size_t)s * M * N * sizeof(float);
@@ -475,10 +571,16 @@ extern "C" int danet_gemm_x6(danet_stream_t stream_, int M, int N,
     g.C = C; g.ldc = ldc;
   }
   g.splitk = s;
-  const int nt = cdiv(M, XBM) * cdiv(N, XBN);
+  const int nt = cdiv(M, 64 * plan.mi) * cdiv(N, XBN);
   dim3 grid((unsigned)(nt * s)), block(256);
-  if (s == 1 && stop) hipExtLaunchKernelGGL(gemm_x6_nt_kernel, grid, block, X6_SMEM_BYTES, stream, nullptr, stop, 0, g);
-  else gemm_x6_nt_kernel<<<grid, block, X6_SMEM_BYTES, stream>>>(g);
+  hipEvent_t kstop = s == 1 ? stop : nullptr;
+#define X6_LAUNCH(MI)                                                                                          \
+  { static std::atomic<unsigned long long> done{0};                                                            \
+    DANET_CHECK_HIP(x6_set_lds((const void*)gemm_x6_nt_kernel<MI>, X6Geo<MI>::SMEM, done));                    \
+    if (kstop) hipExtLaunchKernelGGL(gemm_x6_nt_kernel<MI>, grid, block, X6Geo<MI>::SMEM, stream, nullptr, kstop, 0, g); \
+    else gemm_x6_nt_kernel<MI><<<grid, block, X6Geo<MI>::SMEM, stream>>>(g); }
+  if (plan.mi == 4) X6_LAUNCH(4) else if (plan.mi == 3) X6_LAUNCH(3) else X6_LAUNCH(2)
+#undef X6_LAUNCH
   DANET_CHECK_LAUNCH();
   if (s > 1) {
     dim3 rgrid((unsigned)min((int64_t)2048, cdiv64((int64_t)M * N / 4, 256)));
@@ -533,6 +635,9 @@ struct X6TCtx {
   int mq4;             // first of its 4 columns in load 0: 4 (lane % 16); load 1: + 64
   int woff;            // byte offset of its 8-byte write inside a piece image (load 0; load 1: + 512)
   int roffa[2], roffb[2];   // byte offsets of its first transpose read of A tile 0 / 1, B tile 0 / 1
+  // the k-loop's staging loads (RAGGED = false): byte offset of (k row krow, first column) of load li
+  // inside its operand, X6_OOB for columns beyond the operand; the k-tile travels in the scalar offset
+  unsigned lvo[4];
 };
 
 template <bool RAGGED>
@@ -597,12 +702,12 @@ __device__ __forceinline__ void x6t_mf(f32x16 (&acc)[2][2], const bf16x8 (&fa)[3
 //   slots  0-11  the 12 operand fragments of tile kt + 1 (two transpose reads each)
 //   slots 12-19  split of the 8 value pairs of tile kt + 2 staged two steps ago
 //   slots 20-23  LDS store of one load's pieces + the global load of tile kt + 4 into its registers
-template <bool RAGGED>
+template <bool RAGGED, int SRD, int SWR>
 __device__ __forceinline__ void x6t_step(const X6TCtx& c, char* xsm, int kt, int srd, int swr, f32x16 (&acc)[2][2],
                                          f32x4 (&R)[4], const bf16x8 (&fac)[3][2], const bf16x8 (&fbc)[3][2],
                                          bf16x8 (&fan)[3][2], bf16x8 (&fbn)[3][2]) {
-  const char* srdp = xsm + srd * TSTAGE;
-  char* swrp = xsm + swr * TSTAGE;
+  const char* srdp = xsm + (SRD >= 0 ? SRD : srd) * TSTAGE;      // SRD < 0: run-time stages (the loop's tail)
+  char* swrp = xsm + (SRD >= 0 ? SWR : swr) * TSTAGE;
   uint32_t h[4][2], m[4][2], l[4][2];
 #define X6T_FA(S, PC, I) x6t_mf<S>(acc, fac, fbc); fan[PC][I] = x6t_frag(srdp + (PC) * TIMG, c.roffa[I]); X6_FENCE
 #define X6T_FB(S, PC, I) x6t_mf<S>(acc, fac, fbc); fbn[PC][I] = x6t_frag(srdp + (3 + (PC)) * TIMG, c.roffb[I]); X6_FENCE
@@ -610,12 +715,19 @@ __device__ __forceinline__ void x6t_step(const X6TCtx& c, char* xsm, int kt, int
   X6T_FB(6, 0, 0) X6T_FB(7, 0, 1) X6T_FB(8, 1, 0) X6T_FB(9, 1, 1) X6T_FB(10, 2, 0) X6T_FB(11, 2, 1)
 #undef X6T_FA
 #undef X6T_FB
-#define X6T_S(S, LI, HF) x6t_mf<S>(acc, fac, fbc); split_pair(R[LI][2 * (HF)], R[LI][2 * (HF) + 1], h[LI][HF], m[LI][HF], l[LI][HF]); X6_FENCE
+#define X6T_S(S, LI, HF) x6t_mf<S>(acc, fac, fbc); split_pair_pk(__builtin_shufflevector(R[LI], R[LI], 2 * (HF), 2 * (HF) + 1), h[LI][HF], m[LI][HF], l[LI][HF]); X6_FENCE
   X6T_S(12, 0, 0) X6T_S(13, 0, 1) X6T_S(14, 1, 0) X6T_S(15, 1, 1) X6T_S(16, 2, 0) X6T_S(17, 2, 1) X6T_S(18, 3, 0) X6T_S(19, 3, 1)
 #undef X6T_S
+  // (RAGGED = false: no vector instruction per load but the select of an out-of-range offset for a
+  // k row beyond K / beyond the slice -- one compare per step)
+  const int kta = kt + 4;
+  const bool kok = c.krow < (kta < c.kt1 ? c.K - kta * 16 : 0);
+  const unsigned soa = kta < c.kt1 ? (unsigned)(kta * 16 * c.lda) * 4u : 0u, sob = kta < c.kt1 ? (unsigned)(kta * 16 * c.ldb) * 4u : 0u;
 #define X6T_W(S, LI) x6t_mf<S>(acc, fac, fbc); x6t_write(swrp, c, LI, h[LI], m[LI], l[LI]);          \
-  R[LI] = x6t_load<RAGGED>((LI) < 2 ? c.rsa : c.rsb, (LI) < 2 ? c.lda : c.ldb, (LI) < 2 ? c.mrem : c.nrem, c.K, kt + 4, \
-                           c.kt1, c.krow, c.mq4 + ((LI) & 1) * 64); X6_FENCE
+  if (RAGGED) R[LI] = x6t_load<true>((LI) < 2 ? c.rsa : c.rsb, (LI) < 2 ? c.lda : c.ldb, (LI) < 2 ? c.mrem : c.nrem, c.K, kt + 4, \
+                                     c.kt1, c.krow, c.mq4 + ((LI) & 1) * 64);                              \
+  else R[LI] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((LI) < 2 ? c.rsa : c.rsb,   \
+                                     kok ? c.lvo[LI] : X6_OOB, (LI) < 2 ? soa : sob, 0)); X6_FENCE
   X6T_W(20, 0) X6T_W(21, 1) X6T_W(22, 2) X6T_W(23, 3)
 #undef X6T_W
 }
@@ -652,6 +764,11 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_tn_kernel(X6TArgs g) {
   const int kr = lane >> 4, mq = lane & 15;
   c.krow = 4 * wave + kr;
   c.mq4 = 4 * mq;
+#pragma unroll
+  for (int li = 0; li < 4; ++li) {
+    const int col = c.mq4 + (li & 1) * 64;
+    c.lvo[li] = col < (li < 2 ? c.mrem : c.nrem) ? (unsigned)(c.krow * (li < 2 ? c.lda : c.ldb) + col) * 4u : X6_OOB;
+  }
   // a block's four k-rows sit in slot (k % 4 + m-block) % 4 of its 128 bytes (the transpose read takes
   // one address per lane, so the rows of a block may be permuted): the 16 lanes of a write that share
   // a k-row then cover four m-blocks in four different 32-byte slots -- every bank once
@@ -684,16 +801,31 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_tn_kernel(X6TArgs g) {
     __syncthreads();
     x6t_frags(xsm, c, faA, fbA);
     int kt = kt0, srd = 1, swr = 2;
-#define X6T_STEP(R, FAC, FBC, FAN, FBN)                                                              \
-    { x6t_step<RAGGED>(c, xsm, kt, srd, swr, acc, R, FAC, FBC, FAN, FBN);                            \
+    // (unrolled over the 3 LDS stages x 2 register sets: every LDS address is a loop-invariant
+    // register + an immediate; the tail takes the stages at run time)
+#define X6T_STEP(SRD, SWR, R, FAC, FBC, FAN, FBN)                                                    \
+    { x6t_step<RAGGED, SRD, SWR>(c, xsm, kt, srd, swr, acc, R, FAC, FBC, FAN, FBN);                  \
+      __syncthreads();                                                                               \
+      ++kt; }
+#define X6T_STEP_RT(R, FAC, FBC, FAN, FBN)                                                           \
+    { x6t_step<RAGGED, -1, -1>(c, xsm, kt, srd, swr, acc, R, FAC, FBC, FAN, FBN);                    \
       __syncthreads();                                                                               \
       ++kt; srd = swr; swr = swr == 2 ? 0 : swr + 1; }
-    while (kt + 1 < kt1) {
-      X6T_STEP(R0, faA, fbA, faB, fbB)
-      X6T_STEP(R1, faB, fbB, faA, fbA)
+    while (kt + 5 < kt1) {
+      X6T_STEP(1, 2, R0, faA, fbA, faB, fbB)
+      X6T_STEP(2, 0, R1, faB, fbB, faA, fbA)
+      X6T_STEP(0, 1, R0, faA, fbA, faB, fbB)
+      X6T_STEP(1, 2, R1, faB, fbB, faA, fbA)
+      X6T_STEP(2, 0, R0, faA, fbA, faB, fbB)
+      X6T_STEP(0, 1, R1, faB, fbB, faA, fbA)
     }
-    if (kt < kt1) X6T_STEP(R0, faA, fbA, faB, fbB)
+    while (kt + 1 < kt1) {
+      X6T_STEP_RT(R0, faA, fbA, faB, fbB)
+      X6T_STEP_RT(R1, faB, fbB, faA, fbA)
+    }
+    if (kt < kt1) X6T_STEP_RT(R0, faA, fbA, faB, fbB)
 #undef X6T_STEP
+#undef X6T_STEP_RT
   }
 
   // epilogue: the tile leaves through LDS in two halves of 64 rows (16-byte stores of 512-byte row

@@ -13,6 +13,7 @@ const OptDef kDefs[OPT_COUNT] = {
   {"gemm_yield", 16}, {"lstm_fwd_un", 0}, {"lstm_bwd_s", 0},
   {"lstm_bwd_u", 0}, {"lstm_spin_limit", 0}, {"lstm_fault_inject", 0}, {"lstm_xmap", -1},
   {"lstm_fwd_small", 1}, {"lstm_fwd_fused", -1}, {"lstm_bwd_twin_xcd", 1}, {"gemm_mfma16", 1},
+  {"gemm_x6_plan", 0},
 };
 std::atomic<int> g_val[OPT_COUNT];
 std::atomic<bool> g_init{false};

@@ -21,6 +21,7 @@ enum DanetOpt {
   OPT_LSTM_FWD_FUSED,        // -1 auto (B >= 24) | 0 off | 1 whenever supported
   OPT_LSTM_BWD_TWIN_XCD,     // 1 (default): the twins of a BPTT group share an XCD (L2 hits on their re-reads) | 0
   OPT_GEMM_MFMA16,           // 1: capped groups beside a recurrent kernel use the 16x16x4 k-loop | 0: 32x32x2
+  OPT_GEMM_X6_PLAN,         // 0 modelled | MI + 16 * slices: rows per workgroup tile (64 MI, MI = 2..4) / K slices of danet_gemm_x6
   OPT_COUNT
 };
 
