@@ -59,8 +59,13 @@ struct X6Args {
   int lda[2], K[2], KT[2];
   int NT32;
   float* C;                             // splitk == 1: the result; else slab [splitk][M][N]
-  const float* bias;                    // [N] added to every row, or null (splitk > 1: by the reduce kernel)
+  const float* bias;                    // [N] added to every row, or null
   int M, N, ldc, npair, splitk;
+  // splitk > 1: the workgroup that finishes a tile's LAST slice sums the slices (in slice order) into Cout
+  float* Cout;
+  int ldcout;
+  unsigned* tickets;                    // [tiles]: (launch sequence number << 8) | slices finished
+  unsigned seq;
 };
 
 // x = hi + mid + lo exactly; hi and mid are x and the remainder ROUNDED to 8 significant bits (add
@@ -348,11 +353,77 @@ __global__ __launch_bounds__(256, X6Geo<MI>::WG_PER_CU) void gemm_x6_nt_kernel(X
     if (kt < kt1) X6_STEP_RT(R0, faA, faB, fbA, fbB)
   }
 
+  if (g.splitk > 1) {
+    // K slices (N % 4 == 0, 16-byte aligned Cout: the host's condition for slicing).  Every slice's
+    // partial tile goes to its slab with write-through (sc1) stores; a ticket per tile counts the
+    // slices that have landed, and the workgroup that draws the last ticket sums the slabs IN SLICE
+    // ORDER (its own included: whoever is last, the same additions in the same order) + bias into
+    // Cout.  Nobody ever waits: no assumption about dispatch order or co-residency.  The ticket
+    // cell carries the launch's sequence number, so stale contents (an earlier launch, scratch
+    // shared with other kernels) read as "no slice yet" and nothing has to be cleared.
+    __shared__ unsigned x6_last;
+    float* ct = reinterpret_cast<float*>(xsm);          // [32 MI][XBN + 4]
+    constexpr int LDC_T = G::LDC_T;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+        g.C, 0, (int)((size_t)g.splitk * g.M * g.N * sizeof(float)), 0x00020000);
+    const unsigned plane = (unsigned)g.M * (unsigned)g.N * 4u;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();
+      if (wm == half) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb) * LDC_T + wn * 64 + j * 32 + fi] = acc[i][j][r];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 4 * MI; ++it) {
+        const int rr = (tid >> 5) + 8 * it, c4 = tid & 31;
+        const int row = m0 + half * 32 * MI + rr, col = n0 + c4 * 4;
+        const unsigned off = (row < g.M && col < g.N) ? (unsigned)z * plane + ((unsigned)row * g.N + col) * 4u : X6_OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4u*>(&ct[rr * LDC_T + c4 * 4]), srs, off, 0, 16 /*sc1*/);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      unsigned* cell = g.tickets + bid;
+      const unsigned tag = g.seq << 8;
+      unsigned old = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nw;
+      do {
+        nw = (old & 0xFFFFFF00u) == tag ? old + 1u : (tag | 1u);
+      } while (!__hip_atomic_compare_exchange_strong(cell, &old, nw, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT));
+      x6_last = (nw & 0xFFu) == (unsigned)g.splitk ? 1u : 0u;
+    }
+    __syncthreads();
+    if (x6_last == 0u) return;
+    const float* __restrict__ bias = g.bias;
+#pragma unroll
+    for (int it = 0; it < 8 * MI; ++it) {
+      const int rr = (tid >> 5) + 8 * it, c4 = tid & 31;
+      const int row = m0 + rr, col = n0 + c4 * 4;
+      if (row < g.M && col < g.N) {
+        const unsigned off = ((unsigned)row * g.N + col) * 4u;
+        f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, off, 0, 16 /*sc1*/));
+        for (int zz = 1; zz < g.splitk; ++zz)
+          v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, (unsigned)zz * plane + off, 0, 16 /*sc1*/));
+        if (bias) v += (f32x4){bias[col], bias[col + 1], bias[col + 2], bias[col + 3]};
+        *reinterpret_cast<f32x4*>(g.Cout + (size_t)row * g.ldcout + col) = v;
+      }
+    }
+    return;
+  }
+
   // C/D layout 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  The tile leaves
   // through the (now free) LDS, one wave row's 32 MI rows at a time, as 16-byte stores of full
   // 512-byte row segments when the destination allows it; 4-byte stores otherwise.
-  float* __restrict__ dst = g.C + (g.splitk > 1 ? (size_t)z * g.M * g.ldc : 0);
-  const float* __restrict__ bias = g.splitk > 1 ? nullptr : g.bias;
+  float* __restrict__ dst = g.C;
+  const float* __restrict__ bias = g.bias;
   const bool vec = (g.ldc % 4 == 0) && (((uintptr_t)g.C & 15) == 0) && (n0 + XBN <= g.N) &&
                    (!bias || ((uintptr_t)bias & 15) == 0);                                  // uniform
   if (vec) {
@@ -395,22 +466,6 @@ __global__ __launch_bounds__(256, X6Geo<MI>::WG_PER_CU) void gemm_x6_nt_kernel(X
         if (row < g.M && col < g.N) dst[(size_t)row * g.ldc + col] = acc[i][j][r] + (bias ? bias[col] : 0.f);
       }
     }
-}
-
-// C[m][n] = sum over the K slices, in slice order (slab rows are dense: ld = N)
-__global__ __launch_bounds__(256) void gemm_x6_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C,
-                                                             int M, int N, int ldc, int splitk,
-                                                             const float* __restrict__ bias) {
-  const int64_t n4 = (int64_t)M * N / 4;
-  const int64_t plane = (int64_t)M * N;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    f32x4 v = reinterpret_cast<const f32x4*>(slab)[i];
-    for (int s = 1; s < splitk; ++s) v += reinterpret_cast<const f32x4*>(slab + s * plane)[i];
-    const int64_t e = i * 4;
-    const int row = (int)(e / N), col = (int)(e % N);
-    if (bias) v += (f32x4){bias[col], bias[col + 1], bias[col + 2], bias[col + 3]};
-    *reinterpret_cast<f32x4*>(C + (size_t)row * ldc + col) = v;
-  }
 }
 
 // ------------------------------------------------------------------ weights in operand layout
@@ -514,9 +569,11 @@ static X6Plan x6_plan(int M, int N, int nkt) {
   return p;
 }
 
+// slabs [s][M][N] + a ticket per tile
+static size_t x6_slab_bytes(int s, int M, int N) { return align_up((size_t)s * M * N * sizeof(float), 256); }
 size_t dn_ws_gemm_x6(int M, int N, int K1, int K2) {
-  const int s = x6_plan(M, N, cdiv(K1, XBK) + cdiv(K2, XBK)).s;
-  return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+  const X6Plan p = x6_plan(M, N, cdiv(K1, XBK) + cdiv(K2, XBK));
+  return p.s > 1 ? x6_slab_bytes(p.s, M, N) + (size_t)cdiv(M, 64 * p.mi) * cdiv(N, XBN) * sizeof(unsigned) : 0;
 }
 
 hipEvent_t dn_take_stop_event();   // gemm_f32.hip: the event armed by danet_next_launch_events
@@ -559,21 +616,27 @@ extern "C" int danet_gemm_x6(danet_stream_t stream_, int M, int N,
   const int nkt = cdiv(K1, XBK) + cdiv(K2, XBK);
   const X6Plan plan = x6_plan(M, N, nkt);
   int s = plan.s;
-  if (s > 1 && (N % 4 != 0 || ldc % 4 != 0 || ((uintptr_t)C & 15) != 0)) s = 1;   // (the reduce kernel is vectorised)
+  if (s > 1 && (N % 4 != 0 || ldc % 4 != 0 || ((uintptr_t)C & 15) != 0 ||
+                (size_t)s * M * N * sizeof(float) >= 0xFFFFFFF0ull)) s = 1;   // (the slice sum is vectorised; 32-bit slab offsets)
+  const int nt = cdiv(M, 64 * plan.mi) * cdiv(N, XBN);
+  g.Cout = C; g.ldcout = ldc; g.tickets = nullptr; g.seq = 0;
   if (s > 1) {
-    const size_t need = (size_t)s * M * N * sizeof(float);
+    const size_t need = x6_slab_bytes(s, M, N) + (size_t)nt * sizeof(unsigned);
     if (!ws || ws_bytes < need || ((uintptr_t)ws & 15) != 0) {
       danet_set_error("gemm_x6: workspace %zu < %zu (or not 16-B aligned)", ws_bytes, need);
       return DANET_ERR_WORKSPACE;
     }
+    // ticket tag of this launch: process-wide, so launches from any thread / stream differ
+    static std::atomic<unsigned> launch_seq{0x00a5c3u};
     g.C = (float*)ws; g.ldc = N;
+    g.tickets = (unsigned*)((char*)ws + x6_slab_bytes(s, M, N));
+    g.seq = launch_seq.fetch_add(1, std::memory_order_relaxed) & 0xFFFFFFu;
   } else {
     g.C = C; g.ldc = ldc;
   }
   g.splitk = s;
-  const int nt = cdiv(M, 64 * plan.mi) * cdiv(N, XBN);
   dim3 grid((unsigned)(nt * s)), block(256);
-  hipEvent_t kstop = s == 1 ? stop : nullptr;
+  hipEvent_t kstop = stop;
 #define X6_LAUNCH(MI)                                                                                          \
   { static std::atomic<unsigned long long> done{0};                                                            \
     DANET_CHECK_HIP(x6_set_lds((const void*)gemm_x6_nt_kernel<MI>, X6Geo<MI>::SMEM, done));                    \
@@ -582,13 +645,6 @@ extern "C" int danet_gemm_x6(danet_stream_t stream_, int M, int N,
   if (plan.mi == 4) X6_LAUNCH(4) else if (plan.mi == 3) X6_LAUNCH(3) else X6_LAUNCH(2)
 #undef X6_LAUNCH
   DANET_CHECK_LAUNCH();
-  if (s > 1) {
-    dim3 rgrid((unsigned)min((int64_t)2048, cdiv64((int64_t)M * N / 4, 256)));
-    if (stop) hipExtLaunchKernelGGL(gemm_x6_reduce_kernel, rgrid, block, 0, stream, nullptr, stop, 0,
-                                    (const float*)ws, C, M, N, ldc, s, bias);
-    else gemm_x6_reduce_kernel<<<rgrid, block, 0, stream>>>((const float*)ws, C, M, N, ldc, s, bias);
-    DANET_CHECK_LAUNCH();
-  }
   return DANET_OK;
 }
 
@@ -757,8 +813,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_tn_kernel(X6TArgs g) {
   {
     const float* ab = q.A + m0;
     const float* bb = q.B + n0;
-    c.rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ab), 0, (int)(((size_t)(K - 1) * q.lda + (M - m0)) * 4), 0x00020000);
-    c.rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bb), 0, (int)(((size_t)(K - 1) * q.ldb + (N - n0)) * 4), 0x00020000);
+    // (whole 16-byte groups of the last k row are in range)
+    c.rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ab), 0, (int)(((size_t)(K - 1) * q.lda + ((M - m0 + 3) & ~3)) * 4), 0x00020000);
+    c.rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bb), 0, (int)(((size_t)(K - 1) * q.ldb + ((N - n0 + 3) & ~3)) * 4), 0x00020000);
   }
   c.lda = q.lda; c.ldb = q.ldb; c.K = K; c.kt1 = kt1; c.mrem = M - m0; c.nrem = N - n0;
   const int kr = lane >> 4, mq = lane & 15;
@@ -913,7 +970,7 @@ extern "C" int danet_gemm_x6_tn_grouped(danet_stream_t stream_, int K, int nprob
   X6TArgs g;
   int tiles = 0;
   long long sum_mn = 0;
-  bool ragged = false, slicable = true;
+  bool slicable = true;
   for (int i = 0; i < nprob; ++i) {
     const danet_gemm_problem_t& q = probs[i];
     DANET_CHECK_ARG(q.M > 0 && q.N > 0 && q.A && q.B && q.C, "gemm_x6_tn: bad problem %d", i);
@@ -933,7 +990,9 @@ extern "C" int danet_gemm_x6_tn_grouped(danet_stream_t stream_, int K, int nprob
     p.slab_off = sum_mn;
     tiles += cdiv(q.M, 128) * p.tiles_n;
     sum_mn += (long long)q.M * q.N;
-    ragged = ragged || (q.M % 4) || (q.N % 4);
+    // (M or N not a multiple of 4: the rows are still read in whole 16-byte groups -- lda / ldb are
+    // multiples of 4, so a group never leaves its row's pitch -- and whatever sits in a row's pad only
+    // reaches output rows / columns beyond M / N, which are never stored: no masking, no second kernel)
     slicable = slicable && q.N % 4 == 0 && q.ldc % 4 == 0 && (((uintptr_t)q.C) & 15) == 0 && ((long long)q.M * q.N) % 4 == 0;
   }
   for (int i = nprob; i < X6T_MAX_PROBLEMS; ++i) g.p[i] = g.p[0];
@@ -950,11 +1009,9 @@ extern "C" int danet_gemm_x6_tn_grouped(danet_stream_t stream_, int K, int nprob
     }
   }
   { static std::atomic<unsigned long long> done[2];
-    DANET_CHECK_HIP(x6_set_lds((const void*)gemm_x6_tn_kernel<false>, X6T_SMEM_BYTES, done[0]));
-    DANET_CHECK_HIP(x6_set_lds((const void*)gemm_x6_tn_kernel<true>, X6T_SMEM_BYTES, done[1])); }
+    DANET_CHECK_HIP(x6_set_lds((const void*)gemm_x6_tn_kernel<false>, X6T_SMEM_BYTES, done[0])); }
   dim3 grid((unsigned)(tiles * s)), block(256);
-  if (ragged) gemm_x6_tn_kernel<true><<<grid, block, X6T_SMEM_BYTES, stream>>>(g);
-  else gemm_x6_tn_kernel<false><<<grid, block, X6T_SMEM_BYTES, stream>>>(g);
+  gemm_x6_tn_kernel<false><<<grid, block, X6T_SMEM_BYTES, stream>>>(g);
   DANET_CHECK_LAUNCH();
   if (s > 1) {
     long long most = 0;

@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_gemm_x6.py tests/test_gpu_gemm.py -x -q 2>&1 | tail -3
-timeout 300 python tools/bench_gemm_x6_nt.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/x6_nt.txt
 timeout 300 python tools/bench_gemm_x6_tn.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/x6_tn.txt
 b() { python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-e2e --no-parity-check 2>/dev/null | python -c "
 import sys,json
@@ -10,4 +9,5 @@ for l in sys.stdin:
     except Exception: continue
     print('$1', d['ms_per_step'], d['roofline'].get('lstm_fwd_us'), d['roofline'].get('lstm_bwd_us'))
 "; }
-b new; b new
+P=$GRAFT_REPO_ROOT/danet-tensorflow_amd/csrc/libdanet_hip_prev.so
+b new; DANET_LIB_PATH=$P b prev; b new; DANET_LIB_PATH=$P b prev
