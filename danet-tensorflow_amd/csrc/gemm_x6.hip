@@ -673,6 +673,7 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 struct X6TProblem {
   const float* A; const float* B; float* C;
   int lda, ldb, ldc, M, N;
+  int Mmain;                             // rows covered by 128-row matrix-core tiles; the rest are TAIL rows
   float beta;
   int tile0, tiles_n;
   long long slab_off;                    // this problem's [M][N] inside a K slice's slab (floats)
@@ -680,6 +681,7 @@ struct X6TProblem {
 struct X6TArgs {
   X6TProblem p[X6T_MAX_PROBLEMS];
   int nprob, K, splitk, tiles;
+  int ntail;                             // leading workgroups of the launch that compute tail rows
   long long slab_stride;                 // floats per K slice
   float* slab;
 };
@@ -788,12 +790,83 @@ __device__ __forceinline__ void x6t_step(const X6TCtx& c, char* xsm, int kt, int
 #undef X6T_W
 }
 
+// TAIL rows.  M = 129 (the bottom layer's dWx: 129 spectrogram bins) would cost a second 128-row tile
+// row with ONE valid row -- 20 of the group's 100 tiles at cfg 2.  A problem with 1..X6T_TAIL_MAX rows
+// beyond a multiple of 128 gets those rows from plain fp32 FMA chains instead: the first `ntail`
+// workgroups of the launch (dispatched first, they run in slots the tiles leave idle)
+// take one K slice x 64 columns each -- 16 k-lanes x 16 column groups of 4, the lanes summed in lane
+// order -- and write to the rows of the slice's slab (or of C) that the tiles of the problem do not
+// cover, so the slice sum treats them like any other row.  Exact fp32 products, deterministic.
+// Measured (bottom layer's group, cfg 2, alone): 89.5 -> 85.7 us; workgroups of 256 columns x 4
+// k-lanes (a wave per lane, 1 KB row segments) take longer than the tiles: 114 us.
+#define X6T_TAIL_MAX 4
+__device__ __forceinline__ void x6t_tail(const X6TArgs& g, int t, char* xsm) {
+  int pi = -1, per_p = 0;
+#pragma unroll
+  for (int i = 0; i < X6T_MAX_PROBLEMS; ++i) {
+    if (i < g.nprob && pi < 0 && g.p[i].Mmain < g.p[i].M) {
+      per_p = ((g.p[i].N + 63) / 64) * g.splitk;
+      if (t < per_p) pi = i; else t -= per_p;
+    }
+  }
+  if (pi < 0) return;
+  const X6TProblem& q = g.p[pi];
+  const int chunks = (q.N + 63) / 64;
+  const int z = t / chunks, n0 = (t % chunks) * 64;
+  const int nkt = (g.K + 15) / 16;
+  const int per = (nkt + g.splitk - 1) / g.splitk;
+  const int k0 = z * per * 16, k1 = min(g.K, (z + 1) * per * 16);
+  const int tid = threadIdx.x, kl = tid >> 4, cg = tid & 15;
+  const int n = n0 + cg * 4;
+  const int R = q.M - q.Mmain;                         // 1..X6T_TAIL_MAX
+  f32x4 acc[X6T_TAIL_MAX];
+#pragma unroll
+  for (int r = 0; r < X6T_TAIL_MAX; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (n < q.N) {                                       // (N % 4 == 0: a column group is whole or absent)
+    const float* __restrict__ bp = q.B + n;
+    const float* __restrict__ ap = q.A + q.Mmain;
+#pragma unroll 4
+    for (int k = k0 + kl; k < k1; k += 16) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + (size_t)k * q.ldb);
+#pragma unroll
+      for (int r = 0; r < X6T_TAIL_MAX; ++r)
+        if (r < R) {
+          const float a = ap[(size_t)k * q.lda + r];
+          acc[r][0] = fmaf(a, bv[0], acc[r][0]); acc[r][1] = fmaf(a, bv[1], acc[r][1]);
+          acc[r][2] = fmaf(a, bv[2], acc[r][2]); acc[r][3] = fmaf(a, bv[3], acc[r][3]);
+        }
+    }
+  }
+  f32x4* red = reinterpret_cast<f32x4*>(xsm);          // [16 k-lanes][16 column groups]
+  const bool sliced = g.splitk > 1;
+#pragma unroll
+  for (int r = 0; r < X6T_TAIL_MAX; ++r) {
+    if (r >= R) break;                                 // (uniform)
+    __syncthreads();
+    red[kl * 16 + cg] = acc[r];
+    __syncthreads();
+    if (kl == 0 && n < q.N) {
+      f32x4 v = red[cg];
+      for (int j = 1; j < 16; ++j) v += red[j * 16 + cg];
+      const int row = q.Mmain + r;
+      float* o = sliced ? g.slab + (size_t)z * g.slab_stride + q.slab_off + (size_t)row * q.N + n
+                        : q.C + (size_t)row * q.ldc + n;
+      if (!sliced && q.beta != 0.f) v += *reinterpret_cast<const f32x4*>(o);
+      *reinterpret_cast<f32x4*>(o) = v;
+    }
+  }
+}
+
 template <bool RAGGED>
 __global__ __launch_bounds__(256, 2) void gemm_x6_tn_kernel(X6TArgs g) {
   extern __shared__ __attribute__((aligned(16))) char xsm[];
+  if ((int)blockIdx.x < g.ntail) {                     // (uniform)
+    x6t_tail(g, (int)blockIdx.x, xsm);
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int item = x6_xcd_item(blockIdx.x, gridDim.x);
+  const int item = x6_xcd_item((int)blockIdx.x - g.ntail, (int)gridDim.x - g.ntail);
   const int z = item / g.tiles;                        // K slice
   const int t = item % g.tiles;
   int pi = 0;
@@ -803,7 +876,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_tn_kernel(X6TArgs g) {
   const X6TProblem& q = g.p[pi];
   const int tl = t - q.tile0;
   const int m0 = (tl / q.tiles_n) * 128, n0 = (tl % q.tiles_n) * 128;
-  const int M = q.M, N = q.N, K = g.K;
+  const int M = q.Mmain, N = q.N, K = g.K;             // (tail rows: x6t_tail)
 
   const int nkt = (K + 15) / 16;
   const int per = (nkt + g.splitk - 1) / g.splitk;
@@ -957,6 +1030,13 @@ __global__ __launch_bounds__(256) void gemm_x6_tn_reduce_kernel(X6TArgs g) {
 }
 
 static int x6t_splitk(int tiles, int K) { return x6_slices(tiles, cdiv(K, 16), 16, 8); }
+// rows of a problem covered by 128-row tiles: all of them, unless 1..X6T_TAIL_MAX rows hang over a
+// multiple of 128 (then those are tail rows: x6t_tail).  include/danet_hip.h states the same rule
+// for the tile count a caller passes to danet_workspace_bytes(DANET_WS_GEMM_X6_TN, ...).
+static int x6t_main_rows(int M, int N) {
+  const int tail = M % 128;
+  return (M > 128 && tail >= 1 && tail <= X6T_TAIL_MAX && N % 4 == 0) ? M - tail : M;
+}
 size_t dn_ws_gemm_x6_tn(long long sum_mn, int tiles, int K) {
   const int s = x6t_splitk(tiles, K);
   return s > 1 ? (size_t)s * (size_t)sum_mn * sizeof(float) : 0;
@@ -985,10 +1065,11 @@ extern "C" int danet_gemm_x6_tn_grouped(danet_stream_t stream_, int K, int nprob
     X6TProblem& p = g.p[i];
     p.A = q.A; p.B = q.B; p.C = q.C; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.M = q.M; p.N = q.N;
     p.beta = q.beta;
+    p.Mmain = ((((uintptr_t)q.C) & 15) == 0 && q.ldc % 4 == 0) ? x6t_main_rows(q.M, q.N) : q.M;
     p.tiles_n = cdiv(q.N, 128);
     p.tile0 = tiles;
     p.slab_off = sum_mn;
-    tiles += cdiv(q.M, 128) * p.tiles_n;
+    tiles += cdiv(p.Mmain, 128) * p.tiles_n;
     sum_mn += (long long)q.M * q.N;
     // (M or N not a multiple of 4: the rows are still read in whole 16-byte groups -- lda / ldb are
     // multiples of 4, so a group never leaves its row's pitch -- and whatever sits in a row's pad only
@@ -1001,6 +1082,9 @@ extern "C" int danet_gemm_x6_tn_grouped(danet_stream_t stream_, int K, int nprob
   g.splitk = s;
   g.slab_stride = sum_mn;
   g.slab = (float*)ws;
+  g.ntail = 0;
+  for (int i = 0; i < nprob; ++i)
+    if (g.p[i].Mmain < g.p[i].M) g.ntail += cdiv(g.p[i].N, 64) * s;
   if (s > 1) {
     const size_t need = (size_t)s * (size_t)sum_mn * sizeof(float);
     if (!ws || ws_bytes < need || ((uintptr_t)ws & 15) != 0) {
@@ -1010,7 +1094,7 @@ extern "C" int danet_gemm_x6_tn_grouped(danet_stream_t stream_, int K, int nprob
   }
   { static std::atomic<unsigned long long> done[2];
     DANET_CHECK_HIP(x6_set_lds((const void*)gemm_x6_tn_kernel<false>, X6T_SMEM_BYTES, done[0])); }
-  dim3 grid((unsigned)(tiles * s)), block(256);
+  dim3 grid((unsigned)(tiles * s + g.ntail)), block(256);
   gemm_x6_tn_kernel<false><<<grid, block, X6T_SMEM_BYTES, stream>>>(g);
   DANET_CHECK_LAUNCH();
   if (s > 1) {

@@ -228,6 +228,14 @@ def gemm_w(A, lda, W, sn, sk, C, M, N, K, ldc, tag=None, stop_event=None,
     return C
 
 
+def _x6_tn_tiles(M, N):
+    '''128 x 128 tiles of one product of danet_gemm_x6_tn_grouped (include/danet_hip.h): 1..4 rows
+    beyond a multiple of 128 are tail rows, not a tile row (N a multiple of 4)'''
+    tail = M % 128
+    rows = M - tail if (M > 128 and 1 <= tail <= 4 and N % 4 == 0) else M
+    return ((rows + 127) // 128) * ((N + 127) // 128)
+
+
 def gemm_group(problems, K, transA=False, transB=False, max_workgroups=0):
     '''up to 6 products sharing K and the transpose flags as ONE stream-K launch.
     problems: list of (A, lda, B, ldb, C, ldc, M, N, beta) with tensors whose data_ptr()
@@ -249,7 +257,7 @@ def gemm_group(problems, K, transA=False, transB=False, max_workgroups=0):
         # both operands split inside the kernel (csrc/gemm_x6.hip, TN section); not persistent:
         # `max_workgroups` does not apply
         need = _lib.ws_bytes(_lib.WS_GEMM_X6_TN, sum(pr[6] * pr[7] for pr in problems),
-                             sum(((pr[6] + 127) // 128) * ((pr[7] + 127) // 128) for pr in problems), K)
+                             sum(_x6_tn_tiles(pr[6], pr[7]) for pr in problems), K)
         w = _lib.workspace(need, dev, tag='gemm_x6_tn') if need else None
         with _lib.timed('gemm_x6_tn_group'):
             check(L.danet_gemm_x6_tn_grouped(_lib.stream(), K, len(problems), arr, ptr(w),

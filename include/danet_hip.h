@@ -240,7 +240,9 @@ int danet_gemm_x6(danet_stream_t stream, int M, int N,
  * layer, dW = x^T da with K = T*B.  Both operands are split inside the kernel; `bias` must be NULL,
  * beta 0 or 1.  lda / ldb multiples of 4, A / B 16-byte aligned: DANET_ERR_UNSUPPORTED otherwise.
  * Deterministic (K slices are summed in slice order).  `ws`: DANET_WS_GEMM_X6_TN(sum of M*N over
- * the products, sum of ceil(M/128)*ceil(N/128), K) bytes.                                        */
+ * the products, sum of tile_rows(M)*ceil(N/128), K) bytes, tile_rows(M) = ceil(M/128) -- except that
+ * 1..4 rows beyond a multiple of 128 (M > 128, N % 4 == 0: the 129 spectrogram bins of the bottom
+ * layer's dWx) are not a tile row: tile_rows(M) = M/128, those rows are exact fp32 FMA chains.    */
 int danet_gemm_x6_tn_grouped(danet_stream_t stream, int K, int nprob, const danet_gemm_problem_t* probs,
                              void* ws, size_t ws_bytes);
 

@@ -172,6 +172,10 @@ TN_GROUPS = [
     (2048, [(600, 2580, 600, 2580, 2580, 0.0)]),
     (40, [(5, 7, 8, 8, 7, 1.0), (130, 129, 132, 132, 129, 0.0)]),
     (16, [(128, 128, 128, 128, 128, 0.0)]),
+    # tail rows (1..4 rows beyond a multiple of 128 are fp32 FMA chains, not a tile row): without K
+    # slices (straight into C, beta 1 and 0), three tail rows beside a plain product, 260 = 2 tiles + 4
+    (48, [(131, 12, 132, 12, 16, 1.0), (129, 200, 132, 200, 200, 0.0), (64, 64, 64, 64, 64, 1.0)]),
+    (4096, [(260, 600, 260, 600, 600, 1.0), (129, 1200, 132, 1200, 1200, 0.0)]),
 ]
 
 
