@@ -63,7 +63,7 @@ const char* danet_last_error(void);
  * Names (value meaning in csrc/options.h): gemm_dma, splitk_target, gemm_wgs,
  * gemm_maxsplit, gemm_yield, gemm_mfma16, lstm_fwd_un, lstm_fwd_small,
  * lstm_fwd_fused, lstm_bwd_u, lstm_bwd_s, lstm_bwd_twin_xcd,
- * lstm_xmap, lstm_spin_limit, lstm_fault_inject.
+ * lstm_xmap, lstm_spin_limit, lstm_fault_inject, gemm_x6_plan.
  * danet_set_option / danet_get_option return DANET_ERR_ARG for an unknown
  * name; danet_option_name(i), 0 <= i < danet_option_count(), enumerates.   */
 int danet_set_option(const char* name, int value);
@@ -223,7 +223,8 @@ int danet_gemm_f32_streamk_kcat(danet_stream_t stream, int transA, int transB, i
  * the host re-packs after every optimizer step (one launch for the whole table).  An event armed
  * with danet_next_launch_events completes with this product, as for stream-K launches.
  * B(n, k) = src[n * stride_n + k * stride_k]; `out`: DANET_WS_GEMM_PACK(N, K) bytes, 16-B aligned.
- * `ws`: DANET_WS_GEMM_X6(M, N, K1, K2) bytes.                                                    */
+ * `ws`: DANET_WS_GEMM_X6(M, N, K1, K2) bytes (K-slice slabs + one ticket word per tile; its
+ * contents on entry do not matter).                                                              */
 typedef struct {
   const float* src; long long stride_n, stride_k;
   int N, K;
