@@ -21,6 +21,19 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 // significant bits.  (x0, x1) -> the packed bf16 pairs of their pieces (x0 in the low half):
 // v_cvt_pk_bf16_f32 rounds to nearest even, the remainders are exact in fp32 and the third piece
 // has <= 8 significant bits left.
+//
+// The remainder x - bf16(x) is formed by ONE instruction per value: v_dot2c_f32_bf16 computes
+// d += a.lo * b.lo + a.hi * b.hi in fp32 with a single rounding, so with the piece pair as `a` and
+// (-1, 0) / (0, -1) as `b` it returns x0 - hi0 / x1 - hi1 -- exact, like the subtraction it replaces
+// (tools/csrc/dot2_split_exact.hip: bit-identical pieces for 4 x 8.4 M pairs over every binade,
+// denormals included) -- without the two instructions that expanded the pair to fp32 first: 7 vector
+// instructions per pair of values instead of 9, and on gfx950 every vector instruction of a matrix
+// loop is paid in matrix-core time.  One difference, for non-finite data only: a
+// value whose bf16 rounding is +-Inf (|x| >= 3.39e38, Inf) makes its PARTNER's remainder NaN
+// (Inf * 0); in the subtracting form only the value itself produced Inf - Inf.
+// The multipliers live in scalar registers behind an asm barrier: written as constants, the compiler
+// encodes (-1, 0) as the inline constant -1.0, which the instruction reads as 0xbf800000 = (0, -1).
+#ifdef DANET_SPLIT_SUBTRACT
 __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
   h = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){x0, x1}, bf16x2v));
   const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
@@ -28,6 +41,23 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint
   const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xFFFF0000u);
   l = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){s0, s1}, bf16x2v));
 }
+#else
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  uint32_t c0 = 0x0000bf80u, c1 = 0xbf800000u;          // bf16 pairs (-1, 0) and (0, -1)
+  asm("" : "+s"(c0));
+  asm("" : "+s"(c1));
+  const bf16x2v n0 = __builtin_bit_cast(bf16x2v, c0), n1 = __builtin_bit_cast(bf16x2v, c1);
+  const bf16x2v hv = __builtin_convertvector((f32x2v){x0, x1}, bf16x2v);
+  const float r0 = __builtin_amdgcn_fdot2_f32_bf16(hv, n0, x0, false);
+  const float r1 = __builtin_amdgcn_fdot2_f32_bf16(hv, n1, x1, false);
+  const bf16x2v mv = __builtin_convertvector((f32x2v){r0, r1}, bf16x2v);
+  const float s0 = __builtin_amdgcn_fdot2_f32_bf16(mv, n0, r0, false);
+  const float s1 = __builtin_amdgcn_fdot2_f32_bf16(mv, n1, r1, false);
+  h = __builtin_bit_cast(uint32_t, hv);
+  m = __builtin_bit_cast(uint32_t, mv);
+  l = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){s0, s1}, bf16x2v));
+}
+#endif
 
 extern "C" void danet_set_error(const char* fmt, ...);
 

@@ -77,17 +77,9 @@ __device__ __forceinline__ void split3(float x, uint32_t& h, uint32_t& m, uint32
   m = (__float_as_uint(r) + 0x8000u) & 0xFFFF0000u;
   l = __float_as_uint(r - __uint_as_float(m));
 }
-// (split_pair: csrc/common.h.)  The same split written on 2-vectors, so that both subtractions are
-// one packed instruction each: 9 vector instructions per pair of values.  On gfx950 a vector
-// instruction and a matrix instruction of one SIMD do not overlap (tools/csrc/mfma_bf16_rate.hip), so
-// every vector instruction of the k-loop is paid in matrix-core time.
-__device__ __forceinline__ f32x2v pk_sub(f32x2v a, f32x2v b) { return a - b; }
+// (split_pair: csrc/common.h -- 7 vector instructions per pair of values)
 __device__ __forceinline__ void split_pair_pk(f32x2v x, uint32_t& h, uint32_t& m, uint32_t& l) {
-  h = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2v));
-  const f32x2v r = pk_sub(x, (f32x2v){__uint_as_float(h << 16), __uint_as_float(h & 0xFFFF0000u)});
-  m = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2v));
-  const f32x2v t = pk_sub(r, (f32x2v){__uint_as_float(m << 16), __uint_as_float(m & 0xFFFF0000u)});
-  l = __builtin_bit_cast(uint32_t, __builtin_convertvector(t, bf16x2v));
+  split_pair(x[0], x[1], h, m, l);
 }
 
 // the high halves of two words as one word: [hi16(b) | hi16(a)]
