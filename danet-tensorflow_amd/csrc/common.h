@@ -123,7 +123,7 @@ __device__ __forceinline__ float sigmoid_hw(float x) {
 #ifdef DANET_LSTM_ACCURATE_MATH
   return sigmoid_acc(x);
 #else
-  return __frcp_rn(1.0f + __expf(-x));
+  return __builtin_amdgcn_rcpf(1.0f + __expf(-x));      // v_rcp_f32 (HIP's __frcp_rn is the 11-instruction IEEE division)
 #endif
 }
 __device__ __forceinline__ float tanh_hw(float x) {
@@ -134,7 +134,7 @@ __device__ __forceinline__ float tanh_hw(float x) {
   // no cancellation for large |x|; for tiny |x| the (1 - e) cancellation is
   // absolute-error ~1e-8, relative to the O(1) tensor scale used by the bar
   const float e = __expf(-2.0f * fabsf(x));
-  const float t = (1.0f - e) * __frcp_rn(1.0f + e);
+  const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
   return copysignf(t, x);
 #endif
 }

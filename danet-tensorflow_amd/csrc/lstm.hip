@@ -217,6 +217,14 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
     }
   __syncthreads();
 
+  // owner threads: where step s publishes h / saves its activations; the pointers walk the time axis
+  const int t_first_w = dir ? (T - 1) : 0;
+  const ptrdiff_t tdir_w = dir ? -1 : 1;
+  const ptrdiff_t hstep_w = tdir_w * (ptrdiff_t)B * a.ldy, gstep_w = tdir_w * (ptrdiff_t)B * (4 * H),
+                  cstep_w = tdir_w * (ptrdiff_t)B * H;
+  float* hp_w = a.ypad + (owner ? ((size_t)(t_first_w + 1) * B + bg) * a.ldy + dir * H + unit : 0);
+  float* gs_w = a.gates[dir] + (owner ? ((size_t)t_first_w * B + bg) * (4 * H) + unit : 0);
+  float* cs_w = a.cell[dir] + (owner ? ((size_t)t_first_w * B + bg) * H + unit : 0);
 #define FW_OP(P_) __builtin_bit_cast(bf16x8v, (u32x4v){(P_)[0], (P_)[1], (P_)[2], (P_)[3]})
   for (int s = 0; s < T; ++s) {
     const int t = dir ? (T - 1 - s) : s;
@@ -344,13 +352,13 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_kernel(LstmFwdArgs a) {
       const float og = sigmoid_hw(pre[3]);
       c_state = ig * g + fg * c_state;        // ops.py:146
       const float h = og * tanh_hw(c_state);   // ops.py:147
-      // publish h_t: one write-through 4-byte store, no drain, no flag
-      float* hp = a.ypad + ((size_t)(t + 1) * B + bg) * a.ldy + dir * H + unit;
-      __hip_atomic_store(hp, h, RLX_AGENT);
+      // publish h_t: one write-through 4-byte store, no drain, no flag (owner pointers walk the
+      // time axis: no 64-bit multiplies in front of it)
+      __hip_atomic_store(hp_w, h, RLX_AGENT);
       // saved activations are only read by later kernels (plain stores)
-      float* gs = a.gates[dir] + ((size_t)t * B + bg) * (4 * H) + unit;
-      gs[0] = g; gs[H] = ig; gs[2 * H] = fg; gs[3 * H] = og;
-      a.cell[dir][((size_t)t * B + bg) * H + unit] = c_state;
+      gs_w[0] = g; gs_w[H] = ig; gs_w[2 * H] = fg; gs_w[3 * H] = og;
+      cs_w[0] = c_state;
+      hp_w += hstep_w; gs_w += gstep_w; cs_w += cstep_w;
     }
     // `red` is rewritten only after this wave has seen every h_t word of its
     // cluster, i.e. after every owner thread (in every wave) has finished
@@ -586,6 +594,17 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
 #else
   constexpr int XBA = 1;   // k-blocks of the input half done before the exchange loads are issued (0: retries)
 #endif
+  // ... and k-groups of it where it stays on the fp32 instructions (the bottom layer): ALL of them.
+  // With the gate phase at 45 vector instructions (hardware reciprocal, walking pointers) the next
+  // step's top comes 0.1 us sooner after the publish, and exchange loads issued before the
+  // published words are visible do not fail, they come back LATE (publish -> valid 0.93 -> 1.15 us):
+  // 2 groups in front of the loads 273 us per launch averaged over the three layers, 1 group 278,
+  // none 305 (profiles/r05_k_fwd_load_point.txt).  -DFX_GA_F32=n / -DFX_CHA_ABS=n for A/B builds.
+#ifdef FX_GA_F32
+  constexpr int XGA = FX_GA_F32 < CHX ? FX_GA_F32 : CHX;
+#else
+  constexpr int XGA = CHX;
+#endif
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // smem: recurrent weights [KP/4][32][4] (read once into registers) | red [NW][16][33]
   float* Wl = smem;
@@ -796,6 +815,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
 #define FX_GX(b) FX_BLOCKX(xc[2 * (b)], xc[2 * (b) + 1], wx[b], acc)
 #define FX_GXE(b) FX_BLOCKX(xce[2 * (b)], ((2 * (b) + 1 < CHE) ? xce[(2 * (b) + 1 < CHE) ? 2 * (b) + 1 : 0] : (v4u){0u, 0u, 0u, 0u}), wxe[b], accn)
 
+  // owner threads: where step s publishes h / saves its activations; the pointers walk the time axis
+  const int t_first_w = dir ? (T - 1) : 0;
+  const ptrdiff_t tdir_w = dir ? -1 : 1;
+  const ptrdiff_t hstep_w = tdir_w * (ptrdiff_t)B * a.ldy, gstep_w = tdir_w * (ptrdiff_t)B * (4 * H),
+                  cstep_w = tdir_w * (ptrdiff_t)B * H;
+  float* hp_w = a.ypad + (owner ? ((size_t)(t_first_w + 1) * B + bg) * a.ldy + dir * H + unit : 0);
+  float* gs_w = a.gates[dir] + (owner ? ((size_t)t_first_w * B + bg) * (4 * H) + unit : 0);
+  float* cs_w = a.cell[dir] + (owner ? ((size_t)t_first_w * B + bg) * H + unit : 0);
   // early groups of step 0
   f32x4 accn[2][2];
 #pragma unroll
@@ -830,7 +857,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
       for (int b = 0; b < XBA; ++b) FX_GX(b);
     } else {
 #pragma unroll
-      for (int g = 0; g < (CHX + 3) / 4; ++g) FX_GROUPF(xc[g], wxf[g], acc);
+      for (int g = 0; g < XGA; ++g) FX_GROUPF(xc[g], wxf[g], acc);
     }
     __builtin_amdgcn_sched_barrier(0);
     // (b) exchange loads of h_{t-1} (step 0: out of range -> zeros)
@@ -849,7 +876,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
       for (int b = XBA; b < XBW; ++b) FX_GX(b);
     } else {
 #pragma unroll
-      for (int g = (CHX + 3) / 4; g < CHX; ++g) FX_GROUPF(xc[g], wxf[g], acc);
+      for (int g = XGA; g < CHX; ++g) FX_GROUPF(xc[g], wxf[g], acc);
     }
     __builtin_amdgcn_sched_barrier(0);
     TRACE_AT(0, 2);
@@ -976,11 +1003,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
       const float og = sigmoid_hw(pre[3]);
       c_state = ig * g + fg * c_state;        // ops.py:146
       const float h = og * tanh_hw(c_state);   // ops.py:147
-      float* hp = a.ypad + ((size_t)(t + 1) * B + bg) * a.ldy + dir * H + unit;
-      __hip_atomic_store(hp, h, RLX_AGENT);
-      float* gs = a.gates[dir] + ((size_t)t * B + bg) * (4 * H) + unit;
-      gs[0] = g; gs[H] = ig; gs[2 * H] = fg; gs[3 * H] = og;
-      a.cell[dir][((size_t)t * B + bg) * H + unit] = c_state;
+      // (owner pointers walk the time axis: no 64-bit multiplies in front of the publish store)
+      __hip_atomic_store(hp_w, h, RLX_AGENT);
+      gs_w[0] = g; gs_w[H] = ig; gs_w[2 * H] = fg; gs_w[3 * H] = og;
+      cs_w[0] = c_state;
+      hp_w += hstep_w; gs_w += gstep_w; cs_w += cstep_w;
     }
     TRACE_AT(0, 5);
     __syncthreads();   // `red` reuse
