@@ -865,7 +865,7 @@ __global__ __launch_bounds__(ANCH_NT) void anchor_fwd_kernel(
 #pragma unroll
             for (int c = 0; c < CTT; ++c) den += ea[tb.idx[p][c]];
             under |= (den < 1e-30f);
-            const float inv = __frcp_rn(den);
+            const float inv = __builtin_amdgcn_rcpf(den);          // v_rcp_f32 (__frcp_rn is the 11-instruction IEEE division)
 #pragma unroll
             for (int c = 0; c < CTT; ++c) srow[p * CTT + c] = ea[tb.idx[p][c]] * inv;   // modules.py:516
           }
