@@ -68,6 +68,11 @@ typedef unsigned v4u __attribute__((__vector_size__(16)));
 __device__ __forceinline__ v4u load_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned off) {
   return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16 /*sc1*/);
 }
+// ... with the part of the offset that is the same for the whole wave (the time block) in the
+// instruction's SCALAR offset: no vector instruction per load and step
+__device__ __forceinline__ v4u load_sc1_b128s(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16 /*sc1*/);
+}
 __device__ __forceinline__ bool has_sentinel(v4u v) {
   return v[0] == SENTINEL || v[1] == SENTINEL || v[2] == SENTINEL || v[3] == SENTINEL;
 }
@@ -766,6 +771,16 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
   }
   const unsigned xblk = (unsigned)((size_t)B * a.ldx * 4);
   const unsigned yblk = (unsigned)((size_t)B * a.ldy * 4);
+  // loop-invariant vector offsets (an offset >= the buffer's size reads zeros); the time block goes
+  // into the loads' scalar offset.  Step 0 reads h_{-1} from the zero pad block of ypad (block 0 /
+  // T + 1), which no step ever writes.
+  unsigned xoffv[CHX], xoffev[CHE], hcolv[CH];
+#pragma unroll
+  for (int g = 0; g < CHX; ++g) xoffv[g] = xoff[g] == 0xFFFFFFFFu ? xbytes : xoff[g];
+#pragma unroll
+  for (int g = 0; g < CHE; ++g) xoffev[g] = xoffe[g] == 0xFFFFFFFFu ? xbytes : xoffe[g];
+#pragma unroll
+  for (int g = 0; g < CH; ++g) hcolv[g] = hcol[g] == 0xFFFFFFFFu ? ybytes : hcol[g];
   v4u xc[CHX], xce[CHE];
   {
     const int t0 = dir ? (T - 1) : 0;
@@ -862,12 +877,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     // (b) exchange loads of h_{t-1} (step 0: out of range -> zeros)
     v4u av[CH];
-    unsigned hoff[CH];
+    const unsigned hso = (unsigned)blk_prev * yblk;
 #pragma unroll
-    for (int g = 0; g < CH; ++g) {
-      hoff[g] = (s > 0 && hcol[g] != 0xFFFFFFFFu) ? hcol[g] + (unsigned)blk_prev * yblk : ybytes;
-      av[g] = load_sc1_b128(yres, hoff[g]);
-    }
+    for (int g = 0; g < CH; ++g) av[g] = load_sc1_b128s(yres, hcolv[g], hso);
     __builtin_amdgcn_sched_barrier(0);
     TRACE_AT(0, 1);
     // (c) rest of the input half while the loads fly
@@ -891,7 +903,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
         if (__all(mx != SENTINEL)) break;
         if (spin_fail(spins, a.status, lane, a.spin_limit)) break;
 #pragma unroll
-        for (int g = 0; g < CH; ++g) av[g] = load_sc1_b128(yres, hoff[g]);
+        for (int g = 0; g < CH; ++g) av[g] = load_sc1_b128s(yres, hcolv[g], hso);
       }
       TRACE_AT_VAL(0, 6, spins);
     }
@@ -904,6 +916,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
     v4u xn[CHX], xne[CHE];
     const int tn = dir ? (t - 1) : (t + 1);
     const bool have = (s + 1 < T);
+    const unsigned xso = have ? (unsigned)tn * xblk : 0u;     // (last step: any in-range block, the data is unused)
 #pragma unroll
     for (int g = 0; g < CHE; ++g) xne[g] = (v4u){0u, 0u, 0u, 0u};
     __builtin_amdgcn_sched_barrier(0);
@@ -940,14 +953,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = b; i < CHX; i += NB)
-        xn[i] = __builtin_amdgcn_raw_buffer_load_b128(
-            xres, (!have || xoff[i] == 0xFFFFFFFFu) ? xbytes : xoff[i] + (unsigned)tn * xblk, 0, 0);
+        xn[i] = __builtin_amdgcn_raw_buffer_load_b128(xres, xoffv[i], xso, 0);
       // (waves 0 and 1 skip the early groups' loads: even an out-of-range load costs issue time)
       if (early) {
 #pragma unroll
         for (int i = b; i < CHE; i += NB)
-          xne[i] = __builtin_amdgcn_raw_buffer_load_b128(
-              xres, (!have || xoffe[i] == 0xFFFFFFFFu) ? xbytes : xoffe[i] + (unsigned)tn * xblk, 0, 0);
+          xne[i] = __builtin_amdgcn_raw_buffer_load_b128(xres, xoffev[i], xso, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1181,13 +1192,14 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
   // ring addressing without per-step multiplies or divisions: byte offsets inside a slot are fixed,
   // the slot and its phase are counters
   const unsigned slot_bytes = (unsigned)(slot_floats * sizeof(float));
-  unsigned rd_off[RS_NI_MAX];
+  unsigned rd_off[RS_NI_MAX], rd_offv[RS_NI_MAX];
   bool rd_ok[RS_NI_MAX];
 #pragma unroll
   for (int i = 0; i < RS_NI_MAX; ++i) {
     const int q = qq + PPR * i;
     rd_ok[i] = q < P;
     rd_off[i] = (unsigned)(((size_t)cl * P + q) * a.NT * 1024) + xoff;
+    rd_offv[i] = rd_ok[i] ? rd_off[i] : rbytes;
   }
   unsigned pub_off[NTW];
   bool pub_ok[NTW];
@@ -1217,14 +1229,12 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
   auto exchange = [&](auto ni_c, const unsigned sbase, const unsigned par, const int s) {
     (void)s;   // the trace build stamps by step
     constexpr int NI = decltype(ni_c)::value;
-    unsigned off[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) off[i] = rd_ok[i] ? sbase + rd_off[i] : rbytes;   // out of range: zeros
     v4u av[NI];
     unsigned spins = 0;
     for (;;) {
+      // (rd_offv: the offset inside a slot, or out of range -> zeros; the slot in the scalar offset)
 #pragma unroll
-      for (int i = 0; i < NI; ++i) av[i] = load_sc1_b128(rres, off[i]);
+      for (int i = 0; i < NI; ++i) av[i] = load_sc1_b128s(rres, rd_offv[i], sbase);
       // every word must carry the expected phase in bit 0: one OR tree (phase 0) and one AND tree
       // (phase 1; out-of-range loads return zeros and are masked in) over all words, ONE test --
       // instead of a test and a scalar AND per load
@@ -1356,6 +1366,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
       const unsigned ppub = ppar;
 #pragma unroll
       for (int i = 0; i < NTW; ++i) {
+        // (the slot stays in the VECTOR offset here: with it in the scalar offset the stores of
+        // tiles that do not exist -- vector offset = buffer size -- were NOT dropped, B = 48: wrong dX)
         unsigned o = rbytes;   // out of range: dropped
         if (pub_ok[i]) o = pslot * slot_bytes + pub_off[i];
         v4u w = __builtin_bit_cast(v4u, acc[i]);

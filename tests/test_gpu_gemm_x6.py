@@ -176,6 +176,9 @@ TN_GROUPS = [
     # slices (straight into C, beta 1 and 0), three tail rows beside a plain product, 260 = 2 tiles + 4
     (48, [(131, 12, 132, 12, 16, 1.0), (129, 200, 132, 200, 200, 0.0), (64, 64, 64, 64, 64, 1.0)]),
     (4096, [(260, 600, 260, 600, 600, 1.0), (129, 1200, 132, 1200, 1200, 0.0)]),
+    # K not a multiple of 16 far into the operands: the rows beyond K of the last k-tile must read as
+    # zeros although the loads' scalar offset (the k-tile) is megabytes
+    (4100, [(130, 64, 132, 64, 64, 0.0), (64, 200, 64, 200, 200, 1.0)]),
 ]
 
 
