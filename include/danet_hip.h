@@ -243,7 +243,10 @@ int danet_gemm_x6(danet_stream_t stream, int M, int N,
  * Deterministic (K slices are summed in slice order).  `ws`: DANET_WS_GEMM_X6_TN(sum of M*N over
  * the products, sum of tile_rows(M)*ceil(N/128), K) bytes, tile_rows(M) = ceil(M/128) -- except that
  * 1..4 rows beyond a multiple of 128 (M > 128, N % 4 == 0: the 129 spectrogram bins of the bottom
- * layer's dWx) are not a tile row: tile_rows(M) = M/128, those rows are exact fp32 FMA chains.    */
+ * layer's dWx) are not a tile row: tile_rows(M) = M/128, those rows are exact fp32 FMA chains.
+ * Non-finite data: an operand value that is Inf or rounds to Inf in bf16 (|x| >= 3.39e38) turns the
+ * result rows / columns of BOTH values of its pair (m and m ^ 1, resp. n and n ^ 1) into NaN -- the
+ * split forms remainders as Inf * 0 for the partner (csrc/common.h); finite data are unaffected.  */
 int danet_gemm_x6_tn_grouped(danet_stream_t stream, int K, int nprob, const danet_gemm_problem_t* probs,
                              void* ws, size_t ws_bytes);
 
