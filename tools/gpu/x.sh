@@ -1,13 +1,14 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-python bench.py > gpurun_out/r05_l_bench_default.json 2> gpurun_out/r05_l_bench_default.err; echo rc=$?
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r05_l_bench_default.json').read().strip().splitlines()[-1])
-print(d['ms_per_step'], d['value'], d['parity_ok'], d['roofline']['frac'], d['roofline']['lstm_fwd_us'], d['roofline']['lstm_bwd_us'], d['e2e']['ms_per_step'], d['mask_max_abs_err_vs_oracle'], d['mask_err_f32_oracle'], d['roofline']['gemm_f32']['frac'])
-for k,v in d.get('also',{}).items():
-    print(k, v['ms_per_step'], v['value'], v.get('parity_ok'), v['roofline'].get('frac'), v['wall_s'])
-PY
-bash profiles/run_rocprof.sh r05_l_cfg2 --config cfg2 > gpurun_out/r05_l_rocprof.log 2>&1; cp gpurun_out/prof_r05_l_cfg2/kernel_stats.csv gpurun_out/r05_l_kernel_stats_cfg2.csv
-bash tools/timeline.sh r05_l > /dev/null 2>&1
+timeout 1500 python -m pytest tests/test_gpu_heads.py tests/test_gpu_parity.py tests/test_gpu_model.py tests/test_gpu_fullsize.py tests/test_gpu_trained_parity.py tests/test_gpu_g5.py tests/test_gpu_cli.py -x -q 2>&1 | tail -3
+b() { python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-e2e --no-parity-check $2 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    try: d=json.loads(l)
+    except Exception: continue
+    print('$1', d['ms_per_step'], d['roofline'].get('lstm_fwd_us'), d['roofline'].get('lstm_bwd_us'))
+"; }
+P=$GRAFT_REPO_ROOT/danet-tensorflow_amd/csrc/libdanet_hip_prev.so
+b new; DANET_LIB_PATH=$P b prev; b new; DANET_LIB_PATH=$P b prev
+b cfg4 "--config cfg4"; DANET_LIB_PATH=$P b cfg4prev "--config cfg4"
+bash tools/timeline.sh hx > /dev/null 2>&1; grep "sep_pit\|anchor" gpurun_out/hx_timeline.txt
