@@ -1101,6 +1101,19 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
   constexpr int LDA = 4 * U + 4;
   __shared__ __attribute__((aligned(16))) float psum[PPR * OWN];  // 8 KB
   __shared__ __attribute__((aligned(16))) float atile[16 * LDA];  // da_t own columns [row][k]
+  // OWNSPLIT (U = 32, the wide layers): da_t as the three bf16 piece planes in the matrix instruction's
+  // operand order -- [piece][row][k-block][fq][8 k of the lane], rows padded by 16 bytes.  The OWNER of a
+  // (row, unit) splits its four gate values once (two split_pair) and stores twelve half-words; every
+  // wave then reads its B operands with three 16-byte LDS loads per k-block instead of splitting the fp32
+  // tile itself (112 vector instructions per wave and step behind the second barrier at U = 32).
+  // Measured: H = 600 BPTT 592 -> 544 us per launch beside the groups, cfg 4 as written 8.65 -> 8.49 ms;
+  // at U = 16 (56 instructions per wave, twelve half-word stores against four word stores in the owner
+  // phase) it is a wash to a loss -- 249 against 246 us alone, 320 against 317.5 in the step -- and
+  // stays on the consumer-side split (profiles/r05_l_bptt_owner_split.txt).
+  constexpr bool OWNSPLIT = (U >= 32);
+  constexpr int PKB = (U / 4) / 2 > 0 ? (U / 4) / 2 : 1;
+  constexpr int PRST = PKB * 32 + 8, PPST = 16 * PRST;           // half-words per row / per piece plane
+  __shared__ __attribute__((aligned(16))) uint16_t ptile[OWNSPLIT ? 3 * PPST : 8];
 
   const int H = a.H, B = a.B, T = a.T, P = a.P, S = a.S;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1188,6 +1201,14 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
   const bool owner = othr && bg < B && unit < H;
   float dc_state = 0.f;
   float dbacc[4] = {0.f, 0.f, 0.f, 0.f};   // bias gradient: this (row, unit)'s da summed over time
+  // where the owner's gate g lands in a piece plane: column c = g U + oj is k-group c / 16, position
+  // c % 16 = 4 fq + j4 of it; the lane (row, fq) holds k-block b = (c / 16) / 2 as [half][j4]
+  int powr[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int c = g * U + oj, kg = c >> 4, pos = c & 15;
+    powr[g] = orow * PRST + ((kg >> 1) * 4 + (pos >> 2)) * 8 + (kg & 1) * 4 + (pos & 3);
+  }
 
   // ring addressing without per-step multiplies or divisions: byte offsets inside a slot are fixed,
   // the slot and its phase are counters
@@ -1306,17 +1327,33 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
         dc_state = dc * fg;
         dbacc[0] += dav[0]; dbacc[1] += dav[1]; dbacc[2] += dav[2]; dbacc[3] += dav[3];
       }
-      float* ap = &atile[orow * LDA + oj];
-      ap[0] = dav[0]; ap[U] = dav[1]; ap[2 * U] = dav[2]; ap[3 * U] = dav[3];
+      if constexpr (OWNSPLIT) {
+        uint32_t ph[2], pm[2], pl[2];
+        split_pair(dav[0], dav[1], ph[0], pm[0], pl[0]);
+        split_pair(dav[2], dav[3], ph[1], pm[1], pl[1]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const uint32_t hv = ph[g >> 1], mv = pm[g >> 1], lv = pl[g >> 1];
+          uint16_t* pp = &ptile[powr[g]];
+          pp[0] = (uint16_t)((g & 1) ? (hv >> 16) : (hv & 0xFFFFu));
+          pp[PPST] = (uint16_t)((g & 1) ? (mv >> 16) : (mv & 0xFFFFu));
+          pp[2 * PPST] = (uint16_t)((g & 1) ? (lv >> 16) : (lv & 0xFFFFu));
+        }
+      } else {
+        float* ap = &atile[orow * LDA + oj];
+        ap[0] = dav[0]; ap[U] = dav[1]; ap[2 * U] = dav[2]; ap[3 * U] = dav[3];
+      }
     }
     __syncthreads();
     TRACE(3);
 
     if (s + 1 < T) {
       f32x4 bq[KG];
+      if constexpr (!OWNSPLIT) {
 #pragma unroll
-      for (int kg = 0; kg < KG; ++kg)
-        bq[kg] = *reinterpret_cast<const f32x4*>(&atile[fr * LDA + kg * 16 + fq * 4]);
+        for (int kg = 0; kg < KG; ++kg)
+          bq[kg] = *reinterpret_cast<const f32x4*>(&atile[fr * LDA + kg * 16 + fq * 4]);
+      }
       // NACC independent accumulators per tile: a single dependent 16x16x4 chain
       // cannot issue back to back
       constexpr int NACC = 2;
@@ -1329,16 +1366,25 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
 #define BW_OP(P_) __builtin_bit_cast(bf16x8v, (u32x4v){(P_)[0], (P_)[1], (P_)[2], (P_)[3]})
 #pragma unroll
         for (int b = 0; b < KB; ++b) {
-          uint32_t bp[3][4];
-          split_pair(bq[2 * b][0], bq[2 * b][1], bp[0][0], bp[1][0], bp[2][0]);
-          split_pair(bq[2 * b][2], bq[2 * b][3], bp[0][1], bp[1][1], bp[2][1]);
-          split_pair(bq[2 * b + 1][0], bq[2 * b + 1][1], bp[0][2], bp[1][2], bp[2][2]);
-          split_pair(bq[2 * b + 1][2], bq[2 * b + 1][3], bp[0][3], bp[1][3], bp[2][3]);
+          u32x4v bp[3];
+          if constexpr (OWNSPLIT) {
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+              bp[pc] = *reinterpret_cast<const u32x4v*>(&ptile[pc * PPST + fr * PRST + (b * 4 + fq) * 8]);
+          } else {
+            uint32_t q[3][4];
+            split_pair(bq[2 * b][0], bq[2 * b][1], q[0][0], q[1][0], q[2][0]);
+            split_pair(bq[2 * b][2], bq[2 * b][3], q[0][1], q[1][1], q[2][1]);
+            split_pair(bq[2 * b + 1][0], bq[2 * b + 1][1], q[0][2], q[1][2], q[2][2]);
+            split_pair(bq[2 * b + 1][2], bq[2 * b + 1][3], q[0][3], q[1][3], q[2][3]);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) bp[pc] = (u32x4v){q[pc][0], q[pc][1], q[pc][2], q[pc][3]};
+          }
           // small terms first: (weight piece, da piece)
 #pragma unroll
           for (int t6 = 0; t6 < 6; ++t6) {
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-            const bf16x8v bf = BW_OP(bp[PB[t6]]);
+            const bf16x8v bf = __builtin_bit_cast(bf16x8v, bp[PB[t6]]);
 #pragma unroll
             for (int i = 0; i < NTW; ++i)
               acc2[i][t6 % NACC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BW_OP(wregp[i][b][PA[t6]]), bf,

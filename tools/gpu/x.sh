@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_gpu_heads.py tests/test_gpu_parity.py tests/test_gpu_model.py tests/test_gpu_fullsize.py tests/test_gpu_trained_parity.py tests/test_gpu_g5.py tests/test_gpu_cli.py -x -q 2>&1 | tail -3
+timeout 1500 python -m pytest tests/test_gpu_lstm.py tests/test_gpu_parity.py tests/test_gpu_properties.py tests/test_gpu_fullsize.py -x -q 2>&1 | tail -3
 b() { python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-e2e --no-parity-check $2 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
@@ -10,5 +10,4 @@ for l in sys.stdin:
 "; }
 P=$GRAFT_REPO_ROOT/danet-tensorflow_amd/csrc/libdanet_hip_prev.so
 b new; DANET_LIB_PATH=$P b prev; b new; DANET_LIB_PATH=$P b prev
-b cfg4 "--config cfg4"; DANET_LIB_PATH=$P b cfg4prev "--config cfg4"
-bash tools/timeline.sh hx > /dev/null 2>&1; grep "sep_pit\|anchor" gpurun_out/hx_timeline.txt
+b cfg4h600 "--config cfg4h600"; DANET_LIB_PATH=$P b cfg4h600prev "--config cfg4h600"
