@@ -351,8 +351,9 @@ __global__ __launch_bounds__(256, X6Geo<MI>::WG_PER_CU) void gemm_x6_nt_kernel(X
     // slices that have landed, and the workgroup that draws the last ticket sums the slabs IN SLICE
     // ORDER (its own included: whoever is last, the same additions in the same order) + bias into
     // Cout.  Nobody ever waits: no assumption about dispatch order or co-residency.  The ticket
-    // cell carries the launch's sequence number, so stale contents (an earlier launch, scratch
-    // shared with other kernels) read as "no slice yet" and nothing has to be cleared.
+    // cells live in a fixed region at the start of a workspace that belongs to this entry point
+    // (zero once, cleared by the last arriver); they carry the launch's sequence number while it
+    // runs, so what an aborted launch left behind reads as "no slice yet".
     __shared__ unsigned x6_last;
     float* ct = reinterpret_cast<float*>(xsm);          // [32 MI][XBN + 4]
     constexpr int LDC_T = G::LDC_T;
@@ -408,6 +409,8 @@ __global__ __launch_bounds__(256, X6Geo<MI>::WG_PER_CU) void gemm_x6_nt_kernel(X
         *reinterpret_cast<f32x4*>(g.Cout + (size_t)row * g.ldcout + col) = v;
       }
     }
+    // (every slice has arrived: nobody else touches this ticket in this launch)
+    if (tid == 0) __hip_atomic_store(g.tickets + bid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
 
@@ -561,11 +564,17 @@ static X6Plan x6_plan(int M, int N, int nkt) {
   return p;
 }
 
-// slabs [s][M][N] + a ticket per tile
+// Workspace of a sliced product: a FIXED ticket region at its start (one word per tile, so every call on
+// this workspace agrees where the tickets are and slab data never lands on them), then the slabs
+// [s][M][N].  The caller zero-initialises the workspace once and gives it to nothing else; a ticket is
+// back at zero when its launch has finished (the last arriver clears it), and carries the launch's
+// tag while the launch runs, so even an aborted launch's leftovers read as "no slice yet".
+#define X6_MAX_TICKETS 4096
+#define X6_TICKET_BYTES (X6_MAX_TICKETS * sizeof(unsigned))
 static size_t x6_slab_bytes(int s, int M, int N) { return align_up((size_t)s * M * N * sizeof(float), 256); }
 size_t dn_ws_gemm_x6(int M, int N, int K1, int K2) {
   const X6Plan p = x6_plan(M, N, cdiv(K1, XBK) + cdiv(K2, XBK));
-  return p.s > 1 ? x6_slab_bytes(p.s, M, N) + (size_t)cdiv(M, 64 * p.mi) * cdiv(N, XBN) * sizeof(unsigned) : 0;
+  return p.s > 1 ? X6_TICKET_BYTES + x6_slab_bytes(p.s, M, N) : 0;
 }
 
 hipEvent_t dn_take_stop_event();   // gemm_f32.hip: the event armed by danet_next_launch_events
@@ -608,20 +617,20 @@ extern "C" int danet_gemm_x6(danet_stream_t stream_, int M, int N,
   const int nkt = cdiv(K1, XBK) + cdiv(K2, XBK);
   const X6Plan plan = x6_plan(M, N, nkt);
   int s = plan.s;
-  if (s > 1 && (N % 4 != 0 || ldc % 4 != 0 || ((uintptr_t)C & 15) != 0 ||
-                (size_t)s * M * N * sizeof(float) >= 0xFFFFFFF0ull)) s = 1;   // (the slice sum is vectorised; 32-bit slab offsets)
   const int nt = cdiv(M, 64 * plan.mi) * cdiv(N, XBN);
+  if (s > 1 && (N % 4 != 0 || ldc % 4 != 0 || ((uintptr_t)C & 15) != 0 || nt > X6_MAX_TICKETS ||
+                (size_t)s * M * N * sizeof(float) >= 0xFFFFFFF0ull)) s = 1;   // (the slice sum is vectorised; 32-bit slab offsets)
   g.Cout = C; g.ldcout = ldc; g.tickets = nullptr; g.seq = 0;
   if (s > 1) {
-    const size_t need = x6_slab_bytes(s, M, N) + (size_t)nt * sizeof(unsigned);
+    const size_t need = X6_TICKET_BYTES + x6_slab_bytes(s, M, N);
     if (!ws || ws_bytes < need || ((uintptr_t)ws & 15) != 0) {
       danet_set_error("gemm_x6: workspace %zu < %zu (or not 16-B aligned)", ws_bytes, need);
       return DANET_ERR_WORKSPACE;
     }
     // ticket tag of this launch: process-wide, so launches from any thread / stream differ
     static std::atomic<unsigned> launch_seq{0x00a5c3u};
-    g.C = (float*)ws; g.ldc = N;
-    g.tickets = (unsigned*)((char*)ws + x6_slab_bytes(s, M, N));
+    g.C = (float*)((char*)ws + X6_TICKET_BYTES); g.ldc = N;
+    g.tickets = (unsigned*)ws;
     g.seq = launch_seq.fetch_add(1, std::memory_order_relaxed) & 0xFFFFFFu;
   } else {
     g.C = C; g.ldc = ldc;

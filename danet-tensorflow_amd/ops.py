@@ -216,7 +216,9 @@ def gemm_w(A, lda, W, sn, sk, C, M, N, K, ldc, tag=None, stop_event=None,
     p1 = packed_weight(W, N, K, sn, sk)
     p2 = packed_weight(W2, N, K2, sn if sn2 is None else sn2, sk if sk2 is None else sk2) if K2 else None
     need = _lib.ws_bytes(_lib.WS_GEMM_X6, M, N, K, K2)
-    w, wn = _ws(need, C.device)
+    # dedicated (zero-initialised, never shared) scratch: its first 16 KB are the K-slice tickets
+    w = _lib.workspace(need, C.device, tag='gemm_x6')
+    wn = w.numel()
     with _lib.timed('gemm_x6', tag):
         if stop_event is not None:
             stop_event.arm()

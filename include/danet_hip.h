@@ -223,8 +223,9 @@ int danet_gemm_f32_streamk_kcat(danet_stream_t stream, int transA, int transB, i
  * the host re-packs after every optimizer step (one launch for the whole table).  An event armed
  * with danet_next_launch_events completes with this product, as for stream-K launches.
  * B(n, k) = src[n * stride_n + k * stride_k]; `out`: DANET_WS_GEMM_PACK(N, K) bytes, 16-B aligned.
- * `ws`: DANET_WS_GEMM_X6(M, N, K1, K2) bytes (K-slice slabs + one ticket word per tile; its
- * contents on entry do not matter).                                                              */
+ * `ws`: DANET_WS_GEMM_X6(M, N, K1, K2) bytes: 16 KB of K-slice tickets + the slabs.  A workspace
+ * DEDICATED to this entry point (per stream), zero-initialised once by the caller; it may be grown
+ * (zero the new one) and shared by calls of any shape.                                           */
 typedef struct {
   const float* src; long long stride_n, stride_k;
   int N, K;

@@ -64,8 +64,8 @@ def test_library_loads_and_exports_every_declared_symbol():
     # a BiLSTM layer's four weight-gradient products at cfg 2: 160 tiles -> 3 K slices
     assert _lib.ws_bytes(_lib.WS_GEMM_X6_TN, 2 * 900 * 1200, 160, 4096) == 3 * 2 * 900 * 1200 * 4
     assert _lib.ws_bytes(_lib.WS_GEMM_X6, 4096, 2580, 600, 0) == 0                # enough tiles: no K slices
-    # dX of a BiLSTM layer: 160 tiles -> 3 K slices: the slabs + one ticket per tile
-    assert _lib.ws_bytes(_lib.WS_GEMM_X6, 4096, 600, 1200, 1200) == 3 * 4096 * 600 * 4 + 160 * 4
+    # dX of a BiLSTM layer: 160 tiles -> 3 K slices: 16 KB of tickets + the slabs
+    assert _lib.ws_bytes(_lib.WS_GEMM_X6, 4096, 600, 1200, 1200) == 16384 + 3 * 4096 * 600 * 4
     # three bf16 pieces, 128-column panels, 16-k steps: 600 -> 640 columns, 2580 -> 162 steps
     assert _lib.ws_bytes(_lib.WS_GEMM_PACK, 600, 2580) == 3 * 640 * 162 * 16 * 2
     arr = (ctypes.c_int64 * 3)(1, 2, 3)
