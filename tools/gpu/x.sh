@@ -1,12 +1,12 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_gpu_gemm_x6.py tests/test_gpu_gemm.py tests/test_gpu_fullsize.py tests/test_gpu_model.py tests/test_gpu_dist.py -x -q 2>&1 | tail -3
-timeout 300 python tools/bench_gemm_x6_nt.py 2>&1 | grep -v amdgpu.ids | cut -c1-90
-b() { python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-e2e --no-parity-check 2>/dev/null | python -c "
-import sys,json
-for l in sys.stdin:
-    try: d=json.loads(l)
-    except Exception: continue
-    print('$1', d['ms_per_step'], d['roofline'].get('lstm_fwd_us'), d['roofline'].get('lstm_bwd_us'))
-"; }
-b new; b new
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+python bench.py > gpurun_out/r05_n_bench_default.json 2> gpurun_out/r05_n_bench_default.err; echo rc=$?
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r05_n_bench_default.json').read().strip().splitlines()[-1])
+print(d['ms_per_step'], d['value'], d['parity_ok'], d['roofline']['frac'], d['roofline']['lstm_fwd_us'], d['roofline']['lstm_bwd_us'], d['e2e']['ms_per_step'], d['roofline']['gemm_f32']['frac'])
+for k,v in d.get('also',{}).items():
+    print(k, v['ms_per_step'], v['value'], v.get('parity_ok'), v['roofline'].get('frac'), v['wall_s'])
+PY
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
