@@ -20,7 +20,12 @@
 //     instruction).
 // Tile per workgroup 128 x 128 x 16, 4 waves as 2 x 2 with 2 x 2 MFMA tiles of 32 x 32 each, two
 // workgroups per CU, three LDS stages; products with too few tiles for the GPU are cut along K into
-// `splitk` slices whose partial tiles a second kernel sums in slice order (deterministic).
+// `splitk` slices whose partial tiles the workgroup that finishes a tile's LAST slice sums in slice
+// order (tickets; deterministic, nobody waits).
+// What bounds the k-loop on gfx950 is the vector ALU -- a vector and a matrix instruction of one SIMD
+// do not overlap (tools/csrc/mfma_bf16_rate.hip) -- so it carries no address arithmetic on it: B
+// fragments and staging loads take their k-tile in the instructions' SCALAR offset, the LDS stages
+// are compile-time, and the split is 7 vector instructions per pair of values (csrc/common.h).
 #include "common.h"
 #include <hip/hip_ext.h>
 #include <atomic>
