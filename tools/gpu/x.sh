@@ -1,4 +1,12 @@
+# scratch script for tools/gpu/grun.sh (edit freely): lstm / parity tests + two short bench lines
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 900 python tools/feed_soak.py 2>&1 | grep -v amdgpu | tail -8 | tee gpurun_out/r05_n_feed_soak.txt
-for i in 1 2; do timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -1; done
+timeout 900 python -m pytest tests/test_gpu_lstm.py tests/test_gpu_parity.py tests/test_gpu_properties.py -x -q 2>&1 | tail -2
+b() { python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-e2e --no-parity-check 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    try: d=json.loads(l)
+    except Exception: continue
+    print('$1', d['ms_per_step'], d['roofline'].get('lstm_fwd_us'), d['roofline'].get('lstm_bwd_us'))
+"; }
+b new; b new
