@@ -353,11 +353,12 @@ def _fill_parity(res, rep, mse, model):
     res['parity_ok'] = rep['ok']
     res['parity'] = dict(
         rule='err(HIP,f64) <= max(1e-4, 2*err(f32 oracle,f64)); err = max|a-b|/max|b|; '
-             '4 mixtures of batch 0 at the final (trained) parameters; fused separator+loss '
+             '4 mixtures of batch 0 at the final (trained) parameters; logits = embed.attr^T formed in float64 from each '
+             'path\'s own embedding and attractors, relative to max|logit| (bar 1e-5): what the softmax amplifies; fused separator+loss '
              'kernels (the ones train_step runs): permutation equal to the unfused ones, loss to 1e-6, SNR to 1e-5',
         **{k: dict(hip=rep[k]['hip_vs_f64']['max_rel'], f32=rep[k]['f32_vs_f64']['max_rel'],
                    hip_rms=rep[k]['hip_vs_f64']['rms_rel'], f32_rms=rep[k]['f32_vs_f64']['rms_rel'],
-                   ok=rep[k]['ok']) for k in ('embed', 'attrs', 'masks', 'sep_pwr')},
+                   ok=rep[k]['ok']) for k in ('embed', 'attrs', 'logits', 'masks', 'sep_pwr') if k in rep},
         perm_idx_equal=rep['perm_idx_equal'], fused_heads=rep.get('fused_heads'))
 
 
@@ -415,9 +416,10 @@ def main():
     ap.add_argument('--cpu-sample', type=int)
     ap.add_argument('--no-e2e', action='store_true',
                     help='skip the second timed region (the train loop over host-resident batches)')
-    ap.add_argument('--allreduce-schedule', choices=['0', 'tail', '1'], default=None,
+    ap.add_argument('--allreduce-schedule', choices=['auto', '0', 'tail', '1'], default=None,
                     help="gradient reduction schedule under data parallelism (Model.grad_schedule; "
-                         "default '0' = ONE all-reduce per step)")
+                         "default 'auto': starts as '0' = ONE all-reduce per step and decides between '0' and "
+                         "'tail' from its own measured all-reduce / step times, dist.choose_schedule)")
     ap.add_argument('--no-also', action='store_true',
                     help='default cfg2 run on one GPU: skip the short cfg4h600 / cfg5 sub-records (`also`)')
     ap.add_argument('--no-schedules', action='store_true',
@@ -775,6 +777,7 @@ def run_train(args, cfg, hp, device, rank, world, use_dist):
                            global_batch=B * world, parallelism='dp%d' % world,
                            grad_allreduce_bytes=int(model._grad_store.numel() * 4),
                            grad_allreduce_schedule=model.grad_schedule,
+                           grad_allreduce_decision=model.schedule_decision,
                            collectives_per_step=model.collectives_per_step()),
                init_steps=1, settle_steps=settle,
                untimed_steps_total=1 + settle + args.warmup,

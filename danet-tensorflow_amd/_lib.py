@@ -140,7 +140,7 @@ def load():
             fn = getattr(lib, name)      # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.danet_abi_version() != 5:
+        if lib.danet_abi_version() != 6:
             raise DanetHipError('libdanet_hip.so ABI version mismatch')
         _lib = lib
         apply_env_options()

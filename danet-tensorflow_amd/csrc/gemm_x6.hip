@@ -63,12 +63,15 @@ struct X6Args {
   const u32x4* Bp[2];                   // [pair] -> packed [3][NT32][KT][64] x 16 bytes
   int lda[2], K[2], KT[2];
   int NT32;
-  float* C;                             // splitk == 1: the result; else slab [splitk][M][N]
+  float* C;                             // the result [M][ldc]
   const float* bias;                    // [N] added to every row, or null
   int M, N, ldc, npair, splitk;
-  // splitk > 1: the workgroup that finishes a tile's LAST slice sums the slices (in slice order) into Cout
-  float* Cout;
-  int ldcout;
+  // Tiles [0, nwhole) are computed whole by the launch's first `nwhole` workgroups (a multiple of 8);
+  // every other tile is cut into `splitk` K slices: partial tiles go to slab [splitk][M][N] and the
+  // workgroup that finishes a tile's LAST slice sums the slices (in slice order) into C.
+  // nwhole = 0: every tile sliced (or, splitk == 1, every tile whole) -- the schedules before round 6.
+  int nwhole;
+  float* slab;
   unsigned* tickets;                    // [tiles]: (launch sequence number << 8) | slices finished
   unsigned seq;
 };
@@ -289,14 +292,25 @@ __global__ __launch_bounds__(256, X6Geo<MI>::WG_PER_CU) void gemm_x6_nt_kernel(X
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = (g.N + XBN - 1) / XBN;
   const int nt = ((g.M + G::BM - 1) / G::BM) * tiles_n;
-  const int item = x6_xcd_item(blockIdx.x, gridDim.x);
-  const int z = item / nt;                             // K slice
-  const int bid = item % nt;
+  // HYBRID schedule (round 6): a product with a ragged last round of tiles (the projection: 672 tiles on
+  // 512 slots) runs its first `nwhole` tiles whole and cuts only the remainder along K, so that the last
+  // round is full and short instead of 31 % full and as long as the first
+  int z, bid;
+  bool sliced;                                          // (uniform)
+  if ((int)blockIdx.x < g.nwhole) {
+    bid = x6_xcd_item(blockIdx.x, g.nwhole); z = 0; sliced = false;
+  } else {
+    const int j = x6_xcd_item((int)blockIdx.x - g.nwhole, (int)gridDim.x - g.nwhole);
+    const int nrem = nt - g.nwhole;
+    z = j / nrem;                                       // K slice
+    bid = g.nwhole + j % nrem;
+    sliced = g.splitk > 1;
+  }
   const int m0 = (bid / tiles_n) * G::BM, n0 = (bid % tiles_n) * XBN;
 
   const int nk0 = (g.K[0] + XBK - 1) / XBK;
   const int nkt = nk0 + (g.npair > 1 ? (g.K[1] + XBK - 1) / XBK : 0);
-  const int per = (nkt + g.splitk - 1) / g.splitk;
+  const int per = sliced ? (nkt + g.splitk - 1) / g.splitk : nkt;
   const int kt0 = z * per, kt1 = min(nkt, kt0 + per);
 
   X6Ctx c;
@@ -350,12 +364,12 @@ __global__ __launch_bounds__(256, X6Geo<MI>::WG_PER_CU) void gemm_x6_nt_kernel(X
     if (kt < kt1) X6_STEP_RT(R0, faA, faB, fbA, fbB)
   }
 
-  if (g.splitk > 1) {
-    // K slices (N % 4 == 0, 16-byte aligned Cout: the host's condition for slicing).  Every slice's
+  if (sliced) {
+    // K slices (N % 4 == 0, 16-byte aligned C: the host's condition for slicing).  Every slice's
     // partial tile goes to its slab with write-through (sc1) stores; a ticket per tile counts the
     // slices that have landed, and the workgroup that draws the last ticket sums the slabs IN SLICE
     // ORDER (its own included: whoever is last, the same additions in the same order) + bias into
-    // Cout.  Nobody ever waits: no assumption about dispatch order or co-residency.  The ticket
+    // C.  Nobody ever waits: no assumption about dispatch order or co-residency.  The ticket
     // cells live in a fixed region at the start of a workspace that belongs to this entry point
     // (zero once, cleared by the last arriver); they carry the launch's sequence number while it
     // runs, so what an aborted launch left behind reads as "no slice yet".
@@ -363,7 +377,7 @@ __global__ __launch_bounds__(256, X6Geo<MI>::WG_PER_CU) void gemm_x6_nt_kernel(X
     float* ct = reinterpret_cast<float*>(xsm);          // [32 MI][XBN + 4]
     constexpr int LDC_T = G::LDC_T;
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
-        g.C, 0, (int)((size_t)g.splitk * g.M * g.N * sizeof(float)), 0x00020000);
+        g.slab, 0, (int)((size_t)g.splitk * g.M * g.N * sizeof(float)), 0x00020000);
     const unsigned plane = (unsigned)g.M * (unsigned)g.N * 4u;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -401,17 +415,41 @@ __global__ __launch_bounds__(256, X6Geo<MI>::WG_PER_CU) void gemm_x6_nt_kernel(X
     __syncthreads();
     if (x6_last == 0u) return;
     const float* __restrict__ bias = g.bias;
+    // (the loads of four row groups in flight together; a slice beyond splitk is an out-of-range offset that
+    // returns zeros and is not added.  The modelled plans use <= 4 slices; a pinned plan with more takes the
+    // dependent loop behind them)
+    const int ns = g.splitk;
+    constexpr int XS = 4;
+#pragma unroll 1
+    for (int it0 = 0; it0 < 8 * MI; it0 += 4) {
+      f32x4 w[4][XS];
+      bool ok[4];
 #pragma unroll
-    for (int it = 0; it < 8 * MI; ++it) {
-      const int rr = (tid >> 5) + 8 * it, c4 = tid & 31;
-      const int row = m0 + rr, col = n0 + c4 * 4;
-      if (row < g.M && col < g.N) {
+      for (int u = 0; u < 4; ++u) {
+        const int rr = (tid >> 5) + 8 * (it0 + u), c4 = tid & 31;
+        const int row = m0 + rr, col = n0 + c4 * 4;
+        ok[u] = row < g.M && col < g.N;
         const unsigned off = ((unsigned)row * g.N + col) * 4u;
-        f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, off, 0, 16 /*sc1*/));
-        for (int zz = 1; zz < g.splitk; ++zz)
-          v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, (unsigned)zz * plane + off, 0, 16 /*sc1*/));
-        if (bias) v += (f32x4){bias[col], bias[col + 1], bias[col + 2], bias[col + 3]};
-        *reinterpret_cast<f32x4*>(g.Cout + (size_t)row * g.ldcout + col) = v;
+#pragma unroll
+        for (int zz = 0; zz < XS; ++zz)
+          w[u][zz] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+              srs, (ok[u] && zz < ns) ? (unsigned)zz * plane + off : X6_OOB, 0, 16 /*sc1*/));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = (tid >> 5) + 8 * (it0 + u), c4 = tid & 31;
+        const int row = m0 + rr, col = n0 + c4 * 4;
+        if (ok[u]) {
+          f32x4 v = w[u][0];
+#pragma unroll
+          for (int zz = 1; zz < XS; ++zz)
+            if (zz < ns) v += w[u][zz];               // (uniform)
+          const unsigned off = ((unsigned)row * g.N + col) * 4u;
+          for (int zz = XS; zz < ns; ++zz)
+            v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, (unsigned)zz * plane + off, 0, 16 /*sc1*/));
+          if (bias) v += (f32x4){bias[col], bias[col + 1], bias[col + 2], bias[col + 3]};
+          *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col) = v;
+        }
       }
     }
     // (every slice has arrived: nobody else touches this ticket in this launch)
@@ -557,15 +595,46 @@ static int x6_slices(int tiles, int nkt, int min_steps, int max_slices) {
 // vector instructions per wave run at exactly 1536 / (1536 + 4 * 102) of the matrix-only rate, one
 // or two waves per SIMD alike), and the in-kernel split of A is 1.8 vector instructions per matrix
 // instruction whatever the tile shape.  option gemm_x6_plan = MI + 16 * slices pins either.
-struct X6Plan { int mi, s; };
+// Hybrid (round 6): with more than one round of tiles and a ragged last one, the whole rounds run whole
+// (nwhole = a multiple of 512 tiles) and only the remainder is sliced -- the same model decides: cost of
+// the remainder as a product of its own + the whole rounds, against the unsliced launch.  It pays where K
+// is long enough for the remainder's slab traffic to be small against its k-loop.  Pinned:
+// option gemm_x6_plan += 65536 (hybrid with the given slice count) / 131072 (never hybrid).
+struct X6Plan { int mi, s, nwhole; };
+static double x6_rounds(double r) {
+  const double whole = (double)(long long)r, frac = r - whole;
+  return whole + (frac > 0.0 ? 0.55 + 0.45 * frac : 0.0);
+}
 static X6Plan x6_plan(int M, int N, int nkt) {
   const int pin = danet_opt(OPT_GEMM_X6_PLAN);
-  const int pin_mi = pin & 15, pin_s = pin >> 4;
+  const int pin_mi = pin & 15, pin_s = (pin >> 4) & 0xFFF, pin_h = pin >> 16;
   X6Plan p;
   p.mi = (pin_mi >= 2 && pin_mi <= 4) ? pin_mi : 2;
+  p.nwhole = 0;
   const int tiles = cdiv(M, 64 * p.mi) * cdiv(N, XBN);
   // (one workgroup per CU at MI > 2: the model's 512 slots hold twice the tiles)
-  p.s = pin_s >= 1 ? min(pin_s, max(nkt, 1)) : x6_slices(p.mi == 2 ? tiles : 2 * tiles, nkt, 12, 4);
+  const int slots = p.mi == 2 ? 512 : 256;
+  p.s = pin_s >= 1 ? min(min(pin_s, 255), max(nkt, 1)) :   // (8-bit slice counter in a ticket)
+         x6_slices(p.mi == 2 ? tiles : 2 * tiles, nkt, 12, 4);
+  const int whole = tiles / slots * slots, rem = tiles - whole;
+  if (pin_h != 2 && whole > 0 && rem > 0 && (pin_h == 1 || pin_s == 0)) {
+    const double plain = x6_rounds((double)tiles * p.s / slots) / p.s +
+                         (p.s > 1 ? 0.02 + 0.032 * tiles / max(nkt, 1) * (p.s - 1) : 0.0);
+    // (a margin of 8 %: the model is good to about that, and a short-K product gains nothing measurable --
+    // the projection, 672 tiles x 38 k-steps: 89.1 us plain, 93.0 / 88.2 / 105.0 with 2 / 3 / 4 slices on the
+    // remainder -- while the hoisted input half at H = 600, 608 tiles x 75 k-steps, goes from 146.5 to 128 us:
+    // profiles/r06_b_gemm_x6_hybrid.txt)
+    double best = pin_h == 1 ? 1e30 : 0.92 * plain;
+    int bs = 0;
+    for (int s = 2; s <= 4; ++s) {
+      if (pin_h == 1 && pin_s >= 2 && s != min(pin_s, 4)) continue;
+      if (nkt / s < 8) break;
+      const double cost = (double)whole / slots + x6_rounds((double)rem * s / slots) / s +
+                          0.02 + 0.032 * rem / max(nkt, 1) * (s - 1);
+      if (cost < best - 1e-9) { best = cost; bs = s; }
+    }
+    if (bs) { p.s = bs; p.nwhole = whole; }
+  }
   return p;
 }
 
@@ -614,6 +683,10 @@ extern "C" int danet_gemm_x6(danet_stream_t stream_, int M, int N,
   DANET_CHECK_ARG(((((uintptr_t)B1pk | (uintptr_t)B2pk) & 15) == 0), "gemm_x6: packed weight alignment");
   DANET_CHECK_ARG((int64_t)M * lda1 < (1ll << 29) && (K2 == 0 || (int64_t)M * lda2 < (1ll << 29)),
                   "gemm_x6: an operand spans 2 GiB or more");
+  // (the packed weights are read through buffer resources with 32-bit sizes)
+  DANET_CHECK_ARG((int64_t)3 * x6_nt32(N) * cdiv(K1, XBK) * 1024 < (1ll << 31) &&
+                  (int64_t)3 * x6_nt32(N) * cdiv(K2, XBK) * 1024 < (1ll << 31),
+                  "gemm_x6: a packed weight spans 2 GiB or more");
   X6Args g;
   g.A[0] = A1; g.Bp[0] = (const u32x4*)B1pk; g.lda[0] = lda1; g.K[0] = K1; g.KT[0] = cdiv(K1, XBK);
   g.A[1] = A2; g.Bp[1] = (const u32x4*)B2pk; g.lda[1] = lda2; g.K[1] = K2; g.KT[1] = cdiv(K2, XBK);
@@ -625,7 +698,8 @@ extern "C" int danet_gemm_x6(danet_stream_t stream_, int M, int N,
   const int nt = cdiv(M, 64 * plan.mi) * cdiv(N, XBN);
   if (s > 1 && (N % 4 != 0 || ldc % 4 != 0 || ((uintptr_t)C & 15) != 0 || nt > X6_MAX_TICKETS ||
                 (size_t)s * M * N * sizeof(float) >= 0xFFFFFFF0ull)) s = 1;   // (the slice sum is vectorised; 32-bit slab offsets)
-  g.Cout = C; g.ldcout = ldc; g.tickets = nullptr; g.seq = 0;
+  int nwhole = s > 1 ? plan.nwhole : 0;
+  g.C = C; g.ldc = ldc; g.slab = nullptr; g.tickets = nullptr; g.seq = 0;
   if (s > 1) {
     const size_t need = X6_TICKET_BYTES + x6_slab_bytes(s, M, N);
     if (!ws || ws_bytes < need || ((uintptr_t)ws & 15) != 0) {
@@ -634,14 +708,12 @@ extern "C" int danet_gemm_x6(danet_stream_t stream_, int M, int N,
     }
     // ticket tag of this launch: process-wide, so launches from any thread / stream differ
     static std::atomic<unsigned> launch_seq{0x00a5c3u};
-    g.C = (float*)((char*)ws + X6_TICKET_BYTES); g.ldc = N;
+    g.slab = (float*)((char*)ws + X6_TICKET_BYTES);
     g.tickets = (unsigned*)ws;
     g.seq = launch_seq.fetch_add(1, std::memory_order_relaxed) & 0xFFFFFFu;
-  } else {
-    g.C = C; g.ldc = ldc;
   }
-  g.splitk = s;
-  dim3 grid((unsigned)(nt * s)), block(256);
+  g.splitk = s; g.nwhole = nwhole;
+  dim3 grid((unsigned)(nwhole + (nt - nwhole) * s)), block(256);
   hipEvent_t kstop = stop;
 #define X6_LAUNCH(MI)                                                                                          \
   { static std::atomic<unsigned long long> done{0};                                                            \
@@ -1018,7 +1090,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_tn_kernel(X6TArgs g) {
     }
 }
 
-// C = beta C + the K slices in slice order; blockIdx.y = problem (N % 4 == 0, ldc % 4 == 0)
+// C = beta C + the K slices in slice order; blockIdx.y = problem (N % 4 == 0, ldc % 4 == 0).
+// (Round 6 built the NT kernel's in-launch sum for this kernel as well -- a ticket per tile and per tail
+// chunk, the last arriver adds the slabs -- and measured it SLOWER than this second launch: layer group
+// 136.2 vs 130.6 us, bottom layer's group (6 slices) 93.0 vs 79.3, dWout 95.0 vs 91.0, the cfg-2 step
+// 2.462-2.471 vs 2.434-2.441 ms on one box: 80-160 last arrivers each pull 0.4-0.5 MB through
+// latency-bound write-through loads where 1024 workgroups of this launch stream it.
+// profiles/r06_a_tn_last_arriver.txt, profiles/r06_a_tn_last_arriver_experiment.patch.)
 __global__ __launch_bounds__(256) void gemm_x6_tn_reduce_kernel(X6TArgs g) {
   const X6TProblem& q = g.p[blockIdx.y];
   const int M = q.M, N = q.N, ldc = q.ldc;
@@ -1056,7 +1134,7 @@ extern "C" int danet_gemm_x6_tn_grouped(danet_stream_t stream_, int K, int nprob
   X6TArgs g;
   int tiles = 0;
   long long sum_mn = 0;
-  bool slicable = true;
+  bool slicable = true, ragged = false;
   for (int i = 0; i < nprob; ++i) {
     const danet_gemm_problem_t& q = probs[i];
     DANET_CHECK_ARG(q.M > 0 && q.N > 0 && q.A && q.B && q.C, "gemm_x6_tn: bad problem %d", i);
@@ -1077,9 +1155,13 @@ extern "C" int danet_gemm_x6_tn_grouped(danet_stream_t stream_, int K, int nprob
     p.slab_off = sum_mn;
     tiles += cdiv(p.Mmain, 128) * p.tiles_n;
     sum_mn += (long long)q.M * q.N;
-    // (M or N not a multiple of 4: the rows are still read in whole 16-byte groups -- lda / ldb are
-    // multiples of 4, so a group never leaves its row's pitch -- and whatever sits in a row's pad only
-    // reaches output rows / columns beyond M / N, which are never stored: no masking, no second kernel)
+    // Rows are read in whole 16-byte groups inside the row pitch (lda / ldb are multiples of 4).  What sits
+    // in the pad of a row whose valid length is a multiple of 2 only reaches accumulator rows / columns
+    // beyond M / N, which are never stored.  With an ODD valid length the last valid value shares its
+    // split pair (m, m ^ 1) with the first pad value, and a non-finite pad would turn the valid one's
+    // remainder into NaN (Inf * 0 in split_pair's v_dot2c): such groups take the kernel variant that
+    // masks the pad per element (round 6, advisor finding; the step's own shapes are all even).
+    ragged = ragged || (p.Mmain % 2 != 0) || (q.N % 2 != 0);
     slicable = slicable && q.N % 4 == 0 && q.ldc % 4 == 0 && (((uintptr_t)q.C) & 15) == 0 && ((long long)q.M * q.N) % 4 == 0;
   }
   for (int i = nprob; i < X6T_MAX_PROBLEMS; ++i) g.p[i] = g.p[0];
@@ -1098,10 +1180,15 @@ extern "C" int danet_gemm_x6_tn_grouped(danet_stream_t stream_, int K, int nprob
       return DANET_ERR_WORKSPACE;
     }
   }
-  { static std::atomic<unsigned long long> done[2];
-    DANET_CHECK_HIP(x6_set_lds((const void*)gemm_x6_tn_kernel<false>, X6T_SMEM_BYTES, done[0])); }
+  static std::atomic<unsigned long long> done[2];
   dim3 grid((unsigned)(tiles * s + g.ntail)), block(256);
-  gemm_x6_tn_kernel<false><<<grid, block, X6T_SMEM_BYTES, stream>>>(g);
+  if (ragged) {
+    DANET_CHECK_HIP(x6_set_lds((const void*)gemm_x6_tn_kernel<true>, X6T_SMEM_BYTES, done[1]));
+    gemm_x6_tn_kernel<true><<<grid, block, X6T_SMEM_BYTES, stream>>>(g);
+  } else {
+    DANET_CHECK_HIP(x6_set_lds((const void*)gemm_x6_tn_kernel<false>, X6T_SMEM_BYTES, done[0]));
+    gemm_x6_tn_kernel<false><<<grid, block, X6T_SMEM_BYTES, stream>>>(g);
+  }
   DANET_CHECK_LAUNCH();
   if (s > 1) {
     long long most = 0;

@@ -567,9 +567,6 @@ struct LstmFwdFxArgs {
   int fault;
 };
 
-#ifndef FX_CHA_NUM
-#define FX_CHA_NUM 1
-#endif
 // Input-half k-groups (16 k each): CHX "window" groups per wave, computed in the exchange wait of
 // the step they belong to, plus CHE "early" groups owned by waves 2 and 3 only, computed one step
 // AHEAD while waves 0 and 1 do the gate math of the previous step (the 128 owner threads are all in
@@ -594,22 +591,14 @@ template <int CHX, int CHE>
 __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
   constexpr int NW = 4, CH = FWD_CH;
   constexpr int NB = (CH + 1) / 2;      // k-blocks of 32 = pairs of 16-k groups per wave
-#ifdef FX_CHA_ABS
-  constexpr int XBA = FX_CHA_ABS < CHX / 2 ? FX_CHA_ABS : CHX / 2;
-#else
   constexpr int XBA = 1;   // k-blocks of the input half done before the exchange loads are issued (0: retries)
-#endif
   // ... and k-groups of it where it stays on the fp32 instructions (the bottom layer): ALL of them.
   // With the gate phase at 45 vector instructions (hardware reciprocal, walking pointers) the next
   // step's top comes 0.1 us sooner after the publish, and exchange loads issued before the
   // published words are visible do not fail, they come back LATE (publish -> valid 0.93 -> 1.15 us):
   // 2 groups in front of the loads 273 us per launch averaged over the three layers, 1 group 278,
-  // none 305 (profiles/r05_k_fwd_load_point.txt).  -DFX_GA_F32=n / -DFX_CHA_ABS=n for A/B builds.
-#ifdef FX_GA_F32
-  constexpr int XGA = FX_GA_F32 < CHX ? FX_GA_F32 : CHX;
-#else
+  // none 305 (profiles/r05_k_fwd_load_point.txt).
   constexpr int XGA = CHX;
-#endif
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // smem: recurrent weights [KP/4][32][4] (read once into registers) | red [NW][16][33]
   float* Wl = smem;
@@ -771,8 +760,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_fx_kernel(LstmFwdFxArgs a) {
   }
   const unsigned xblk = (unsigned)((size_t)B * a.ldx * 4);
   const unsigned yblk = (unsigned)((size_t)B * a.ldy * 4);
-  // loop-invariant vector offsets (an offset >= the buffer's size reads zeros); the time block goes
-  // into the loads' scalar offset.  Step 0 reads h_{-1} from the zero pad block of ypad (block 0 /
+  // loop-invariant vector offsets (an offset >= the buffer's size reads zeros: the raw-buffer range check
+  // covers the VECTOR offset, the scalar offset is outside it -- the standard shape depends on it at every
+  // step: H = 300 leaves the lanes with k0 >= 300 of the 320-wide k range out of range, and a non-zero
+  // fragment there would meet zero weights as 0 * garbage; tests/test_gpu_lstm.py covers H = 300 / 600 and
+  // ragged B); the time block goes into the loads' scalar offset.  Step 0 reads h_{-1} from the zero pad block of ypad (block 0 /
   // T + 1), which no step ever writes.
   unsigned xoffv[CHX], xoffev[CHE], hcolv[CH];
 #pragma unroll
@@ -1215,12 +1207,20 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
   const unsigned slot_bytes = (unsigned)(slot_floats * sizeof(float));
   unsigned rd_off[RS_NI_MAX], rd_offv[RS_NI_MAX];
   bool rd_ok[RS_NI_MAX];
+  // a load for a producer that does not exist (q >= P) is issued out of range and returns zeros on this
+  // hardware (raw buffer: the range check covers the vector offset, the slot in the scalar offset is
+  // outside it) -- but nothing DEPENDS on that: its words are masked out of the phase test and of the sum
+  // (rd_any / rd_keep: an AND with a loop-invariant register where an OR / an AND with a constant stood,
+  // the same instruction count; round 6, advisor finding)
+  unsigned rd_any[RS_NI_MAX], rd_keep[RS_NI_MAX];
 #pragma unroll
   for (int i = 0; i < RS_NI_MAX; ++i) {
     const int q = qq + PPR * i;
     rd_ok[i] = q < P;
     rd_off[i] = (unsigned)(((size_t)cl * P + q) * a.NT * 1024) + xoff;
     rd_offv[i] = rd_ok[i] ? rd_off[i] : rbytes;
+    rd_any[i] = rd_ok[i] ? 0xFFFFFFFFu : 0u;
+    rd_keep[i] = rd_ok[i] ? 0xFFFFFFFEu : 0u;
   }
   unsigned pub_off[NTW];
   bool pub_ok[NTW];
@@ -1257,13 +1257,13 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
 #pragma unroll
       for (int i = 0; i < NI; ++i) av[i] = load_sc1_b128s(rres, rd_offv[i], sbase);
       // every word must carry the expected phase in bit 0: one OR tree (phase 0) and one AND tree
-      // (phase 1; out-of-range loads return zeros and are masked in) over all words, ONE test --
-      // instead of a test and a scalar AND per load
+      // (phase 1) over all words of the producers that exist, ONE test -- instead of a test and a
+      // scalar AND per load
       unsigned orall = 0u, andall = 0xFFFFFFFFu;
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        orall |= (av[i][0] | av[i][1]) | (av[i][2] | av[i][3]);
-        andall &= ((av[i][0] & av[i][1]) & (av[i][2] & av[i][3])) | (rd_ok[i] ? 0u : 0xFFFFFFFFu);
+        orall |= ((av[i][0] | av[i][1]) | (av[i][2] | av[i][3])) & rd_any[i];
+        andall &= ((av[i][0] & av[i][1]) & (av[i][2] & av[i][3])) | ~rd_any[i];
       }
       const bool ok = par ? ((andall & 1u) != 0u) : ((orall & 1u) == 0u);
       if (__all(ok)) break;
@@ -1274,7 +1274,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_rs_kernel(LstmBwdRsArgs a) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       v4u w = av[i];
-      w[0] &= ~1u; w[1] &= ~1u; w[2] &= ~1u; w[3] &= ~1u;   // (out of range = zeros already)
+      w[0] &= rd_keep[i]; w[1] &= rd_keep[i]; w[2] &= rd_keep[i]; w[3] &= rd_keep[i];   // phase bit off; no producer: 0
       sum += __builtin_bit_cast(f32x4, w);
     }
     *reinterpret_cast<f32x4*>(&psum[qq * OWN + within * 4]) = sum;

@@ -98,8 +98,56 @@ def _complement(covered, n):
     return out
 
 
+# ---- which reduction schedule?  (Model(grad_schedule='auto'), the default) ---------------------------
+# '0' (ONE all-reduce after backward, the north_star form) exposes the whole collective; 'tail' hides all but
+# the bottom encoder layer's share of the bytes (15 % at cfg 2) under that layer's BPTT kernel and weight-
+# gradient GEMMs at the price of a second collective launch (~20-30 us), a cross-stream wait on the main
+# stream (~10 us) and ~25 % of the collective's duration in slow-down of the recurrent kernel it runs beside
+# (law 1).  So 'tail' pays once the collective is long enough, relative to the step, for 60 % of
+# it to outweigh those ~40 us: ONE threshold on  (stand-alone all-reduce time) / (step time),  both MEASURED
+# by the model on its own bucket and its own steps and MAX-reduced over the ranks, so that every rank takes
+# the same decision.  3 % of a 2.4 ms step = 73 us.  DANET_ALLREDUCE_TAIL_RATIO overrides the threshold,
+# DANET_OVERLAP_ALLREDUCE / Model(grad_schedule=...) pins the schedule.
+TAIL_RATIO = float(os.environ.get('DANET_ALLREDUCE_TAIL_RATIO', '0.03'))
+
+
+def choose_schedule(allreduce_ms, step_ms, ratio=None):
+    '''-> '0' | 'tail' from the measured stand-alone all-reduce time of the gradient bucket and the measured
+    train-step time (both already identical on every rank)'''
+    r = TAIL_RATIO if ratio is None else float(ratio)
+    if not (allreduce_ms >= 0.0 and step_ms > 0.0):        # (NaN / nonsense: stay with the plain form)
+        return '0'
+    return 'tail' if allreduce_ms > r * step_ms else '0'
+
+
+def measure_allreduce_ms(numel, device, reps=3):
+    '''stand-alone all-reduce time of a scratch fp32 bucket of `numel` elements (a collective: every rank
+    calls it at the same point), MAX over ranks; 0.0 without a process group'''
+    if not is_dist():
+        return 0.0
+    t = torch.zeros(int(numel), dtype=torch.float32, device=device)
+    dist.all_reduce(t)                                      # (communicator / buffers warm)
+    if t.is_cuda:
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            dist.all_reduce(t)
+        e1.record()
+        torch.cuda.synchronize(device)
+        ms = e0.elapsed_time(e1) / reps
+    else:
+        import time
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dist.all_reduce(t)
+        ms = (time.perf_counter() - t0) * 1e3 / reps
+    return allreduce_max_scalar(ms, device)
+
+
 class TailOverlap(object):
-    '''Default gradient reduction schedule under data parallelism.
+    '''The 'tail' gradient reduction schedule (opt-in, or picked by Model(grad_schedule='auto') when the
+    measured all-reduce is long against the measured step: `choose_schedule`).
 
     When the BOTTOM encoder layer's BPTT kernel has been issued, every gradient except
     that layer's own is final (backward runs top-down and nothing with parameters sits
@@ -113,10 +161,12 @@ class TailOverlap(object):
     waits for both.  Every rank issues the same collectives in the same order; without a
     ('rest',) event (another encoder type) finish() reduces the whole bucket at once.'''
 
-    def __init__(self, flat_grad, offsets):
-        '''offsets: {param data_ptr: (start, end)} element ranges in flat_grad'''
+    def __init__(self, flat_grad, offsets, last=()):
+        '''offsets: {param data_ptr: (start, end)} element ranges in flat_grad; last: ranges that must
+        ride in the LAST collective of the step (the hand-off status words: see Model._flatten)'''
         self.flat = flat_grad
         self.offsets = offsets
+        self.last = list(last)
         self.works = []
         self.covered = []
         self.fired = False
@@ -130,7 +180,7 @@ class TailOverlap(object):
             return                      # not this model's encoder
         self.fired = True
         n = self.flat.numel()
-        for lo, hi in _complement(rng, n):
+        for lo, hi in _complement(rng + self.last, n):
             self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM,
                                               async_op=True))
             self.covered.append((lo, hi))
@@ -166,10 +216,12 @@ class GradBuckets(object):
     estimator variables) and makes the current stream wait for every piece.
     Every rank issues the same collectives in the same order.'''
 
-    def __init__(self, flat_grad, offsets):
-        '''offsets: {param data_ptr: (start, end)} element ranges in flat_grad'''
+    def __init__(self, flat_grad, offsets, last=()):
+        '''offsets: {param data_ptr: (start, end)} element ranges in flat_grad; last: ranges for
+        finish() (never covered by a hook's piece: the status words)'''
         self.flat = flat_grad
         self.offsets = offsets
+        self.last = list(last)
         self.works = []
         self.covered = []
         self.launched = 0

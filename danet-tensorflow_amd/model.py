@@ -29,15 +29,22 @@ class Model(object):
     '''Base class for a fully trainable model (main.py:61-548)'''
 
     def __init__(self, name='BaseModel', device=None, seed=1337, grad_schedule=None):
-        '''grad_schedule (data parallelism only; default: env DANET_OVERLAP_ALLREDUCE or '0'):
+        '''grad_schedule (data parallelism only; default: env DANET_OVERLAP_ALLREDUCE or 'auto'):
         '0' = ONE all-reduce of the flat gradient bucket after backward (the north_star
-        form, the default); 'tail' = two collectives (everything outside the bottom encoder
-        layer under that layer's weight-gradient GEMMs, the rest after backward); '1' =
-        per-layer buckets under the remaining BPTT kernels.  The overlapped forms are opt-in
-        until a multi-GPU measurement justifies them (tools/scale_sweep.sh).'''
+        form); 'tail' = two collectives (everything outside the bottom encoder layer under
+        that layer's weight-gradient GEMMs, the rest after backward); '1' = per-layer buckets
+        under the remaining BPTT kernels (opt-in only).  'auto' (default) starts as '0' and
+        DECIDES between '0' and 'tail' after AUTO_DECIDE_AT train steps from two measurements of
+        its own -- the stand-alone all-reduce time of its bucket and its step time, MAX-reduced
+        over the ranks -- with one threshold (dist.choose_schedule, DANET_ALLREDUCE_TAIL_RATIO);
+        `schedule_decision` records what was measured.  Without a process group 'auto' is '0'.'''
         self.grad_schedule = str(grad_schedule if grad_schedule is not None else
-                                 os.environ.get('DANET_OVERLAP_ALLREDUCE', '0'))
-        assert self.grad_schedule in ('0', 'tail', '1'), self.grad_schedule
+                                 os.environ.get('DANET_OVERLAP_ALLREDUCE', 'auto'))
+        assert self.grad_schedule in ('0', 'tail', '1', 'auto'), self.grad_schedule
+        self.schedule_decision = None
+        self._auto = self.grad_schedule == 'auto'
+        if self._auto:
+            self.grad_schedule = '0'
         self.name = name
         self.device = torch.device(device if device is not None else
                                    'cuda:%d' % torch.cuda.current_device())
@@ -122,10 +129,16 @@ class Model(object):
     def _flatten(self):
         n = sum(self.vars[k].numel() for k in self._order)
         flat = torch.empty(n, device=self.device)
-        # 4 spare floats behind the gradients: under data parallelism they carry the
-        # persistent kernels' hand-off status through the gradient all-reduce (ops.py)
+        # 4 spare floats IN FRONT of the gradients: under data parallelism they carry the
+        # persistent kernels' hand-off status through the gradient all-reduce (ops.py).  In front,
+        # because the variables are laid out bottom encoder layer first: the LAST collective of
+        # every schedule ('0': the whole bucket; 'tail': the bottom layer's range, reduced after
+        # backward) then covers them as part of one contiguous range, i.e. AFTER every recurrent
+        # kernel of the step has run -- a timeout in the bottom layer's BPTT kernel reaches every
+        # rank with the step it happened in (round 6; behind the gradients the 'tail' schedule
+        # reduced them with its early piece, before that kernel ran)
         self._grad_store = torch.zeros(n + 4, device=self.device)
-        grad = self._grad_store[:n]
+        grad = self._grad_store[4:]
         off = 0
         for k in self._order:
             v = self.vars[k]
@@ -150,20 +163,20 @@ class Model(object):
                 m._grads_clean = False
         for k in self._order:
             self.vars[k].register_post_accumulate_grad_hook(_mark_dirty)
-        # gradient reduction schedule (dist.py, see __init__): '0' (default) = one all-reduce
-        # after backward; 'tail' / '1' = overlapped pieces (opt-in)
+        # gradient reduction schedule (dist.py, see __init__): '0' = one all-reduce after backward;
+        # 'tail' / '1' = overlapped pieces; 'auto' starts as '0' and decides after a few steps
         self._buckets = None
-        mode = self.grad_schedule
         offs, off = {}, 0
         for k in self._order:
             v = self.vars[k]
             offs[v.data_ptr()] = (off, off + v.numel())
             off += v.numel()
         self._offs = offs
-        if mode in ('1', 'tail'):
-            cls = dist.GradBuckets if mode == '1' else dist.TailOverlap
-            self._buckets = cls(self._grad_store if dist.is_dist() else grad, offs)
-            ops.add_grad_ready_hook(self._buckets.hook)
+        self._install_schedule(self.grad_schedule)
+        if self._auto and not dist.is_dist():
+            self._auto = False            # nothing to decide without a process group
+            self.schedule_decision = dict(schedule='0', reason='single process')
+        self._auto_ev = None
         # early optimizer step (opt-in: DANET_EXPERT early_adam=1): once the bottom encoder layer's BPTT
         # kernel has been issued every other gradient is final (and, under data parallelism with
         # the 'tail' schedule, reduced), so clip + Adam over everything outside that layer's range
@@ -177,12 +190,49 @@ class Model(object):
         self._early_adam = _lib.expert('early_adam', False)
         if dist.is_dist():
             # the status word rides in the gradient all-reduce: every rank sees the same value
-            ops.set_status_word(self.device, self._grad_store[n:].view(torch.int32))
+            ops.set_status_word(self.device, self._grad_store[:4].view(torch.int32))
         elif ops.status_word(self.device).is_cuda and ops.STATUS_HOST:
             ops.set_status_word(self.device, None)     # a previous data-parallel model's word
         self._early = None          # (ranges, stream) of this step's early update
         self.early_steps = 0        # steps that took the early path (diagnostics / tests)
         self._in_step = False
+
+    # ---- 'auto': '0' or 'tail', decided from the model's own measurements ------------------------
+    AUTO_DECIDE_AT = 6       # train steps before the decision; steps 4..6 are the timed ones
+
+    def _install_schedule(self, mode):
+        self.grad_schedule = mode
+        if mode in ('1', 'tail') and self._buckets is None:
+            cls = dist.GradBuckets if mode == '1' else dist.TailOverlap
+            if dist.is_dist():      # ranges inside the store: 4 status words in front, reduced LAST
+                offs = {k: (lo + 4, hi + 4) for k, (lo, hi) in self._offs.items()}
+                self._buckets = cls(self._grad_store, offs, last=[(0, 4)])
+            else:
+                self._buckets = cls(self._flat_grad, self._offs)
+            ops.add_grad_ready_hook(self._buckets.hook)
+
+    def _auto_tick(self):
+        '''called at the end of every train step while the schedule is undecided.  Every rank runs
+        the same steps, so every rank reaches the decision -- which contains collectives -- at the
+        same point; the inputs are MAX-reduced, so every rank decides the same.'''
+        n = self.step_count
+        if n == self.AUTO_DECIDE_AT - 3:
+            self._auto_ev = torch.cuda.Event(enable_timing=True)
+            self._auto_ev.record()
+        if n < self.AUTO_DECIDE_AT or self._auto_ev is None:
+            return
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        end.synchronize()
+        step_ms = dist.allreduce_max_scalar(self._auto_ev.elapsed_time(end) / 3.0, self.device)
+        ar_ms = dist.measure_allreduce_ms(self._grad_store.numel(), self.device)
+        mode = dist.choose_schedule(ar_ms, step_ms)
+        self.schedule_decision = dict(schedule=mode, allreduce_ms=round(ar_ms, 4), step_ms=round(step_ms, 4),
+                                      ratio=round(ar_ms / step_ms, 5), threshold=dist.TAIL_RATIO,
+                                      bucket_bytes=4 * self._grad_store.numel(), decided_at_step=n,
+                                      world=dist.world_size())
+        self._auto, self._auto_ev = False, None
+        self._install_schedule(mode)
 
     # (the gradient-ready hook is registered only when the early step is wanted: with no hook at
     # all ops does not fire the 'rest' event, whose cross-stream wait costs the main stream ~10 us)
@@ -331,6 +381,8 @@ class Model(object):
             torch.cuda.current_stream(self.device).wait_stream(early_stream)
         self._grads_clean = not self.keep_grads
         ops.step_done(self.device)
+        if self._auto:
+            self._auto_tick()
         return dict(loss=out['loss'].detach(), SNR=out['SNR'], LR=self.learn_rate)
 
     def collectives_per_step(self):
@@ -375,6 +427,10 @@ class Model(object):
         sweep, before parameters or separated signals are written); raises DanetHipError
         after a timeout -- on every rank together under data parallelism'''
         ops.check_status(self.device)
+
+    def status_words(self):
+        '''the 4 spare floats of the gradient store (word 0 = hand-off status under data parallelism)'''
+        return self._grad_store[:4]
 
     def zero_grad(self):
         self._flat_grad.zero_()

@@ -50,7 +50,11 @@ extern "C" {
 #define DANET_ERR_UNSUPPORTED (-3)  /* shape outside the compiled envelope     */
 #define DANET_ERR_WORKSPACE (-4)    /* ws too small                            */
 
-#define DANET_ABI_VERSION 5
+/* 6 (round 6): the workspace of danet_gemm_x6 starts with a 16 KB region of K-slice tickets (since the end
+ * of round 5, then without a version bump) and must be DEDICATED to that entry point (per stream) and
+ * zero-initialised once by the caller -- a v5 caller that handed it any shared scratch must change; the
+ * option gemm_x6_plan gained the hybrid-schedule bits; danet_gemm_x6_tn_grouped masks odd row pads.     */
+#define DANET_ABI_VERSION 6
 
 typedef void* danet_stream_t;
 
@@ -245,6 +249,10 @@ int danet_gemm_x6(danet_stream_t stream, int M, int N,
  * the products, sum of tile_rows(M)*ceil(N/128), K) bytes, tile_rows(M) = ceil(M/128) -- except that
  * 1..4 rows beyond a multiple of 128 (M > 128, N % 4 == 0: the 129 spectrogram bins of the bottom
  * layer's dWx) are not a tile row: tile_rows(M) = M/128, those rows are exact fp32 FMA chains.
+ * Row pads: rows are read in whole 16-byte groups inside their pitch (lda / ldb).  Pad values never reach a
+ * stored result: for an even M / N they only meet accumulator rows / columns that are not stored, for an
+ * odd M / N (where the last valid value shares its split pair with the first pad value) the launch takes
+ * a kernel variant that masks the pad per element -- the pad need not be initialised or finite.
  * Non-finite data: an operand value that is Inf or rounds to Inf in bf16 (|x| >= 3.39e38) turns the
  * result rows / columns of BOTH values of its pair (m and m ^ 1, resp. n and n ^ 1) into NaN -- the
  * split forms remainders as Inf * 0 for the partner (csrc/common.h); finite data are unaffected.  */

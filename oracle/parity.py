@@ -13,6 +13,12 @@ for every checked tensor, with err = max |a - b| / max |b| (the SURVEY-sanctione
 relative-to-tensor-max form; for masks, max |b| = 1 so it is the absolute error).
 An RMS-relative figure ||a - b||_2 / ||b||_2 is reported next to it.
 
+`logits` (the separator's pre-activation embed . attr^T, app/modules.py:587-589) is a DERIVED
+entry: formed here in float64 from each path's own embedding and attractors, relative to the
+largest |logit| (bar 1e-5).  It separates "error carried into the softmax" from "amplification by
+the softmax": trained masks are sharp (|logit| ~ 1e3), so a logit error of 1e-6 of the maximum is an
+absolute error of 1e-3 in the exponent and moves a mask by up to 2.5e-4 -- for ANY float32 path.
+
 Reference lines restated by the functions this calls: main.py:208-337,
 app/modules.py:207-260,490-603, app/ops.py:139-147,374-431 (see danet_oracle.py).
 '''
@@ -22,6 +28,7 @@ from . import danet_oracle as O
 
 KEYS = ('embed', 'attrs', 'masks', 'sep_pwr')
 BAR = 1e-4
+BAR_LOGITS = 1e-5
 
 
 def _err(a, b):
@@ -51,6 +58,27 @@ def torch_f32(src, params, cfg, keys):
     return {k: r[k].numpy() for k in keys if k in r}
 
 
+def _logits(r):
+    '''embed_flat . attr^T (app/modules.py:587-589) in float64 from a path's own tensors'''
+    e = np.asarray(r['embed'], dtype=np.float64)
+    a = np.asarray(r['attrs'], dtype=np.float64)
+    B, C, E = a.shape
+    return np.einsum('bne,bce->bnc', e.reshape(B, -1, E), a)
+
+
+def _logits_entry(got, r64, r32, t32):
+    ref = _logits(r64)
+    e_hip = _err(_logits(got), ref)
+    e_f32 = _err(_logits(r32), ref)
+    if 'embed' in t32 and 'attrs' in t32:
+        e_t32 = _err(_logits(t32), ref)
+        if e_t32['max_rel'] > e_f32['max_rel']:
+            e_f32 = e_t32
+    bound = max(BAR_LOGITS, 2.0 * e_f32['max_rel'])
+    return dict(hip_vs_f64=e_hip, f32_vs_f64=e_f32, bound=bound, ok=bool(e_hip['max_rel'] <= bound),
+                max_abs_logit=float(np.abs(ref).max()))
+
+
 def parity_report(got, src, params, cfg, keys=KEYS):
     '''got: {key: ndarray} product outputs for the mixtures in `src` (masks as
     [B,T,F,C]).  Returns {key: {hip_vs_f64: {max_rel, rms_rel}, f32_vs_f64: {...},
@@ -76,6 +104,9 @@ def parity_report(got, src, params, cfg, keys=KEYS):
         rep[k] = dict(hip_vs_f64=e_hip, f32_vs_f64=e_f32, bound=bound,
                       ok=bool(e_hip['max_rel'] <= bound))
         ok = ok and rep[k]['ok']
+    if 'embed' in got and 'attrs' in got:
+        rep['logits'] = _logits_entry(got, r64, r32, t32)
+        ok = ok and rep['logits']['ok']
     rep['perm_idx_equal_f32_f64'] = bool(np.array_equal(r32['perm_idx'], r64['perm_idx']))
     if 'perm_idx' in got:
         rep['perm_idx_equal'] = bool(np.array_equal(np.asarray(got['perm_idx']), r64['perm_idx']))

@@ -303,7 +303,7 @@ torch.cuda.synchronize()
 model.check_status()
 # the bucket now holds the SUM over the ranks (1/world is folded into the optimiser kernel)
 np.savez(os.path.join(os.environ['DP_OUT'], 'rank%%d.npz' %% rank), loss=float(out['loss']),
-         collectives=model.collectives_per_step(), status_tail=model._grad_store[-4:].cpu().numpy(),
+         collectives=model.collectives_per_step(), status_tail=model.status_words().cpu().numpy(),
          **{'g:' + k: v for k, v in model.grad_dict().items()},
          **{'p0:' + k: v for k, v in p0.items()},
          **{'p1:' + k: v for k, v in model.param_dict().items()})

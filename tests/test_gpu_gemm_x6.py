@@ -211,6 +211,31 @@ def test_x6_tn_group_vs_float64(K, shapes):
         assert torch.equal(pr[4], o)
 
 
+@pytest.mark.parametrize('M,N,lda,ldb', [(77, 131, 80, 132), (129, 1200, 132, 1200), (255, 50, 256, 52),
+                                         (130, 66, 132, 68)])
+def test_x6_tn_row_pads_never_reach_a_result(M, N, lda, ldb):
+    '''the pad of every operand row (columns M..lda-1 / N..ldb-1) holds NaN: odd M / N share a split pair
+    with the first pad value and take the masking kernel variant, even ones only feed accumulator rows
+    that are never stored, 1..4 rows over a multiple of 128 are FMA chains that never read the pad
+    (include/danet_hip.h: the pad need not be initialised)'''
+    from danet_amd import ops
+    K = 1030
+    g = torch.Generator(device='cuda').manual_seed(M * N)
+    A = torch.full((K, lda), float('nan'), device='cuda')
+    Bm = torch.full((K, ldb), float('nan'), device='cuda')
+    A[:, :M] = torch.randn(K, M, device='cuda', generator=g)
+    Bm[:, :N] = torch.randn(K, N, device='cuda', generator=g)
+    ldc = (N + 3) // 4 * 4
+    C = torch.zeros(M, ldc, device='cuda')
+    probs = [(A, lda, Bm, ldb, C, ldc, M, N, 0.0)]
+    assert ops._x6_tn_ok(probs, K)
+    ops.gemm_group(probs, K, transA=True)
+    ref = A[:, :M].double().t() @ Bm[:, :N].double()
+    assert torch.isfinite(C[:, :N]).all()
+    assert _err(C[:, :N], ref) <= TOL
+    assert torch.equal(C[:, N:], torch.zeros_like(C[:, N:]))
+
+
 def test_x6_tn_transposition_and_identity():
     '''transpose-detecting: A = one-hot rows picks single rows of B exactly (the split is exact),
     and an asymmetric pattern lands at [m][n], not [n][m]'''

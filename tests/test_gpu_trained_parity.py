@@ -95,6 +95,11 @@ def test_cfg2_parity_after_training(hp):
     for k in P.KEYS:
         assert rep[k]['ok'], (k, rep[k])
     assert rep['perm_idx_equal']
+    # what the softmax amplifies (app/modules.py:587-597): the logits embed . attr^T formed from the HIP
+    # path's own embedding and attractors sit within 1e-5 of the float64 oracle's, relative to the
+    # largest |logit| -- the mask error above that is the saturated softmax's gain
+    assert rep['logits']['hip_vs_f64']['max_rel'] <= 1e-5, rep['logits']
+    assert rep['logits']['ok'], rep['logits']
     # the masks are a simplex: the max error is an absolute error in [0, 1]
     assert rep['masks']['hip_vs_f64']['max_rel'] <= max(1e-4, 2 * rep['masks']['f32_vs_f64']['max_rel'])
     # the SAME trained parameters with every product on the bf16 matrix cores (six

@@ -347,3 +347,22 @@ def test_est_kmeans_restatement():
     start = R.est_anchor(emb, anchors, C)[0].numpy()
     both_found = len(set(np.argmax(truth @ start.T, axis=1))) == 2
     assert (not both_found) or err < 1e-6 * np.abs(truth).max()
+
+
+def test_parity_report_logits_entry():
+    '''oracle/parity.py: the derived `logits` entry (embed . attr^T, app/modules.py:587-589, relative
+    to the largest |logit|) exists, is exact for the float64 oracle's own tensors, reads a
+    perturbed embedding as a failure and leaves the other entries alone'''
+    from oracle import g5, parity as P
+    src, params, cfg = g5.case_inputs('tiny_anchor_softmax')
+    r64, _ = P.oracle_pair(src, params, cfg)
+    got = {k: np.asarray(r64[k]) for k in P.KEYS}
+    got['perm_idx'] = r64['perm_idx']
+    rep = P.parity_report(got, src, params, cfg)
+    assert rep['ok'] and rep['logits']['ok']
+    assert rep['logits']['hip_vs_f64']['max_rel'] == 0.0
+    assert rep['logits']['bound'] >= P.BAR_LOGITS and rep['logits']['max_abs_logit'] > 0
+    bad = dict(got, embed=got['embed'] * (1 + 1e-3))
+    rep_b = P.parity_report(bad, src, params, cfg)
+    assert not rep_b['logits']['ok'] and not rep_b['ok']
+    assert rep_b['logits']['hip_vs_f64']['max_rel'] > 1e-4
