@@ -84,7 +84,7 @@ PROTOTYPES = {
                                           c_p, c_f32, c_p]),
     'danet_attractor_truth_bwd_sep': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p, c_p,
                                               c_f32, c_p, c_p, c_int, c_int, c_p, c_p, c_p, c_p, c_f32,
-                                              c_p, c_p]),
+                                              c_p, c_p, c_p]),
     'danet_attractor_anchor_fwd': (c_int, [c_p, c_int, c_int, c_i64, c_int, c_int, c_p, c_p, c_p,
                                            c_p, c_p, c_p, c_p, c_sz]),
     'danet_separate_fwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p, c_p, c_p]),
@@ -95,13 +95,13 @@ PROTOTYPES = {
     'danet_separate_pit_bwd': (c_int, [c_p, c_int, c_int, c_int, c_int, c_i64, c_int, c_p, c_p, c_p,
                                        c_p, c_p, c_p, c_p, c_f32, c_p, c_p, c_p, c_p, c_sz]),
     'danet_separate_pit_fwd_records': (c_int, [c_p, c_int, c_int, c_int, c_int, c_i64, c_int, c_p, c_p,
-                                               c_p, c_p, c_p, c_p, c_p]),
+                                               c_p, c_p, c_p, c_p, c_p, c_p]),
     'danet_separate_pit_final': (c_int, [c_p, c_int, c_int, c_i64, c_f32, c_p, c_p, c_p, c_p]),
     'danet_attractor_anchor_bwd_embed': (c_int, [c_p, c_int, c_int, c_i64, c_int, c_int, c_p, c_p, c_p,
                                                  c_p, c_p, c_p, c_p, c_p, c_sz]),
     'danet_attractor_anchor_bwd_embed_sep': (c_int, [c_p, c_int, c_int, c_i64, c_int, c_int, c_p, c_p, c_p,
                                                      c_p, c_p, c_p, c_int, c_int, c_p, c_p, c_p, c_p, c_p,
-                                                     c_f32, c_p, c_p, c_p, c_sz]),
+                                                     c_f32, c_p, c_p, c_p, c_sz, c_p]),
     'danet_attractor_anchor_bwd_anchors': (c_int, [c_p, c_int, c_int, c_i64, c_int, c_int, c_p, c_p,
                                                    c_p, c_sz, c_f32]),
     'danet_pit_mse_fwd': (c_int, [c_p, c_int, c_int, c_int, c_i64, c_p, c_p, c_p, c_f32, c_p,
@@ -157,6 +157,7 @@ def load():
 # (names: the lower-case module constants of ops.py / model.py that call `expert()`, and the library
 # options of csrc/options.h).  Defaults are the shipped, measured configuration.
 _expert = None
+_expert_seen = set()      # every name some module has asked for (typos in DANET_EXPERT are reported, below)
 
 
 def expert(name, default):
@@ -169,6 +170,7 @@ def expert(name, default):
             if item.strip():
                 k, _, v = item.partition('=')
                 _expert[k.strip().lower()] = v.strip()
+    _expert_seen.add(name.lower())
     v = _expert.get(name.lower())
     if v is None:
         return default
@@ -199,6 +201,13 @@ def apply_env_options():
             v = expert(name, '')
         if v != '':
             check(lib.danet_set_option(name.encode(), int(v)))
+    # a key of DANET_EXPERT that neither a module constant nor a library option answers to is a typo: say so
+    # (the library is loaded at the first kernel call, after ops.py / model.py have read their settings)
+    unknown = sorted(set(_expert or {}) - _expert_seen)
+    if unknown:
+        import warnings
+        warnings.warn('DANET_EXPERT: unknown setting(s) %s (known: the lower-case constants of ops.py / model.py '
+                      'that call _lib.expert(), and the library options %s)' % (unknown, option_names()))
 
 
 def set_option(name, value):
@@ -221,7 +230,7 @@ def check(rc):
 # DANET_WS_* (include/danet_hip.h)
 (WS_ISTFT, WS_GEMM, WS_GEMM_STREAMK, WS_COLSUM, WS_LSTM, WS_ATTRACTOR_TRUTH, WS_ATTRACTOR_ANCHOR,
  WS_SEPARATE_BWD, WS_SEPARATE_PIT, WS_SEPARATE_PIT_RECORDS, WS_PIT_MSE, WS_CENTER_MEAN,
- WS_GEMM_X6, WS_GEMM_PACK, WS_GEMM_X6_TN) = range(15)
+ WS_GEMM_X6, WS_GEMM_PACK, WS_GEMM_X6_TN, WS_SEPARATE_PIT_GRAD) = range(16)
 
 
 def ws_bytes(op, *dims):

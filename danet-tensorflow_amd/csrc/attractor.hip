@@ -381,22 +381,25 @@ __global__ __launch_bounds__(256) void separate_bwd_kernel(
     if (c < C) block_reduce_store<EP>(accs[c], EP, red, out + c * EP);
 }
 
+// sum_ch pp[ch * stride]: 4 independent partial sums -- the chunk loads are in flight together instead of
+// one dependent load per add (fixed combination order: deterministic)
+__device__ __forceinline__ float chunk_sum4(const float* __restrict__ pp, int nch, int64_t stride) {
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  int ch = 0;
+  for (; ch + 4 <= nch; ch += 4)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] += pp[(int64_t)(ch + u) * stride];
+  for (; ch < nch; ++ch) s[0] += pp[(int64_t)ch * stride];
+  return (s[0] + s[1]) + (s[2] + s[3]);
+}
+
 __global__ void sum_chunks_kernel(int nch, int C, int E, int EP,
                                   const float* __restrict__ partial, float* __restrict__ out) {
   // out[b][c][e] = sum_ch partial[b][ch][c][e(EP)]
   const int b = blockIdx.x;
   for (int i = threadIdx.x; i < C * E; i += blockDim.x) {
     const int c = i / E, e = i % E;
-    // 4 independent partial sums: the chunk loads are in flight together instead of one
-    // dependent load per add (fixed combination order: deterministic)
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    const float* pp = partial + ((int64_t)b * nch * C + c) * EP + e;
-    int ch = 0;
-    for (; ch + 4 <= nch; ch += 4)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) s[u] += pp[(int64_t)(ch + u) * C * EP];
-    for (; ch < nch; ++ch) s[0] += pp[(int64_t)ch * C * EP];
-    out[((int64_t)b * C + c) * E + e] = (s[0] + s[1]) + (s[2] + s[3]);
+    out[((int64_t)b * C + c) * E + e] = chunk_sum4(partial + ((int64_t)b * nch * C + c) * EP + e, nch, (int64_t)C * EP);
   }
 }
 
@@ -459,16 +462,36 @@ __device__ __forceinline__ void sep_masks_lds(int act, const float (&x)[EP], con
   }
 }
 
-template <int EP, int CP, bool EF>
+// GRAD (round 6; CP == 2, the two-speaker configurations): the same pass ALSO accumulates the attractor-gradient partials of the fused
+// separator + loss backward -- sep_pit_bwd_kernel's accs[c][e] += dL/dlogit_c x_e -- for EVERY permutation
+// (C! = 2 sets of C x EP sums per thread), with the upstream gradient left out (scale = 2 / (B N); the
+// consumer multiplies by dloss).  Which permutation an utterance takes is only known once all of its
+// chunks' cross errors are summed; the estimator's backward (anchor_sep_bwd_kernel / truth_sep_bwd_kernel)
+// derives it from the records as before and then adds up the partials of THAT permutation itself -- so on
+// the training path the launches danet_separate_pit_bwd (one more read of the 42 MB embedding, 21.5 us at
+// cfg 2) and sum_chunks (5.6 us) do not exist.  Same products and sums in the same order as the backward
+// kernel's (equal to an ulp per chunk partial: the compiler contracts the shared expressions differently).
+template <int CP>
+__device__ __forceinline__ void sep_pit_dlogit(int act, int mode, const float (&m)[CP], float mp,
+                                               float2 ph, const float2 (&s)[CP],
+                                               const int (&inv)[MAXC], float scale, float (&dl)[CP]);
+template <int CP> struct NPerm { static constexpr int value = CP * NPerm<CP - 1>::value; };
+template <> struct NPerm<1> { static constexpr int value = 1; };
+#define SEP_GRAD_MAXC 2
+
+template <int EP, int CP, bool EF, bool GRAD>
 __global__ __launch_bounds__(SEP_NT) void sep_pit_fwd_kernel(
-    int act, int mode, int64_t N, int E_, const float* __restrict__ mix_pwr,
+    int act, int mode, int B, int64_t N, int E_, const float* __restrict__ mix_pwr,
     const float* __restrict__ attr, const float* __restrict__ embed,
     const float2* __restrict__ src, const float2* __restrict__ phasor,
-    float* __restrict__ out /* optional [B][C][N] */, float* __restrict__ partial /* [B][nch][REC] */) {
+    float* __restrict__ out /* optional [B][C][N] */, float* __restrict__ partial /* [B][nch][REC] */,
+    float* __restrict__ gpartial /* GRAD: [B][nch][C!][C][EP] */) {
   const int E = EF ? EP : E_;   // EF: E == EP known at compile time (guard-free 16-byte row accesses)
   constexpr int C = CP;
+  constexpr int NP = GRAD ? NPerm<CP>::value : 1;
   __shared__ float tab[CP * EP];
   __shared__ float red[SEP_NW * REC];
+  __shared__ float gred[GRAD ? SEP_NW * EP : 1];
   const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
   for (int i = threadIdx.x; i < C * EP; i += SEP_NT) {
     const int c = i / EP, e = i % EP;
@@ -480,6 +503,21 @@ __global__ __launch_bounds__(SEP_NT) void sep_pit_fwd_kernel(
   float acc[REC];
 #pragma unroll
   for (int i = 0; i < REC; ++i) acc[i] = 0.f;
+  float gacc[NP][CP][GRAD ? EP : 1];
+  int inv[NP][MAXC];
+  if constexpr (GRAD) {
+#pragma unroll
+    for (int pq = 0; pq < NP; ++pq) {
+      int perm[MAXC];
+      nth_perm(C, pq, perm);
+      for (int i = 0; i < C; ++i) inv[pq][perm[i]] = i;          // estimate j is paired with truth inv[j]
+#pragma unroll
+      for (int c = 0; c < CP; ++c)
+#pragma unroll
+        for (int e = 0; e < EP; ++e) gacc[pq][c][e] = 0.f;
+    }
+  }
+  const float gscale = 2.f / ((float)B * (float)N);              // (sep_pit_bwd_kernel's scale at dloss = 1)
   for (int64_t n = n0 + threadIdx.x; n < n1; n += SEP_NT) {
     float x[EP];
     load_row<EP>(eb + n * E, E, x);
@@ -496,6 +534,17 @@ __global__ __launch_bounds__(SEP_NT) void sep_pit_fwd_kernel(
       if (out) out[((int64_t)b * C + c) * N + n] = p[c];
     }
     pit_accumulate<C>(mode, s, p, ph, acc);
+    if constexpr (GRAD) {
+#pragma unroll
+      for (int pq = 0; pq < NP; ++pq) {
+        float dl[CP];
+        sep_pit_dlogit<CP>(act, mode, m, mp, ph, s, inv[pq], gscale, dl);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+          for (int e = 0; e < EP; ++e) gacc[pq][c][e] += dl[c] * x[e];
+      }
+    }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -511,6 +560,24 @@ __global__ __launch_bounds__(SEP_NT) void sep_pit_fwd_kernel(
     for (int w = 1; w < SEP_NW; ++w) t += red[w * REC + i];
     po[i] = t;
   }
+  if constexpr (GRAD) {
+    __syncthreads();
+    float* go = gpartial + ((int64_t)b * nch + ch) * NP * C * EP;
+#pragma unroll
+    for (int pq = 0; pq < NP; ++pq)
+#pragma unroll
+      for (int c = 0; c < CP; ++c) block_reduce_store<EP, SEP_NW>(gacc[pq][c], EP, gred, go + (pq * C + c) * EP);
+  }
+}
+
+// dattr[c][e] of utterance b into LDS from the forward's gradient partials of permutation `perm`
+// (sum_chunks_kernel's sum, times the upstream gradient); the caller's next __syncthreads() publishes it
+template <int EP, int CP>
+__device__ __forceinline__ void dattr_from_partials(const float* __restrict__ gpartial, int b, int nch,
+                                                    int perm, float dscale, float* Dr) {
+  constexpr int NP = NPerm<CP>::value;
+  for (int i = threadIdx.x; i < CP * EP; i += blockDim.x)
+    Dr[i] = dscale * chunk_sum4(gpartial + (((int64_t)b * nch) * NP + perm) * CP * EP + i, nch, (int64_t)NP * CP * EP);
 }
 
 // dL/dlogit_c of the fused separator + PIT loss for one bin (masks m, mixture magnitude mp,
@@ -661,7 +728,8 @@ __global__ __launch_bounds__(SEP_NT) void truth_sep_bwd_kernel(
     const float* __restrict__ embed, const float* __restrict__ attr,
     int act, int mode, int B, const float2* __restrict__ src, const float2* __restrict__ phasor,
     const int32_t* __restrict__ perm_idx, const float* __restrict__ records,
-    float dloss, const float* __restrict__ dloss_dev, float* __restrict__ dembed) {
+    float dloss, const float* __restrict__ dloss_dev, float* __restrict__ dembed,
+    const float* __restrict__ gpartial /* or null: dattr = the forward's partials of the utterance's permutation */) {
   const int E = EF ? EP : E_;   // EF: E == EP known at compile time (guard-free 16-byte row accesses)
   constexpr int C = CP;
   __shared__ float dtab[CP * EP];   // dattr / (denom + add)
@@ -670,17 +738,26 @@ __global__ __launch_bounds__(SEP_NT) void truth_sep_bwd_kernel(
   __shared__ int perm_s;
   const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
   sep_pit_perm<CP>(records, perm_idx, b, nch, N, rec_s, &perm_s);
+  const float dscale = dloss * (dloss_dev ? *dloss_dev : 1.f);
+  if (gpartial != nullptr) {
+    if constexpr (CP == SEP_GRAD_MAXC) {
+      __syncthreads();                // perm_s
+      dattr_from_partials<EP, CP>(gpartial, b, nch, perm_s, dscale, dtab);
+      __syncthreads();
+    }
+  }
   for (int i = threadIdx.x; i < C * EP; i += SEP_NT) {
     const int c = i / EP, e = i % EP;
     const float add = (tmode == 0) ? 1.f : eps;
-    dtab[i] = (e < E) ? dattr[((int64_t)b * C + c) * E + e] / (denom[b * C + c] + add) : 0.f;
+    const float d = gpartial ? dtab[i] : ((e < E) ? dattr[((int64_t)b * C + c) * E + e] : 0.f);
+    dtab[i] = (e < E) ? d / (denom[b * C + c] + add) : 0.f;
     tab[i] = (e < E) ? attr[((int64_t)b * C + c) * E + e] : 0.f;
   }
   __syncthreads();
   int perm[MAXC], inv[MAXC];
   nth_perm(C, perm_s, perm);
   for (int i = 0; i < C; ++i) inv[perm[i]] = i;
-  const float scale = dloss * (dloss_dev ? *dloss_dev : 1.f) * 2.f / ((float)B * (float)N);
+  const float scale = dscale * 2.f / ((float)B * (float)N);
   const int64_t n0 = (int64_t)ch * CHUNK_N, n1 = min(N, n0 + CHUNK_N);
   const float* eb = embed + (int64_t)b * N * E;
   const float* sp = src_pwr + (int64_t)b * C * N;
@@ -1082,7 +1159,8 @@ __device__ __forceinline__ void anchor_bwd_tables(int b, int E, const AnchorComb
     const int c = i / EP, e = i % EP;
     const int a = cb.idx[pstar][c];
     const float den = asum[((int64_t)b * cb.P + pstar) * C + c];
-    const float d = (e < E) ? dattr[((int64_t)b * C + c) * E + e] : 0.f;
+    // (dattr == nullptr: the caller has put it into Dr -- dattr_from_partials -- and synchronised)
+    const float d = dattr ? ((e < E) ? dattr[((int64_t)b * C + c) * E + e] : 0.f) : Dr[i];
     An[i] = (e < E) ? anchors[a * E + e] : 0.f;
     G[i] = (e < E) ? d / den : 0.f;
     Dr[i] = d;
@@ -1188,7 +1266,8 @@ __global__ __launch_bounds__(SEP_NT) void anchor_sep_bwd_kernel(
     const float2* __restrict__ src, const float2* __restrict__ phasor,
     const int32_t* __restrict__ perm_idx, const float* __restrict__ records,
     float dloss, const float* __restrict__ dloss_dev,
-    float* __restrict__ dembed, float* __restrict__ partial /* [B][chunks][C][EP] */) {
+    float* __restrict__ dembed, float* __restrict__ partial /* [B][chunks][C][EP] */,
+    const float* __restrict__ gpartial /* or null: dattr = the forward's partials of the utterance's permutation */) {
   const int E = EF ? EP : E_;   // EF: E == EP known at compile time (guard-free 16-byte row accesses)
   constexpr int C = CP;
   __shared__ float An[MAXC * EP];   // chosen anchors
@@ -1202,12 +1281,22 @@ __global__ __launch_bounds__(SEP_NT) void anchor_sep_bwd_kernel(
   const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
   const int pstar = choice[b];      // (issued before the record sums: its latency hides behind them)
   sep_pit_perm<CP>(records, perm_idx, b, nch, N, rec_s, &perm_s);
-  anchor_bwd_tables<EP, CP>(b, E, cb, pstar, dattr, anchors, attr, asum, An, G, Dr, tab, dn);
+  const float dscale = dloss * (dloss_dev ? *dloss_dev : 1.f);
+  if (gpartial != nullptr) {
+    if constexpr (CP == SEP_GRAD_MAXC) {
+      __syncthreads();                // perm_s
+      dattr_from_partials<EP, CP>(gpartial, b, nch, perm_s, dscale, Dr);
+      __syncthreads();
+      anchor_bwd_tables<EP, CP>(b, E, cb, pstar, nullptr, anchors, attr, asum, An, G, Dr, tab, dn);
+    }
+  } else {
+    anchor_bwd_tables<EP, CP>(b, E, cb, pstar, dattr, anchors, attr, asum, An, G, Dr, tab, dn);
+  }
   __syncthreads();
   int perm[MAXC], inv[MAXC];
   nth_perm(C, perm_s, perm);
   for (int i = 0; i < C; ++i) inv[perm[i]] = i;
-  const float scale = dloss * (dloss_dev ? *dloss_dev : 1.f) * 2.f / ((float)B * (float)N);
+  const float scale = dscale * 2.f / ((float)B * (float)N);
   const int64_t n0 = (int64_t)ch * CHUNK_N, n1 = min(N, n0 + CHUNK_N);
   const float* eb = embed + (int64_t)b * N * E;
   float* db = dembed + (int64_t)b * N * E;
@@ -1438,11 +1527,16 @@ extern "C" int danet_attractor_truth_bwd_sep(danet_stream_t stream_, int tmode, 
                                              const float* attr, int act, int mode,
                                              const float* src_c64, const float* phasor,
                                              const int32_t* perm_idx, const float* records,
-                                             float dloss, const float* dloss_dev, float* dembed) {
+                                             float dloss, const float* dloss_dev, float* dembed,
+                                             const float* dattr_partials) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_common("attractor_truth_bwd_sep", B, C, N, E);
   if (rc) return rc;
-  DANET_CHECK_ARG(dattr && src_pwr && mix_pwr && denom && dembed && embed && attr && src_c64 && phasor &&
+  if (dattr_partials && (C != SEP_GRAD_MAXC || !records)) {
+    danet_set_error("attractor_truth_bwd_sep: dattr_partials needs C == %d and records", SEP_GRAD_MAXC);
+    return DANET_ERR_UNSUPPORTED;
+  }
+  DANET_CHECK_ARG((dattr || dattr_partials) && src_pwr && mix_pwr && denom && dembed && embed && attr && src_c64 && phasor &&
                   (perm_idx || records), "attractor_truth_bwd_sep: null pointer");
   DANET_CHECK_ARG(tmode >= 0 && tmode <= 2 && (act == 0 || act == 1) && (mode == 0 || mode == 1),
                   "attractor_truth_bwd_sep: mode");
@@ -1451,7 +1545,7 @@ extern "C" int danet_attractor_truth_bwd_sep(danet_stream_t stream_, int tmode, 
   DISPATCH_EP(EPV, DISPATCH_CP(C, DISPATCH_EF(E == EPV, truth_sep_bwd_kernel<EP, CP, EF><<<grid, SEP_NT, 0, stream>>>(
                        tmode, N, E, dattr, src_pwr, mix_pwr, denom, eps, embed, attr, act, mode, B,
                        (const float2*)src_c64, (const float2*)phasor, perm_idx, records, dloss,
-                       dloss_dev, dembed))));
+                       dloss_dev, dembed, dattr_partials))));
   DANET_CHECK_LAUNCH();
   return DANET_OK;
 }
@@ -1518,20 +1612,37 @@ extern "C" int danet_separate_pit_fwd_records(danet_stream_t stream_, int act, i
                                               int C, int64_t N, int E, const float* mix_pwr,
                                               const float* attr, const float* embed,
                                               const float* src_c64, const float* phasor,
-                                              float* sep_pwr_out, float* records) {
+                                              float* sep_pwr_out, float* records, float* dattr_partials) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_common("separate_pit_fwd", B, C, N, E);
   if (rc) return rc;
+  if (dattr_partials && C != SEP_GRAD_MAXC) {
+    danet_set_error("separate_pit_fwd: dattr_partials is offered for C == %d (C! x C x E sums per thread)", SEP_GRAD_MAXC);
+    return DANET_ERR_UNSUPPORTED;
+  }
   DANET_CHECK_ARG((act == 0 || act == 1) && (mode == 0 || mode == 1), "separate_pit_fwd: act / mode");
   DANET_CHECK_ARG(mix_pwr && attr && embed && src_c64 && phasor && records,
                   "separate_pit_fwd: null pointer");
   const int nch = n_chunks(N), EPV = pick_ep(E);
   dim3 grid(nch, B);
-  DISPATCH_EP(EPV, DISPATCH_CP(C, DISPATCH_EF(E == EPV, sep_pit_fwd_kernel<EP, CP, EF><<<grid, SEP_NT, 0, stream>>>(
-                       act, mode, N, E, mix_pwr, attr, embed, (const float2*)src_c64,
-                       (const float2*)phasor, sep_pwr_out, records))));
+  if (dattr_partials) {
+    DISPATCH_EP(EPV, DISPATCH_EF(E == EPV, sep_pit_fwd_kernel<EP, SEP_GRAD_MAXC, EF, true><<<grid, SEP_NT, 0, stream>>>(
+                         act, mode, B, N, E, mix_pwr, attr, embed, (const float2*)src_c64, (const float2*)phasor,
+                         sep_pwr_out, records, dattr_partials)));
+  } else {
+    DISPATCH_EP(EPV, DISPATCH_CP(C, DISPATCH_EF(E == EPV, sep_pit_fwd_kernel<EP, CP, EF, false><<<grid, SEP_NT, 0, stream>>>(
+                         act, mode, B, N, E, mix_pwr, attr, embed, (const float2*)src_c64,
+                         (const float2*)phasor, sep_pwr_out, records, nullptr))));
+  }
   DANET_CHECK_LAUNCH();
   return DANET_OK;
+}
+
+size_t dn_ws_separate_pit_grad(int B, int C, int64_t N, int E) {
+  if (C != SEP_GRAD_MAXC) return 0;                      // (not offered: the caller keeps danet_separate_pit_bwd)
+  int np = 1;
+  for (int i = 2; i <= C; ++i) np *= i;
+  return (size_t)B * n_chunks(N) * np * C * pick_ep(E) * sizeof(float);
 }
 
 extern "C" int danet_separate_pit_final(danet_stream_t stream_, int B, int C, int64_t N, float eps,
@@ -1684,11 +1795,15 @@ extern "C" int danet_attractor_anchor_bwd_embed_sep(
     const float* embed, const float* anchors, const float* attr, const float* asum,
     const int32_t* choice, int act, int mode, const float* mix_pwr, const float* src_c64,
     const float* phasor, const int32_t* perm_idx, const float* records, float dloss,
-    const float* dloss_dev, float* dembed, void* ws, size_t ws_bytes) {
+    const float* dloss_dev, float* dembed, void* ws, size_t ws_bytes, const float* dattr_partials) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = anchor_check("attractor_anchor_bwd", B, C, N, E, A);
   if (rc) return rc;
-  DANET_CHECK_ARG(dattr && embed && anchors && attr && asum && choice && dembed && mix_pwr && src_c64 &&
+  if (dattr_partials && (C != SEP_GRAD_MAXC || !records)) {
+    danet_set_error("attractor_anchor_bwd_embed_sep: dattr_partials needs C == %d and records", SEP_GRAD_MAXC);
+    return DANET_ERR_UNSUPPORTED;
+  }
+  DANET_CHECK_ARG((dattr || dattr_partials) && embed && anchors && attr && asum && choice && dembed && mix_pwr && src_c64 &&
                   phasor && (perm_idx || records), "attractor_anchor_bwd_embed_sep: null pointer");
   DANET_CHECK_ARG((act == 0 || act == 1) && (mode == 0 || mode == 1), "attractor_anchor_bwd_embed_sep: act / mode");
   if (!ws || ws_bytes < dn_ws_attractor_anchor(B, C, N, E, A)) {
@@ -1702,7 +1817,7 @@ extern "C" int danet_attractor_anchor_bwd_embed_sep(
   DISPATCH_EP(EPV, DISPATCH_CP(C, DISPATCH_EF(E == EPV, anchor_sep_bwd_kernel<EP, CP, EF><<<grid, SEP_NT, 0, stream>>>(
                        N, E, A, cb, dattr, embed, anchors, attr, asum, choice, act, mode, B, mix_pwr,
                        (const float2*)src_c64, (const float2*)phasor, perm_idx, records, dloss,
-                       dloss_dev, dembed, (float*)ws))));
+                       dloss_dev, dembed, (float*)ws, dattr_partials))));
   DANET_CHECK_LAUNCH();
   return DANET_OK;
 }

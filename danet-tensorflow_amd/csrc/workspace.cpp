@@ -22,9 +22,10 @@ int dn_center_mean_elems(int B);
 size_t dn_ws_gemm_x6(int M, int N, int K1, int K2);
 size_t dn_ws_gemm_pack(int N, int K);
 size_t dn_ws_gemm_x6_tn(long long sum_mn, int tiles, int K);
+size_t dn_ws_separate_pit_grad(int B, int C, int64_t N, int E);
 
 extern "C" size_t danet_workspace_bytes(int op, const int64_t* d, int n) {
-  static const int kDims[DANET_WS_COUNT] = {4, 3, 3, 2, 4, 4, 5, 4, 4, 2, 3, 1, 4, 2, 3};
+  static const int kDims[DANET_WS_COUNT] = {4, 3, 3, 2, 4, 4, 5, 4, 4, 2, 3, 1, 4, 2, 3, 4};
   if (op < 0 || op >= DANET_WS_COUNT || !d || n != kDims[op]) {
     danet_set_error("workspace_bytes: op %d takes %d dims, got %d", op,
                     (op >= 0 && op < DANET_WS_COUNT) ? kDims[op] : -1, n);
@@ -54,6 +55,7 @@ extern "C" size_t danet_workspace_bytes(int op, const int64_t* d, int n) {
     case DANET_WS_GEMM_X6: return dn_ws_gemm_x6((int)d[0], (int)d[1], (int)d[2], (int)d[3]);
     case DANET_WS_GEMM_PACK: return dn_ws_gemm_pack((int)d[0], (int)d[1]);
     case DANET_WS_GEMM_X6_TN: return dn_ws_gemm_x6_tn((long long)d[0], (int)d[1], (int)d[2]);
+    case DANET_WS_SEPARATE_PIT_GRAD: return dn_ws_separate_pit_grad((int)d[0], (int)d[1], d[2], (int)d[3]);
   }
   return (size_t)-1;
 }

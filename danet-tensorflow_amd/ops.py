@@ -594,6 +594,9 @@ OVERLAP_GEMM_WGS = _lib.expert('overlap_gemm_wgs', 0)
 
 
 def _side_streams(dev, n):
+    # (stream priorities were measured in round 6 -- side streams at priority 1 / -1 against the main
+    # stream's 0: 2.402 / 2.399 against 2.401 ms per cfg-2 step, BPTT 316.0 / 315.6 against 315.6 us: the
+    # weight-gradient group's cost to the BPTT kernel is not a matter of dispatch priority)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     pool = _side.setdefault(key, [])
     while len(pool) < n:
@@ -1332,6 +1335,12 @@ FUSE_DEMBED = _lib.expert('fuse_dembed', 1)
 # one pass (danet_attractor_anchor_bwd_embed_sep) -- the separator's term is not written to HBM
 # and read back.  DANET_HEADS_RECOMPUTE=0: the two-pass accumulate-in-place form.
 HEADS_RECOMPUTE = _lib.expert('heads_recompute', 1)
+# ... and, where the library offers it (C == 2), the fused separator + loss FORWARD already leaves the
+# attractor-gradient partials of every permutation behind: its backward then launches nothing at all -- the
+# estimator's backward derives the permutation from the records, adds up that permutation's partials and
+# uses them as dattr (round 6: one read of the embedding, danet_separate_pit_bwd and its chunk sum gone from
+# the train step).  DANET_EXPERT heads_gradfwd=0: the round-5 form.
+HEADS_GRADFWD = _lib.expert('heads_gradfwd', 1)
 
 
 # "Heads chain" scope (entered by Model.train_step around forward + backward): inside it the two
@@ -1477,13 +1486,15 @@ class TruthAttractorFn(torch.autograd.Function):
             recipe, ctx.token.recipe = ctx.token.recipe, None
         if recipe is not None:
             # the separator's embedding-gradient term is recomputed here (one pass, one store)
-            act, lmode, s_mix, src, phasor, records, dl = recipe
+            act, lmode, s_mix, src, phasor, records, dl, gpart = recipe
             dembed = torch.empty(B, T, F, E, device=dattr.device)
+            # (gpart: dattr is formed by the kernel from the forward's partials; the tensor autograd
+            # handed over is a placeholder)
             check(_L().danet_attractor_truth_bwd_sep(
-                _lib.stream(), mode, B, C, N, E, ptr(_f32(dattr.contiguous())), ptr(src_pwr),
-                ptr(s_mix), ptr(denom), eps, ptr(embed), ptr(attr), act, lmode,
+                _lib.stream(), mode, B, C, N, E, None if gpart is not None else ptr(_f32(dattr.contiguous())),
+                ptr(src_pwr), ptr(s_mix), ptr(denom), eps, ptr(embed), ptr(attr), act, lmode,
                 ptr(torch.view_as_real(src)), ptr(phasor), None, ptr(records), 1.0, ptr(dl),
-                ptr(dembed)))
+                ptr(dembed), ptr(gpart)))
             return dembed, None, None, None, None
         shared = _take_dembed(ctx.token, B * T * F * E)
         dembed = shared if shared is not None else torch.zeros(B, T, F, E, device=dattr.device)
@@ -1548,12 +1559,13 @@ class AnchorAttractorFn(torch.autograd.Function):
         dattr = _f32(dattr.contiguous())
         if recipe is not None:
             # the separator's embedding-gradient term is recomputed here (one pass, one store)
-            act, mode, mix_pwr, src, phasor, records, dl = recipe
+            act, mode, mix_pwr, src, phasor, records, dl, gpart = recipe
             w = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             check(L.danet_attractor_anchor_bwd_embed_sep(
-                _lib.stream(), B, C, N, E, A, ptr(dattr), ptr(embed), ptr(anchors), ptr(attr),
-                ptr(asum), ptr(choice), act, mode, ptr(mix_pwr), ptr(torch.view_as_real(src)),
-                ptr(phasor), None, ptr(records), 1.0, ptr(dl), ptr(dembed), ptr(w), nbytes))
+                _lib.stream(), B, C, N, E, A, None if gpart is not None else ptr(dattr), ptr(embed),
+                ptr(anchors), ptr(attr), ptr(asum), ptr(choice), act, mode, ptr(mix_pwr),
+                ptr(torch.view_as_real(src)), ptr(phasor), None, ptr(records), 1.0, ptr(dl), ptr(dembed),
+                ptr(w), nbytes, ptr(gpart)))
             _on_side(dev, lambda: check(L.danet_attractor_anchor_bwd_anchors(
                 _lib.stream(), B, C, N, E, A, ptr(choice), ptr(danchors), ptr(w), nbytes,
                 1.0 if direct else 0.0)), keep=(w, choice, danchors))
@@ -1690,9 +1702,21 @@ class SeparatePitFn(torch.autograd.Function):
         perm_idx = torch.empty(B, dtype=torch.int32, device=dev)
         L = _L()
         records = torch.empty(_lib.ws_bytes(_lib.WS_SEPARATE_PIT_RECORDS, B, N) // 4, device=dev)
+        # the backward's attractor-gradient partials already here?  Only where the backward will be able
+        # to leave everything to the estimator's backward (the conditions of `defer` below, as far as
+        # they are known now) and the library offers it for the shape
+        tok = getattr(attr, '_danet_dembed_token', None)
+        gpart = None
+        if (HEADS_GRADFWD and HEADS_RECOMPUTE and _chain() and tok is not None and
+                tok.kind in ('anchor', 'truth') and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and
+                tok.same_inputs(embed_flat, mix_pwr)):
+            nb = _lib.ws_bytes(_lib.WS_SEPARATE_PIT_GRAD, B, C, N, E)
+            if nb:
+                gpart = torch.empty(nb // 4, device=dev)
         check(L.danet_separate_pit_fwd_records(
             _lib.stream(), act, mode, B, C, N, E, ptr(mix_pwr), ptr(attr_c), ptr(embed_flat),
-            ptr(torch.view_as_real(src)), ptr(phasor), None, ptr(records)))
+            ptr(torch.view_as_real(src)), ptr(phasor), None, ptr(records), ptr(gpart)))
+        ctx.gpart = gpart
 
         def final():
             check(L.danet_separate_pit_final(_lib.stream(), B, C, N, eps, ptr(records), ptr(loss),
@@ -1716,6 +1740,7 @@ class SeparatePitFn(torch.autograd.Function):
         mix_pwr, attr, embed_flat, src, phasor, perm_idx = ctx.saved_tensors
         act, mode, B, C, N, E = ctx.args
         records, ctx.records = ctx.records, None
+        gpart, ctx.gpart = ctx.gpart, None
         dev = dloss.device
         tok = ctx.token
         defer = (HEADS_RECOMPUTE and _chain() and tok is not None and tok.kind in ('anchor', 'truth') and
@@ -1725,6 +1750,12 @@ class SeparatePitFn(torch.autograd.Function):
         dattr = torch.empty(B, C, E, device=dev)
         dl = _f32(dloss.contiguous())
         L = _L()
+        if defer and gpart is not None:
+            # nothing to launch: the estimator's backward (next node) forms dattr from the forward's
+            # partials and the whole embedding gradient; `dattr` is a placeholder that only keeps
+            # autograd walking to that node
+            tok.recipe = (act, mode, mix_pwr, src, phasor, records, dl, gpart)
+            return None, dattr, None, None, None, None, None, None
         w, wn = _ws(_lib.ws_bytes(_lib.WS_SEPARATE_PIT, B, C, N, E), dev)
         # dloss is a device scalar: the kernel reads it (no host sync, no extra pass)
         check(L.danet_separate_pit_bwd(_lib.stream(), act, mode, B, C, N, E, ptr(mix_pwr),
@@ -1734,7 +1765,7 @@ class SeparatePitFn(torch.autograd.Function):
         if defer:
             # the estimator's backward (next node) recomputes this kernel's dembed term
             # and returns the whole embedding gradient
-            tok.recipe = (act, mode, mix_pwr, src, phasor, records, dl)
+            tok.recipe = (act, mode, mix_pwr, src, phasor, records, dl, None)
             return None, dattr, None, None, None, None, None, None
         if ctx.token is not None and ctx.needs_input_grad[1]:
             # the estimator that made `attr` runs its backward next and adds into `dembed`

@@ -96,6 +96,8 @@ enum {
   DANET_WS_GEMM_X6,              /* M, N, K1, K2            danet_gemm_x6 (split-K slabs; may be 0) */
   DANET_WS_GEMM_PACK,            /* N, K                    `out` of a danet_gemm_pack_weights job  */
   DANET_WS_GEMM_X6_TN,           /* sum M*N, 128x128 tiles, K   danet_gemm_x6_tn_grouped (may be 0)  */
+  DANET_WS_SEPARATE_PIT_GRAD,    /* B, C, N, E              `dattr_partials` of danet_separate_pit_fwd_records;
+                                                            0 = not offered for this shape (C != 2)         */
   DANET_WS_COUNT
 };
 size_t danet_workspace_bytes(int op, const int64_t* dims, int n_dims);
@@ -403,7 +405,8 @@ int danet_attractor_truth_bwd_sep(danet_stream_t stream, int tmode, int B, int C
                                   const float* attr, int act, int mode, const float* src_c64,
                                   const float* phasor, const int32_t* perm_idx,
                                   const float* records, float dloss, const float* dloss_dev,
-                                  float* dembed);
+                                  float* dembed, const float* dattr_partials /* or NULL, see
+                                  danet_separate_pit_fwd_records; then dattr may be NULL */);
 
 /* ---------------------------------------------------------------- a11
  * Anchor estimator (app/modules.py:490-545, app/ops.py:273-292), fused: one
@@ -432,7 +435,9 @@ int danet_attractor_anchor_bwd_embed_sep(danet_stream_t stream, int B, int C, in
                                          int act, int mode, const float* mix_pwr, const float* src_c64,
                                          const float* phasor, const int32_t* perm_idx,
                                          const float* records, float dloss, const float* dloss_dev,
-                                         float* dembed, void* ws, size_t ws_bytes);
+                                         float* dembed, void* ws, size_t ws_bytes,
+                                         const float* dattr_partials /* or NULL, see
+                                         danet_separate_pit_fwd_records; then dattr may be NULL */);
 int danet_attractor_anchor_bwd_anchors(danet_stream_t stream, int B, int C, int64_t N, int E, int A,
                                        const int32_t* choice, float* danchors, const void* ws,
                                        size_t ws_bytes, float danchors_beta);
@@ -468,10 +473,17 @@ int danet_separate_bwd(danet_stream_t stream, int act, int B, int C,
  * perm_idx = NULL) and derives each utterance's permutation from them itself -- the same sums
  * in the same order, hence the same index -- so part 2 is off the forward -> backward critical
  * path and a host may issue it on another stream.                                          */
+/* `dattr_partials` (round 6; optional, DANET_WS_SEPARATE_PIT_GRAD bytes, offered for C == 2): the same pass
+ * also leaves the per-chunk attractor-gradient sums of the backward -- for EVERY permutation, without the
+ * upstream gradient -- so that the training path needs no danet_separate_pit_bwd at all: hand the buffer
+ * (with `records`) to danet_attractor_anchor_bwd_embed_sep / danet_attractor_truth_bwd_sep, which derive each
+ * utterance's permutation from the records, add up the partials of that permutation (x dloss) and use the
+ * result as dattr.  One read of the embedding and two launches fewer per train step; the same products
+ * and sums in the same order as danet_separate_pit_bwd's (dattr equal to an ulp per chunk partial).          */
 int danet_separate_pit_fwd_records(danet_stream_t stream, int act, int mode, int B, int C,
                                    int64_t N, int E, const float* mix_pwr, const float* attr,
                                    const float* embed, const float* src_c64, const float* phasor,
-                                   float* sep_pwr_out, float* records);
+                                   float* sep_pwr_out, float* records, float* dattr_partials);
 int danet_separate_pit_final(danet_stream_t stream, int B, int C, int64_t N, float eps,
                              const float* records, float* loss, float* snr, int32_t* perm_idx);
 int danet_separate_pit_bwd(danet_stream_t stream, int act, int mode, int B, int C, int64_t N,

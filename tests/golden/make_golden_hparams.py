@@ -11,6 +11,12 @@ reference's own `default.json`.  Two stand-ins, both in memory: an empty module 
 `scipy.signal.hann(...)`, which scipy >= 1.13 only provides under `scipy.signal.windows`; same
 function, symmetric by default).
 
+TRUST: this script EXECUTES code from the untrusted reference tree -- `app/hparams.py` at import, and
+`Hyperparameter.digest()` eval()s the expression strings of `default.json` (app/hparams.py:42: the
+FFT window, the dtype names).  It is a build-container tool for whoever regenerates the fixture, to be
+run by hand in a sandbox (no credentials, no network: this container) after reading those two files;
+nothing in tests/, bench.py or the product imports it, and the GPU box never sees the reference.
+
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_hparams.py
 '''
 import sys

@@ -59,8 +59,13 @@ def test_library_loads_and_exports_every_declared_symbol():
     for op, d in dims.items():
         assert 0 < _lib.ws_bytes(op, *d) < (1 << 32), op
     txt = open(os.path.join(ROOT, 'include', 'danet_hip.h')).read()
-    assert re.search(r'DANET_WS_GEMM_X6_TN,[^\n]*\n\s*DANET_WS_COUNT', txt)         # enum order == _lib's
+    assert re.search(r'DANET_WS_GEMM_X6_TN,[^\n]*\n\s*DANET_WS_SEPARATE_PIT_GRAD,.{0,300}?DANET_WS_COUNT', txt, re.S)   # enum order == _lib's
     assert _lib.WS_CENTER_MEAN == 11 and _lib.WS_GEMM_PACK == 13 and _lib.WS_GEMM_X6_TN == 14
+    assert _lib.WS_SEPARATE_PIT_GRAD == 15
+    # the attractor-gradient partials of the fused separator + loss forward: C! x C x EP sums per chunk,
+    # offered for C == 2 (0 = not offered: the caller keeps danet_separate_pit_bwd)
+    assert _lib.ws_bytes(_lib.WS_SEPARATE_PIT_GRAD, 32, 2, 16512, 20) == 32 * 9 * 2 * 2 * 20 * 4
+    assert _lib.ws_bytes(_lib.WS_SEPARATE_PIT_GRAD, 32, 3, 16512, 40) == 0 == _lib.ws_bytes(_lib.WS_SEPARATE_PIT_GRAD, 32, 1, 16512, 20)
     # a BiLSTM layer's four weight-gradient products at cfg 2: 160 tiles -> 3 K slices
     assert _lib.ws_bytes(_lib.WS_GEMM_X6_TN, 2 * 900 * 1200, 160, 4096) == 3 * 2 * 900 * 1200 * 4
     assert _lib.ws_bytes(_lib.WS_GEMM_X6, 4096, 2580, 600, 0) == 0                # enough tiles: no K slices

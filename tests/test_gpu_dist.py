@@ -1,119 +1,26 @@
 '''
 GPU tests (run with -m gpu): data parallelism on the HIP path: reduction schedules, two ranks on one GPU, the bench spawn path.
-Filed by component in round 5 (they used to live in test_gpu_round2/3/4.py; the helpers of each
-former file keep a _r2 / _r3 / _r4 suffix).
+Shared helpers: tests/gpu_helpers.py.
 '''
+import json
+import os
+import subprocess
+import sys
+import time
 
-
+import numpy as np
 import pytest
+import torch
+from gpu_helpers import FakeWork, ROOT, check_lstm_status, oracle_threads, rand_src, small_model
 
 pytestmark = pytest.mark.gpu
 
 
-# ----------------------------------------------------------------------------
-# from test_gpu_round2.py
-# ----------------------------------------------------------------------------
-
-
-import json
-
-
-import os
-
-
-import random
-
-
-import subprocess
-
-
-import sys
-
-
-import numpy as np
-
-
-import pytest
-
-
-import torch
-
-
-from oracle import danet_oracle as O
-
-
-from oracle import torch_ref as R
-
-
-TOL_r2 = 1e-4
-
-
-ROOT_r2 = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def relerr_r2(a, b):
-    a = np.asarray(a); b = np.asarray(b)
-    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
-
-
-def cu_r2(x, dtype=torch.float32):
-    return torch.as_tensor(np.asarray(x)).to('cuda', dtype)
-
-
 @pytest.fixture(autouse=True)
-def _lstm_status_r2():
-    yield
-    from danet_amd import ops
-    torch.cuda.synchronize()
-    assert ops.lstm_status_ok(), 'persistent LSTM kernel reported a hand-off timeout'
-
-
-def _small_model_r2(hp, seed=3, **kw):
-    from danet_amd.model import Model
-    base = dict(BATCH_SIZE=4, MAX_N_SIGNAL=2, FFT_SIZE=64, FFT_STRIDE=16, EMBED_SIZE=4,
-                NUM_LSTM_LAYERS=2, LSTM_HDIM=16, NUM_ANCHOR=4, ENCODER_TYPE='bilstm-orig',
-                TRAIN_ESTIMATOR_METHOD='anchor', INFER_ESTIMATOR_METHOD='anchor',
-                SEPARATOR_TYPE='dot-softmax-orig')
-    base.update(kw)
-    hp.load(base)
-    hp.digest()
-    return Model('r2', device='cuda', seed=seed).build()
-
-
-def _rand_src_r2(hp, T, seed=0, scale=4.0):
-    rng = np.random.RandomState(seed)
-    B, C, F = hp.BATCH_SIZE, hp.MAX_N_SIGNAL, hp.FEATURE_SIZE
-    return ((rng.randn(B, C, T, F) + 1j * rng.randn(B, C, T, F)) * scale).astype(np.complex64)
-
-
-def _cfg_r2(hp, **kw):
-    d = dict(H=hp.LSTM_HDIM, L=hp.NUM_LSTM_LAYERS, E=hp.EMBED_SIZE, C=hp.MAX_N_SIGNAL,
-             A=hp.NUM_ANCHOR, train_est=hp.TRAIN_ESTIMATOR_METHOD,
-             infer_est=hp.INFER_ESTIMATOR_METHOD, separator=hp.SEPARATOR_TYPE,
-             encoder=hp.ENCODER_TYPE)
-    d.update(kw)
-    return d
-
-
-class _FakeWork(object):
-    def __init__(self, ev):
-        self.ev = ev
-
-    def wait(self):
-        torch.cuda.current_stream().wait_event(self.ev)
-
-
-# ------------------------------- forward with the input projection fused into the scan
-def _lstm_ref_r2(x, Ws, bs, H, dy):
-    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
-    Wt = [torch.tensor(W, dtype=torch.float64, requires_grad=True) for W in Ws]
-    bt = [torch.tensor(b, dtype=torch.float64, requires_grad=True) for b in bs]
-    outs = [R.lstm_scan(xt, Wt[0], bt[0], H)]
-    if len(Ws) == 2:
-        outs.append(R.lstm_scan(xt, Wt[1], bt[1], H, reverse=True))
-    y = torch.cat(outs, dim=-1)
-    (y * torch.tensor(dy)).sum().backward()
-    return y.detach().numpy(), xt.grad.numpy(), [w.grad.numpy() for w in Wt], [b.grad.numpy() for b in bt]
+def _lstm_status():
+    with oracle_threads():
+        yield
+    check_lstm_status()
 
 
 def test_reduction_schedules_respect_stream_order(hp, monkeypatch):
@@ -134,7 +41,7 @@ def test_reduction_schedules_respect_stream_order(hp, monkeypatch):
         with torch.cuda.stream(coll):
             t.mul_(2.0)
             done = coll.record_event()
-        w = _FakeWork(done)
+        w = FakeWork(done)
         if not async_op:
             w.wait()
             return None
@@ -148,11 +55,11 @@ def test_reduction_schedules_respect_stream_order(hp, monkeypatch):
     for mode in ('0', 'tail', '1'):
         monkeypatch.setenv('DANET_OVERLAP_ALLREDUCE', mode)
         hp.reset()
-        model = _small_model_r2(hp, BATCH_SIZE=32, FFT_SIZE=256, FFT_STRIDE=64, EMBED_SIZE=20,
+        model = small_model(hp, BATCH_SIZE=32, FFT_SIZE=256, FFT_STRIDE=64, EMBED_SIZE=20,
                              NUM_LSTM_LAYERS=3, LSTM_HDIM=300, NUM_ANCHOR=6)
         model.keep_grads = True
         model.set_learn_rate(0.0)
-        src = torch.as_tensor(_rand_src_r2(hp, 48, 1)).cuda()
+        src = torch.as_tensor(rand_src(hp, 48, 1)).cuda()
         for _ in range(2):
             model.train_step(src)
         torch.cuda.synchronize()
@@ -167,11 +74,11 @@ def test_reduction_schedules_respect_stream_order(hp, monkeypatch):
     hp.reset()
     monkeypatch.setenv('DANET_OVERLAP_ALLREDUCE', '0')
     monkeypatch.setattr(ddist, 'is_dist', lambda: False)
-    model = _small_model_r2(hp, BATCH_SIZE=32, FFT_SIZE=256, FFT_STRIDE=64, EMBED_SIZE=20,
+    model = small_model(hp, BATCH_SIZE=32, FFT_SIZE=256, FFT_STRIDE=64, EMBED_SIZE=20,
                          NUM_LSTM_LAYERS=3, LSTM_HDIM=300, NUM_ANCHOR=6)
     model.keep_grads = True
     model.set_learn_rate(0.0)
-    src = torch.as_tensor(_rand_src_r2(hp, 48, 1)).cuda()
+    src = torch.as_tensor(rand_src(hp, 48, 1)).cuda()
     for _ in range(2):
         model.train_step(src)
     g1 = model.grad_dict()
@@ -185,9 +92,9 @@ def test_bench_spawn_path_one_rank():
     env = dict(os.environ, DANET_FORCE_DIST='1')
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT_r2, 'bench.py'), '--gpus', '1', '--steps', '4',
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '4',
                           '--warmup', '1', '--no-cpu-baseline'],
-                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT_r2)
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert res['n_gpus'] == 1 and res['rccl_ranks'] == 1 and res['value'] > 0
@@ -196,86 +103,8 @@ def test_bench_spawn_path_one_rank():
     assert res['roofline']['events_in_timed_region'] is True
 
 
-# ----------------------------------------------------------------------------
-# from test_gpu_round4.py
-# ----------------------------------------------------------------------------
-
-
-import os
-
-
-import time
-
-
-import numpy as np
-
-
-import pytest
-
-
-import torch
-
-
-from oracle import torch_ref as R
-
-
-from test_gpu_fullsize import _setup, _synth, _cfg, relerr
-
-
-GTOL_r4 = 2e-4
-
-
-@pytest.fixture(autouse=True)
-def _lstm_status_r4():
-    # the float64 oracle's per-timestep products are tiny: on a 256-thread host torch's intra-op
-    # pool makes them 8x SLOWER than 16 threads do (56 s vs 7 s for one cfg-2 step)
-    import os
-    n0 = torch.get_num_threads()
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    yield
-    torch.set_num_threads(n0)
-    from danet_amd import ops
-    torch.cuda.synchronize()
-    assert ops.lstm_status_ok(), 'persistent LSTM kernel reported a hand-off timeout'
-
-
-def _oracle_step_r4(src, params, cfg):
-    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params.items()}
-    r = R.model_forward(src.cpu().to(torch.complex128), tp, cfg)
-    r['loss'].backward()
-    return r, tp
-
-
-def _train_step_vs_oracle_r4(hp, model, src, min_checked):
-    from danet_amd import ops
-    model.keep_grads = True                  # the optimiser leaves the bucket readable
-    assert model.fuse_heads                  # the path bench.py times
-    params = model.param_dict()              # BEFORE the step (Adam moves them)
-    out = model.train_step(src)
-    torch.cuda.synchronize()
-    assert ops.lstm_status_ok()
-    t0 = time.time()
-    ref, tp = _oracle_step_r4(src, params, _cfg(hp))
-    print('float64 oracle forward+backward: %.1f s' % (time.time() - t0))
-    assert relerr(float(out['loss']), float(ref['loss'].detach())) < 1e-4
-    assert relerr(float(out['SNR']), float(ref['SNR'].detach())) < 1e-4
-    g = model.grad_dict()
-    worst, checked = {}, 0
-    for k in tp:
-        if tp[k].grad is None:               # e.g. the inference estimator's anchors (main.py:362)
-            assert not np.any(g[k]), k
-            continue
-        worst[k] = relerr(g[k], tp[k].grad.numpy())
-        checked += 1
-    bad = {k: v for k, v in worst.items() if not v < GTOL_r4}
-    print('worst gradient error: %s' % max(worst.items(), key=lambda kv: kv[1]).__repr__())
-    assert not bad, bad
-    assert checked >= min_checked, checked
-    return out, ref
-
-
 # ------------------------------------------------ data parallel, 2 ranks, the HIP path (one GPU)
-_DP2_WORKER_r4 = r'''
+_DP2_WORKER = r'''
 import os, sys
 sys.path.insert(0, %(root)r)
 import numpy as np, torch
@@ -358,7 +187,7 @@ def test_data_parallel_two_ranks_on_the_hip_path(hp, tmp_path):
     np.save(tmp_path / 'src.npy', src)
     script = tmp_path / 'dp2_worker.py'
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script.write_text(_DP2_WORKER_r4 % dict(root=ROOT, hp=hpd))
+    script.write_text(_DP2_WORKER % dict(root=ROOT, hp=hpd))
     import socket
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
@@ -417,7 +246,15 @@ def test_bench_two_ranks_functional(tmp_path):
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert res['n_gpus'] == 2 and res['rccl_ranks'] == 2 and res['scaling'] == 'weak'
     assert res['config']['global_batch'] == 16 and res['config']['parallelism'] == 'dp2'
-    assert res['config']['collectives_per_step'] == 1 and res['allreduce_ms_standalone'] > 0
+    # the schedule is a DECISION since round 6 (Model(grad_schedule='auto'), dist.choose_schedule): the
+    # line says what was measured and what was picked, and the collective count follows the pick (gloo
+    # staging a device bucket through the host is slow against this tiny step: 'tail' here)
+    dec = res['config']['grad_allreduce_decision']
+    assert dec is not None and dec['schedule'] == res['config']['grad_allreduce_schedule'] in ('0', 'tail')
+    assert dec['allreduce_ms'] > 0 and dec['step_ms'] > 0 and dec['world'] == 2
+    assert dec['schedule'] == ('tail' if dec['allreduce_ms'] > dec['threshold'] * dec['step_ms'] else '0')
+    assert res['config']['collectives_per_step'] == {'0': 1, 'tail': 2}[dec['schedule']]
+    assert res['allreduce_ms_standalone'] > 0
     per_step = 8 * 32 * 64 / 8000.0
     assert abs(res['value'] - 2 * per_step / (res['ms_per_step'] * 1e-3)) < 1e-2 * res['value']
     assert res['e2e']['ms_per_step'] > 0 and 'test_mode' in res

@@ -161,3 +161,9 @@ def test_overlapped_allreduce_matches_single_allreduce_one_rank():
     out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_overlap_allreduce.py'), '50'],
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and 'OK' in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+    # ... and BASELINE configs[3] as written (4 x 600, C = 3, 142.5 MB bucket; the weight-gradient groups and
+    # the hoisted forward take other kernel paths there): 8 steps, incl. the 'auto' decision
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_overlap_allreduce.py'), '8', 'cfg4h600'],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0 and 'OK' in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+    assert "'schedule': '0'" in out.stdout

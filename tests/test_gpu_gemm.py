@@ -1,119 +1,19 @@
 '''
 GPU tests (run with -m gpu): the exact-fp32 GEMM schedules (stream-K, K-concatenated, capped groups) and ops.lyr_linear.
-Filed by component in round 5 (they used to live in test_gpu_round2/3/4.py; the helpers of each
-former file keep a _r2 / _r3 / _r4 suffix).
+Shared helpers: tests/gpu_helpers.py.
 '''
-
-
+import numpy as np
 import pytest
+import torch
+from gpu_helpers import TOL, check_lstm_status, cu, relerr
 
 pytestmark = pytest.mark.gpu
 
 
-# ----------------------------------------------------------------------------
-# from test_gpu_round2.py
-# ----------------------------------------------------------------------------
-
-
-import json
-
-
-import os
-
-
-import random
-
-
-import subprocess
-
-
-import sys
-
-
-import numpy as np
-
-
-import pytest
-
-
-import torch
-
-
-from oracle import danet_oracle as O
-
-
-from oracle import torch_ref as R
-
-
-TOL_r2 = 1e-4
-
-
-ROOT_r2 = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def relerr_r2(a, b):
-    a = np.asarray(a); b = np.asarray(b)
-    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
-
-
-def cu_r2(x, dtype=torch.float32):
-    return torch.as_tensor(np.asarray(x)).to('cuda', dtype)
-
-
 @pytest.fixture(autouse=True)
-def _lstm_status_r2():
+def _lstm_status():
     yield
-    from danet_amd import ops
-    torch.cuda.synchronize()
-    assert ops.lstm_status_ok(), 'persistent LSTM kernel reported a hand-off timeout'
-
-
-def _small_model_r2(hp, seed=3, **kw):
-    from danet_amd.model import Model
-    base = dict(BATCH_SIZE=4, MAX_N_SIGNAL=2, FFT_SIZE=64, FFT_STRIDE=16, EMBED_SIZE=4,
-                NUM_LSTM_LAYERS=2, LSTM_HDIM=16, NUM_ANCHOR=4, ENCODER_TYPE='bilstm-orig',
-                TRAIN_ESTIMATOR_METHOD='anchor', INFER_ESTIMATOR_METHOD='anchor',
-                SEPARATOR_TYPE='dot-softmax-orig')
-    base.update(kw)
-    hp.load(base)
-    hp.digest()
-    return Model('r2', device='cuda', seed=seed).build()
-
-
-def _rand_src_r2(hp, T, seed=0, scale=4.0):
-    rng = np.random.RandomState(seed)
-    B, C, F = hp.BATCH_SIZE, hp.MAX_N_SIGNAL, hp.FEATURE_SIZE
-    return ((rng.randn(B, C, T, F) + 1j * rng.randn(B, C, T, F)) * scale).astype(np.complex64)
-
-
-def _cfg_r2(hp, **kw):
-    d = dict(H=hp.LSTM_HDIM, L=hp.NUM_LSTM_LAYERS, E=hp.EMBED_SIZE, C=hp.MAX_N_SIGNAL,
-             A=hp.NUM_ANCHOR, train_est=hp.TRAIN_ESTIMATOR_METHOD,
-             infer_est=hp.INFER_ESTIMATOR_METHOD, separator=hp.SEPARATOR_TYPE,
-             encoder=hp.ENCODER_TYPE)
-    d.update(kw)
-    return d
-
-
-class _FakeWork(object):
-    def __init__(self, ev):
-        self.ev = ev
-
-    def wait(self):
-        torch.cuda.current_stream().wait_event(self.ev)
-
-
-# ------------------------------- forward with the input projection fused into the scan
-def _lstm_ref_r2(x, Ws, bs, H, dy):
-    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
-    Wt = [torch.tensor(W, dtype=torch.float64, requires_grad=True) for W in Ws]
-    bt = [torch.tensor(b, dtype=torch.float64, requires_grad=True) for b in bs]
-    outs = [R.lstm_scan(xt, Wt[0], bt[0], H)]
-    if len(Ws) == 2:
-        outs.append(R.lstm_scan(xt, Wt[1], bt[1], H, reverse=True))
-    y = torch.cat(outs, dim=-1)
-    (y * torch.tensor(dy)).sum().backward()
-    return y.detach().numpy(), xt.grad.numpy(), [w.grad.numpy() for w in Wt], [b.grad.numpy() for b in bt]
+    check_lstm_status()
 
 
 @pytest.mark.parametrize('M,K,N,bias', [(37, 19, 23, True), (256, 129, 512, True), (8, 5, 3, False)])
@@ -122,42 +22,16 @@ def test_linear_fn_forward_backward(M, K, N, bias):
     from danet_amd import ops
     rng = np.random.RandomState(M + N)
     x = rng.randn(2, M, K); W = rng.randn(K, N) * 0.3; b = rng.randn(N); dy = rng.randn(2, M, N)
-    xt = cu_r2(x).requires_grad_(True); Wt = cu_r2(W).requires_grad_(True)
-    bt = cu_r2(b).requires_grad_(True) if bias else None
+    xt = cu(x).requires_grad_(True); Wt = cu(W).requires_grad_(True)
+    bt = cu(b).requires_grad_(True) if bias else None
     y = ops.lyr_linear(xt, Wt, bt)
     want = x @ W + (b if bias else 0.0)
-    assert relerr_r2(y.detach().cpu().numpy(), want) < TOL_r2
-    y.backward(cu_r2(dy))
-    assert relerr_r2(xt.grad.cpu().numpy(), dy @ W.T) < TOL_r2
-    assert relerr_r2(Wt.grad.cpu().numpy(), np.einsum('bmk,bmn->kn', x, dy)) < TOL_r2
+    assert relerr(y.detach().cpu().numpy(), want) < TOL
+    y.backward(cu(dy))
+    assert relerr(xt.grad.cpu().numpy(), dy @ W.T) < TOL
+    assert relerr(Wt.grad.cpu().numpy(), np.einsum('bmk,bmn->kn', x, dy)) < TOL
     if bias:
-        assert relerr_r2(bt.grad.cpu().numpy(), dy.sum((0, 1))) < TOL_r2
-
-
-# ----------------------------------------------------------------------------
-# from test_gpu_round3.py
-# ----------------------------------------------------------------------------
-
-
-import threading
-
-
-import numpy as np
-
-
-import pytest
-
-
-import torch
-
-
-def cu_r3(x, dtype=torch.float32):
-    return torch.as_tensor(np.asarray(x)).to('cuda', dtype)
-
-
-def relerr_r3(a, b):
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+        assert relerr(bt.grad.cpu().numpy(), dy.sum((0, 1))) < TOL
 
 
 @pytest.mark.parametrize('M,N,K1,K2,ta,tb', [(4096, 600, 1200, 1200, 0, 1), (4096, 1200, 2400, 2400, 0, 1),
@@ -169,13 +43,13 @@ def test_gemm_streamk_kcat(M, N, K1, K2, ta, tb):
     pairs are one concatenated contraction): correct, bit-reproducible'''
     from danet_amd import ops
     rng = np.random.RandomState(M + N + K1 + K2)
-    cu_r3 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    cu = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).cuda()
     mk = lambda K: (rng.randn(K, M) if ta else rng.randn(M, K), rng.randn(N, K) if tb else rng.randn(K, N))
     (A1, B1), (A2, B2) = mk(K1), mk(K2)
     op = lambda A, Bm: (A.T if ta else A) @ (Bm.T if tb else Bm)
     ref = op(A1, B1) + op(A2, B2)
     bias, C0 = rng.randn(N), rng.randn(M, N)
-    d = [cu_r3(x) for x in (A1, B1, A2, B2)]
+    d = [cu(x) for x in (A1, B1, A2, B2)]
     outs = []
     for _ in range(2):
         C = torch.empty(M, N, device='cuda')
@@ -185,9 +59,9 @@ def test_gemm_streamk_kcat(M, N, K1, K2, ta, tb):
     err = np.abs(outs[0].cpu().numpy() - ref).max() / np.abs(ref).max()
     assert err < 2e-5, err
     assert torch.equal(outs[0], outs[1])
-    C = cu_r3(C0)
+    C = cu(C0)
     ops.gemm_kcat(d[0], d[0].shape[1], d[1], d[1].shape[1], K1, d[2], d[2].shape[1], d[3],
-                  d[3].shape[1], K2, C, M, N, N, transA=ta, transB=tb, bias=cu_r3(bias), beta=1.0,
+                  d[3].shape[1], K2, C, M, N, N, transA=ta, transB=tb, bias=cu(bias), beta=1.0,
                   streamk=True)
     assert np.abs(C.cpu().numpy() - (ref + bias + C0)).max() / np.abs(ref).max() < 2e-5
 
@@ -232,17 +106,17 @@ def test_capped_group_on_the_short_mfma_instruction(K, shapes, ta, tb):
         C0 = rng.randn(M, N)
         beta = float(i % 2)
         refs.append(((A.T if ta else A) @ (Bm.T if tb else Bm) + beta * C0, C0))
-        dA, dB, dC = cu_r3(A), cu_r3(Bm), cu_r3(C0)
+        dA, dB, dC = cu(A), cu(Bm), cu(C0)
         probs.append((dA, dA.shape[1], dB, dB.shape[1], dC, N, M, N, beta))
         outs.append(dC)
     res = {}
     for mf in (1, 0):
         _lib.set_option('gemm_mfma16', mf)
         for (ref, C0), dC in zip(refs, outs):
-            dC.copy_(cu_r3(C0))
+            dC.copy_(cu(C0))
         ops.gemm_group(probs, K, transA=ta, transB=tb, max_workgroups=256)
         torch.cuda.synchronize()
         res[mf] = [dC.clone() for dC in outs]
     for (ref, _), a, b in zip(refs, res[1], res[0]):
-        assert relerr_r3(a.cpu().numpy(), ref) < 2e-5
+        assert relerr(a.cpu().numpy(), ref) < 2e-5
         assert torch.equal(a, b)       # both instructions are k-ordered fp32 fma chains: the same bits

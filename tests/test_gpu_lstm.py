@@ -1,119 +1,25 @@
 '''
 GPU tests (run with -m gpu): the recurrent kernels and their entry points (Model.lyr_lstm, _lyr_bilstm, fused forward, BPTT, bias gradients).
-Filed by component in round 5 (they used to live in test_gpu_round2/3/4.py; the helpers of each
-former file keep a _r2 / _r3 / _r4 suffix).
+Shared helpers: tests/gpu_helpers.py.
 '''
+import os
+import time
 
-
+import numpy as np
 import pytest
+import torch
+
+from oracle import danet_oracle as O
+from oracle import torch_ref as R
+from gpu_helpers import TOL, check_lstm_status, cu, lstm_ref, relerr
 
 pytestmark = pytest.mark.gpu
 
 
-# ----------------------------------------------------------------------------
-# from test_gpu_round2.py
-# ----------------------------------------------------------------------------
-
-
-import json
-
-
-import os
-
-
-import random
-
-
-import subprocess
-
-
-import sys
-
-
-import numpy as np
-
-
-import pytest
-
-
-import torch
-
-
-from oracle import danet_oracle as O
-
-
-from oracle import torch_ref as R
-
-
-TOL_r2 = 1e-4
-
-
-ROOT_r2 = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def relerr_r2(a, b):
-    a = np.asarray(a); b = np.asarray(b)
-    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
-
-
-def cu_r2(x, dtype=torch.float32):
-    return torch.as_tensor(np.asarray(x)).to('cuda', dtype)
-
-
 @pytest.fixture(autouse=True)
-def _lstm_status_r2():
+def _lstm_status():
     yield
-    from danet_amd import ops
-    torch.cuda.synchronize()
-    assert ops.lstm_status_ok(), 'persistent LSTM kernel reported a hand-off timeout'
-
-
-def _small_model_r2(hp, seed=3, **kw):
-    from danet_amd.model import Model
-    base = dict(BATCH_SIZE=4, MAX_N_SIGNAL=2, FFT_SIZE=64, FFT_STRIDE=16, EMBED_SIZE=4,
-                NUM_LSTM_LAYERS=2, LSTM_HDIM=16, NUM_ANCHOR=4, ENCODER_TYPE='bilstm-orig',
-                TRAIN_ESTIMATOR_METHOD='anchor', INFER_ESTIMATOR_METHOD='anchor',
-                SEPARATOR_TYPE='dot-softmax-orig')
-    base.update(kw)
-    hp.load(base)
-    hp.digest()
-    return Model('r2', device='cuda', seed=seed).build()
-
-
-def _rand_src_r2(hp, T, seed=0, scale=4.0):
-    rng = np.random.RandomState(seed)
-    B, C, F = hp.BATCH_SIZE, hp.MAX_N_SIGNAL, hp.FEATURE_SIZE
-    return ((rng.randn(B, C, T, F) + 1j * rng.randn(B, C, T, F)) * scale).astype(np.complex64)
-
-
-def _cfg_r2(hp, **kw):
-    d = dict(H=hp.LSTM_HDIM, L=hp.NUM_LSTM_LAYERS, E=hp.EMBED_SIZE, C=hp.MAX_N_SIGNAL,
-             A=hp.NUM_ANCHOR, train_est=hp.TRAIN_ESTIMATOR_METHOD,
-             infer_est=hp.INFER_ESTIMATOR_METHOD, separator=hp.SEPARATOR_TYPE,
-             encoder=hp.ENCODER_TYPE)
-    d.update(kw)
-    return d
-
-
-class _FakeWork(object):
-    def __init__(self, ev):
-        self.ev = ev
-
-    def wait(self):
-        torch.cuda.current_stream().wait_event(self.ev)
-
-
-# ------------------------------- forward with the input projection fused into the scan
-def _lstm_ref_r2(x, Ws, bs, H, dy):
-    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
-    Wt = [torch.tensor(W, dtype=torch.float64, requires_grad=True) for W in Ws]
-    bt = [torch.tensor(b, dtype=torch.float64, requires_grad=True) for b in bs]
-    outs = [R.lstm_scan(xt, Wt[0], bt[0], H)]
-    if len(Ws) == 2:
-        outs.append(R.lstm_scan(xt, Wt[1], bt[1], H, reverse=True))
-    y = torch.cat(outs, dim=-1)
-    (y * torch.tensor(dy)).sum().backward()
-    return y.detach().numpy(), xt.grad.numpy(), [w.grad.numpy() for w in Wt], [b.grad.numpy() for b in bt]
+    check_lstm_status()
 
 
 # ---------------------------------- a6 / a5 entry points called directly (main.py:76-132)
@@ -130,30 +36,30 @@ def test_model_lyr_lstm_entry_point(hp):
     x = rng.randn(B, T, D)
     w_init = modules._uniform_init(0.4)
     b_init = modules._const_init(O.lstm_bias_init(H))
-    xt = cu_r2(x).requires_grad_(True)
+    xt = cu(x).requires_grad_(True)
     y = m.lyr_lstm('enc/l0', xt, H, t_axis=-2, w_init=w_init, b_init=b_init)
     assert set(m.vars) == {'global/enc/l0/LSTM/linear/W', 'global/enc/l0/LSTM/linear/B'}
     W, b = m.vars['global/enc/l0/LSTM/linear/W'], m.vars['global/enc/l0/LSTM/linear/B']
     assert tuple(W.shape) == (D + H, 4 * H) and tuple(b.shape) == (4 * H,)
     Wn, bn = W.detach().cpu().double().numpy(), b.detach().cpu().double().numpy()
     want = O.lyr_lstm(x, Wn, bn, H)
-    assert relerr_r2(y.detach().cpu().numpy(), want) < TOL_r2
+    assert relerr(y.detach().cpu().numpy(), want) < TOL
     # time-major call (t_axis=0), same variables (get_variable reuses them)
-    y2 = m.lyr_lstm('enc/l0', cu_r2(x).transpose(0, 1).contiguous(), H, t_axis=0,
+    y2 = m.lyr_lstm('enc/l0', cu(x).transpose(0, 1).contiguous(), H, t_axis=0,
                     w_init=w_init, b_init=b_init)
     assert tuple(y2.shape) == (T, B, H)
-    assert relerr_r2(y2.transpose(0, 1).detach().cpu().numpy(), want) < TOL_r2
+    assert relerr(y2.transpose(0, 1).detach().cpu().numpy(), want) < TOL
     # second call starts from the zero state again (main.py:108-123, :538-540)
     y3 = m.lyr_lstm('enc/l0', xt, H, t_axis=-2, w_init=w_init, b_init=b_init)
     assert torch.equal(y3, y)
     dy = rng.randn(B, T, H)
-    y.backward(cu_r2(dy))
+    y.backward(cu(dy))
     xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
     Wr = torch.tensor(Wn, requires_grad=True); br = torch.tensor(bn, requires_grad=True)
     (R.lstm_scan(xr, Wr, br, H) * torch.tensor(dy)).sum().backward()
-    assert relerr_r2(xt.grad.cpu().numpy(), xr.grad.numpy()) < TOL_r2
-    assert relerr_r2(W.grad.cpu().numpy(), Wr.grad.numpy()) < TOL_r2
-    assert relerr_r2(b.grad.cpu().numpy(), br.grad.numpy()) < TOL_r2
+    assert relerr(xt.grad.cpu().numpy(), xr.grad.numpy()) < TOL
+    assert relerr(W.grad.cpu().numpy(), Wr.grad.numpy()) < TOL
+    assert relerr(b.grad.cpu().numpy(), br.grad.numpy()) < TOL
 
 
 def test_lyr_bilstm_entry_point(hp):
@@ -167,14 +73,14 @@ def test_lyr_bilstm_entry_point(hp):
     B, T, D, H = 2, 7, 6, 8
     rng = np.random.RandomState(9)
     x = rng.randn(B, T, D)
-    y = modules._lyr_bilstm('encoder/lstm0', m, cu_r2(x), H, -2, -1, modules._uniform_init(0.5),
+    y = modules._lyr_bilstm('encoder/lstm0', m, cu(x), H, -2, -1, modules._uniform_init(0.5),
                             modules._const_init(O.lstm_bias_init(H)), 1.)
     names = ['global/encoder/lstm0_%s/LSTM/linear/%s' % (d, v) for d in ('fwd', 'bwd') for v in 'WB']
     assert sorted(m.vars) == sorted(names)
     p = {k: m.vars[k].detach().cpu().double().numpy() for k in names}
     want = O.lyr_bilstm(x, p[names[0]], p[names[1]], p[names[2]], p[names[3]], H)
     assert tuple(y.shape) == (B, T, 2 * H)
-    assert relerr_r2(y.detach().cpu().numpy(), want) < TOL_r2
+    assert relerr(y.detach().cpu().numpy(), want) < TOL
 
 
 def test_bptt_vs_oracle_long_sequence():
@@ -195,17 +101,17 @@ def test_bptt_vs_oracle_long_sequence():
     bt = [torch.tensor(b, dtype=torch.float64, requires_grad=True) for b in bs]
     yr = torch.cat([R.lstm_scan(xt, Wt[0], bt[0], H), R.lstm_scan(xt, Wt[1], bt[1], H, reverse=True)], -1)
     (yr * torch.tensor(dy)).sum().backward()
-    xc = cu_r2(x).requires_grad_(True)
+    xc = cu(x).requires_grad_(True)
     params = []
     for W, b in zip(Ws, bs):
-        params += [cu_r2(W).requires_grad_(True), cu_r2(b).requires_grad_(True)]
+        params += [cu(W).requires_grad_(True), cu(b).requires_grad_(True)]
     y = ops.LstmLayerFn.apply(xc, H, *params)
-    assert relerr_r2(y.detach().cpu().numpy(), yr.detach().numpy()) < TOL_r2
-    y.backward(cu_r2(dy))
-    assert relerr_r2(xc.grad.cpu().numpy(), xt.grad.numpy()) < TOL_r2
+    assert relerr(y.detach().cpu().numpy(), yr.detach().numpy()) < TOL
+    y.backward(cu(dy))
+    assert relerr(xc.grad.cpu().numpy(), xt.grad.numpy()) < TOL
     for d in range(2):
-        assert relerr_r2(params[2 * d].grad.cpu().numpy(), Wt[d].grad.numpy()) < TOL_r2
-        assert relerr_r2(params[2 * d + 1].grad.cpu().numpy(), bt[d].grad.numpy()) < TOL_r2
+        assert relerr(params[2 * d].grad.cpu().numpy(), Wt[d].grad.numpy()) < TOL
+        assert relerr(params[2 * d + 1].grad.cpu().numpy(), bt[d].grad.numpy()) < TOL
 
 
 @pytest.mark.parametrize('B,T,D,H,ndir', [
@@ -228,18 +134,18 @@ def test_lstm_forward_fused_input_projection(B, T, D, H, ndir, fused, monkeypatc
     bs = [O.lstm_bias_init(H) + rng.randn(4 * H) * 0.1 for _ in range(ndir)]
     dy = rng.randn(B, T, ndir * H)
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
-    ry, rdx, rdW, rdb = _lstm_ref_r2(x, Ws, bs, H, dy)
-    xc = cu_r2(x).requires_grad_(True)
+    ry, rdx, rdW, rdb = lstm_ref(x, Ws, bs, H, dy)
+    xc = cu(x).requires_grad_(True)
     params = []
     for W, b in zip(Ws, bs):
-        params += [cu_r2(W).requires_grad_(True), cu_r2(b).requires_grad_(True)]
+        params += [cu(W).requires_grad_(True), cu(b).requires_grad_(True)]
     y = ops.LstmLayerFn.apply(xc, H, *params)
-    assert relerr_r2(y.detach().cpu().numpy(), ry) < TOL_r2
-    y.backward(cu_r2(dy))
-    assert relerr_r2(xc.grad.cpu().numpy(), rdx) < TOL_r2
+    assert relerr(y.detach().cpu().numpy(), ry) < TOL
+    y.backward(cu(dy))
+    assert relerr(xc.grad.cpu().numpy(), rdx) < TOL
     for d in range(ndir):
-        assert relerr_r2(params[2 * d].grad.cpu().numpy(), rdW[d]) < TOL_r2
-        assert relerr_r2(params[2 * d + 1].grad.cpu().numpy(), rdb[d]) < TOL_r2
+        assert relerr(params[2 * d].grad.cpu().numpy(), rdW[d]) < TOL
+        assert relerr(params[2 * d + 1].grad.cpu().numpy(), rdb[d]) < TOL
 
 
 def test_lstm_fused_envelope_query(monkeypatch):
@@ -257,32 +163,6 @@ def test_lstm_fused_envelope_query(monkeypatch):
     assert L.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 644) == 0      # D > 640
     assert L.danet_lstm_fwd_fused_supported(128, 64, 300, 2, 600) == 0      # 304 workgroups
     assert L.danet_lstm_fwd_fused_supported(128, 32, 302, 2, 600) == 0      # H % 4
-
-
-# ----------------------------------------------------------------------------
-# from test_gpu_round3.py
-# ----------------------------------------------------------------------------
-
-
-import threading
-
-
-import numpy as np
-
-
-import pytest
-
-
-import torch
-
-
-def cu_r3(x, dtype=torch.float32):
-    return torch.as_tensor(np.asarray(x)).to('cuda', dtype)
-
-
-def relerr_r3(a, b):
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
 
 
 def test_deferred_bias_gradient_reduce_is_bit_identical(hp, monkeypatch):

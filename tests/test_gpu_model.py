@@ -1,119 +1,29 @@
 '''
 GPU tests (run with -m gpu): whole-model tests on the HIP path: forward / gradients / train steps against the oracle, soak, fault injection.
-Filed by component in round 5 (they used to live in test_gpu_round2/3/4.py; the helpers of each
-former file keep a _r2 / _r3 / _r4 suffix).
+Shared helpers: tests/gpu_helpers.py.
 '''
+import os
+import random
+import time
 
-
+import numpy as np
 import pytest
+import torch
+
+from oracle import danet_oracle as O
+from oracle import torch_ref as R
+from gpu_helpers import (TOL, cfg_of, check_lstm_status, cu, oracle_threads, rand_src, relerr, small_model,
+                         train_step_vs_oracle)
+from test_gpu_fullsize import _setup, _synth, _cfg
 
 pytestmark = pytest.mark.gpu
 
 
-# ----------------------------------------------------------------------------
-# from test_gpu_round2.py
-# ----------------------------------------------------------------------------
-
-
-import json
-
-
-import os
-
-
-import random
-
-
-import subprocess
-
-
-import sys
-
-
-import numpy as np
-
-
-import pytest
-
-
-import torch
-
-
-from oracle import danet_oracle as O
-
-
-from oracle import torch_ref as R
-
-
-TOL_r2 = 1e-4
-
-
-ROOT_r2 = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def relerr_r2(a, b):
-    a = np.asarray(a); b = np.asarray(b)
-    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
-
-
-def cu_r2(x, dtype=torch.float32):
-    return torch.as_tensor(np.asarray(x)).to('cuda', dtype)
-
-
 @pytest.fixture(autouse=True)
-def _lstm_status_r2():
-    yield
-    from danet_amd import ops
-    torch.cuda.synchronize()
-    assert ops.lstm_status_ok(), 'persistent LSTM kernel reported a hand-off timeout'
-
-
-def _small_model_r2(hp, seed=3, **kw):
-    from danet_amd.model import Model
-    base = dict(BATCH_SIZE=4, MAX_N_SIGNAL=2, FFT_SIZE=64, FFT_STRIDE=16, EMBED_SIZE=4,
-                NUM_LSTM_LAYERS=2, LSTM_HDIM=16, NUM_ANCHOR=4, ENCODER_TYPE='bilstm-orig',
-                TRAIN_ESTIMATOR_METHOD='anchor', INFER_ESTIMATOR_METHOD='anchor',
-                SEPARATOR_TYPE='dot-softmax-orig')
-    base.update(kw)
-    hp.load(base)
-    hp.digest()
-    return Model('r2', device='cuda', seed=seed).build()
-
-
-def _rand_src_r2(hp, T, seed=0, scale=4.0):
-    rng = np.random.RandomState(seed)
-    B, C, F = hp.BATCH_SIZE, hp.MAX_N_SIGNAL, hp.FEATURE_SIZE
-    return ((rng.randn(B, C, T, F) + 1j * rng.randn(B, C, T, F)) * scale).astype(np.complex64)
-
-
-def _cfg_r2(hp, **kw):
-    d = dict(H=hp.LSTM_HDIM, L=hp.NUM_LSTM_LAYERS, E=hp.EMBED_SIZE, C=hp.MAX_N_SIGNAL,
-             A=hp.NUM_ANCHOR, train_est=hp.TRAIN_ESTIMATOR_METHOD,
-             infer_est=hp.INFER_ESTIMATOR_METHOD, separator=hp.SEPARATOR_TYPE,
-             encoder=hp.ENCODER_TYPE)
-    d.update(kw)
-    return d
-
-
-class _FakeWork(object):
-    def __init__(self, ev):
-        self.ev = ev
-
-    def wait(self):
-        torch.cuda.current_stream().wait_event(self.ev)
-
-
-# ------------------------------- forward with the input projection fused into the scan
-def _lstm_ref_r2(x, Ws, bs, H, dy):
-    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
-    Wt = [torch.tensor(W, dtype=torch.float64, requires_grad=True) for W in Ws]
-    bt = [torch.tensor(b, dtype=torch.float64, requires_grad=True) for b in bs]
-    outs = [R.lstm_scan(xt, Wt[0], bt[0], H)]
-    if len(Ws) == 2:
-        outs.append(R.lstm_scan(xt, Wt[1], bt[1], H, reverse=True))
-    y = torch.cat(outs, dim=-1)
-    (y * torch.tensor(dy)).sum().backward()
-    return y.detach().numpy(), xt.grad.numpy(), [w.grad.numpy() for w in Wt], [b.grad.numpy() for b in bt]
+def _lstm_status():
+    with oracle_threads():
+        yield
+    check_lstm_status()
 
 
 # ----------------------------------------------------------- product robustness
@@ -122,8 +32,8 @@ def test_train_soak_memory_flat(hp):
     view of every launch workspace: ~53 MB per step at cfg 2) and the status monitor holds
     ONE word per device'''
     from danet_amd import ops
-    model = _small_model_r2(hp)
-    src = [torch.as_tensor(_rand_src_r2(hp, 12, s)).cuda() for s in range(3)]
+    model = small_model(hp)
+    src = [torch.as_tensor(rand_src(hp, 12, s)).cuda() for s in range(3)]
     for i in range(50):
         model.train_step(src[i % 3])
     torch.cuda.synchronize()
@@ -146,8 +56,8 @@ def test_injected_handoff_timeout_raises_from_train_step(hp, monkeypatch):
     launch exits without publishing) surfaces as DanetHipError from Model.train_step
     within ops.MAX_STEPS_IN_FLIGHT steps, and the model is usable again afterwards'''
     from danet_amd import ops, _lib
-    model = _small_model_r2(hp)
-    src = torch.as_tensor(_rand_src_r2(hp, 10)).cuda()
+    model = small_model(hp)
+    src = torch.as_tensor(rand_src(hp, 10)).cuda()
     model.train_step(src)
     model.check_status()
     _lib.set_option('lstm_fault_inject', 1)
@@ -176,8 +86,8 @@ def test_injected_handoff_timeout_raises_from_train_step(hp, monkeypatch):
 def test_fast_backward_equals_plain_autograd(hp):
     '''inside train_step the kernels add straight into the flat bucket; outside, autograd
     gets ordinary gradient tensors (torch.autograd.grad works) -- same numbers'''
-    model = _small_model_r2(hp, TRAIN_ESTIMATOR_METHOD='truth-weighted')
-    src = torch.as_tensor(_rand_src_r2(hp, 9, 2)).cuda()
+    model = small_model(hp, TRAIN_ESTIMATOR_METHOD='truth-weighted')
+    src = torch.as_tensor(rand_src(hp, 9, 2)).cuda()
     out = model.forward(src, fuse_heads=model.fuse_heads)     # the kernels train_step runs
     names = [k for k in model._order]
     plist = [model.vars[k] for k in names]
@@ -193,7 +103,9 @@ def test_fast_backward_equals_plain_autograd(hp):
         if plain[k] is None:
             assert np.all(fast[k] == 0), k
         else:
-            assert np.array_equal(fast[k], plain[k]), k
+            # (bit-equal until round 6: inside train_step the attractor gradient now comes from the fused
+            # forward's partials -- the same products and sums, contracted differently by the compiler: an ulp)
+            assert np.abs(fast[k] - plain[k]).max() <= 1e-6 * np.abs(plain[k]).max(), k
     # a stray backward outside train_step is cleared by the next train_step
     model.forward(src)['loss'].backward()
     model.train_step(src)
@@ -207,9 +119,9 @@ def test_toy_encoder_model_vs_oracle(hp):
     '''the reference's DEFAULT encoder (default.json:33, app/modules.py:96-116): linear ->
     leaky relu -> linear through ops.lyr_linear / LinearFn; forward, loss and every
     parameter gradient vs the oracle'''
-    model = _small_model_r2(hp, ENCODER_TYPE='toy', TRAIN_ESTIMATOR_METHOD='truth-weighted',
+    model = small_model(hp, ENCODER_TYPE='toy', TRAIN_ESTIMATOR_METHOD='truth-weighted',
                          SEPARATOR_TYPE='dot-sigmoid-orig', FFT_SIZE=32, FFT_STRIDE=8)
-    src = _rand_src_r2(hp, 7, 5)
+    src = rand_src(hp, 7, 5)
     params = model.param_dict()
     assert params['global/encoder/linear0/W'].shape == (hp.FEATURE_SIZE, 2 * hp.FFT_SIZE)
     assert params['global/encoder/linear1/B'].shape == (hp.FEATURE_SIZE * hp.EMBED_SIZE,)
@@ -220,11 +132,11 @@ def test_toy_encoder_model_vs_oracle(hp):
     model.load_param_dict(params)
     out = model.forward(torch.as_tensor(src).cuda(), with_valid=True)
     out['loss'].backward()
-    cfg = _cfg_r2(hp, fft_size=hp.FFT_SIZE, relu_leak=hp.RELU_LEAKAGE, with_valid=True)
+    cfg = cfg_of(hp, fft_size=hp.FFT_SIZE, relu_leak=hp.RELU_LEAKAGE, with_valid=True)
     ref = O.model_forward(src.astype(np.complex128), params, cfg)
     for k in ('embed', 'attrs', 'sep_pwr', 'sep_pwr_valid'):
-        assert relerr_r2(out[k].detach().cpu().numpy(), ref[k]) < TOL_r2, k
-    assert relerr_r2(float(out['loss']), ref['loss']) < TOL_r2
+        assert relerr(out[k].detach().cpu().numpy(), ref[k]) < TOL, k
+    assert relerr(float(out['loss']), ref['loss']) < TOL
     tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params.items()}
     R.model_forward(torch.tensor(src.astype(np.complex128)), tp, cfg)['loss'].backward()
     g = model.grad_dict()
@@ -232,7 +144,7 @@ def test_toy_encoder_model_vs_oracle(hp):
         if tp[k].grad is None:
             assert np.all(g[k] == 0), k
         else:
-            assert relerr_r2(g[k], tp[k].grad.numpy()) < 2 * TOL_r2, k
+            assert relerr(g[k], tp[k].grad.numpy()) < 2 * TOL, k
 
 
 # -------------------------- f-2: variable-length batches (random_zeropad) through the model
@@ -270,19 +182,19 @@ def test_varlen_zero_padded_batch_through_full_model(hp):
         params = model.param_dict()
         out = model.forward(torch.as_tensor(src).cuda(), with_valid=True)
         out['loss'].backward()
-        cfg = _cfg_r2(hp, with_valid=True)
+        cfg = cfg_of(hp, with_valid=True)
         ref = O.model_forward(src.astype(np.complex128), params, cfg)
         for k in ('embed', 'attrs', 'sep_pwr', 'valid_attrs', 'sep_pwr_valid'):
-            assert relerr_r2(out[k].detach().cpu().numpy(), ref[k]) < TOL_r2, (est, k)
+            assert relerr(out[k].detach().cpu().numpy(), ref[k]) < TOL, (est, k)
         for k in ('loss', 'SNR', 'valid_loss'):
-            assert relerr_r2(float(out[k]), ref[k]) < TOL_r2, (est, k)
+            assert relerr(float(out[k]), ref[k]) < TOL, (est, k)
         assert np.array_equal(out['perm_idx'].cpu().numpy(), ref['perm_idx'])
         tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params.items()}
         R.model_forward(torch.tensor(src.astype(np.complex128)), tp, cfg)['loss'].backward()
         g = model.grad_dict()
         for k in params:
             if tp[k].grad is not None:
-                assert relerr_r2(g[k], tp[k].grad.numpy()) < 2 * TOL_r2, (est, k)
+                assert relerr(g[k], tp[k].grad.numpy()) < 2 * TOL, (est, k)
     # the train loop consumes such batches (crop disabled: MAX_TRAIN_LEN None)
     import io
     import types
@@ -312,13 +224,13 @@ def test_cfg4_as_written_4x600_model_level(hp):
     src = utils.stft(torch.as_tensor(waves).cuda()).reshape(32, 3, T, hp.FEATURE_SIZE).contiguous()
     out = model.forward(src, with_valid=True)
     out['loss'].backward()
-    assert relerr_r2(out['sep_pwr'].detach().sum(1).cpu().numpy(), out['mix_pwr'].cpu().numpy()) < 1e-5
+    assert relerr(out['sep_pwr'].detach().sum(1).cpu().numpy(), out['mix_pwr'].cpu().numpy()) < 1e-5
     params = {k: torch.tensor(v, dtype=torch.float64) for k, v in model.param_dict().items()}
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
     with torch.no_grad():
-        ref = R.model_forward(src[:1].cpu().to(torch.complex128), params, _cfg_r2(hp, with_valid=True))
+        ref = R.model_forward(src[:1].cpu().to(torch.complex128), params, cfg_of(hp, with_valid=True))
     for k in ('embed', 'attrs', 'sep_pwr', 'valid_attrs', 'sep_pwr_valid'):
-        assert relerr_r2(out[k][:1].detach().cpu().numpy(), ref[k].numpy()) < TOL_r2, k
+        assert relerr(out[k][:1].detach().cpu().numpy(), ref[k].numpy()) < TOL, k
     assert np.array_equal(out['perm_idx'][:1].cpu().numpy(), ref['perm_idx'].numpy())
     g = model.grad_dict()
     assert all(np.isfinite(v).all() for v in g.values())
@@ -336,155 +248,14 @@ def test_leaky_relu_kernel(alpha):
     x = rng.randn(3, 37, 11).astype(np.float32)
     x[0, 0, :4] = 0.0
     dy = rng.randn(3, 37, 11).astype(np.float32)
-    xt = cu_r2(x).requires_grad_(True)
+    xt = cu(x).requires_grad_(True)
     y = ops.relu(xt, alpha)
     assert np.array_equal(y.detach().cpu().numpy(), O.relu(x, alpha).astype(np.float32))
-    y.backward(cu_r2(dy))
+    y.backward(cu(dy))
     assert np.array_equal(xt.grad.cpu().numpy(), dy * np.where(x > 0, 1.0, alpha).astype(np.float32))
 
 
-# ----------------------------------------------------------------------------
-# from test_gpu_round4.py
-# ----------------------------------------------------------------------------
-
-
-import os
-
-
-import time
-
-
-import numpy as np
-
-
-import pytest
-
-
-import torch
-
-
-from oracle import torch_ref as R
-
-
-from test_gpu_fullsize import _setup, _synth, _cfg, relerr
-
-
-GTOL_r4 = 2e-4
-
-
-@pytest.fixture(autouse=True)
-def _lstm_status_r4():
-    # the float64 oracle's per-timestep products are tiny: on a 256-thread host torch's intra-op
-    # pool makes them 8x SLOWER than 16 threads do (56 s vs 7 s for one cfg-2 step)
-    import os
-    n0 = torch.get_num_threads()
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    yield
-    torch.set_num_threads(n0)
-    from danet_amd import ops
-    torch.cuda.synchronize()
-    assert ops.lstm_status_ok(), 'persistent LSTM kernel reported a hand-off timeout'
-
-
-def _oracle_step_r4(src, params, cfg):
-    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params.items()}
-    r = R.model_forward(src.cpu().to(torch.complex128), tp, cfg)
-    r['loss'].backward()
-    return r, tp
-
-
-def _train_step_vs_oracle_r4(hp, model, src, min_checked):
-    from danet_amd import ops
-    model.keep_grads = True                  # the optimiser leaves the bucket readable
-    assert model.fuse_heads                  # the path bench.py times
-    params = model.param_dict()              # BEFORE the step (Adam moves them)
-    out = model.train_step(src)
-    torch.cuda.synchronize()
-    assert ops.lstm_status_ok()
-    t0 = time.time()
-    ref, tp = _oracle_step_r4(src, params, _cfg(hp))
-    print('float64 oracle forward+backward: %.1f s' % (time.time() - t0))
-    assert relerr(float(out['loss']), float(ref['loss'].detach())) < 1e-4
-    assert relerr(float(out['SNR']), float(ref['SNR'].detach())) < 1e-4
-    g = model.grad_dict()
-    worst, checked = {}, 0
-    for k in tp:
-        if tp[k].grad is None:               # e.g. the inference estimator's anchors (main.py:362)
-            assert not np.any(g[k]), k
-            continue
-        worst[k] = relerr(g[k], tp[k].grad.numpy())
-        checked += 1
-    bad = {k: v for k, v in worst.items() if not v < GTOL_r4}
-    print('worst gradient error: %s' % max(worst.items(), key=lambda kv: kv[1]).__repr__())
-    assert not bad, bad
-    assert checked >= min_checked, checked
-    return out, ref
-
-
 # ------------------------------------------------ data parallel, 2 ranks, the HIP path (one GPU)
-_DP2_WORKER_r4 = r'''
-import os, sys
-sys.path.insert(0, %(root)r)
-import numpy as np, torch
-import __graft_entry__ as g; g.load_package()
-from danet_amd import dist, ops
-from danet_amd.hparams import hparams
-from danet_amd.model import Model
-torch.cuda.set_device(0)                      # both ranks share the one GPU of the box
-dev = torch.device('cuda', 0)
-ops.prepare_streams(dev)
-torch.distributed.init_process_group('gloo')  # (RCCL refuses two ranks on one device; the Model
-rank, world = dist.rank(), dist.world_size()  #  code under test is backend-agnostic)
-assert world == 2 and dist.is_dist()
-hparams.reset()
-hparams.load(%(hp)r)
-hparams.digest()
-model = Model('dp2', device=dev, seed=11).build()          # rank 0's parameters are broadcast
-model.keep_grads = True
-src = np.load(os.path.join(os.environ['DP_OUT'], 'src.npy'))
-B = hparams.BATCH_SIZE
-mine = torch.as_tensor(src[rank * B:(rank + 1) * B]).to(dev)
-p0 = model.param_dict()
-out = model.train_step(mine)
-torch.cuda.synchronize()
-model.check_status()
-# the bucket now holds the SUM over the ranks (1/world is folded into the optimiser kernel)
-np.savez(os.path.join(os.environ['DP_OUT'], 'rank%%d.npz' %% rank), loss=float(out['loss']),
-         collectives=model.collectives_per_step(), status_tail=model.status_words().cpu().numpy(),
-         **{'g:' + k: v for k, v in model.grad_dict().items()},
-         **{'p0:' + k: v for k, v in p0.items()},
-         **{'p1:' + k: v for k, v in model.param_dict().items()})
-for _ in range(3):                            # a few more steps: replicas must stay identical
-    model.train_step(mine)
-torch.cuda.synchronize()
-flat = model._flat.detach().clone()
-other = [torch.empty_like(flat) for _ in range(2)]
-torch.distributed.all_gather(other, flat)
-assert torch.equal(other[0], other[1]), 'replicas drifted apart'
-# a hand-off timeout on ONE rank (fault injection: workgroup 0 of its recurrent launches exits
-# without publishing): the status word rides in the gradient all-reduce, so BOTH ranks must raise
-# DanetHipError, at the admission of the SAME step
-from danet_amd import _lib
-model.check_status()
-start = model.step_count
-FAULT_AT = 2
-raised_at = None
-for i in range(12):
-    if rank == 1 and i == FAULT_AT:
-        _lib.set_option('lstm_fault_inject', 1)
-        _lib.set_option('lstm_spin_limit', 2048)
-    try:
-        model.train_step(mine)
-    except _lib.DanetHipError:
-        raised_at = model.step_count - start
-        break
-    if rank == 1 and i == FAULT_AT:
-        _lib.set_option('lstm_fault_inject', 0)
-        _lib.set_option('lstm_spin_limit', 0)
-open(os.path.join(os.environ['DP_OUT'], 'fault%%d.txt' %% rank), 'w').write(str(raised_at))
-torch.cuda.synchronize()
-torch.distributed.destroy_process_group()
-'''
 
 
 def test_cfg2_b32_train_step_gradients_vs_oracle(hp):
@@ -498,7 +269,7 @@ def test_cfg2_b32_train_step_gradients_vs_oracle(hp):
     assert L.danet_lstm_fwd_fused_supported(128, 32, 300, 2, 600) == 1
     assert L.danet_lstm_bwd_db_supported(128, 32, 300, 2) == 1
     src = _synth(hp, 32, 128, 1337)
-    out, ref = _train_step_vs_oracle_r4(hp, model, src, min_checked=14)
+    out, ref = train_step_vs_oracle(hp, model, src, min_checked=14)
     # (the fused path returns the permutation through the side-stream finalizer)
     with torch.no_grad():
         o2 = model.forward(src, fuse_heads=True)        # parameters have moved: only a smoke check
@@ -536,7 +307,7 @@ def test_cfg4_b32_train_step_gradients_vs_oracle(hp):
     model = _setup(hp, BATCH_SIZE=32, MAX_N_SIGNAL=3, EMBED_SIZE=40, NUM_LSTM_LAYERS=4,
                    TRAIN_ESTIMATOR_METHOD='truth-weighted')
     src = _synth(hp, 32, 128, 4)
-    out, ref = _train_step_vs_oracle_r4(hp, model, src, min_checked=17)
+    out, ref = train_step_vs_oracle(hp, model, src, min_checked=17)
 
 
 def test_cfg4_h600_b32_train_step_gradients_vs_oracle(hp):
@@ -546,4 +317,4 @@ def test_cfg4_h600_b32_train_step_gradients_vs_oracle(hp):
     model = _setup(hp, BATCH_SIZE=32, MAX_N_SIGNAL=3, EMBED_SIZE=40, NUM_LSTM_LAYERS=4,
                    LSTM_HDIM=600, TRAIN_ESTIMATOR_METHOD='truth-weighted')
     src = _synth(hp, 32, 128, 6)
-    out, ref = _train_step_vs_oracle_r4(hp, model, src, min_checked=17)
+    out, ref = train_step_vs_oracle(hp, model, src, min_checked=17)

@@ -1,119 +1,21 @@
 '''
 GPU tests (run with -m gpu): value clip + TF1-Adam kernel.
-Filed by component in round 5 (they used to live in test_gpu_round2/3/4.py; the helpers of each
-former file keep a _r2 / _r3 / _r4 suffix).
+Shared helpers: tests/gpu_helpers.py.
 '''
-
-
+import numpy as np
 import pytest
+import torch
+
+from oracle import torch_ref as R
+from gpu_helpers import cfg_of, check_lstm_status, rand_src, small_model
 
 pytestmark = pytest.mark.gpu
 
 
-# ----------------------------------------------------------------------------
-# from test_gpu_round2.py
-# ----------------------------------------------------------------------------
-
-
-import json
-
-
-import os
-
-
-import random
-
-
-import subprocess
-
-
-import sys
-
-
-import numpy as np
-
-
-import pytest
-
-
-import torch
-
-
-from oracle import danet_oracle as O
-
-
-from oracle import torch_ref as R
-
-
-TOL_r2 = 1e-4
-
-
-ROOT_r2 = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def relerr_r2(a, b):
-    a = np.asarray(a); b = np.asarray(b)
-    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
-
-
-def cu_r2(x, dtype=torch.float32):
-    return torch.as_tensor(np.asarray(x)).to('cuda', dtype)
-
-
 @pytest.fixture(autouse=True)
-def _lstm_status_r2():
+def _lstm_status():
     yield
-    from danet_amd import ops
-    torch.cuda.synchronize()
-    assert ops.lstm_status_ok(), 'persistent LSTM kernel reported a hand-off timeout'
-
-
-def _small_model_r2(hp, seed=3, **kw):
-    from danet_amd.model import Model
-    base = dict(BATCH_SIZE=4, MAX_N_SIGNAL=2, FFT_SIZE=64, FFT_STRIDE=16, EMBED_SIZE=4,
-                NUM_LSTM_LAYERS=2, LSTM_HDIM=16, NUM_ANCHOR=4, ENCODER_TYPE='bilstm-orig',
-                TRAIN_ESTIMATOR_METHOD='anchor', INFER_ESTIMATOR_METHOD='anchor',
-                SEPARATOR_TYPE='dot-softmax-orig')
-    base.update(kw)
-    hp.load(base)
-    hp.digest()
-    return Model('r2', device='cuda', seed=seed).build()
-
-
-def _rand_src_r2(hp, T, seed=0, scale=4.0):
-    rng = np.random.RandomState(seed)
-    B, C, F = hp.BATCH_SIZE, hp.MAX_N_SIGNAL, hp.FEATURE_SIZE
-    return ((rng.randn(B, C, T, F) + 1j * rng.randn(B, C, T, F)) * scale).astype(np.complex64)
-
-
-def _cfg_r2(hp, **kw):
-    d = dict(H=hp.LSTM_HDIM, L=hp.NUM_LSTM_LAYERS, E=hp.EMBED_SIZE, C=hp.MAX_N_SIGNAL,
-             A=hp.NUM_ANCHOR, train_est=hp.TRAIN_ESTIMATOR_METHOD,
-             infer_est=hp.INFER_ESTIMATOR_METHOD, separator=hp.SEPARATOR_TYPE,
-             encoder=hp.ENCODER_TYPE)
-    d.update(kw)
-    return d
-
-
-class _FakeWork(object):
-    def __init__(self, ev):
-        self.ev = ev
-
-    def wait(self):
-        torch.cuda.current_stream().wait_event(self.ev)
-
-
-# ------------------------------- forward with the input projection fused into the scan
-def _lstm_ref_r2(x, Ws, bs, H, dy):
-    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
-    Wt = [torch.tensor(W, dtype=torch.float64, requires_grad=True) for W in Ws]
-    bt = [torch.tensor(b, dtype=torch.float64, requires_grad=True) for b in bs]
-    outs = [R.lstm_scan(xt, Wt[0], bt[0], H)]
-    if len(Ws) == 2:
-        outs.append(R.lstm_scan(xt, Wt[1], bt[1], H, reverse=True))
-    y = torch.cat(outs, dim=-1)
-    (y * torch.tensor(dy)).sum().backward()
-    return y.detach().numpy(), xt.grad.numpy(), [w.grad.numpy() for w in Wt], [b.grad.numpy() for b in bt]
+    check_lstm_status()
 
 
 def test_adam_parameters_to_1e5(hp):
@@ -121,11 +23,11 @@ def test_adam_parameters_to_1e5(hp):
     (to the parameter tensor's max) -- an epsilon inside the root or a missing bias
     correction moves the first steps by O(LR) = 3e-4 relative, 30 x the bar'''
     hp.load(dict(LR=3e-4))
-    model = _small_model_r2(hp, BATCH_SIZE=2, FFT_SIZE=16, FFT_STRIDE=4, EMBED_SIZE=3,
+    model = small_model(hp, BATCH_SIZE=2, FFT_SIZE=16, FFT_STRIDE=4, EMBED_SIZE=3,
                          NUM_LSTM_LAYERS=1, LSTM_HDIM=4, TRAIN_ESTIMATOR_METHOD='truth-weighted',
                          SEPARATOR_TYPE='dot-sigmoid-orig')
-    src = _rand_src_r2(hp, 6, 8, scale=6.0)
-    cfg = _cfg_r2(hp)
+    src = rand_src(hp, 6, 8, scale=6.0)
+    cfg = cfg_of(hp)
     p0 = model.param_dict()
     tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p0.items()}
     m = {k: torch.zeros_like(v) for k, v in tp.items()}
@@ -158,10 +60,10 @@ def test_early_optimizer_step_is_the_same_update(hp):
     for early in (True, False):
         torch.manual_seed(5)
         np.random.seed(5)
-        model = _small_model_r2(hp, BATCH_SIZE=3, FFT_SIZE=16, FFT_STRIDE=4, EMBED_SIZE=4,
+        model = small_model(hp, BATCH_SIZE=3, FFT_SIZE=16, FFT_STRIDE=4, EMBED_SIZE=4,
                              NUM_LSTM_LAYERS=2, LSTM_HDIM=8)
         if src is None:
-            src = _rand_src_r2(hp, 6, 8, scale=6.0)
+            src = rand_src(hp, 6, 8, scale=6.0)
             p0 = model.param_dict()
         else:
             model.load_param_dict(p0)

@@ -1,39 +1,15 @@
 '''
 GPU tests (run with -m gpu): host threads and the hand-off status word.
-Filed by component in round 5 (they used to live in test_gpu_round2/3/4.py; the helpers of each
-former file keep a _r2 / _r3 / _r4 suffix).
+Shared helpers: tests/gpu_helpers.py.
 '''
-
-
-import pytest
-
-pytestmark = pytest.mark.gpu
-
-
-# ----------------------------------------------------------------------------
-# from test_gpu_round3.py
-# ----------------------------------------------------------------------------
-
-
 import threading
-
+import time
 
 import numpy as np
-
-
 import pytest
-
-
 import torch
 
-
-def cu_r3(x, dtype=torch.float32):
-    return torch.as_tensor(np.asarray(x)).to('cuda', dtype)
-
-
-def relerr_r3(a, b):
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+pytestmark = pytest.mark.gpu
 
 
 def test_two_host_threads_launch_concurrently():

@@ -67,7 +67,21 @@ def main():
 
     def s_fwd():
         chk(L.danet_separate_pit_fwd_records(st(), 0, 0, B, C, N, E, p(mix), p(attr), p(embed), p(src),
-                                             p(phasor), None, p(rec)))
+                                             p(phasor), None, p(rec), None))
+
+    # round 6: the forward also leaves the attractor-gradient partials of every permutation (C <= 2)
+    gn = _lib.ws_bytes(_lib.WS_SEPARATE_PIT_GRAD, B, C, N, E)
+    gpart = torch.empty(max(gn, 4), dtype=torch.uint8, device=dev)
+
+    def s_fwd_g():
+        chk(L.danet_separate_pit_fwd_records(st(), 0, 0, B, C, N, E, p(mix), p(attr), p(embed), p(src),
+                                             p(phasor), None, p(rec), p(gpart)))
+
+    def a_bwd_g():
+        chk(L.danet_attractor_anchor_bwd_embed_sep(st(), B, C, N, E, A, None, p(embed), p(anchors),
+                                                   p(attr), p(asum), p(choice), 0, 0, p(mix), p(src),
+                                                   p(phasor), None, p(rec), 1.0, None, p(dembed), p(ws), wn,
+                                                   p(gpart)))
 
     def s_bwd():
         chk(L.danet_separate_pit_bwd(st(), 0, 0, B, C, N, E, p(mix), p(attr), p(embed), p(src), p(phasor),
@@ -76,7 +90,7 @@ def main():
     def a_bwd():
         chk(L.danet_attractor_anchor_bwd_embed_sep(st(), B, C, N, E, A, p(dattr), p(embed), p(anchors),
                                                    p(attr), p(asum), p(choice), 0, 0, p(mix), p(src),
-                                                   p(phasor), None, p(rec), 1.0, None, p(dembed), p(ws), wn))
+                                                   p(phasor), None, p(rec), 1.0, None, p(dembed), p(ws), wn, None))
 
     for _ in range(30):
         a_fwd()
@@ -92,6 +106,22 @@ def main():
     def chain():
         a_fwd(); s_fwd(); s_bwd(); a_bwd()
     print('%-40s %7.1f us   (sum of the four: %.1f)' % ('chain', timeit(chain), tot))
+    if gn:
+        tot_g = 0.0
+        for name, fn, mbs in [('sep_pit_fwd + gradient partials', s_fwd_g, mb + small),
+                              ('anchor_bwd_embed_sep from the partials', a_bwd_g, 2 * mb + small)]:
+            us = timeit(fn)
+            tot_g += us
+            print('%-40s %7.1f us   %.2f TB/s on %.0f MB' % (name, us, mbs / us, mbs))
+
+        def chain_g():
+            a_fwd(); s_fwd_g(); a_bwd_g()
+        print('%-40s %7.1f us   (round 6: three launches)' % ('chain, gradient partials in the forward', timeit(chain_g)))
+        s_fwd(); s_bwd(); a_bwd()
+        ref = dembed.clone()
+        s_fwd_g(); a_bwd_g()
+        torch.cuda.synchronize()
+        print('dembed vs the four-launch chain: max |diff| / max |ref| = %.2e' % float((ref - dembed).abs().max() / ref.abs().max()))
 
 
 if __name__ == '__main__':

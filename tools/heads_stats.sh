@@ -1,9 +1,9 @@
 #!/bin/bash
-# Usage (GPU box): bash tools/heads_stats.sh [--cfg4]  -- per-kernel average of tools/bench_heads.py under rocprofv3
+# Usage (GPU box): bash tools/heads_stats.sh [--cfg4]  -- per-kernel average of tools/bench_heads_fused.py (the train step's head kernels, through the C ABI) under rocprofv3
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/hs
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/hs -o hs -- python $ROOT/tools/bench_heads.py "$@" > /tmp/hs.log 2>&1 < /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/hs -o hs -- python $ROOT/tools/bench_heads_fused.py "$@" > /tmp/hs.log 2>&1 < /dev/null
 f=$(find /tmp/hs -name "*kernel_stats.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys
