@@ -149,7 +149,7 @@ def load():
 
 # ---- switches ------------------------------------------------------------------
 # USER switches (README): DANET_GEMM_X6, DANET_LSTM_FWD_FUSED, DANET_SIDE_STREAMS, DANET_FEED_MODE,
-# DANET_OVERLAP_ALLREDUCE, DANET_MAX_STEPS_IN_FLIGHT, DANET_STATUS_HOST, DANET_FUSE_HEADS,
+# DANET_OVERLAP_ALLREDUCE, DANET_ALLREDUCE_TAIL_RATIO, DANET_MAX_STEPS_IN_FLIGHT, DANET_STATUS_HOST, DANET_FUSE_HEADS,
 # DANET_LSTM_SPIN_LIMIT, DANET_LSTM_FAULT_INJECT, DANET_LIB_PATH (+ three of bench.py).  Everything
 # else -- the schedule knobs of the exact-fp32 fallback kernels, placement and fork details, the
 # remaining library options -- is an EXPERT setting behind ONE variable:

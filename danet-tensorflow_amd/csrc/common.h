@@ -86,10 +86,24 @@ __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- wave64 reductions -----------------------------------------------------
+// Sum over the 64 lanes, the same value in every lane.  Round 6: data-parallel-primitive adds inside a row
+// of 16 lanes (v_add_f32_dpp: quad swaps, half-row and row mirrors), two row broadcasts and ONE v_readlane --
+// seven vector instructions, no LDS -- instead of six ds_bpermute round trips through the LDS crossbar per value
+// (__shfl_xor): the head kernels reduce 33-113 accumulators per wave in their epilogues, 656 of the fused
+// separator + loss forward's 3 017 instructions were ds_bpermute.  Fixed order: deterministic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_shuffled(float v) {
+  // (rows outside ROW_MASK, and lanes whose source lane does not exist, read 0)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_shuffled<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]: lane ^ 1
+  v += dpp_shuffled<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]: lane ^ 2      -> every quad uniform
+  v += dpp_shuffled<0x141, 0xF>(v);    // row_half_mirror: the other quad of the half-row
+  v += dpp_shuffled<0x140, 0xF>(v);    // row_mirror: the other half of the row -> every row of 16 uniform
+  v += dpp_shuffled<0x142, 0xA>(v);    // row_bcast:15 into rows 1 and 3: row 0 + row 1, row 2 + row 3
+  v += dpp_shuffled<0x143, 0xC>(v);    // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's sum
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

@@ -346,6 +346,26 @@ for trial in range(3):                       # the bucket object is reused step 
     assert len(b.works) == 2 and sorted(b.covered) == [(47, 84), (84, 89)]
     scale = b.finish()                                   # reduces [0, 47) and waits for all
     ok = ok and scale == 0.5 and bool(torch.equal(gbuf, expect)) and not b.works and not b.covered
+# 'tail' schedule over a store with the 4 status words IN FRONT (Model._flatten, round 6): the early piece
+# leaves them alone, they ride the LAST collective -- a hand-off timeout of the bottom layer's BPTT kernel,
+# which runs after the early piece was launched, reaches every rank with the step it happened in
+store = torch.cat([torch.zeros(4), flat_g.clone()])
+store[0] = float(rank)                                   # "rank 1 timed out"
+offs4 = {k: (lo + 4, hi + 4) for k, (lo, hi) in offs.items()}
+t = dist.TailOverlap(store, offs4, last=[(0, 4)])
+t.hook(('rest',), [views[0], views[1]])                  # bottom layer = the first two variables
+assert t.launched == 1 and t.covered == [(4 + 47, 4 + 89)], t.covered
+t.wait_launched()
+status_after_early_piece = float(store[0])
+scale = t.finish()
+ok = ok and scale == 0.5 and status_after_early_piece == float(rank) and float(store[0]) == 1.0
+ok = ok and bool(torch.equal(store[4:], expect))
+# the measured decision: every rank gets the same (MAX-reduced) time, hence the same schedule
+ms = dist.measure_allreduce_ms(1 << 16, torch.device('cpu'))
+got = [torch.zeros(1, dtype=torch.float64) for _ in range(2)]
+torch.distributed.all_gather(got, torch.tensor([ms], dtype=torch.float64))
+ok = ok and ms > 0 and float(got[0]) == float(got[1])
+ok = ok and dist.choose_schedule(ms, 1e9) == '0' and dist.choose_schedule(ms, 1e-9) == 'tail'
 open(os.path.join(os.environ['DP_OUT'], 'bucket' + str(rank) + '.txt'), 'w').write('OK' if ok else 'BAD')
 '''
 
@@ -367,6 +387,18 @@ def test_gradient_buckets_gloo_world2(tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     for r in range(2):
         assert (tmp_path / ('bucket%d.txt' % r)).read_text() == 'OK'
+
+
+def test_choose_schedule_threshold(monkeypatch):
+    '''dist.choose_schedule: ONE threshold on measured all-reduce / measured step (default 5 %), NaN-safe'''
+    from danet_amd import dist
+    assert dist.TAIL_RATIO == 0.05
+    assert dist.choose_schedule(0.09, 2.43) == '0'          # N = 8 over all links (DESIGN.md 6)
+    assert dist.choose_schedule(0.36, 2.43) == 'tail'       # N = 2
+    assert dist.choose_schedule(0.46, 8.5) == 'tail' and dist.choose_schedule(0.40, 8.5) == '0'
+    assert dist.choose_schedule(0.09, 2.43, ratio=0.03) == 'tail'
+    assert dist.choose_schedule(float('nan'), 2.43) == '0' and dist.choose_schedule(0.5, 0.0) == '0'
+    assert dist.measure_allreduce_ms(1000, 'cpu') == 0.0    # no process group: nothing to measure
 
 
 def test_cli_flags_match_reference(hp):
