@@ -657,7 +657,8 @@ def run_train(args, cfg, hp, device, rank, world, use_dist):
         log('e2e train loop: %.3f ms/step (resident %.3f, sync feed %.3f)'
             % (e2e['ms_per_step'], 1e3 * dt / args.steps, e2e['sync_feed_ms_per_step']))
     # N > 1: ONE run settles the reduction schedule.  `value` above is the schedule the model was
-    # built with (default '0': one all-reduce after backward); the same K steps are now timed with
+    # built with (default 'auto': '0' = one all-reduce after backward, or 'tail' if the model's own measurement of the
+    # collective against its step says so -- `grad_allreduce_decision`); the same K steps are now timed with
     # the other schedules and with NO reduction at all (what the step costs without communication),
     # every rank taking part in every pass.  exposed = schedule - no_reduction.
     sched_ms = None
