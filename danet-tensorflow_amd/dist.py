@@ -99,18 +99,18 @@ def _complement(covered, n):
 
 
 # ---- which reduction schedule?  (Model(grad_schedule='auto'), the default) ---------------------------
-# '0' (ONE all-reduce after backward, the north_star form) exposes the whole collective; 'tail' hides all but
-# the bottom encoder layer's share of the bytes (15 % at cfg 2) under that layer's BPTT kernel and weight-
-# gradient GEMMs at the price of a second collective launch (~20-30 us), a cross-stream wait on the main
-# stream (~10 us) and ~25 % of the collective's duration in slow-down of the recurrent kernel it runs beside
-# (law 1).  So 'tail' pays once the collective is long enough, relative to the step, for 60 % of
-# it to outweigh those ~40 us: ONE threshold on  (stand-alone all-reduce time) / (step time),  both MEASURED
-# by the model on its own bucket and its own steps and MAX-reduced over the ranks, so that every rank takes
-# the same decision.  Break-even by that arithmetic is 3 % of a 2.4 ms step (73 us); the default is 5 %: the
-# interference term is a law measured with GEMM neighbours, not with a collective, and below 5 % the two
-# schedules are predicted within a point and a half of each other -- there the plain north_star form stays.
-# DANET_ALLREDUCE_TAIL_RATIO overrides the threshold, DANET_OVERLAP_ALLREDUCE / Model(grad_schedule=...) pins
-# the schedule.
+# '0' (ONE all-reduce after backward, the north_star form) exposes the whole collective.  'tail' launches
+# everything outside the bottom encoder layer's share of the bytes (85 % at cfg 2) on the side stream once
+# that layer's BPTT kernel has finished, so that it runs under that layer's weight-gradient GEMMs (ordinary
+# tile kernels; it deliberately never runs beside a persistent recurrent kernel), and reduces the rest -- with
+# the status words -- after backward.  What it can hide is bounded by that cover, ~3 % of the step (75 us at
+# cfg 2, 0.3 ms at cfg 4 as written); what it costs is a second collective launch (~20-30 us) and a
+# cross-stream wait on the main stream (~10 us).  So it pays once the collective is about as long as the cover:
+# ONE threshold on  (stand-alone all-reduce time) / (step time),  both MEASURED by the model on its own bucket
+# and its own steps and MAX-reduced over the ranks, so that every rank takes the same decision.  Default 5 %;
+# above it 'tail' is worth cover - 0.04 ms = 1-3 points of scaling efficiency, below it the
+# plain north_star form stays.  DANET_ALLREDUCE_TAIL_RATIO overrides the threshold, DANET_OVERLAP_ALLREDUCE /
+# Model(grad_schedule=...) pins the schedule.
 TAIL_RATIO = float(os.environ.get('DANET_ALLREDUCE_TAIL_RATIO', '0.05'))
 
 

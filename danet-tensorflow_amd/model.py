@@ -133,10 +133,10 @@ class Model(object):
         # persistent kernels' hand-off status through the gradient all-reduce (ops.py).  In front,
         # because the variables are laid out bottom encoder layer first: the LAST collective of
         # every schedule ('0': the whole bucket; 'tail': the bottom layer's range, reduced after
-        # backward) then covers them as part of one contiguous range, i.e. AFTER every recurrent
-        # kernel of the step has run -- a timeout in the bottom layer's BPTT kernel reaches every
-        # rank with the step it happened in (round 6; behind the gradients the 'tail' schedule
-        # reduced them with its early piece, before that kernel ran)
+        # backward) then covers them as part of one contiguous range -- behind every kernel of the
+        # step, wherever a schedule launches its early pieces (round 6; behind the gradients they
+        # travelled with 'tail''s early piece, safe only as long as that piece starts after the
+        # last recurrent kernel)
         self._grad_store = torch.zeros(n + 4, device=self.device)
         grad = self._grad_store[4:]
         off = 0

@@ -347,8 +347,8 @@ for trial in range(3):                       # the bucket object is reused step 
     scale = b.finish()                                   # reduces [0, 47) and waits for all
     ok = ok and scale == 0.5 and bool(torch.equal(gbuf, expect)) and not b.works and not b.covered
 # 'tail' schedule over a store with the 4 status words IN FRONT (Model._flatten, round 6): the early piece
-# leaves them alone, they ride the LAST collective -- a hand-off timeout of the bottom layer's BPTT kernel,
-# which runs after the early piece was launched, reaches every rank with the step it happened in
+# leaves them alone, they ride the LAST collective -- behind every kernel of the step, wherever a schedule
+# launches its early pieces
 store = torch.cat([torch.zeros(4), flat_g.clone()])
 store[0] = float(rank)                                   # "rank 1 timed out"
 offs4 = {k: (lo + 4, hi + 4) for k, (lo, hi) in offs.items()}
