@@ -81,13 +81,10 @@ template <int CNT, int NW = 4>
 __device__ __forceinline__ void block_reduce_store(float (&v)[CNT], int cnt, float* red,
                                                    float* __restrict__ dst) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  wave_sum_n<CNT>(v);                 // (all CNT values: the ones past cnt are never stored)
 #pragma unroll
-  for (int i = 0; i < CNT; ++i) {
-    if (i < cnt) {
-      const float s = wave_sum(v[i]);
-      if (lane == 0) red[wave * CNT + i] = s;
-    }
-  }
+  for (int i = 0; i < CNT; ++i)
+    if (i < cnt && lane == 0) red[wave * CNT + i] = v[i];
   __syncthreads();
   for (int i = threadIdx.x; i < cnt; i += 64 * NW) {
     float t = red[i];
@@ -547,11 +544,10 @@ __global__ __launch_bounds__(SEP_NT) void sep_pit_fwd_kernel(
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  wave_sum_n<REC>(acc);
 #pragma unroll
-  for (int i = 0; i < REC; ++i) {
-    const float v = wave_sum(acc[i]);
-    if (lane == 0) red[wave * REC + i] = v;
-  }
+  for (int i = 0; i < REC; ++i)
+    if (lane == 0) red[wave * REC + i] = acc[i];
   __syncthreads();
   float* po = partial + ((int64_t)b * nch + ch) * REC;
   for (int i = threadIdx.x; i < REC; i += SEP_NT) {

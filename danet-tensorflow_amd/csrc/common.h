@@ -105,6 +105,27 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_shuffled<0x143, 0xC>(v);    // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's sum
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// the same for N values at once, step by step ACROSS the values: consecutive instructions are independent,
+// so the two wait states a DPP read needs behind the vector write it depends on cost nothing (one value at a
+// time the compiler fills them with s_nop: 814 of them in the fused separator + loss forward's epilogue)
+template <int N>
+__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_shuffled<0xB1, 0xF>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_shuffled<0x4E, 0xF>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_shuffled<0x141, 0xF>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_shuffled<0x140, 0xF>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_shuffled<0x142, 0xA>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_shuffled<0x143, 0xC>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    v[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i]), 63));
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
