@@ -659,6 +659,9 @@ __global__ __launch_bounds__(SEP_NT) void sep_pit_bwd_kernel(
     tab[i] = (e < E) ? attr[((int64_t)b * C + c) * E + e] : 0.f;
   }
   __syncthreads();
+  // (at C = 3, E = 40 the 120 values overflow the scalar register file and the compiler parks the excess in
+  // vector-register lanes -- 332 v_readlane in this kernel; reading the table from LDS instead was measured in
+  // round 6: cfg 4 3.45 ms either way)
   float st[CP][EP];
 #pragma unroll
   for (int c = 0; c < CP; ++c)
@@ -1301,7 +1304,10 @@ __global__ __launch_bounds__(SEP_NT) void anchor_sep_bwd_kernel(
   for (int c = 0; c < CP; ++c) {
     sg0[c] = uniform(anchor_bwd_g0<EP>(Dr, tab, dn, c));
 #pragma unroll
-    for (int e = 0; e < EP; ++e) { sAn[c][e] = uniform(An[c * EP + e]); sG[c][e] = uniform(G[c * EP + e]); }
+    // (only ONE of the two tables as wave-uniform scalars: both -- 80 values at E = 20 -- overflow the scalar
+    // register file, and the compiler parked the excess in the lanes of a vector register: 50 v_readlane +
+    // 29 s_nop per bin; the anchors stay per-lane copies in vector registers, round 6)
+    for (int e = 0; e < EP; ++e) { sAn[c][e] = An[c * EP + e]; sG[c][e] = uniform(G[c * EP + e]); }
   }
   float accs[CP][EP];
 #pragma unroll
