@@ -113,6 +113,22 @@ __device__ __forceinline__ float truth_weight(int mode, float mix) {
   return mix;                                      // app/modules.py:468-469
 }
 
+// (utterance, chunk) of this workgroup of a (nch, B) grid, XCD-aware.  Workgroups are dealt to the 8 XCDs
+// round-robin by linear id, each XCD has its own L2, and clean lines survive from one kernel to the next.  The
+// output projection writes utterance b's embedding from XCD b / (B / 8) (gemm_x6.hip x6_xcd_item: contiguous
+// row tiles per XCD), so every head kernel runs utterance b's workgroups on THAT XCD: the estimator finds part
+// of the embedding in L2, the separator and the backward kernels find what the kernel before them read
+// (measured, cfg 2: the three-launch chain 81.8 -> 67.7 us alone, the train step -18 us;
+// profiles/EXPERIMENTS.md round 6).  B not a multiple of 8: the plain mapping.
+__device__ __forceinline__ void utterance_chunk(int& b, int& ch) {
+  const int nch = gridDim.x, B = gridDim.y;
+  b = blockIdx.y; ch = blockIdx.x;
+  if ((B & 7) == 0) {
+    const int i = blockIdx.x + nch * blockIdx.y, per = B >> 3, x = i & 7, j = i >> 3;
+    b = x * per + j % per; ch = j / per;
+  }
+}
+
 // =========================================================================
 // truth family forward (app/modules.py:390-487)
 // =========================================================================
@@ -123,7 +139,8 @@ __global__ __launch_bounds__(256) void truth_fwd_kernel(
     float* __restrict__ partial /* [B][chunks][C][EP+1] */) {
   const int E = EF ? EP : E_;   // EF: E == EP known at compile time (guard-free 16-byte row accesses)
   __shared__ float red[4 * (EP + 1)];
-  const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  int b, ch; utterance_chunk(b, ch);
+  const int nch = gridDim.x;
   const int64_t n0 = (int64_t)ch * CHUNK_N, n1 = min(N, n0 + CHUNK_N);
   const float* eb = embed + (int64_t)b * N * E;
   const float* sp = src_pwr + (int64_t)b * C * N;
@@ -159,7 +176,8 @@ __global__ __launch_bounds__(SEP_NT) void truth_fwd1_kernel(
   const int E = EF ? EP : E_;   // EF: E == EP known at compile time (guard-free 16-byte row accesses)
   constexpr int C = CP;
   __shared__ float red[SEP_NW * (EP + 1)];
-  const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  int b, ch; utterance_chunk(b, ch);
+  const int nch = gridDim.x;
   const int64_t n0 = (int64_t)ch * CHUNK_N, n1 = min(N, n0 + CHUNK_N);
   const float* eb = embed + (int64_t)b * N * E;
   const float* sp = src_pwr + (int64_t)b * C * N;
@@ -212,7 +230,7 @@ __global__ __launch_bounds__(256) void truth_bwd_kernel(
     const float* __restrict__ src_pwr, const float* __restrict__ mix_pwr,
     const float* __restrict__ denom, float eps, float* __restrict__ dembed) {
   __shared__ float tab[MAXC * EP];
-  const int b = blockIdx.y;
+  int b, ch; utterance_chunk(b, ch);
   for (int i = threadIdx.x; i < C * EP; i += 256) {
     const int c = i / EP, e = i % EP;
     const float add = (mode == 0) ? 1.f : eps;
@@ -222,7 +240,7 @@ __global__ __launch_bounds__(256) void truth_bwd_kernel(
   const float* sp = src_pwr + (int64_t)b * C * N;
   const float* mp = mix_pwr + (int64_t)b * N;
   float* db = dembed + (int64_t)b * N * E;
-  for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
+  for (int64_t n = (int64_t)ch * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
     const int c = argmax_src(sp, C, N, n);
     const float w = truth_weight(mode, mp[n]);
     float x[EP];
@@ -243,14 +261,14 @@ __global__ __launch_bounds__(256) void separate_fwd_kernel(
     float* __restrict__ out, float* __restrict__ masks) {
   const int E = EF ? EP : E_;   // EF: E == EP known at compile time (guard-free 16-byte row accesses)
   __shared__ float tab[MAXC * EP];
-  const int b = blockIdx.y;
+  int b, ch; utterance_chunk(b, ch);
   for (int i = threadIdx.x; i < C * EP; i += 256) {
     const int c = i / EP, e = i % EP;
     tab[i] = (e < E) ? attr[((int64_t)b * C + c) * E + e] : 0.f;
   }
   __syncthreads();
   const float* eb = embed + (int64_t)b * N * E;
-  for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
+  for (int64_t n = (int64_t)ch * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
     float x[EP];
     load_row<EP>(eb + n * E, E, x);
     float lg[MAXC];
@@ -296,7 +314,8 @@ __global__ __launch_bounds__(256) void separate_bwd_kernel(
   (void)C_;
   __shared__ float tab[CP * EP];
   __shared__ float red[4 * EP];
-  const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  int b, ch; utterance_chunk(b, ch);
+  const int nch = gridDim.x;
   for (int i = threadIdx.x; i < C * EP; i += 256) {
     const int c = i / EP, e = i % EP;
     tab[i] = (e < E) ? attr[((int64_t)b * C + c) * E + e] : 0.f;
@@ -459,6 +478,7 @@ __device__ __forceinline__ void sep_masks_lds(int act, const float (&x)[EP], con
   }
 }
 
+
 // GRAD (round 6; CP == 2, the two-speaker configurations): the same pass ALSO accumulates the attractor-gradient partials of the fused
 // separator + loss backward -- sep_pit_bwd_kernel's accs[c][e] += dL/dlogit_c x_e -- for EVERY permutation
 // (C! = 2 sets of C x EP sums per thread), with the upstream gradient left out (scale = 2 / (B N); the
@@ -489,7 +509,8 @@ __global__ __launch_bounds__(SEP_NT) void sep_pit_fwd_kernel(
   __shared__ float tab[CP * EP];
   __shared__ float red[SEP_NW * REC];
   __shared__ float gred[GRAD ? SEP_NW * EP : 1];
-  const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  int b, ch; utterance_chunk(b, ch);
+  const int nch = gridDim.x;
   for (int i = threadIdx.x; i < C * EP; i += SEP_NT) {
     const int c = i / EP, e = i % EP;
     tab[i] = (e < E) ? attr[((int64_t)b * C + c) * E + e] : 0.f;
@@ -652,7 +673,8 @@ __global__ __launch_bounds__(SEP_NT) void sep_pit_bwd_kernel(
   __shared__ float red[SEP_NW * EP];
   __shared__ float rec_s[REC + 1];
   __shared__ int perm_s;
-  const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  int b, ch; utterance_chunk(b, ch);
+  const int nch = gridDim.x;
   sep_pit_perm<CP>(records, perm_idx, b, nch, N, rec_s, &perm_s);
   for (int i = threadIdx.x; i < C * EP; i += SEP_NT) {
     const int c = i / EP, e = i % EP;
@@ -735,7 +757,8 @@ __global__ __launch_bounds__(SEP_NT) void truth_sep_bwd_kernel(
   __shared__ float tab[CP * EP];    // attractors (the separator's table)
   __shared__ float rec_s[REC + 1];
   __shared__ int perm_s;
-  const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  int b, ch; utterance_chunk(b, ch);
+  const int nch = gridDim.x;
   sep_pit_perm<CP>(records, perm_idx, b, nch, N, rec_s, &perm_s);
   const float dscale = dloss * (dloss_dev ? *dloss_dev : 1.f);
   if (gpartial != nullptr) {
@@ -867,7 +890,8 @@ __global__ __launch_bounds__(ANCH_NT) void anchor_fwd_kernel(
   float* Xs = smem;                     // [ANCH_TN][EPA]
   float* Ss = Xs + ANCH_TN * EPA;       // [ANCH_TN][lds]
   float* An = Ss + ANCH_TN * lds;       // [A][EP]
-  const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  int b, ch; utterance_chunk(b, ch);
+  const int nch = gridDim.x;
   const int tid = threadIdx.x;
   for (int i = tid; i < A * EP; i += ANCH_NT) {
     const int a = i / EP, e = i % EP;
@@ -1192,7 +1216,8 @@ __global__ __launch_bounds__(256) void anchor_bwd_kernel(
   __shared__ float At[MAXC * EP];   // attractors
   __shared__ float dn[MAXC];        // soft-assignment sums of the chosen subset
   __shared__ float red[4 * EP];
-  const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  int b, ch; utterance_chunk(b, ch);
+  const int nch = gridDim.x;
   const int pstar = choice[b];
   anchor_bwd_tables<EP, CP>(b, E, cb, pstar, dattr, anchors, attr, asum, An, G, Dr, At, dn);
   __syncthreads();
@@ -1277,7 +1302,8 @@ __global__ __launch_bounds__(SEP_NT) void anchor_sep_bwd_kernel(
   __shared__ float red[SEP_NW * EP];
   __shared__ float rec_s[REC + 1];
   __shared__ int perm_s;
-  const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  int b, ch; utterance_chunk(b, ch);
+  const int nch = gridDim.x;
   const int pstar = choice[b];      // (issued before the record sums: its latency hides behind them)
   sep_pit_perm<CP>(records, perm_idx, b, nch, N, rec_s, &perm_s);
   const float dscale = dloss * (dloss_dev ? *dloss_dev : 1.f);

@@ -302,8 +302,8 @@ __global__ __launch_bounds__(256, X6Geo<MI>::WG_PER_CU) void gemm_x6_nt_kernel(X
   } else {
     const int j = x6_xcd_item((int)blockIdx.x - g.nwhole, (int)gridDim.x - g.nwhole);
     const int nrem = nt - g.nwhole;
-    z = j / nrem;                                       // K slice
-    bid = g.nwhole + j % nrem;
+    z = j / nrem;                                       // K slice (slice-major: an XCD's items share the K range of
+    bid = g.nwhole + j % nrem;                          // both operands; a tile's slices on ONE XCD measured 0.5 % slower)
     sliced = g.splitk > 1;
   }
   const int m0 = (bid / tiles_n) * G::BM, n0 = (bid % tiles_n) * XBN;
