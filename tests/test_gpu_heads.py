@@ -71,7 +71,8 @@ def test_cfg5_kmeans_at_full_length(hp):
 @pytest.mark.parametrize('mode', [0, 1])
 @pytest.mark.parametrize('B,C,T,F,E', [(3, 2, 9, 33, 20), (2, 3, 17, 129, 40), (1, 1, 5, 7, 4),
                                        (2, 2, 40, 129, 20), (2, 2, 11, 33, 16), (2, 3, 9, 17, 7),
-                                       (1, 2, 300, 129, 33)])   # E != EP: the guarded row accesses
+                                       (1, 2, 300, 129, 33),    # E != EP: the guarded row accesses
+                                       (8, 2, 40, 129, 20), (16, 2, 33, 129, 20)])   # B % 8 == 0: XCD-aware mapping
 def test_fused_separator_pit_matches_unfused_and_oracle(act, mode, B, C, T, F, E):
     '''danet_separate_pit_fwd / _bwd (separator + phase re-attach + PIT-MSE + SNR in one pass,
     app/modules.py:548-603 -> main.py:281-290 -> app/ops.py:374-431) against (i) the two-kernel

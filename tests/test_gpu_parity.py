@@ -368,7 +368,8 @@ def _embed_case(rng, B, C, T, F, E):
 
 
 @pytest.mark.parametrize('mode', ['truth', 'truth-threshold', 'truth-weighted'])
-@pytest.mark.parametrize('B,C,T,F,E', [(2, 2, 5, 7, 3), (3, 3, 40, 129, 20), (2, 2, 33, 65, 40)])
+@pytest.mark.parametrize('B,C,T,F,E', [(2, 2, 5, 7, 3), (3, 3, 40, 129, 20), (2, 2, 33, 65, 40),
+                                       (8, 2, 40, 129, 20)])   # B % 8 == 0: the XCD-aware workgroup mapping
 def test_truth_estimators(mode, B, C, T, F, E):
     from danet_amd import ops
     rng = np.random.RandomState(5)
@@ -405,7 +406,8 @@ def test_truth_kats():
 
 
 @pytest.mark.parametrize('B,C,T,F,E,A', [(2, 2, 5, 7, 3, 4), (3, 2, 40, 129, 20, 6),
-                                         (2, 3, 17, 65, 20, 5), (1, 2, 300, 129, 20, 6)])
+                                         (2, 3, 17, 65, 20, 5), (1, 2, 300, 129, 20, 6),
+                                         (8, 2, 40, 129, 20, 6), (16, 2, 17, 129, 20, 6)])   # B % 8 == 0: XCD-aware mapping
 def test_anchor_estimator(B, C, T, F, E, A):
     from danet_amd import ops
     rng = np.random.RandomState(11)
@@ -445,7 +447,7 @@ def test_anchor_kat_diagonal_in_max():
 
 # --------------------------------------------------------------- separators
 @pytest.mark.parametrize('act', [0, 1])
-@pytest.mark.parametrize('B,C,T,F,E', [(2, 2, 5, 7, 3), (3, 3, 40, 129, 20), (2, 2, 20, 65, 40)])
+@pytest.mark.parametrize('B,C,T,F,E', [(2, 2, 5, 7, 3), (3, 3, 40, 129, 20), (2, 2, 20, 65, 40), (8, 2, 40, 129, 20)])
 def test_separators(act, B, C, T, F, E):
     from danet_amd import ops
     rng = np.random.RandomState(7)
