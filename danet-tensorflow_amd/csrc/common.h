@@ -16,6 +16,9 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 #define DANET_WAVE 64
 
+// compute units of the current device (csrc/lstm.hip; 256 when no device answers)
+int dn_num_cus();
+
 // fp32 products on the bf16 matrix cores (csrc/gemm_x6.hip; the recurrent half of
 // lstm_fwd_fx_kernel): every fp32 value is EXACTLY hi + mid + lo with three bf16 pieces of 8
 // significant bits.  (x0, x1) -> the packed bf16 pairs of their pieces (x0 in the low half):

@@ -1517,7 +1517,7 @@ struct LstmPlan { int MT, G, P, KP, NW, UN; size_t lds; };
 
 // compute units of the current device (one persistent workgroup per CU must be co-resident);
 // gfx950 = 256, also the fallback when no device is visible (size queries on a CPU-only host)
-static int num_cus() {
+int dn_num_cus() {
   static std::atomic<int> n{0};          // cached once a device answered (idempotent: benign race)
   int c = n.load(std::memory_order_relaxed);
   if (c) return c;
@@ -1539,14 +1539,14 @@ static LstmPlan make_plan(int B, int H, int ndir) {
   pl.UN = LSTM_UNITS_FWD;
   pl.P = cdiv(H, pl.UN);
   pl.KP = cdiv(H, 16) * 16;
-  pl.MT = (ndir * cdiv(B, 16) * pl.P > num_cus()) ? 2 : 1;
+  pl.MT = (ndir * cdiv(B, 16) * pl.P > dn_num_cus()) ? 2 : 1;
   // wide layers: 12 units per workgroup keep 16-row clusters on the GPU where 8 units
   // would need 32-row clusters (cfg 4 as written, H = 600: 200 workgroups of 16 rows instead of
   // 150 of 32: 5.8 -> 4.6 us per timestep, 12.15 -> 11.55 ms per cfg-4h600 step).
   // option lstm_fwd_un = 8|12 overrides.
   if (B > 4) {
     const int want = danet_opt(OPT_LSTM_FWD_UN);
-    const bool fits12 = ndir * cdiv(B, 16) * cdiv(H, 12) <= num_cus();
+    const bool fits12 = ndir * cdiv(B, 16) * cdiv(H, 12) <= dn_num_cus();
     if ((want == 12 || (want != 8 && pl.MT == 2)) && fits12) {
       pl.UN = 12; pl.P = cdiv(H, 12); pl.MT = 1;
     }
@@ -1570,7 +1570,7 @@ static RsPlan make_rs_plan(int B, int H, int ndir, int U) {
   r.NT = cdiv(r.P * U, 16); r.D = 3;
   r.NI = cdiv(r.P, 512 / (4 * U));
   const int ncl = ndir * r.G;
-  int smax = num_cus() / (ncl * r.P);
+  int smax = dn_num_cus() / (ncl * r.P);
   if (smax > r.NT) smax = r.NT;
   // twins: the fewest that leave at most two tiles per SIMD, else as many as fit
   r.S = smax;
@@ -1706,8 +1706,8 @@ extern "C" int danet_lstm_fwd(danet_stream_t stream_, int T, int B, int H, int n
     return DANET_ERR_UNSUPPORTED;
   }
   const int nblk = ndir * pl.G * pl.P;
-  if (nblk > num_cus()) {  // 1 workgroup per CU must be co-resident
-    danet_set_error("lstm_fwd: %d workgroups exceed the %d CUs", nblk, num_cus());
+  if (nblk > dn_num_cus()) {  // 1 workgroup per CU must be co-resident
+    danet_set_error("lstm_fwd: %d workgroups exceed the %d CUs", nblk, dn_num_cus());
     return DANET_ERR_UNSUPPORTED;
   }
   LstmFwdArgs a;
@@ -1760,7 +1760,7 @@ static bool fwd_fused_ok(int T, int B, int H, int ndir, int D, int* CHX) {
   if (T <= 0 || B <= 0 || H <= 0 || D <= 0 || (ndir != 1 && ndir != 2)) return false;
   if (H % 4 != 0 || H > 16 * FWD_CH * 4 || D > 640) return false;
   const int P = cdiv(H, LSTM_UNITS_FWD), G = cdiv(B, 16);
-  if (ndir * G * P > num_cus()) return false;
+  if (ndir * G * P > dn_num_cus()) return false;
   // DANET_LSTM_FWD_FUSED=0 turns the path off, =1 forces it inside the envelope; otherwise it is
   // used where it beats the hoisted GEMM: the input-half MFMAs add ~1.0 us * D/600 to a step
   // (measured, profiles/r02_d_fused_fwd_trace.txt), the hoisted GEMM costs ~1.15 us * B/32 *
@@ -1925,7 +1925,7 @@ extern "C" int danet_lstm_bwd(danet_stream_t stream_, int T, int B, int H, int n
       if (danet_opt(OPT_LSTM_BWD_TWIN_XCD) == 1 && a.xmap == 1 && ncl <= 8 && 8 % ncl == 0 && rs.S > 1) {
         const int npar = 8 / ncl;
         const int g2 = 8 * cdiv(rs.P, npar) * rs.S;
-        if (g2 <= num_cus()) { a.xmap = 2; nblk = g2; }
+        if (g2 <= dn_num_cus()) { a.xmap = 2; nblk = g2; }
       }
     }
 #define LAUNCH_RS(UV, NTWV) DN_LAUNCH_EV((lstm_bwd_rs_kernel<UV, NTWV>), nblk, 512, 0, stream, a)

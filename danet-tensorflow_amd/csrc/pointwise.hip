@@ -6,6 +6,7 @@
 // the complex spectra are read as interleaved (re,im) float2.
 #include "common.h"
 #include "options.h"
+#include <atomic>
 
 // ------------------------------------------------------------------ front-end
 __global__ void frontend_kernel(int B, int C, int64_t N, const float2* __restrict__ src,
@@ -118,12 +119,43 @@ __device__ __forceinline__ int64_t center_index(int layout, int B, int T, int ld
 // parameters (tools/parity_decompose.py): centred-input error 3.2e-7 rms with the float32 sum vs
 // 1.9e-7 for numpy's float32 pairwise mean; with the double sum the mean is the correctly
 // rounded float32 value.  16512 adds per utterance: free.
-__global__ void center_sum_kernel(int B, int T, int D, const float* __restrict__ in,
-                                  int layout, int ld, double* __restrict__ partial) {
-  __shared__ double redd[16];
-  const int b = blockIdx.y, ch = blockIdx.x;
-  const int tper = cdiv(T, CENTER_CHUNKS);
-  const int t0 = ch * tper, t1 = min(T, t0 + tper);
+// One thread's share of the chunk sum (rows t0 .. t1 - 1 of utterance b), the SAME terms in the
+// same order in the two-launch and the one-launch form.  `vec` (host: D, ld and the base address
+// are multiples of four floats): the chunk is walked as 16-byte groups, group tid + 256 k in step
+// k, all of a thread's loads in flight together; with KEEP the first CENTER_NV groups stay in
+// registers for the caller (the one-launch form subtracts the mean from them: no second read).
+#define CENTER_NV 8
+template <bool KEEP>
+__device__ __forceinline__ double center_thread_sum(int B, int T, int D, const float* __restrict__ in,
+                                                    int layout, int ld, int b, int t0, int t1,
+                                                    int vec, f32x4* regs) {
+  if (vec) {
+    const int D4 = D >> 2, n = (t1 - t0) * D4;
+    double acc = 0.0;
+    int k0 = 0;
+    if (KEEP) {
+#pragma unroll
+      for (int k = 0; k < CENTER_NV; ++k) {
+        const int idx = threadIdx.x + k * 256;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (idx < n) {
+          const int tr = idx / D4, d4 = idx - tr * D4;
+          v = *reinterpret_cast<const f32x4*>(in + center_index(layout, B, T, ld, b, t0 + tr) + 4 * d4);
+        }
+        regs[k] = v;
+      }
+#pragma unroll
+      for (int k = 0; k < CENTER_NV; ++k)       // (groups beyond n add exact zeros)
+        acc += ((double)regs[k][0] + (double)regs[k][1]) + ((double)regs[k][2] + (double)regs[k][3]);
+      k0 = CENTER_NV;
+    }
+    for (int idx = threadIdx.x + k0 * 256; idx < n; idx += 256) {
+      const int tr = idx / D4, d4 = idx - tr * D4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(in + center_index(layout, B, T, ld, b, t0 + tr) + 4 * d4);
+      acc += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+    }
+    return acc;
+  }
   double s0 = 0.0, s1 = 0.0;
   for (int t = t0; t < t1; ++t) {
     const float* row = in + center_index(layout, B, T, ld, b, t);
@@ -131,7 +163,17 @@ __global__ void center_sum_kernel(int B, int T, int D, const float* __restrict__
     for (; d + (int)blockDim.x < D; d += 2 * blockDim.x) { s0 += (double)row[d]; s1 += (double)row[d + blockDim.x]; }
     if (d < D) s0 += (double)row[d];
   }
-  double v = wave_sum_d(s0 + s1);
+  return s0 + s1;
+}
+
+__global__ __launch_bounds__(256) void center_sum_kernel(int B, int T, int D, const float* __restrict__ in,
+                                                         int layout, int ld, int vec,
+                                                         double* __restrict__ partial) {
+  __shared__ double redd[16];
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const int tper = cdiv(T, CENTER_CHUNKS);
+  const int t0 = ch * tper, t1 = min(T, t0 + tper);
+  double v = wave_sum_d(center_thread_sum<false>(B, T, D, in, layout, ld, b, t0, t1, vec, nullptr));
   const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   if ((threadIdx.x & 63) == 0) redd[w] = v;
   __syncthreads();
@@ -160,9 +202,109 @@ __global__ void center_apply_kernel(int B, int T, int D, const float* __restrict
   }
 }
 
-// `mean` doubles as scratch: [B] means (padded to an even count) followed by
-// [B][CENTER_CHUNKS] DOUBLE partial sums (keeps the ABI allocation-free and re-entrant).
-int dn_center_mean_elems(int B) { return ((B + 1) & ~1) + 2 * B * CENTER_CHUNKS; }
+// Both phases in ONE launch (round 6): the grid is the sum kernel's -- CENTER_CHUNKS workgroups per
+// utterance --, every workgroup sums its rows, publishes the partial, waits until the other chunks
+// of ITS utterance have published theirs, and then subtracts the mean from the rows it has just
+// read (they come back from L1 / L2).  The wait needs no zeroed memory and no fence: a partial is
+// ONE 16-byte write-through (sc1) store of {sum, tag ^ bits(sum)} with `tag` a process-wide launch
+// counter that no earlier launch has used, and a consumer polls the 32 slots of its utterance with
+// 16-byte L1-bypassing (sc1) loads until every slot satisfies word1 ^ word0 == tag -- a slot that
+// is stale, uninitialised or torn between two stores does not (2^-64) -- and then adds the sums in
+// chunk order: same partials, same order, same mean as the two-launch form, bit for bit.  (An
+// agent-scope release / acquire pair instead of the self-validating slot costs a write-back of
+// the whole L2 behind a kernel that has just filled it: 23-27 us per launch against 13-15 for
+// the two launches, `profiles/r06_f_center_one_launch.txt`.)  All workgroups of an utterance must be
+// co-resident, so the host takes this form only when B * CENTER_CHUNKS workgroups fit the GPU four
+// to a CU (B <= 32 on 256 CUs); kernels of other streams that hold CUs end, so waiting for a slot
+// cannot deadlock.  A wait that exceeds its bound (a GPU fault elsewhere) yields NaN means: loud,
+// not a hang.
+typedef unsigned cv4u __attribute__((__vector_size__(16)));
+#define CENTER_SPIN_LIMIT (1u << 16)
+
+__global__ __launch_bounds__(256) void center_fused_kernel(
+    int B, int T, int D, const float* __restrict__ in, int in_layout, int ld_in,
+    float* __restrict__ out, int out_layout, int ld_out,
+    void* slots_ /* NOT restrict: other workgroups write it while this one polls */,
+    unsigned long long tag, float* __restrict__ mean_out, int vec, int keep) {
+  __shared__ double redd[16];
+  __shared__ float mean_s;
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const int tper = cdiv(T, CENTER_CHUNKS);
+  const int t0 = ch * tper, t1 = min(T, t0 + tper);
+  f32x4 regs[CENTER_NV];
+  // (keep: the host has checked that the chunk fits CENTER_NV groups per thread and that `out`
+  // takes 16-byte stores with ld_out == D)
+  const double ts = keep ? center_thread_sum<true>(B, T, D, in, in_layout, ld_in, b, t0, t1, vec, regs)
+                         : center_thread_sum<false>(B, T, D, in, in_layout, ld_in, b, t0, t1, vec, nullptr);
+  double v = wave_sum_d(ts);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) redd[w] = v;
+  __syncthreads();
+  // the 32 slots of this utterance: 512 bytes behind one buffer descriptor
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      static_cast<char*>(slots_) + (size_t)b * CENTER_CHUNKS * 16, 0, CENTER_CHUNKS * 16, 0x00020000);
+  if (threadIdx.x < 64) {          // wave 0
+    if (threadIdx.x == 0) {
+      double s = 0.0;
+      for (int i = 0; i < nw; ++i) s += redd[i];
+      const unsigned long long sb = __builtin_bit_cast(unsigned long long, s), x = sb ^ tag;
+      const cv4u word = {(unsigned)sb, (unsigned)(sb >> 32), (unsigned)x, (unsigned)(x >> 32)};
+      __builtin_amdgcn_raw_buffer_store_b128(word, rs, ch * 16, 0, 16 /*sc1: write-through*/);
+    }
+    // lane i polls slot i mod CENTER_CHUNKS
+    const int i = threadIdx.x & (CENTER_CHUNKS - 1);
+    unsigned spins = 0;
+    bool all_ok;                   // wave-uniform
+    unsigned long long sb;
+    for (;;) {
+      const cv4u g = __builtin_amdgcn_raw_buffer_load_b128(rs, i * 16, 0, 16 /*sc1*/);
+      sb = (unsigned long long)g[0] | ((unsigned long long)g[1] << 32);
+      const unsigned long long x = (unsigned long long)g[2] | ((unsigned long long)g[3] << 32);
+      all_ok = __all((x ^ sb) == tag);
+      if (all_ok || ++spins > CENTER_SPIN_LIMIT) break;
+      __builtin_amdgcn_s_sleep(1);
+      asm volatile("" :: "v"(slots_) : "memory");     // the next poll is a NEW load (the builtin is not volatile)
+    }
+    // the sums in chunk order (every lane of the wave holds slot (lane mod 32)'s)
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < CENTER_CHUNKS; ++k) {
+      const unsigned lo = __builtin_amdgcn_readlane((unsigned)sb, k);
+      const unsigned hi = __builtin_amdgcn_readlane((unsigned)(sb >> 32), k);
+      s += __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
+    }
+    if (threadIdx.x == 0) mean_s = all_ok ? (float)(s / (double)((int64_t)T * D)) : __builtin_nanf("");
+  }
+  __syncthreads();
+  const float mean = mean_s;
+  if (mean_out && ch == 0 && threadIdx.x == 0) mean_out[b] = mean;
+  if (keep) {
+    const int D4 = D >> 2, n = (t1 - t0) * D4;
+#pragma unroll
+    for (int k = 0; k < CENTER_NV; ++k) {
+      const int idx = threadIdx.x + k * 256;
+      if (idx < n) {
+        const int tr = idx / D4, d4 = idx - tr * D4;
+        *reinterpret_cast<f32x4*>(out + center_index(out_layout, B, T, ld_out, b, t0 + tr) + 4 * d4) =
+            regs[k] - mean;
+      }
+    }
+    return;
+  }
+  for (int t = t0; t < t1; ++t) {
+    const float* src = in + center_index(in_layout, B, T, ld_in, b, t);
+    float* dst = out + center_index(out_layout, B, T, ld_out, b, t);
+    for (int d = threadIdx.x; d < ld_out; d += blockDim.x)
+      dst[d] = (d < D) ? src[d] - mean : 0.f;
+  }
+}
+
+// `mean` doubles as scratch: [B] means (padded to a multiple of four) followed by
+// [B][CENTER_CHUNKS] 16-byte slots {double partial sum, launch tag ^ its bits} (keeps the ABI allocation-free and
+// re-entrant; nothing in it needs initialising).
+int dn_center_mean_elems(int B) { return ((B + 3) & ~3) + 4 * B * CENTER_CHUNKS; }
+
+static std::atomic<unsigned long long> g_center_tag{0x9E3779B97F4A7C15ull};
 
 extern "C" int danet_center(danet_stream_t stream, int B, int T, int D, const float* in,
                             int in_layout, int ld_in, float* out, int out_layout,
@@ -170,10 +312,24 @@ extern "C" int danet_center(danet_stream_t stream, int B, int T, int D, const fl
   DANET_CHECK_ARG(B > 0 && T > 0 && D > 0 && in && out && mean, "center: bad args (mean scratch is required)");
   DANET_CHECK_ARG(ld_in >= D && ld_out >= D, "center: ld < D");
   DANET_CHECK_ARG((in_layout | 1) == 1 && (out_layout | 1) == 1, "center: layout must be 0/1");
-  DANET_CHECK_ARG(((uintptr_t)mean & 7) == 0, "center: mean scratch must be 8-byte aligned");
-  double* partial = reinterpret_cast<double*>(mean + ((B + 1) & ~1));
+  DANET_CHECK_ARG(((uintptr_t)mean & 15) == 0, "center: mean scratch must be 16-byte aligned");
   dim3 g1(CENTER_CHUNKS, B);
-  center_sum_kernel<<<g1, 256, 0, (hipStream_t)stream>>>(B, T, D, in, in_layout, ld_in, partial);
+  // 16-byte groups: the same decision in both forms (it fixes the order of the sum)
+  const int vec = D % 4 == 0 && ld_in % 4 == 0 && ((uintptr_t)in & 15) == 0;
+#ifndef DANET_CENTER_TWO_LAUNCHES
+  if ((int64_t)B * CENTER_CHUNKS <= 4ll * dn_num_cus() && in != out) {
+    void* slots = mean + ((B + 3) & ~3);
+    const unsigned long long tag = g_center_tag.fetch_add(1, std::memory_order_relaxed);
+    const int keep = vec && ld_out == D && ((uintptr_t)out & 15) == 0 &&
+                     (int64_t)cdiv(T, CENTER_CHUNKS) * (D / 4) <= CENTER_NV * 256;
+    center_fused_kernel<<<g1, 256, 0, (hipStream_t)stream>>>(B, T, D, in, in_layout, ld_in, out, out_layout,
+                                                             ld_out, slots, tag, mean, vec, keep);
+    DANET_CHECK_LAUNCH();
+    return DANET_OK;
+  }
+#endif
+  double* partial = reinterpret_cast<double*>(mean + ((B + 3) & ~3));
+  center_sum_kernel<<<g1, 256, 0, (hipStream_t)stream>>>(B, T, D, in, in_layout, ld_in, vec, partial);
   DANET_CHECK_LAUNCH();
   const int gx = T < 64 ? T : 64;   // row-strided
   dim3 g2(gx, B);

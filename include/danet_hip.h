@@ -147,8 +147,8 @@ int danet_reattach_phase(danet_stream_t stream, int B, int C, int64_t N,
  * the encoder switches between the API's batch-major tensors and the LSTM
  * stack's time-major ones).  Columns D..ld_out-1 of `out` are zero-filled.
  * `mean` is REQUIRED scratch+output of DANET_WS_CENTER_MEAN bytes,
- * 8-byte aligned: the first B hold the per-utterance means, the rest per-chunk
- * partial sums.  The sum is accumulated in double and the mean is its correctly
+ * 16-byte aligned: the first B hold the per-utterance means, the rest per-chunk
+ * partial sums (nothing in it needs initialising; one scratch per call in flight).  The sum is accumulated in double and the mean is its correctly
  * rounded float32 value (the mean's error is a common-mode error of every
  * element; a float32 tree sum is off by more than any single element's rounding).
  * The same call is its own backward.                                        */

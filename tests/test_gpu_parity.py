@@ -262,7 +262,7 @@ def test_gemm_rejects_operands_of_2gib():
 
 
 # ------------------------------------------------------------------ centre
-@pytest.mark.parametrize('B,T,D', [(2, 3, 5), (4, 16, 129), (32, 8, 600)])
+@pytest.mark.parametrize('B,T,D', [(2, 3, 5), (4, 16, 129), (32, 8, 600), (3, 640, 1200), (5, 130, 132)])
 def test_center_layouts(B, T, D):
     from danet_amd import ops
     rng = np.random.RandomState(0)
@@ -278,6 +278,34 @@ def test_center_layouts(B, T, D):
     back = torch.empty(B, T, D, device='cuda')
     ops.center(out, B, T, D, 1, ldo, back, 0, D)
     assert relerr(back.cpu().numpy(), ref) < 1e-5
+
+
+def test_center_one_launch_equals_two_launches():
+    '''B * 32 workgroups fit the GPU four to a CU -> both centring phases run in ONE launch
+    (csrc/pointwise.hip center_fused_kernel); larger batches take the sum + apply launches.  Same
+    partial sums in the same order: the same utterances give the same bits either way, call after
+    call on the same scratch (the launch tags), with the scratch holding arbitrary bits.'''
+    from danet_amd import ops, _lib
+    L = _lib.load()
+    rng = np.random.RandomState(5)
+    T, D = 128, 600
+    x = (rng.randn(40, T, D) * 2 + 1.5).astype(np.float32)
+    xg = cu(x)
+    big = torch.empty(T, 40, D, device='cuda')
+    m40 = ops.center(xg, 40, T, D, 0, D, big, 1, D).clone()          # 1280 workgroups: two launches
+    n = _lib.ws_bytes(_lib.WS_CENTER_MEAN, 32) // 4
+    scratch = torch.full((n,), float('nan'), device='cuda')           # nothing in it needs initialising
+    x32 = xg[:32].contiguous()
+    for it in range(3):
+        out = torch.full((T, 32, D), 7.0, device='cuda')
+        rc = L.danet_center(_lib.stream(), 32, T, D, _lib.ptr(x32), 0, D, _lib.ptr(out), 1, D, _lib.ptr(scratch))
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out, big[:, :32]), it
+        assert torch.equal(scratch[:32], m40[:32]), it
+    ref = x[:32].astype(np.float64)
+    ref = ref - ref.mean(axis=(1, 2), keepdims=True)
+    assert relerr(out.cpu().numpy().transpose(1, 0, 2), ref) < 1e-6
 
 
 # ---------------------------------------------------------------- frontend
