@@ -64,7 +64,8 @@ PROTOTYPES = {
                                c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_sz, c_p, c_int]),
     'danet_lstm_fwd_prefill': (c_int, [c_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_p),
                                        ctypes.POINTER(c_p)]),
-    'danet_lstm_bwd_prefill': (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_p)]),
+    'danet_lstm_train_prefill': (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_p),
+                                         ctypes.POINTER(c_p), ctypes.POINTER(c_p)]),
     'danet_lstm_fwd_fused_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'danet_lstm_fwd_fused_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'danet_lstm_fwd_fused': (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_int, c_int, c_p, c_p,
@@ -140,7 +141,7 @@ def load():
             fn = getattr(lib, name)      # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.danet_abi_version() != 6:
+        if lib.danet_abi_version() != 7:
             raise DanetHipError('libdanet_hip.so ABI version mismatch')
         _lib = lib
         apply_env_options()

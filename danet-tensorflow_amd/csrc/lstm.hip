@@ -1473,7 +1473,7 @@ __global__ __launch_bounds__(256) void lstm_db_reduce_kernel(
 // (hipMemsetAsync with a byte value lowers to a fill kernel PLUS copy kernels on this
 // runtime, and each memset is its own node on the critical path of the layer)
 // ---------------------------------------------------------------------------
-#define FILL_MAXSEG 16
+#define FILL_MAXSEG 32
 struct FillArgs {
   void* ptr[FILL_MAXSEG];
   unsigned long long n16[FILL_MAXSEG];   // 16-byte words per segment
@@ -1646,40 +1646,61 @@ static int lstm_check_common(int T, int B, int H, int ndir, void* ws, size_t ws_
 // 1.  Inside the entry points that is one fill launch per call (~6 us each: 6 per cfg-2 train
 // step); a host that allocates the buffers of all layers up front prefills them with ONE call
 // here and passes DANET_LSTM_PREFILLED to the launches.
-extern "C" int danet_lstm_fwd_prefill(danet_stream_t stream_, int T, int B, int ldy, int n,
-                                      float* const* ypads, void* const* wss) {
-  hipStream_t stream = (hipStream_t)stream_;
-  DANET_CHECK_ARG(T > 0 && B > 0 && ldy > 0 && ldy % 4 == 0 && n > 0 && ypads, "lstm_fwd_prefill: bad argument");
+static int prefill_fwd_segments(FillList& fl, hipStream_t stream, int T, int B, int ldy, int n,
+                                float* const* ypads, void* const* wss) {
   const size_t blk = (size_t)B * ldy * sizeof(float);
-  FillList fl;
   for (int i = 0; i < n; ++i) {
-    DANET_CHECK_ARG(ypads[i] && ((uintptr_t)ypads[i] & 15) == 0, "lstm_fwd_prefill: ypad %d null / misaligned", i);
+    DANET_CHECK_ARG(ypads[i] && ((uintptr_t)ypads[i] & 15) == 0, "lstm_prefill: ypad %d null / misaligned", i);
     if (fl.a.nseg + 4 > FILL_MAXSEG) { DANET_CHECK_HIP(fl.launch(stream)); fl = FillList(); }
     if (wss && wss[i]) fl.add(wss[i], 64 + TRACE_BYTES(T), 0u);
     fl.add((char*)ypads[i] + blk, (size_t)T * blk, SENTINEL);
     fl.add(ypads[i], blk, 0u);
     fl.add((char*)ypads[i] + (size_t)(T + 1) * blk, blk, 0u);
   }
-  if (fl.a.nseg) DANET_CHECK_HIP(fl.launch(stream));
   return DANET_OK;
 }
 
-extern "C" int danet_lstm_bwd_prefill(danet_stream_t stream_, int T, int B, int H, int ndir, int n,
-                                      void* const* wss) {
-  hipStream_t stream = (hipStream_t)stream_;
-  DANET_CHECK_ARG(T > 0 && B > 0 && H > 0 && (ndir == 1 || ndir == 2) && n > 0 && wss, "lstm_bwd_prefill: bad argument");
-  const RsPlan rs = choose_rs_plan(B, H, ndir);
-  if (!rs.ok) {
-    danet_set_error("lstm_bwd_prefill: B=%d H=%d outside the reduce-scatter geometry", B, H);
-    return DANET_ERR_UNSUPPORTED;
-  }
-  FillList fl;
+static int prefill_bwd_segments(FillList& fl, hipStream_t stream, int T, const RsPlan& rs, int n,
+                                void* const* wss) {
   for (int i = 0; i < n; ++i) {
-    DANET_CHECK_ARG(wss[i] && ((uintptr_t)wss[i] & 15) == 0, "lstm_bwd_prefill: ws %d null / misaligned", i);
+    DANET_CHECK_ARG(wss[i] && ((uintptr_t)wss[i] & 15) == 0, "lstm_prefill: ws %d null / misaligned", i);
     if (fl.a.nseg + 2 > FILL_MAXSEG) { DANET_CHECK_HIP(fl.launch(stream)); fl = FillList(); }
     fl.add(wss[i], 64 + TRACE_BYTES(T), 0u);
     fl.add((char*)wss[i] + ring_offset(T), rs.ring_bytes, 1u);   // phase 1 in bit 0 of every word
   }
+  return DANET_OK;
+}
+
+extern "C" int danet_lstm_fwd_prefill(danet_stream_t stream_, int T, int B, int ldy, int n,
+                                      float* const* ypads, void* const* wss) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DANET_CHECK_ARG(T > 0 && B > 0 && ldy > 0 && ldy % 4 == 0 && n > 0 && ypads, "lstm_fwd_prefill: bad argument");
+  FillList fl;
+  const int rc = prefill_fwd_segments(fl, stream, T, B, ldy, n, ypads, wss);
+  if (rc) return rc;
+  if (fl.a.nseg) DANET_CHECK_HIP(fl.launch(stream));
+  return DANET_OK;
+}
+
+// A train step knows at the head of its forward pass that a backward pass follows: the forward
+// launches' buffers AND the BPTT launches' rings in one fill launch (the rings are 4 MB each at cfg 2;
+// the 6-us launch in front of the first BPTT kernel leaves the critical path).
+extern "C" int danet_lstm_train_prefill(danet_stream_t stream_, int T, int B, int H, int ndir, int ldy,
+                                        int n, float* const* ypads, void* const* fwd_wss,
+                                        void* const* bwd_wss) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DANET_CHECK_ARG(T > 0 && B > 0 && H > 0 && (ndir == 1 || ndir == 2) && ldy > 0 && ldy % 4 == 0 && n > 0 &&
+                  ypads && bwd_wss, "lstm_train_prefill: bad argument");
+  const RsPlan rs = choose_rs_plan(B, H, ndir);
+  if (!rs.ok) {
+    danet_set_error("lstm_train_prefill: B=%d H=%d outside the reduce-scatter geometry", B, H);
+    return DANET_ERR_UNSUPPORTED;
+  }
+  FillList fl;
+  int rc = prefill_fwd_segments(fl, stream, T, B, ldy, n, ypads, fwd_wss);
+  if (rc) return rc;
+  rc = prefill_bwd_segments(fl, stream, T, rs, n, bwd_wss);
+  if (rc) return rc;
   if (fl.a.nseg) DANET_CHECK_HIP(fl.launch(stream));
   return DANET_OK;
 }

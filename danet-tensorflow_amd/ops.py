@@ -862,12 +862,15 @@ def lstm_prefill_fwd(T, B, ldy, ypads, wss):
     check(_L().danet_lstm_fwd_prefill(_lib.stream(), T, B, ldy, n, yp, wp))
 
 
-def lstm_prefill_bwd(T, B, H, ndir, wss):
-    '''ONE fill launch for the partial-dh rings of several BPTT launches; False when the shape
-    takes the all-gather kernel (which prefills its own exchange medium)'''
-    n = len(wss)
-    wp = (_lib.c_p * n)(*[ptr(w) for w in wss])
-    return _L().danet_lstm_bwd_prefill(_lib.stream(), T, B, H, ndir, n, wp) == 0
+def lstm_prefill_train(T, B, H, ndir, ypads, fwd_wss, bwd_wss):
+    '''ONE fill launch for the forward launches' buffers AND the partial-dh rings of the BPTT launches
+    that will follow; False (nothing launched) when the shape takes the all-gather BPTT kernel, which
+    prefills its own exchange medium'''
+    n = len(ypads)
+    yp = (_lib.c_p * n)(*[ptr(y) for y in ypads])
+    fp = (_lib.c_p * n)(*[ptr(w) for w in fwd_wss])
+    bp = (_lib.c_p * n)(*[ptr(w) for w in bwd_wss])
+    return _L().danet_lstm_train_prefill(_lib.stream(), T, B, H, ndir, ndir * H, n, yp, fp, bp) == 0
 
 
 def lstm_layer_fwd(x, ldx, D, T, B, H, Ws, bs, x_pad_zero=False, ypad=None, ws=None):
@@ -963,7 +966,7 @@ DB_DEFER = _lib.expert('lstm_db_defer', True)
 
 def lstm_layer_bwd(c, dy, need_dx, layer_tag=None, is_top=False, ws_prefilled=None):
     '''dy: [T, B, ndir*H] contiguous.  Returns (dx [T*B, D] or None, dWs, dbs).
-    ws_prefilled: a workspace whose ring the caller prefilled (lstm_prefill_bwd)'''
+    ws_prefilled: a workspace whose ring the caller prefilled (lstm_prefill_train)'''
     T, B, H, D, ndir = c.T, c.B, c.H, c.D, c.ndir
     dev = dy.device
     das = [torch.empty(T * B, 4 * H, device=dev) for _ in range(ndir)]
@@ -1176,7 +1179,16 @@ class RnnEncoderFn(torch.autograd.Function):
         # output buffers + workspaces of ALL layers, prefilled by one fill launch
         ypads = [torch.empty(T + 2, B, ndir * H, device=dev) for _ in range(L)]
         wss = [_lstm_ws(T, B, H, ndir, dev)[0] for _ in range(L)]
-        lstm_prefill_fwd(T, B, ndir * H, ypads, wss)
+        # (a train step: the BPTT launches' rings in the same fill launch -- 6 us less in front of the
+        # first BPTT kernel)
+        bwss = None
+        if any(ctx.needs_input_grad) and BWD_DB and _L().danet_lstm_bwd_db_supported(T, B, H, ndir) == 1:
+            bwss = [_lstm_ws(T, B, H, ndir, dev)[0] for _ in range(L)]
+            if not lstm_prefill_train(T, B, H, ndir, ypads, wss, bwss):
+                bwss = None
+        if bwss is None:
+            lstm_prefill_fwd(T, B, ndir * H, ypads, wss)
+        ctx.bwss = bwss
         for l in range(L):                                    # modules.py:223-242
             Ws = [params[(l * ndir + d) * 2] for d in range(ndir)]
             bs = [params[(l * ndir + d) * 2 + 1] for d in range(ndir)]
@@ -1232,14 +1244,9 @@ class RnnEncoderFn(torch.autograd.Function):
         dy = torch.empty(T, B, D, device=dev)
         center(dyc, B, T, D, 0, D, dy, 1, D)                 # centre is self-adjoint
         grads = [None] * (2 * L * ndir)
-        # partial-dh rings of all layers' BPTT launches, prefilled by one fill launch
-        bwss = [None] * L
-        plain = list(range(L))
-        if plain and BWD_DB and _L().danet_lstm_bwd_db_supported(T, B, H, ndir) == 1:
-            cand = [_lstm_ws(T, B, H, ndir, dev)[0] for _ in plain]
-            if lstm_prefill_bwd(T, B, H, ndir, cand):
-                for l, w in zip(plain, cand):
-                    bwss[l] = w
+        # partial-dh rings of all layers' BPTT launches: prefilled by the forward pass's fill launch
+        bwss = ctx.bwss if ctx.bwss is not None else [None] * L
+        ctx.bwss = None
         for l in reversed(range(L)):
             dx, dWs, dbs = lstm_layer_bwd(ctx.ctxs[l], dy, need_dx=(l > 0), layer_tag=l,
                                           is_top=(l == L - 1), ws_prefilled=bwss[l])

@@ -54,7 +54,10 @@ extern "C" {
  * of round 5, then without a version bump) and must be DEDICATED to that entry point (per stream) and
  * zero-initialised once by the caller -- a v5 caller that handed it any shared scratch must change; the
  * option gemm_x6_plan gained the hybrid-schedule bits; danet_gemm_x6_tn_grouped masks odd row pads.     */
-#define DANET_ABI_VERSION 6
+/* 7 (round 6, second half): danet_lstm_bwd_prefill is replaced by danet_lstm_train_prefill (the forward
+ * launches' buffers and the BPTT rings in one fill launch); the `mean` scratch of danet_center is 16-byte
+ * aligned and DANET_WS_CENTER_MEAN grew (16-byte slots of the one-launch form).                        */
+#define DANET_ABI_VERSION 7
 
 typedef void* danet_stream_t;
 
@@ -320,7 +323,7 @@ int danet_lstm_fwd(danet_stream_t stream, int T, int B, int H, int ndir,
                    void* ws, size_t ws_bytes, int32_t* status, int flags);
 
 /* `flags` of danet_lstm_fwd / danet_lstm_fwd_fused / danet_lstm_bwd: DANET_LSTM_PREFILLED = the
- * caller has prefilled this launch's buffers with danet_lstm_fwd_prefill / danet_lstm_bwd_prefill
+ * caller has prefilled this launch's buffers with danet_lstm_fwd_prefill / danet_lstm_train_prefill
  * (one fill launch for the buffers of ALL layers instead of one per call); 0 = the call prefills
  * its own buffers.                                                                          */
 #define DANET_LSTM_PREFILLED 1
@@ -330,8 +333,15 @@ int danet_lstm_fwd(danet_stream_t stream, int T, int B, int H, int ndir,
 #define DANET_LSTM_DB_DEFERRED 2
 int danet_lstm_fwd_prefill(danet_stream_t stream, int T, int B, int ldy, int n,
                            float* const* ypads, void* const* wss /* NULL or n workspaces */);
-int danet_lstm_bwd_prefill(danet_stream_t stream, int T, int B, int H, int ndir, int n,
-                           void* const* wss);
+/* (ABI 7, replaces danet_lstm_bwd_prefill) a TRAIN step prefills the n forward launches' buffers AND the
+ * rings of the n BPTT launches that will follow (workspaces of their own, DANET_WS_LSTM bytes each) in
+ * ONE fill launch at the head of the forward pass; danet_lstm_bwd then takes DANET_LSTM_PREFILLED too.
+ * DANET_ERR_UNSUPPORTED (nothing launched) when (B, H, ndir) is outside the reduce-scatter BPTT
+ * geometry (danet_lstm_bwd_db_supported): prefill the forward with danet_lstm_fwd_prefill and let
+ * danet_lstm_bwd prefill its own medium.                                                        */
+int danet_lstm_train_prefill(danet_stream_t stream, int T, int B, int H, int ndir, int ldy, int n,
+                             float* const* ypads, void* const* fwd_wss /* NULL or n */,
+                             void* const* bwd_wss /* n */);
 
 /* The same layer forward with the INPUT projection fused (no hoisted GEMM, no gx
  * tensor): the kernel computes a_t = [x_t, h_{t-1}] W + b itself -- x_t*Wx of step t
