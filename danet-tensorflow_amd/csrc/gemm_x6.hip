@@ -520,6 +520,7 @@ __global__ __launch_bounds__(256) void gemm_x6_pack_kernel(X6PackArgs a) {
   const float* __restrict__ src = q.src;
   u32x4* __restrict__ out = q.out;
   const int64_t sn = q.sn, sk = q.sk;
+  const bool kvec = sk == 1 && (sn & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
   const int64_t total = (int64_t)NT32 * KT * 64;
   const size_t plane = (size_t)total;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
@@ -527,11 +528,20 @@ __global__ __launch_bounds__(256) void gemm_x6_pack_kernel(X6PackArgs a) {
     const int kt = (int)((idx >> 6) % KT), nt = (int)((idx >> 6) / KT);
     const int n = nt * 32 + (l & 31), k0 = kt * 16 + 8 * (l >> 5);
     uint32_t h[8], m[8], lo[8];
+    float x[8];
+    if (kvec && n < N && k0 + 8 <= K) {
+      // k-contiguous weight (dYc, dX: sk == 1, rows and base 16-byte aligned): the lane's 8 values are
+      // two 16-byte loads instead of eight 4-byte loads a row stride apart
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + n * sn + k0);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + n * sn + k0 + 4);
+      x[0] = a0[0]; x[1] = a0[1]; x[2] = a0[2]; x[3] = a0[3];
+      x[4] = a1[0]; x[5] = a1[1]; x[6] = a1[2]; x[7] = a1[3];
+    } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float x = (n < N && k0 + j < K) ? src[n * sn + (k0 + j) * sk] : 0.f;
-      split3(x, h[j], m[j], lo[j]);
+      for (int j = 0; j < 8; ++j) x[j] = (n < N && k0 + j < K) ? src[n * sn + (k0 + j) * sk] : 0.f;
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split3(x[j], h[j], m[j], lo[j]);
     out[idx] = (u32x4){pack_hi(h[0], h[1]), pack_hi(h[2], h[3]), pack_hi(h[4], h[5]), pack_hi(h[6], h[7])};
     out[plane + idx] = (u32x4){pack_hi(m[0], m[1]), pack_hi(m[2], m[3]), pack_hi(m[4], m[5]), pack_hi(m[6], m[7])};
     out[2 * plane + idx] = (u32x4){pack_hi(lo[0], lo[1]), pack_hi(lo[2], lo[3]), pack_hi(lo[4], lo[5]), pack_hi(lo[6], lo[7])};
