@@ -64,6 +64,9 @@ PROTOTYPES = {
                                c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_sz, c_p, c_int]),
     'danet_lstm_fwd_prefill': (c_int, [c_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_p),
                                        ctypes.POINTER(c_p)]),
+    'danet_encoder_prologue': (c_int, [c_p, c_int, c_int, c_int, c_p, c_int, c_int, c_p, c_int, c_int, c_p,
+                                       c_int, c_int, c_int, c_int, ctypes.POINTER(c_p), ctypes.POINTER(c_p),
+                                       ctypes.POINTER(c_p)]),
     'danet_lstm_train_prefill': (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_p),
                                          ctypes.POINTER(c_p), ctypes.POINTER(c_p)]),
     'danet_lstm_fwd_fused_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),

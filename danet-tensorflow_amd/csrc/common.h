@@ -19,6 +19,29 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 // compute units of the current device (csrc/lstm.hip; 256 when no device answers)
 int dn_num_cus();
 
+// ---- fill lists: every "not yet published" pattern / zero block of one call in ONE launch (csrc/lstm.hip)
+#define FILL_MAXSEG 32
+struct FillArgs {
+  void* ptr[FILL_MAXSEG];
+  unsigned long long n16[FILL_MAXSEG];   // 16-byte words per segment
+  unsigned value[FILL_MAXSEG];
+  int nseg;
+};
+// thread `tid` of `stride` fills its share of every segment
+__device__ __forceinline__ void fill_share(const FillArgs& a, unsigned long long tid, unsigned long long stride) {
+  typedef unsigned fv4u __attribute__((__vector_size__(16)));
+  for (int sgi = 0; sgi < a.nseg; ++sgi) {
+    const unsigned v = a.value[sgi];
+    const fv4u w = {v, v, v, v};
+    fv4u* p = reinterpret_cast<fv4u*>(a.ptr[sgi]);
+    for (unsigned long long i = tid; i < a.n16[sgi]; i += stride) p[i] = w;
+  }
+}
+// csrc/pointwise.hip: danet_center with an optional rider (taken only by the one-launch form:
+// *rider_taken says whether the launch carried it)
+int dn_center(hipStream_t stream, int B, int T, int D, const float* in, int in_layout, int ld_in, float* out,
+              int out_layout, int ld_out, float* mean, const FillArgs* rider, bool* rider_taken);
+
 // fp32 products on the bf16 matrix cores (csrc/gemm_x6.hip; the recurrent half of
 // lstm_fwd_fx_kernel): every fp32 value is EXACTLY hi + mid + lo with three bf16 pieces of 8
 // significant bits.  (x0, x1) -> the packed bf16 pairs of their pieces (x0 in the low half):

@@ -1473,23 +1473,10 @@ __global__ __launch_bounds__(256) void lstm_db_reduce_kernel(
 // (hipMemsetAsync with a byte value lowers to a fill kernel PLUS copy kernels on this
 // runtime, and each memset is its own node on the critical path of the layer)
 // ---------------------------------------------------------------------------
-#define FILL_MAXSEG 32
-struct FillArgs {
-  void* ptr[FILL_MAXSEG];
-  unsigned long long n16[FILL_MAXSEG];   // 16-byte words per segment
-  unsigned value[FILL_MAXSEG];
-  int nseg;
-};
-
+// (FILL_MAXSEG, FillArgs, fill_share: csrc/common.h -- danet_center's one-launch kernel can carry a
+// fill list as a rider, danet_encoder_prologue)
 __global__ __launch_bounds__(256) void multi_fill_kernel(FillArgs a) {
-  const unsigned long long tid = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-  const unsigned long long stride = (unsigned long long)gridDim.x * 256;
-  for (int sgi = 0; sgi < a.nseg; ++sgi) {
-    const unsigned v = a.value[sgi];
-    const v4u w = {v, v, v, v};
-    v4u* p = reinterpret_cast<v4u*>(a.ptr[sgi]);
-    for (unsigned long long i = tid; i < a.n16[sgi]; i += stride) p[i] = w;
-  }
+  fill_share(a, (unsigned long long)blockIdx.x * 256 + threadIdx.x, (unsigned long long)gridDim.x * 256);
 }
 
 struct FillList {
@@ -1702,6 +1689,43 @@ extern "C" int danet_lstm_train_prefill(danet_stream_t stream_, int T, int B, in
   rc = prefill_bwd_segments(fl, stream, T, rs, n, bwd_wss);
   if (rc) return rc;
   if (fl.a.nseg) DANET_CHECK_HIP(fl.launch(stream));
+  return DANET_OK;
+}
+
+// The head of the encoder (app/modules.py:209-223) in ONE launch: the input's mean-centre
+// (danet_center) with the prefill of every recurrent launch that follows as a rider -- the centring
+// kernel's workgroups wait for each other's partial sums anyway, three of their four waves stream the
+// fill meanwhile (csrc/pointwise.hip).  bwd_wss == NULL: no backward pass follows (inference).  Falls
+// back to danet_center + one fill launch where the one-launch centring form is not taken.
+extern "C" int danet_encoder_prologue(danet_stream_t stream_, int B, int T, int D, const float* in,
+                                      int in_layout, int ld_in, float* out, int out_layout, int ld_out,
+                                      float* mean, int H, int ndir, int ldy, int n, float* const* ypads,
+                                      void* const* fwd_wss, void* const* bwd_wss) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DANET_CHECK_ARG(T > 0 && B > 0 && H > 0 && (ndir == 1 || ndir == 2) && ldy > 0 && ldy % 4 == 0 && n > 0 &&
+                  ypads, "encoder_prologue: bad argument");
+  FillList fl;
+  int rc;
+  const bool one = 4 * n + (bwd_wss ? 2 * n : 0) <= FILL_MAXSEG;   // else: the list's own launches
+  if (bwd_wss) {
+    const RsPlan rs = choose_rs_plan(B, H, ndir);
+    if (!rs.ok) {
+      danet_set_error("encoder_prologue: B=%d H=%d outside the reduce-scatter geometry", B, H);
+      return DANET_ERR_UNSUPPORTED;
+    }
+    rc = prefill_fwd_segments(fl, stream, T, B, ldy, n, ypads, fwd_wss);
+    if (rc) return rc;
+    rc = prefill_bwd_segments(fl, stream, T, rs, n, bwd_wss);
+    if (rc) return rc;
+  } else {
+    rc = prefill_fwd_segments(fl, stream, T, B, ldy, n, ypads, fwd_wss);
+    if (rc) return rc;
+  }
+  bool taken = false;
+  rc = dn_center(stream, B, T, D, in, in_layout, ld_in, out, out_layout, ld_out, mean,
+                 one && fl.a.nseg ? &fl.a : nullptr, &taken);
+  if (rc) return rc;
+  if (!taken && fl.a.nseg) DANET_CHECK_HIP(fl.launch(stream));
   return DANET_OK;
 }
 

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void center_fused_kernel(
     int B, int T, int D, const float* __restrict__ in, int in_layout, int ld_in,
     float* __restrict__ out, int out_layout, int ld_out,
     void* slots_ /* NOT restrict: other workgroups write it while this one polls */,
-    unsigned long long tag, float* __restrict__ mean_out, int vec, int keep) {
+    unsigned long long tag, float* __restrict__ mean_out, int vec, int keep, FillArgs rider) {
   __shared__ double redd[16];
   __shared__ float mean_s;
   const int b = blockIdx.y, ch = blockIdx.x;
@@ -243,6 +243,12 @@ __global__ __launch_bounds__(256) void center_fused_kernel(
   // the 32 slots of this utterance: 512 bytes behind one buffer descriptor
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       static_cast<char*>(slots_) + (size_t)b * CENTER_CHUNKS * 16, 0, CENTER_CHUNKS * 16, 0x00020000);
+  if (rider.nseg > 0 && threadIdx.x >= 64) {
+    // the rider (danet_encoder_prologue: the recurrent launches' prefill): waves 1-3 stream their share
+    // of the fill while wave 0 waits for the utterance's other chunks
+    const unsigned long long nb = (unsigned long long)gridDim.x * gridDim.y;
+    fill_share(rider, ((unsigned long long)blockIdx.y * gridDim.x + blockIdx.x) * 192 + (threadIdx.x - 64), nb * 192);
+  }
   if (threadIdx.x < 64) {          // wave 0
     if (threadIdx.x == 0) {
       double s = 0.0;
@@ -306,9 +312,9 @@ int dn_center_mean_elems(int B) { return ((B + 3) & ~3) + 4 * B * CENTER_CHUNKS;
 
 static std::atomic<unsigned long long> g_center_tag{0x9E3779B97F4A7C15ull};
 
-extern "C" int danet_center(danet_stream_t stream, int B, int T, int D, const float* in,
-                            int in_layout, int ld_in, float* out, int out_layout,
-                            int ld_out, float* mean) {
+int dn_center(hipStream_t stream, int B, int T, int D, const float* in, int in_layout, int ld_in, float* out,
+              int out_layout, int ld_out, float* mean, const FillArgs* rider, bool* rider_taken) {
+  if (rider_taken) *rider_taken = false;
   DANET_CHECK_ARG(B > 0 && T > 0 && D > 0 && in && out && mean, "center: bad args (mean scratch is required)");
   DANET_CHECK_ARG(ld_in >= D && ld_out >= D, "center: ld < D");
   DANET_CHECK_ARG((in_layout | 1) == 1 && (out_layout | 1) == 1, "center: layout must be 0/1");
@@ -322,21 +328,30 @@ extern "C" int danet_center(danet_stream_t stream, int B, int T, int D, const fl
     const unsigned long long tag = g_center_tag.fetch_add(1, std::memory_order_relaxed);
     const int keep = vec && ld_out == D && ((uintptr_t)out & 15) == 0 &&
                      (int64_t)cdiv(T, CENTER_CHUNKS) * (D / 4) <= CENTER_NV * 256;
-    center_fused_kernel<<<g1, 256, 0, (hipStream_t)stream>>>(B, T, D, in, in_layout, ld_in, out, out_layout,
-                                                             ld_out, slots, tag, mean, vec, keep);
+    FillArgs none; none.nseg = 0;
+    center_fused_kernel<<<g1, 256, 0, stream>>>(B, T, D, in, in_layout, ld_in, out, out_layout, ld_out, slots,
+                                                 tag, mean, vec, keep, rider ? *rider : none);
     DANET_CHECK_LAUNCH();
+    if (rider && rider_taken) *rider_taken = true;
     return DANET_OK;
   }
 #endif
   double* partial = reinterpret_cast<double*>(mean + ((B + 3) & ~3));
-  center_sum_kernel<<<g1, 256, 0, (hipStream_t)stream>>>(B, T, D, in, in_layout, ld_in, vec, partial);
+  center_sum_kernel<<<g1, 256, 0, stream>>>(B, T, D, in, in_layout, ld_in, vec, partial);
   DANET_CHECK_LAUNCH();
   const int gx = T < 64 ? T : 64;   // row-strided
   dim3 g2(gx, B);
-  center_apply_kernel<<<g2, 256, 0, (hipStream_t)stream>>>(
+  center_apply_kernel<<<g2, 256, 0, stream>>>(
       B, T, D, in, in_layout, ld_in, out, out_layout, ld_out, partial, mean);
   DANET_CHECK_LAUNCH();
   return DANET_OK;
+}
+
+extern "C" int danet_center(danet_stream_t stream, int B, int T, int D, const float* in,
+                            int in_layout, int ld_in, float* out, int out_layout,
+                            int ld_out, float* mean) {
+  return dn_center((hipStream_t)stream, B, T, D, in, in_layout, ld_in, out, out_layout, ld_out, mean, nullptr,
+                   nullptr);
 }
 
 // -------------------------------------------------------------------- colsum

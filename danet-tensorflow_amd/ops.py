@@ -862,6 +862,27 @@ def lstm_prefill_fwd(T, B, ldy, ypads, wss):
     check(_L().danet_lstm_fwd_prefill(_lib.stream(), T, B, ldy, n, yp, wp))
 
 
+# the input's centring and the recurrent launches' prefill in one launch (danet_encoder_prologue)
+ENC_PROLOGUE = _lib.expert('enc_prologue', True)
+
+
+def encoder_prologue(x, B, T, F, xc, Fp, H, ndir, ypads, fwd_wss, bwd_wss):
+    '''xc[T, B, Fp] = x[B, T, F] - mean_{t,f}(x) (time-major, zero pad) AND the prefill of the n recurrent
+    launches' buffers (bwd_wss: + the BPTT rings), one launch; False: the rings were NOT prefilled'''
+    n = len(ypads)
+    yp = (_lib.c_p * n)(*[ptr(y) for y in ypads])
+    fp = (_lib.c_p * n)(*[ptr(w) for w in fwd_wss])
+    bp = (_lib.c_p * n)(*[ptr(w) for w in bwd_wss]) if bwd_wss is not None else None
+    scratch = torch.empty(_lib.ws_bytes(_lib.WS_CENTER_MEAN, B) // 4, dtype=torch.float32, device=x.device)
+    args = (_lib.stream(), B, T, F, ptr(_f32(x)), 0, F, ptr(xc), 1, Fp, ptr(scratch), H, ndir, ndir * H, n, yp, fp)
+    rc = _L().danet_encoder_prologue(*args, bp)
+    if rc == -3 and bp is not None:      # BPTT geometry outside the reduce-scatter kernel: it prefills itself
+        check(_L().danet_encoder_prologue(*args, None))
+        return False
+    check(rc)
+    return True
+
+
 def lstm_prefill_train(T, B, H, ndir, ypads, fwd_wss, bwd_wss):
     '''ONE fill launch for the forward launches' buffers AND the partial-dh rings of the BPTT launches
     that will follow; False (nothing launched) when the shape takes the all-gather BPTT kernel, which
@@ -1171,23 +1192,25 @@ class RnnEncoderFn(torch.autograd.Function):
         dev = x.device
         Wout = params[-1]
         Fp = (F + 3) // 4 * 4
-        # x - mean_{t,f}(x), switched to time-major, zero-padded to a float4 row
+        # x - mean_{t,f}(x), switched to time-major, zero-padded to a float4 row       modules.py:209-210
         xc = torch.empty(T, B, Fp, device=dev)
-        center(x, B, T, F, 0, F, xc, 1, Fp)                  # modules.py:209-210
         ctxs = []
         cur, ld, D = xc, Fp, F
-        # output buffers + workspaces of ALL layers, prefilled by one fill launch
+        # output buffers + workspaces of ALL layers (a train step: + the BPTT launches' rings), prefilled
+        # by ONE fill -- which rides in the centring launch (danet_encoder_prologue)
         ypads = [torch.empty(T + 2, B, ndir * H, device=dev) for _ in range(L)]
         wss = [_lstm_ws(T, B, H, ndir, dev)[0] for _ in range(L)]
-        # (a train step: the BPTT launches' rings in the same fill launch -- 6 us less in front of the
-        # first BPTT kernel)
         bwss = None
         if any(ctx.needs_input_grad) and BWD_DB and _L().danet_lstm_bwd_db_supported(T, B, H, ndir) == 1:
             bwss = [_lstm_ws(T, B, H, ndir, dev)[0] for _ in range(L)]
-            if not lstm_prefill_train(T, B, H, ndir, ypads, wss, bwss):
+        if not ENC_PROLOGUE:
+            center(x, B, T, F, 0, F, xc, 1, Fp)
+            if bwss is None or not lstm_prefill_train(T, B, H, ndir, ypads, wss, bwss):
                 bwss = None
-        if bwss is None:
-            lstm_prefill_fwd(T, B, ndir * H, ypads, wss)
+                lstm_prefill_fwd(T, B, ndir * H, ypads, wss)
+        else:
+            if not encoder_prologue(x, B, T, F, xc, Fp, H, ndir, ypads, wss, bwss):
+                bwss = None
         ctx.bwss = bwss
         for l in range(L):                                    # modules.py:223-242
             Ws = [params[(l * ndir + d) * 2] for d in range(ndir)]

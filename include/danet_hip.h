@@ -55,8 +55,9 @@ extern "C" {
  * zero-initialised once by the caller -- a v5 caller that handed it any shared scratch must change; the
  * option gemm_x6_plan gained the hybrid-schedule bits; danet_gemm_x6_tn_grouped masks odd row pads.     */
 /* 7 (round 6, second half): danet_lstm_bwd_prefill is replaced by danet_lstm_train_prefill (the forward
- * launches' buffers and the BPTT rings in one fill launch); the `mean` scratch of danet_center is 16-byte
- * aligned and DANET_WS_CENTER_MEAN grew (16-byte slots of the one-launch form).                        */
+ * launches' buffers and the BPTT rings in one fill launch); danet_encoder_prologue added (the input's
+ * centring + that prefill in one launch); the `mean` scratch of danet_center is 16-byte aligned and
+ * DANET_WS_CENTER_MEAN grew (16-byte slots of the one-launch form).                                      */
 #define DANET_ABI_VERSION 7
 
 typedef void* danet_stream_t;
@@ -342,6 +343,15 @@ int danet_lstm_fwd_prefill(danet_stream_t stream, int T, int B, int ldy, int n,
 int danet_lstm_train_prefill(danet_stream_t stream, int T, int B, int H, int ndir, int ldy, int n,
                              float* const* ypads, void* const* fwd_wss /* NULL or n */,
                              void* const* bwd_wss /* n */);
+/* The head of the encoder (app/modules.py:209-223) in ONE launch: danet_center of the input (same
+ * arguments, same result bit for bit) with the prefill above as a rider of its kernel -- bwd_wss != NULL:
+ * danet_lstm_train_prefill's lists, NULL: danet_lstm_fwd_prefill's (inference).  Where the one-launch
+ * centring form is not taken (B * 32 workgroups do not fit the GPU four to a CU) it is danet_center
+ * followed by one fill launch.                                                                    */
+int danet_encoder_prologue(danet_stream_t stream, int B, int T, int D, const float* in, int in_layout,
+                           int ld_in, float* out, int out_layout, int ld_out, float* mean,
+                           int H, int ndir, int ldy, int n, float* const* ypads,
+                           void* const* fwd_wss /* NULL or n */, void* const* bwd_wss /* NULL or n */);
 
 /* The same layer forward with the INPUT projection fused (no hoisted GEMM, no gx
  * tensor): the kernel computes a_t = [x_t, h_{t-1}] W + b itself -- x_t*Wx of step t

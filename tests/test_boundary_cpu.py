@@ -34,7 +34,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, s), 'missing export: ' + s
     assert set(_lib.PROTOTYPES) == set(syms), set(_lib.PROTOTYPES) ^ set(syms)
     assert lib.danet_abi_version() == 7
-    assert len(syms) <= 50                  # round 4: the ABI is what ships, not every experiment
+    assert len(syms) <= 51                  # round 4: the ABI is what ships, not every experiment
     # ... and NOTHING else of the library's own is exported (-fvisibility=hidden + csrc/exports.map):
     # the dynamic symbol table holds the declared entry points only
     import subprocess

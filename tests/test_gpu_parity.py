@@ -308,6 +308,42 @@ def test_center_one_launch_equals_two_launches():
     assert relerr(out.cpu().numpy().transpose(1, 0, 2), ref) < 1e-6
 
 
+@pytest.mark.parametrize('B,train', [(32, True), (32, False), (8, True), (40, True)])
+def test_encoder_prologue_equals_center_plus_prefill(B, train):
+    '''danet_encoder_prologue = danet_center of the input + the recurrent launches' prefill riding in the
+    same launch (B = 40: the two-launch centring form + a fill launch of its own): every buffer bit-equal to
+    the separate calls'''
+    from danet_amd import ops, _lib
+    rng = np.random.RandomState(11)
+    T, F, H, ndir, L = 128, 129, 300, 2, 3
+    Fp = (F + 3) // 4 * 4
+    x = cu((rng.randn(B, T, F) * 2 + 0.7).astype(np.float32))
+    if train and _lib.load().danet_lstm_bwd_db_supported(T, B, H, ndir) != 1:
+        pytest.skip('BPTT geometry outside the reduce-scatter kernel')
+
+    def buffers():
+        yp = [torch.zeros(T + 2, B, ndir * H, device='cuda') for _ in range(L)]
+        n = _lib.ws_bytes(_lib.WS_LSTM, T, B, H, ndir)
+        fw = [torch.zeros(n, dtype=torch.uint8, device='cuda') for _ in range(L)]
+        bw = [torch.zeros(n, dtype=torch.uint8, device='cuda') for _ in range(L)] if train else None
+        return yp, fw, bw
+    yp1, fw1, bw1 = buffers()
+    xc1 = torch.full((T, B, Fp), 5.0, device='cuda')
+    ops.center(x, B, T, F, 0, F, xc1, 1, Fp)
+    if train:
+        assert ops.lstm_prefill_train(T, B, H, ndir, yp1, fw1, bw1)
+    else:
+        ops.lstm_prefill_fwd(T, B, ndir * H, yp1, fw1)
+    yp2, fw2, bw2 = buffers()
+    xc2 = torch.full((T, B, Fp), 5.0, device='cuda')
+    assert ops.encoder_prologue(x, B, T, F, xc2, Fp, H, ndir, yp2, fw2, bw2)
+    torch.cuda.synchronize()
+    assert torch.equal(xc1, xc2)
+    for a, b in zip(yp1 + fw1 + (bw1 or []), yp2 + fw2 + (bw2 or [])):
+        assert torch.equal(a.view(torch.uint8).view(-1), b.view(torch.uint8).view(-1))
+    assert int(yp2[0].view(torch.int32)[1, 0, 0]) == -1 and float(yp2[0][0].abs().max()) == 0.0
+
+
 # ---------------------------------------------------------------- frontend
 def test_frontend_and_reattach():
     from danet_amd import ops
