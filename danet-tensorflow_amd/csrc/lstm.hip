@@ -1578,6 +1578,15 @@ static RsPlan choose_rs_plan(int B, int H, int ndir) {
   // fewest MFMAs per SIMD and step (tiles of a workgroup spread over 4 SIMDs, 4U/4
   // k-steps each); ties go to the smaller U (shorter dependent chains).  Measured at
   // cfg 2: U=16,S=3 2.4 us/step; U=32,S=5 2.8; U=8,S=1 3.0 (all-gather kernel: 3.5)
+  // Wide layers (H > 384): the host runs this launch beside a ~1 ms weight-gradient group (ops._overlap_dw:
+  // always, with the groups on the bf16 matrix cores).  There the 152-workgroup geometry U = 16 without twins
+  // leaves the group and dX more of the GPU than U = 32 with three twins (228 workgroups): cfg 4 as written
+  // 8.25-8.28 -> 7.97-8.01 ms per step, three alternating pairs (groups 1 040 -> 830 us, dX 516 -> 460), although
+  // the kernel itself is slower beside the group (575 against 548 us) and alone.
+  if (!pin && H > 384) {
+    const RsPlan r = make_rs_plan(B, H, ndir, 16);
+    if (r.ok) return r;
+  }
   RsPlan best = none;
   int best_cost = 1 << 30;
   for (int U = 8; U <= 32; U *= 2) {
