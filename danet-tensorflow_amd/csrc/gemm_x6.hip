@@ -582,7 +582,7 @@ extern "C" int danet_gemm_pack_weights(danet_stream_t stream, int n, const danet
 // cfg 4: 0.032 tile-times per slice for tiles / nkt = 1, i.e. a short-K product with a large output
 // is never sliced).  Measured against it: 160 tiles x 150-256 steps -> 3 (2 / 4: +15 %), 100 -> 5,
 // 105 -> 4, 570 x 256 -> 2-3 (1: +2 % of the cfg-4h600 step), 266 x 256 -> 3.
-static int x6_slices(int tiles, int nkt, int min_steps, int max_slices) {
+static int x6_slices(int tiles, int nkt, int min_steps, int max_slices, double slab_cost = 0.032) {
   double best = 1e30;
   int bs = 1;
   for (int s = 1; s <= max_slices; ++s) {
@@ -590,7 +590,7 @@ static int x6_slices(int tiles, int nkt, int min_steps, int max_slices) {
     const double r = (double)tiles * s / 512.0;
     const double whole = (double)(long long)r, frac = r - whole;
     const double rounds = whole + (frac > 0.0 ? 0.55 + 0.45 * frac : 0.0);
-    const double cost = rounds / s + (s > 1 ? 0.02 + 0.032 * tiles / max(nkt, 1) * (s - 1) : 0.0);
+    const double cost = rounds / s + (s > 1 ? 0.02 + slab_cost * tiles / max(nkt, 1) * (s - 1) : 0.0);
     if (cost < best - 1e-9) { best = cost; bs = s; }
   }
   return bs;
@@ -1123,7 +1123,15 @@ __global__ __launch_bounds__(256) void gemm_x6_tn_reduce_kernel(X6TArgs g) {
   }
 }
 
-static int x6t_splitk(int tiles, int K) { return x6_slices(tiles, cdiv(K, 16), 16, 8); }
+#ifdef X6T_FORCE_S   // experiment builds: a pinned slice count for the layer groups (tools, EXPERIMENTS)
+static int x6t_splitk(int tiles, int K) { return tiles >= 100 ? X6T_FORCE_S : x6_slices(tiles, cdiv(K, 16), 16, 8); }
+#else
+// (slab cost 0.045 per slice instead of the NT products' 0.032: the groups run BESIDE a BPTT kernel, where the slab
+// round trip shares the memory system with the kernel's exchange.  It changes one decision among the step's shapes
+// -- the 570-tile layer groups of H = 600: 3 -> 2 slices, cfg 4 as written 7.85-7.87 -> 7.75-7.76 ms, two alternating
+// pairs of pinned builds; cfg 2's 160-tile groups stay at 3 (2: the same within noise; 4 / 5: +5-10 us))
+static int x6t_splitk(int tiles, int K) { return x6_slices(tiles, cdiv(K, 16), 16, 8, 0.045); }
+#endif
 // rows of a problem covered by 128-row tiles: all of them, unless 1..X6T_TAIL_MAX rows hang over a
 // multiple of 128 (then those are tail rows: x6t_tail).  include/danet_hip.h states the same rule
 // for the tile count a caller passes to danet_workspace_bytes(DANET_WS_GEMM_X6_TN, ...).
