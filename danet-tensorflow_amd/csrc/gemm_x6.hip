@@ -521,11 +521,14 @@ __global__ __launch_bounds__(256) void gemm_x6_pack_kernel(X6PackArgs a) {
   u32x4* __restrict__ out = q.out;
   const int64_t sn = q.sn, sk = q.sk;
   const bool kvec = sk == 1 && (sn & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
-  const int64_t total = (int64_t)NT32 * KT * 64;
+  // (32-bit index arithmetic: the host checks NT32 * KT * 64 < 2^31 -- a 64-bit divide and modulo per
+  // 8 values were a third of this kernel's instructions)
+  const unsigned total = (unsigned)NT32 * (unsigned)KT * 64u;
   const size_t plane = (size_t)total;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int l = (int)(idx & 63);
-    const int kt = (int)((idx >> 6) % KT), nt = (int)((idx >> 6) / KT);
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const int l = (int)(idx & 63u);
+    const unsigned t = idx >> 6;
+    const int nt = (int)(t / (unsigned)KT), kt = (int)(t - (unsigned)nt * (unsigned)KT);
     const int n = nt * 32 + (l & 31), k0 = kt * 16 + 8 * (l >> 5);
     uint32_t h[8], m[8], lo[8];
     float x[8];
@@ -566,6 +569,7 @@ extern "C" int danet_gemm_pack_weights(danet_stream_t stream, int n, const danet
       q.N = j.N; q.K = j.K; q.NT32 = x6_nt32(j.N); q.KT = cdiv(j.K, XBK);
       most = max(most, (int64_t)q.NT32 * q.KT * 64);
     }
+    DANET_CHECK_ARG(most < (1ll << 31), "gemm_pack_weights: a weight of 2^31 / 8 values or more");
     for (int i = cnt; i < X6_MAX_PACK; ++i) a.job[i] = a.job[0];
     dim3 grid((unsigned)min((int64_t)1024, cdiv64(most, 256)), (unsigned)cnt);
     gemm_x6_pack_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
